@@ -1,0 +1,130 @@
+// gf_action.hip — Phase A: GenesisEnv.step bookkeeping + PositionActionManager.step, one launch.
+//
+// Replaces (reference, /root/reference/genesis_forge/):
+//   genesis_env.py:196-203          episode_length += 1; last_actions <- actions; actions <- new
+//   managers/action/base.py:67-82   raw -> manager copy
+//   managers/action/position_action_manager.py:402-414   NaN/Inf scan, a*scale+offset, clamp(lo,hi)
+//   managers/action/position_within_limits.py:125-126    clamp(-1,1), a*scale+offset
+// which the reference runs as ~13 separate elementwise launches + 2 host syncs.
+//
+// Layout: the [N,D] arrays are treated as one flat stream of N*D floats; each lane owns one
+// float4 (16 B/lane, 1 KiB per wave instruction, fully coalesced).  The [D] constants are
+// indexed with (4*i+j) % D and come from L1/K$.  Algorithmic traffic: 20*D B/env
+// (R new, R prev, W last, W actions, W targets) + 8 B/env for episode_length.
+#include "gf_launch.h"
+
+namespace gf {
+
+__device__ __forceinline__ float action_target(float x, float s, float o, float lo, float hi, int mode) {
+    if (mode == GF_ACTION_WITHIN_LIMITS) {
+        x = clamp_min(x, -1.0f);
+        x = clamp_max(x, 1.0f);
+        return x * s + o;
+    }
+    float t = x * s + o;
+    t = clamp_min(t, lo);
+    t = clamp_max(t, hi);
+    return t;
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void action_kernel(const GfActionArgs a, const int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = a.num_dofs;
+    const int mode = a.mode;
+    int flags = 0;
+
+    // episode_length += 1  (genesis_env.py:197) — first N/4 lanes, int4 RMW
+    if (a.episode_length) {
+        const int64_t N = a.num_envs;
+        if (VEC4 && (N & 3) == 0) {
+            if (i < (N >> 2)) {
+                int4* p = reinterpret_cast<int4*>(a.episode_length) + i;
+                int4 v = *p;
+                v.x += 1; v.y += 1; v.z += 1; v.w += 1;
+                *p = v;
+            }
+        } else if (i < N) {
+            a.episode_length[i] += 1;
+        }
+    }
+
+    if (VEC4) {
+        if (i < (total >> 2)) {
+            const float4 x = reinterpret_cast<const float4*>(a.actions_in)[i];
+            if (a.env_actions) {
+                const float4 prev = reinterpret_cast<const float4*>(a.env_actions)[i];
+                reinterpret_cast<float4*>(a.env_last_actions)[i] = prev;
+                reinterpret_cast<float4*>(a.env_actions)[i] = x;
+            }
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+            float ts[4];
+            int d = (int)((i * 4) % D);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = mode == GF_ACTION_POSITION ? a.clip_lo[d] : 0.f;
+                const float hi = mode == GF_ACTION_POSITION ? a.clip_hi[d] : 0.f;
+                ts[j] = action_target(xs[j], a.scale[d], a.offset[d], lo, hi, mode);
+                if (a.check_finite && mode == GF_ACTION_POSITION) {
+                    flags |= isnan(xs[j]) ? 1 : 0;
+                    flags |= isinf(xs[j]) ? 2 : 0;
+                }
+                d = d + 1 == D ? 0 : d + 1;
+            }
+            reinterpret_cast<float4*>(a.targets)[i] = make_float4(ts[0], ts[1], ts[2], ts[3]);
+        }
+    } else {
+        if (i < total) {
+            const float x = a.actions_in[i];
+            if (a.env_actions) {
+                a.env_last_actions[i] = a.env_actions[i];
+                a.env_actions[i] = x;
+            }
+            const int d = (int)(i % D);
+            const float lo = mode == GF_ACTION_POSITION ? a.clip_lo[d] : 0.f;
+            const float hi = mode == GF_ACTION_POSITION ? a.clip_hi[d] : 0.f;
+            a.targets[i] = action_target(x, a.scale[d], a.offset[d], lo, hi, mode);
+            if (a.check_finite && mode == GF_ACTION_POSITION) {
+                flags |= isnan(x) ? 1 : 0;
+                flags |= isinf(x) ? 2 : 0;
+            }
+        }
+    }
+
+    // NaN/Inf detection (position_action_manager.py:402-406): the reference syncs twice per step
+    // to print; here a flag word is OR-ed on device and polled lazily by the host.
+    if (a.stats && a.check_finite) {
+        const unsigned long long nan_m = __ballot(flags & 1);
+        const unsigned long long inf_m = __ballot(flags & 2);
+        if ((nan_m | inf_m) && (threadIdx.x & (GF_WAVE - 1)) == 0) atomicOr(&a.stats->action_flags, (nan_m ? 1 : 0) | (inf_m ? 2 : 0));
+    }
+}
+
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_action_step(const GfActionArgs* a, void* stream) {
+    if (!a || !a->actions_in || !a->targets || !a->scale || !a->offset) return GF_E_NULL;
+    if (a->mode == GF_ACTION_POSITION && (!a->clip_lo || !a->clip_hi)) return GF_E_NULL;
+    if (a->mode != GF_ACTION_POSITION && a->mode != GF_ACTION_WITHIN_LIMITS) return GF_E_RANGE;
+    if (a->env_actions && !a->env_last_actions) return GF_E_NULL;
+    if (a->num_envs < 0 || a->num_dofs <= 0) return GF_E_RANGE;
+    if (a->num_envs == 0) return GF_OK;
+    const int64_t total = (int64_t)a->num_envs * a->num_dofs;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool vec = (total & 3) == 0 && al16(a->actions_in) && al16(a->targets) && (!a->env_actions || (al16(a->env_actions) && al16(a->env_last_actions))) &&
+                     (!a->episode_length || al16(a->episode_length));
+    hipStream_t s = (hipStream_t)stream;
+    gf::PhaseScope scope(GF_PHASE_ACTION, s);
+    if (vec) {
+        int64_t lanes = total >> 2;
+        if (a->episode_length) {
+            const int64_t need = (a->num_envs & 3) == 0 ? (a->num_envs >> 2) : a->num_envs;
+            if (need > lanes) lanes = need;
+        }
+        gf::action_kernel<true><<<gf::env_grid(lanes, 256), 256, 0, s>>>(*a, total);
+    } else {
+        int64_t lanes = total > a->num_envs ? total : a->num_envs;
+        gf::action_kernel<false><<<gf::env_grid(lanes, 256), 256, 0, s>>>(*a, total);
+    }
+    return gf::launch_status();
+}

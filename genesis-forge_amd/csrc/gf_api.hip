@@ -1,0 +1,70 @@
+// gf_api.hip — library-level entry points: version, error strings, stats clear, opt-in
+// HIP-event profiling around the kernel of one phase (used by bench.py for roofline.achieved).
+#include <vector>
+
+#include "gf_launch.h"
+
+namespace gf {
+Profiler g_prof;
+}
+
+#define GF_EXPORT __attribute__((visibility("default")))
+extern "C" {
+
+GF_EXPORT int gf_abi_version(void) { return GF_ABI_VERSION; }
+
+GF_EXPORT const char* gf_build_info(void) { return "genesis-forge_amd gf_step: gfx950 HIP, -ffp-contract=off, built " __DATE__ " " __TIME__; }
+
+GF_EXPORT const char* gf_error_string(int code) {
+    switch (code) {
+        case GF_OK: return "ok";
+        case GF_E_NULL: return "required pointer is NULL";
+        case GF_E_RANGE: return "size or count out of supported range";
+        case GF_E_OPCODE: return "unknown opcode in term table";
+        case GF_E_SLOT: return "term references an unbound view/slot";
+        case GF_E_UNSUPPORTED: return "unsupported configuration";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown error";
+}
+
+GF_EXPORT int gf_stats_clear(GfStepStats* stats, void* stream) {
+    if (!stats) return GF_E_NULL;
+    GF_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(GfStepStats), (hipStream_t)stream));
+    return GF_OK;
+}
+
+GF_EXPORT int gf_profile_begin(int phase, int max_samples) {
+    if (phase < 0 || phase >= GF_PHASE_COUNT || max_samples <= 0) return GF_E_RANGE;
+    gf::Profiler& p = gf::g_prof;
+    for (hipEvent_t e : p.events) hipEventDestroy(e);
+    p.events.clear();
+    p.events.resize((size_t)max_samples * 2);
+    for (auto& e : p.events) GF_HIP_CHECK(hipEventCreate(&e));
+    p.count = 0;
+    p.max_samples = max_samples;
+    p.phase = phase;
+    return GF_OK;
+}
+
+GF_EXPORT int gf_profile_end(double* total_ms, int* samples) {
+    gf::Profiler& p = gf::g_prof;
+    double tot = 0.0;
+    for (int i = 0; i < p.count; ++i) {
+        GF_HIP_CHECK(hipEventSynchronize(p.events[2 * i + 1]));
+        float ms = 0.f;
+        GF_HIP_CHECK(hipEventElapsedTime(&ms, p.events[2 * i], p.events[2 * i + 1]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (samples) *samples = p.count;
+    for (hipEvent_t e : p.events) hipEventDestroy(e);
+    p.events.clear();
+    p.phase = -1;
+    p.count = 0;
+    p.max_samples = 0;
+    return GF_OK;
+}
+
+}  // extern "C"

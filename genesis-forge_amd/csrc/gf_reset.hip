@@ -1,0 +1,110 @@
+// gf_reset.hip — Phase R: masked reset of every piece of manager-owned state, one launch.
+//
+// Replaces the fan-out of ManagedEnvironment.reset (managed_env.py:336-366):
+//   GenesisEnv.reset              genesis_env.py:233-252   actions/last_actions/episode_length <- 0, max length jitter
+//   PositionActionManager.reset   position_action_manager.py:455-464   dof_pos <- default (+noise)   [scene side]
+//   EntityManager.reset → mdp.reset.position   mdp/reset.py:102-124   pos/quat <- fixed pose, zero velocity [scene side]
+//   ContactManager.reset          contact_manager.py:316-329   4 air-time arrays <- 0
+//   RewardManager.reset           reward_manager.py:202-222    value/=secs; mean -> log; value<-0; secs<-1e-10
+// The reference reaches these through nonzero() (host sync) + index gathers/scatters (~84 aten ops,
+// 6 .item() syncs).  Here the done mask is applied per lane; waves without a done env exit after
+// two byte loads.  The per-term episode means are wave-reduced in f64 and added with one f64
+// atomic per wave and term (the only floating atomics in the library: Σ over ≤N values feeding a
+// log line, accumulated in double so the f32-rounded result does not depend on arrival order).
+#include "gf_launch.h"
+
+namespace gf {
+
+__global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
+    const bool live = n < a.num_envs;
+    const bool go = live && (a.mask[n] || (a.mask2 && a.mask2[n]));
+    const unsigned long long wave_go = __ballot(go);
+    if (!wave_go) return;  // wave-uniform
+    const int64_t N = a.num_envs;
+    const int D = a.num_dofs;
+
+    if (a.stats && threadIdx.x == 0) atomicAdd(&a.stats->reset_count, popc64(wave_go));
+
+    // ---- RewardManager.reset: needs every lane for the wave reduction --------------------------
+    if (a.episode_seconds) {
+        if (a.reward_logging && a.episode_sums) {
+            const float secs = go ? a.episode_seconds[n] : 1.0f;
+            for (int t = 0; t < a.num_reward_terms; ++t) {
+                float* v = a.episode_sums + (int64_t)t * N + (live ? n : 0);
+                if (a.reward_log_mask & (1u << t)) {
+                    const float per_sec = go ? (*v / secs) : 0.0f;  // value[envs_idx] /= episode_seconds
+                    if (a.stats) {
+                        const double s = wave_sum((double)per_sec);
+                        if (threadIdx.x == 0) atomicAdd(&a.stats->reward_episode_sum[t], s);
+                    }
+                }
+                if (go) *v = 0.0f;
+            }
+        }
+        if (go) a.episode_seconds[n] = 1e-10f;
+    }
+    if (!go) return;
+
+    // ---- GenesisEnv.reset -----------------------------------------------------------------------
+    if (a.env_actions) {
+        float* r0 = a.env_actions + n * D;
+        float* r1 = a.env_last_actions + n * D;
+        for (int d = 0; d < D; ++d) { r0[d] = 0.0f; r1[d] = 0.0f; }
+    }
+    if (a.episode_length) a.episode_length[n] = 0;
+    if (a.max_episode_length && a.max_random_scaling > 0.0f) {
+        const float u = draw_u(a.len_draws, n, a.seed, a.stream, (uint32_t)n, 0u);
+        const float r = uniform_range(u, -1.0f, 1.0f) * a.max_random_scaling;
+        a.max_episode_length[n] = (int32_t)rintf((float)a.base_max_episode_length + r);  // torch.round: half-to-even
+    }
+
+    // ---- ContactManager.reset -------------------------------------------------------------------
+    for (int m = 0; m < a.num_contact; ++m) {
+        const int L = a.air_links[m];
+        for (int s = 0; s < 4; ++s) {
+            float* p = a.air_state[m][s];
+            if (p)
+                for (int l = 0; l < L; ++l) p[n * L + l] = 0.0f;
+        }
+    }
+
+    // ---- scene side (synthetic scene exposes masked setters; NULL for real Genesis) ----------------
+    if (a.scene_dof_pos) {
+        for (int d = 0; d < D; ++d) {
+            float p = a.default_dof_pos[d];
+            if (a.dof_noise_scale != 0.0f) {
+                const float u = draw_u(a.dof_draws, n * D + d, a.seed, a.stream, (uint32_t)n, (uint32_t)(4 + d));
+                p = p + uniform_range(u, -1.0f, 1.0f) * a.dof_noise_scale;
+            }
+            a.scene_dof_pos[n * D + d] = p;
+            if (a.scene_dof_vel) a.scene_dof_vel[n * D + d] = 0.0f;
+        }
+    }
+    if (a.scene_pos) {
+        for (int j = 0; j < 3; ++j) a.scene_pos[3 * n + j] = a.reset_pos[j];
+        if (a.set_quat && a.scene_quat)
+            for (int j = 0; j < 4; ++j) a.scene_quat[4 * n + j] = a.reset_quat[j];
+        if (a.zero_velocity) {
+            if (a.scene_lin_vel) for (int j = 0; j < 3; ++j) a.scene_lin_vel[3 * n + j] = 0.0f;
+            if (a.scene_ang_vel) for (int j = 0; j < 3; ++j) a.scene_ang_vel[3 * n + j] = 0.0f;
+            if (a.scene_dof_vel) for (int d = 0; d < D; ++d) a.scene_dof_vel[n * D + d] = 0.0f;
+        }
+    }
+}
+
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_masked_reset(const GfResetArgs* a, void* stream) {
+    if (!a || !a->mask) return GF_E_NULL;
+    if (a->num_envs < 0 || a->num_dofs < 0) return GF_E_RANGE;
+    if (a->num_reward_terms < 0 || a->num_reward_terms > GF_MAX_TERMS) return GF_E_RANGE;
+    if (a->num_contact < 0 || a->num_contact > GF_MAX_CONTACT_VIEWS) return GF_E_RANGE;
+    if (a->env_actions && !a->env_last_actions) return GF_E_NULL;
+    if (a->scene_dof_pos && !a->default_dof_pos) return GF_E_NULL;
+    if (a->num_envs == 0) return GF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    gf::PhaseScope scope(GF_PHASE_RESET, s);
+    gf::reset_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a);
+    return gf::launch_status();
+}

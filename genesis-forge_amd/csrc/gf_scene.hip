@@ -1,0 +1,128 @@
+// gf_scene.hip — EntityManager body-frame getters as a standalone call, and the synthetic scene tick.
+//
+// gf_entity_rotate: EntityManager.get_projected_gravity / get_linear_velocity / get_angular_velocity
+//   (managers/entity_manager.py:130-146, utils.py:13-55) for callers that ask for one vector outside a
+//   fused phase (opaque user terms).  7-10 torch launches per call in the reference.
+//
+// gf_synth_scene_step: stands in for Genesis' scene.step() (managed_env.py:292) so the manager
+//   pipeline can be driven, benchmarked and parity-tested without the simulator.
+//   It is NOT physics: joints track their PD targets with a first-order lag, the base does a damped
+//   random walk driven by Philox draws, contacts are sampled per slot.  What matters is that the
+//   update is deterministic and integer-RNG driven with f32 ops in a fixed order, so this kernel, the
+//   C oracle and the numpy model that drives the reference produce the same bits.
+#include "gf_launch.h"
+
+namespace gf {
+
+__global__ __launch_bounds__(kEnvBlock) void rotate_kernel(const GfRotateArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
+    if (n >= a.num_envs) return;
+    const float4 q = load_quat(a.entity.quat, n);
+    V3 v{0.f, 0.f, -1.f};
+    if (a.what == GF_ROT_LIN_VEL) v = load3(a.entity.lin_vel, n);
+    else if (a.what == GF_ROT_ANG_VEL) v = load3(a.entity.ang_vel, n);
+    const V3 o = rot_inv(q, v);
+    float* r = a.out + 3 * n;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z;
+}
+
+__global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSceneArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
+    if (n >= a.num_envs) return;
+    const int D = a.num_dofs, C = a.num_contacts, NL = a.num_scene_links;
+    const float dt = a.dt;
+    for (int d = 0; d < D; ++d) {
+        const float cur = a.dof_pos[n * D + d];
+        const float err = a.targets[n * D + d] - cur;
+        const float v = err * a.joint_rate;
+        a.dof_vel[n * D + d] = v;
+        a.dof_pos[n * D + d] = cur + v * dt;
+    }
+    float s[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s[j] = philox_uniform(a.seed, a.tick, (uint32_t)n, (uint32_t)j) * 2.0f - 1.0f;
+    float* wp = a.ang_vel + 3 * n;
+    float* vp = a.lin_vel + 3 * n;
+    float* pp = a.pos + 3 * n;
+    float* qp = a.quat + 4 * n;
+    float w[3], v[3], p[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { w[j] = wp[j]; v[j] = vp[j]; p[j] = pp[j]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) w[j] = w[j] * 0.9f + s[j] * a.ang_noise;
+    v[0] = v[0] * 0.9f + s[3] * a.lin_noise;
+    v[1] = v[1] * 0.9f + s[4] * a.lin_noise;
+    v[2] = (v[2] * 0.9f + (a.height_target - p[2]) * 2.0f) + s[5] * a.lin_noise;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) p[j] = p[j] + v[j] * dt;
+    const float h = 0.5f * dt;
+    const float4 q4 = load_quat(a.quat, n);
+    const float qw = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
+    const float dw = ((-(w[0] * qx)) - w[1] * qy) - w[2] * qz;
+    const float dx = (w[0] * qw + w[1] * qz) - w[2] * qy;
+    const float dy = (w[1] * qw + w[2] * qx) - w[0] * qz;
+    const float dz = (w[2] * qw + w[0] * qy) - w[1] * qx;
+    float nq[4] = {qw + dw * h, qx + dx * h, qy + dy * h, qz + dz * h};
+    const float nrm = sqrtf(((nq[0] * nq[0] + nq[1] * nq[1]) + nq[2] * nq[2]) + nq[3] * nq[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nq[j] = nq[j] / nrm;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { wp[j] = w[j]; vp[j] = v[j]; pp[j] = p[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qp[j] = nq[j];
+    if (a.links_quat_out)
+        for (int l = 0; l < NL; ++l)
+            for (int j = 0; j < 4; ++j) a.links_quat_out[(n * NL + l) * 4 + j] = nq[j];
+    if (a.links_vel_out)
+        for (int l = 0; l < NL; ++l)
+            for (int j = 0; j < 3; ++j) a.links_vel_out[(n * NL + l) * 3 + j] = v[j] + (float)(l % 3 == j ? 1 : 0) * 0.05f * w[j];
+    if (C > 0 && a.contact_force_out) {
+        for (int c = 0; c < C; ++c) {
+            const uint32_t col = (uint32_t)(8 + 8 * c);
+            // columns col..col+3 share one Philox block, col+4 starts the next
+            const U4 r0 = philox4x32_10((uint32_t)n, col >> 2, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            const U4 r1 = philox4x32_10((uint32_t)n, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            const float u_act = u24_to_unit(r0.x), u_link = u24_to_unit(r0.y);
+            const float fx = u24_to_unit(r0.z) * 2.0f - 1.0f, fy = u24_to_unit(r0.w) * 2.0f - 1.0f, fz = u24_to_unit(r1.x);
+            const bool active = u_act < a.contact_prob;
+            const int64_t k = n * C + c;
+            int lb = 1 + (int)(u_link * (float)(NL - 1));
+            if (lb > NL - 1) lb = NL - 1;
+            a.link_a_out[k] = active ? 0 : -1;
+            a.link_b_out[k] = active ? lb : -1;
+            a.contact_force_out[k * 3 + 0] = active ? fx * a.contact_force * 0.25f : 0.0f;
+            a.contact_force_out[k * 3 + 1] = active ? fy * a.contact_force * 0.25f : 0.0f;
+            a.contact_force_out[k * 3 + 2] = active ? fz * a.contact_force : 0.0f;
+            a.contact_pos_out[k * 3 + 0] = active ? p[0] + fx * 0.2f : 0.0f;
+            a.contact_pos_out[k * 3 + 1] = active ? p[1] + fy * 0.2f : 0.0f;
+            a.contact_pos_out[k * 3 + 2] = 0.0f;
+        }
+    }
+}
+
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_entity_rotate(const GfRotateArgs* a, void* stream) {
+    if (!a || !a->out || !a->entity.quat) return GF_E_NULL;
+    if (a->what < GF_ROT_PROJ_GRAVITY || a->what > GF_ROT_ANG_VEL || a->num_envs < 0) return GF_E_RANGE;
+    if (a->what == GF_ROT_LIN_VEL && !a->entity.lin_vel) return GF_E_NULL;
+    if (a->what == GF_ROT_ANG_VEL && !a->entity.ang_vel) return GF_E_NULL;
+    if (reinterpret_cast<uintptr_t>(a->entity.quat) & 15u) return GF_E_UNSUPPORTED;
+    if (a->num_envs == 0) return GF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    gf::PhaseScope scope(GF_PHASE_ROTATE, s);
+    gf::rotate_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a);
+    return gf::launch_status();
+}
+
+extern "C" __attribute__((visibility("default"))) int gf_synth_scene_step(const GfSynthSceneArgs* a, void* stream) {
+    if (!a || !a->pos || !a->quat || !a->lin_vel || !a->ang_vel || !a->dof_pos || !a->dof_vel || !a->targets) return GF_E_NULL;
+    if (a->num_envs < 0 || a->num_dofs <= 0 || a->num_contacts < 0) return GF_E_RANGE;
+    if (a->num_contacts > 0 && a->contact_force_out && (!a->contact_pos_out || !a->link_a_out || !a->link_b_out || a->num_scene_links < 2)) return GF_E_NULL;
+    if (reinterpret_cast<uintptr_t>(a->quat) & 15u) return GF_E_UNSUPPORTED;
+    if (a->num_envs == 0) return GF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    gf::PhaseScope scope(GF_PHASE_SCENE, s);
+    gf::synth_scene_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a);
+    return gf::launch_status();
+}

@@ -1,0 +1,447 @@
+/*
+ * gf_step.h — C ABI of the MI355X-native ManagedEnvironment manager-step pipeline.
+ *
+ * One entry point per phase of the reference's ManagedEnvironment.step()
+ * (/root/reference/genesis_forge/managed_env.py:274-334).  Every function takes a POD
+ * descriptor of caller-owned device buffers (row-major, contiguous, f32 unless noted)
+ * plus the HIP stream to launch on, and returns an int status:
+ *      0            success
+ *      < 0          argument validation failure (GF_E_*)
+ *      > 0          hipError_t of the failing runtime call
+ * The library allocates nothing, keeps no global mutable state and never synchronises the
+ * device: ownership never crosses the ABI.  No torch types appear here; the
+ * Python host (genesis_forge_amd) hands over `tensor.data_ptr()` values via ctypes.
+ *
+ * Conventions
+ *   N = num_envs, D = controlled DOFs, L = tracked links of one ContactManager,
+ *   C = contact slots, T/K = number of reward/termination terms, O = observation width.
+ *   Masks are 1 byte per env (torch.bool).  Counters are int32.  Quaternions are (w,x,y,z).
+ *   "draws": wherever the reference consumes torch's global RNG (Tensor.uniform_), the kernel
+ *   takes either a dense array of U[0,1) floats (parity mode) or NULL, in which case it
+ *   generates the same kind of draw with Philox4x32-10 keyed by (seed, stream, env, lane).
+ */
+#ifndef GF_STEP_H
+#define GF_STEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF_ABI_VERSION 1
+
+#define GF_MAX_TERMS 24          /* reward terms per manager          */
+#define GF_MAX_TERM_TERMS 16     /* termination terms per manager     */
+#define GF_MAX_OBS_ITEMS 24      /* observation items per manager     */
+#define GF_MAX_CONTACT_VIEWS 4   /* ContactManagers visible to a term */
+#define GF_MAX_COMMAND_VIEWS 4   /* CommandManagers visible to a term */
+#define GF_MAX_EXT 16            /* opaque Python-evaluated columns   */
+#define GF_MAX_LINK_IDS 32       /* target / with link ids            */
+#define GF_MAX_RANGES 8          /* command ranges per CommandManager */
+#define GF_MAX_OBS_WIDTH 256     /* single-frame observation width    */
+
+/* error codes */
+#define GF_OK 0
+#define GF_E_NULL (-1)      /* required pointer is NULL              */
+#define GF_E_RANGE (-2)     /* size / count out of supported range   */
+#define GF_E_OPCODE (-3)    /* unknown opcode in a term table        */
+#define GF_E_SLOT (-4)      /* term references an unbound view/slot  */
+#define GF_E_UNSUPPORTED (-5)
+
+/* ------------------------------------------------------------------------------------------
+ * Shared views
+ * ---------------------------------------------------------------------------------------- */
+
+/* World-frame base-link state of one entity, as returned by RigidEntity.get_pos/quat/vel/ang
+ * (call sites: genesis_forge/utils.py:13-55, managers/entity_manager.py:130-146,189-195). */
+typedef struct GfEntityView {
+    const float* pos;      /* [N,3] */
+    const float* quat;     /* [N,4] (w,x,y,z) */
+    const float* lin_vel;  /* [N,3] world frame */
+    const float* ang_vel;  /* [N,3] world frame */
+} GfEntityView;
+
+/* Buffers a ContactManager publishes (managers/contact/contact_manager.py:142-156,300-314). */
+typedef struct GfContactView {
+    const float* contacts;              /* [N,L,3] link-local net force  */
+    const float* last_air_time;         /* [N,L] or NULL                 */
+    const float* current_contact_time;  /* [N,L] or NULL                 */
+    const float* link_vel;              /* [N,L,3] world link velocity (feet_slide) or NULL */
+    int32_t num_links;                  /* L */
+    int32_t _pad;
+} GfContactView;
+
+/* CommandManager._command (managers/command/command_manager.py:77-81). */
+typedef struct GfCommandView {
+    const float* command;  /* [N,width] */
+    int32_t width;
+    int32_t _pad;
+} GfCommandView;
+
+/* One row of a term table.  Meaning of p[]/i[] is per opcode (see enums below). */
+typedef struct GfTerm {
+    int32_t op;
+    int32_t flags;
+    float w;        /* rewards: (float)(weight*dt)  (reward_manager.py:185-186)  */
+    float p[4];
+    int32_t i[4];
+    int32_t row;    /* rewards: row of episode_sums / term_out this term owns      */
+} GfTerm;           /* 48 bytes */
+
+/* Per-step scalar statistics, accumulated on device, read back lazily by the host.
+ * These are the only cross-env reductions of the path; at world_size>1 this
+ * block (cast to f64) is the payload of the single RCCL all-reduce. */
+typedef struct GfStepStats {
+    int32_t term_fired[GF_MAX_TERM_TERMS]; /* #envs for which termination term k fired (termination_manager.py:178-182) */
+    int32_t reset_count;                   /* #envs reset this step (managed_env.py:308-323) */
+    int32_t action_flags;                  /* bit0: NaN action seen, bit1: Inf action seen (position_action_manager.py:402-406) */
+    int32_t contact_flags;                 /* bit0: non-finite contact force sanitised (contact_manager.py:399-403) */
+    int32_t resample_count;                /* #envs whose command was resampled by command.step() */
+    int32_t _pad[4];
+    double reward_episode_sum[GF_MAX_TERMS]; /* Σ over reset envs of episode_sum[t]/episode_seconds (reward_manager.py:207-216) */
+} GfStepStats;
+
+/* ------------------------------------------------------------------------------------------
+ * Phase A — GenesisEnv.step bookkeeping + PositionActionManager.step
+ *   genesis_env.py:181-205; managers/action/base.py:67-82;
+ *   managers/action/position_action_manager.py:376-419; position_within_limits.py:100-131
+ * ---------------------------------------------------------------------------------------- */
+enum { GF_ACTION_POSITION = 0, GF_ACTION_WITHIN_LIMITS = 1 };
+
+typedef struct GfActionArgs {
+    int32_t num_envs;
+    int32_t num_dofs;
+    int32_t mode;            /* GF_ACTION_* */
+    int32_t check_finite;    /* !quiet_action_errors: set stats->action_flags bits */
+    const float* actions_in; /* [N,D] policy output (never written) */
+    const float* scale;      /* [D] */
+    const float* offset;     /* [D] */
+    const float* clip_lo;    /* [D] */
+    const float* clip_hi;    /* [D] */
+    float* env_actions;      /* [N,D] GenesisEnv._actions      (may be NULL: bookkeeping skipped) */
+    float* env_last_actions; /* [N,D] GenesisEnv._last_actions */
+    int32_t* episode_length; /* [N] += 1 (may be NULL) */
+    float* targets;          /* [N,D] out: clamped PD targets == action_manager.get_actions() */
+    GfStepStats* stats;      /* may be NULL */
+} GfActionArgs;
+
+/* ------------------------------------------------------------------------------------------
+ * Phase B2 — ContactManager.step
+ *   managers/contact/kernel.py:5-90 (accumulation), contact_manager.py:384-477 (sanitise, air time)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct GfContactArgs {
+    int32_t num_envs;
+    int32_t num_contacts;     /* C */
+    int32_t num_scene_links;  /* second dim of links_quat */
+    int32_t num_targets;      /* L */
+    int32_t num_with;         /* W */
+    int32_t has_with_filter;
+    int32_t track_air_time;
+    int32_t _pad;
+    const float* force;       /* [N,C,3] world frame, force on link_b */
+    const float* position;    /* [N,C,3] */
+    const int32_t* link_a;    /* [N,C] */
+    const int32_t* link_b;    /* [N,C] */
+    const float* links_quat;  /* [N,num_scene_links,4] */
+    int32_t target_link_ids[GF_MAX_LINK_IDS];
+    int32_t with_link_ids[GF_MAX_LINK_IDS];
+    float air_time_threshold; /* (float)air_time_contact_threshold */
+    float dt;                 /* (float)scene.dt */
+    float* contacts;          /* [N,L,3] out */
+    float* contact_positions; /* [N,L,3] out (mean position) */
+    float* position_counts;   /* [N,L]   out */
+    float* last_air_time;     /* [N,L] in/out, NULL unless track_air_time */
+    float* current_air_time;
+    float* last_contact_time;
+    float* current_contact_time;
+    GfStepStats* stats;       /* may be NULL */
+} GfContactArgs;
+
+/* ------------------------------------------------------------------------------------------
+ * Phase B3 — TerminationManager.step   (managers/termination_manager.py:151-190,
+ *                                        mdp/terminations.py)
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    GF_T_TIMEOUT = 1,              /* episode_length > max_episode_length          (terminations.py:17-23)  */
+    GF_T_BAD_ORIENTATION = 2,      /* p0 = tilt threshold in sin-space, i0 = grace  (terminations.py:26-71)  */
+    GF_T_BASE_HEIGHT_BELOW = 3,    /* p0 = minimum height                           (terminations.py:74-99)  */
+    GF_T_OUT_OF_BOUNDS = 4,        /* p0..p3 = xmin,xmax,ymin,ymax incl. margin     (terminations.py:102-137)*/
+    GF_T_HAS_CONTACT = 5,          /* i0 = contact view, p0 = thr, i1 = min_contacts (terminations.py:139-155)*/
+    GF_T_CONTACT_FORCE = 6,        /* i0 = contact view, p0 = thr                   (terminations.py:158-172)*/
+    GF_T_CONTACT_FORCE_GRACE = 7,  /* i0 = view, p0 = thr, i1 = grace steps         (terminations.py:175-205)*/
+    GF_T_EXTERNAL = 8              /* i0 = ext slot (bool column evaluated by the host) */
+};
+#define GF_TERM_FLAG_TIME_OUT 1    /* TerminationConfigItem.time_out → OR into truncated */
+
+typedef struct GfTerminationArgs {
+    int32_t num_envs;
+    int32_t num_terms;
+    GfEntityView entity;
+    const int32_t* episode_length;
+    const int32_t* max_episode_length;  /* may be NULL → timeout never fires */
+    GfContactView contact[GF_MAX_CONTACT_VIEWS];
+    const uint8_t* ext[GF_MAX_EXT];
+    uint8_t* terminated;   /* [N] out */
+    uint8_t* truncated;    /* [N] out */
+    uint8_t* term_out;     /* [K,N] optional: raw per-term masks (direct mdp.* calls) */
+    GfStepStats* stats;    /* may be NULL */
+    GfTerm terms[GF_MAX_TERM_TERMS];
+} GfTerminationArgs;
+
+/* ------------------------------------------------------------------------------------------
+ * Phase B4 — RewardManager.step   (managers/reward_manager.py:166-195, mdp/rewards.py)
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    GF_R_IS_ALIVE = 1,           /* rewards.py:31-37  */
+    GF_R_TERMINATED = 2,         /* rewards.py:40-46  */
+    GF_R_BASE_HEIGHT = 3,        /* p0 = target | i0 = command view (flag CMD), i1 = ext slot of terrain height (flag TERRAIN)  rewards.py:54-90 */
+    GF_R_DOF_SIMILAR_TO_DEFAULT = 4, /* rewards.py:93-109  */
+    GF_R_LIN_VEL_Z_L2 = 5,       /* rewards.py:112-135 */
+    GF_R_ANG_VEL_XY_L2 = 6,      /* rewards.py:138-161 */
+    GF_R_FLAT_ORIENTATION_L2 = 7,/* rewards.py:164-193 */
+    GF_R_BODY_ACCEL_EXP = 8,     /* p0 = sensitivity, i0 = state slot, flag FIRST_CALL  rewards.py:196-249 */
+    GF_R_ACTION_RATE_L2 = 9,     /* rewards.py:257-271 */
+    GF_R_CMD_TRACK_LIN_VEL = 10, /* i0 = command view, p0 = sensitivity   rewards.py:279-317 */
+    GF_R_CMD_TRACK_ANG_VEL = 11, /* i0 = command view, i1 = column, p0 = sensitivity  rewards.py:320-358 */
+    GF_R_STAND_STILL = 12,       /* i0 = command view, p0 = command threshold  rewards.py:361-385 */
+    GF_R_HAS_CONTACT = 13,       /* i0 = contact view, p0 = thr, i1 = min_contacts  rewards.py:393-410 */
+    GF_R_CONTACT_FORCE = 14,     /* i0 = contact view, p0 = thr   rewards.py:413-428 */
+    GF_R_FEET_AIR_TIME = 15,     /* i0 = contact view, i1 = command view or -1, p0 = time_threshold, p1 = max-thr (flag MAX), p2 = (float)(dt+1e-8)  rewards.py:431-469 */
+    GF_R_FEET_SLIDE = 16,        /* i0 = contact view  rewards.py:472-504 */
+    GF_R_EXTERNAL = 17           /* i0 = ext slot ([N] f32 column evaluated by the host) */
+};
+#define GF_RW_FLAG_CMD 1         /* base_height: target from command view i0 column 0 */
+#define GF_RW_FLAG_TERRAIN 2     /* base_height: subtract ext[i1] terrain height */
+#define GF_RW_FLAG_MAX 4         /* feet_air_time: clamp max */
+#define GF_RW_FLAG_FIRST_CALL 8  /* body_acceleration_exp: no prev state yet */
+
+enum { GF_REWARD_MODE_STEP = 0, GF_REWARD_MODE_EVAL = 1 };
+
+typedef struct GfRewardArgs {
+    int32_t num_envs;
+    int32_t num_dofs;
+    int32_t num_terms;
+    int32_t mode;              /* GF_REWARD_MODE_* */
+    float dt;                  /* (float)env.dt, added to episode_seconds */
+    int32_t logging_enabled;
+    GfEntityView entity;
+    const float* dof_pos;          /* [N,D] */
+    const float* default_dof_pos;  /* [D]   */
+    const float* actions;          /* [N,D] raw env.actions      */
+    const float* last_actions;     /* [N,D] raw env.last_actions */
+    const uint8_t* terminated;     /* [N] extras["terminations"] */
+    GfContactView contact[GF_MAX_CONTACT_VIEWS];
+    GfCommandView command[GF_MAX_COMMAND_VIEWS];
+    const float* ext[GF_MAX_EXT];
+    float* state[4];           /* body_acceleration_exp prev (lin,ang) body-frame velocities, [N,6] each */
+    float* reward;             /* [N]   out (STEP) */
+    float* episode_sums;       /* [T,N] in/out (STEP, logging) */
+    float* episode_seconds;    /* [N]   in/out (STEP) */
+    float* term_out;           /* [T,N] out (EVAL): unweighted term values */
+    GfTerm terms[GF_MAX_TERMS];
+} GfRewardArgs;
+
+/* ------------------------------------------------------------------------------------------
+ * Phase B5 — CommandManager.step / reset / resample_command
+ *   managers/command/command_manager.py:152-170,290-303
+ * ---------------------------------------------------------------------------------------- */
+enum { GF_CMD_STEP = 0, GF_CMD_MASKED = 1, GF_CMD_ALL = 2 };
+
+typedef struct GfCommandArgs {
+    int32_t num_envs;
+    int32_t num_ranges;       /* R */
+    int32_t mode;             /* GF_CMD_* */
+    int32_t resample_steps;   /* int(resample_time_sec/dt) */
+    const int32_t* episode_length; /* STEP */
+    const uint8_t* mask;      /* MASKED: resample where mask!=0 */
+    const uint8_t* mask2;     /* MASKED: optional second mask OR-ed in (terminated|truncated) */
+    const float* draws;       /* [N,R] U[0,1) or NULL → Philox */
+    uint64_t seed;
+    uint64_t stream;          /* distinct per (manager, call) so draws never repeat */
+    float lo[GF_MAX_RANGES];
+    float hi[GF_MAX_RANGES];
+    float* command;           /* [N,R] in/out */
+    GfStepStats* stats;       /* may be NULL (STEP mode counts resamples) */
+} GfCommandArgs;
+
+/* ------------------------------------------------------------------------------------------
+ * Phase R — masked reset of all manager-owned state (ManagedEnvironment.reset fan-out)
+ *   managed_env.py:336-371; genesis_env.py:207-254; reward_manager.py:197-222;
+ *   contact_manager.py:316-329; position_action_manager.py:421-464; mdp/reset.py:67-124
+ * The reference compacts done envs with nonzero() and gathers/scatters; this is the same
+ * update expressed as a mask so no host sync is needed.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct GfResetArgs {
+    int32_t num_envs;
+    int32_t num_dofs;
+    int32_t num_reward_terms;   /* rows of episode_sums */
+    int32_t num_contact;        /* contact managers with air-time state */
+    const uint8_t* mask;        /* [N] reset where mask|mask2 != 0 */
+    const uint8_t* mask2;       /* optional */
+    /* GenesisEnv.reset */
+    float* env_actions;         /* [N,D] → 0 */
+    float* env_last_actions;    /* [N,D] → 0 */
+    int32_t* episode_length;    /* [N]   → 0 */
+    int32_t* max_episode_length;/* [N]   → round(base + (2u-1)*max_random_scaling) when scaling>0 */
+    int32_t base_max_episode_length;
+    float max_random_scaling;   /* (float)(base*max_episode_random_scaling); 0 disables */
+    const float* len_draws;     /* [N] U[0,1) or NULL → Philox */
+    /* RewardManager.reset */
+    float* episode_sums;        /* [T,N] */
+    float* episode_seconds;     /* [N] → 1e-10 */
+    uint32_t reward_log_mask;   /* bit t set: term t has weight != 0 → value/=secs, accumulate mean */
+    int32_t reward_logging;     /* logging_enabled */
+    /* ContactManager.reset: 4 air-time arrays per manager */
+    float* air_state[GF_MAX_CONTACT_VIEWS][4];
+    int32_t air_links[GF_MAX_CONTACT_VIEWS];
+    /* Scene-side state, only when the scene exposes masked setters (synthetic scene).
+     * NULL pointers skip the section (real Genesis: host calls the envs_idx setters). */
+    float* scene_dof_pos;       /* [N,D] ← default_dof_pos + (2u-1)*noise_scale */
+    float* scene_dof_vel;       /* [N,D] ← 0 */
+    const float* default_dof_pos; /* [D] */
+    float dof_noise_scale;
+    const float* dof_draws;     /* [N,D] U[0,1) or NULL → Philox (only read when noise_scale != 0) */
+    float* scene_pos;           /* [N,3] ← reset_pos    (mdp.reset.position) */
+    float* scene_quat;          /* [N,4] ← reset_quat   */
+    float* scene_lin_vel;       /* [N,3] ← 0 when zero_velocity */
+    float* scene_ang_vel;       /* [N,3] ← 0 when zero_velocity */
+    float reset_pos[3];
+    float reset_quat[4];
+    int32_t set_quat;
+    int32_t zero_velocity;
+    uint64_t seed;
+    uint64_t stream;
+    GfStepStats* stats;         /* may be NULL */
+} GfResetArgs;
+
+/* ------------------------------------------------------------------------------------------
+ * Phase O — ObservationManager.get_observations
+ *   managers/observation_manager.py:218-256, mdp/observations.py
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    GF_O_COMMAND = 1,          /* i0 = command view; width = view width */
+    GF_O_ANG_VEL_BODY = 2,     /* EntityManager.get_angular_velocity  (entity_manager.py:142-146) */
+    GF_O_LIN_VEL_BODY = 3,     /* EntityManager.get_linear_velocity   (entity_manager.py:136-140) */
+    GF_O_PROJ_GRAVITY = 4,     /* EntityManager.get_projected_gravity (entity_manager.py:130-134) */
+    GF_O_DOF_POS = 5,          /* action_manager.get_dofs_position()  */
+    GF_O_DOF_VEL = 6,          /* action_manager.get_dofs_velocity()  */
+    GF_O_DOF_FORCE = 7,        /* action_manager.get_dofs_force()     */
+    GF_O_ACTIONS = 8,          /* action_manager.get_actions() == clamped targets (quirk q1) */
+    GF_O_RAW_ACTIONS = 9,      /* env.actions */
+    GF_O_CONTACT_FORCE_NORM = 10, /* i0 = contact view; width = L  (observations.py:182-193) */
+    GF_O_EXTERNAL = 11,        /* i0 = ext slot, i1 = width: [N,width] f32 evaluated by the host */
+    GF_O_BASE_POS = 12,
+    GF_O_BASE_QUAT = 13
+};
+
+typedef struct GfObsItem {
+    int32_t op;
+    int32_t width;
+    int32_t i0;
+    int32_t i1;
+    float scale;   /* ObservationConfigItem.scale (1.0 = none) */
+    float noise;   /* item noise or manager noise; 0 = none     */
+} GfObsItem;
+
+typedef struct GfObservationArgs {
+    int32_t num_envs;
+    int32_t num_dofs;
+    int32_t num_items;
+    int32_t obs_width;        /* O = Σ width */
+    int32_t history_len;      /* H >= 1 */
+    int32_t _pad;
+    GfEntityView entity;
+    const float* dof_pos;     /* [N,D] */
+    const float* dof_vel;     /* [N,D] */
+    const float* dof_force;   /* [N,D] */
+    const float* targets;     /* [N,D] */
+    const float* env_actions; /* [N,D] */
+    GfContactView contact[GF_MAX_CONTACT_VIEWS];
+    GfCommandView command[GF_MAX_COMMAND_VIEWS];
+    const float* ext[GF_MAX_EXT];
+    const float* noise_draws; /* [N,O] U[0,1) or NULL → Philox */
+    uint64_t seed;
+    uint64_t stream;
+    const float* prev_obs;    /* [N,O*H] previous output (history shift source); NULL when H==1 */
+    float* obs;               /* [N,O*H] out, newest frame first (observation_manager.py:224-226) */
+    GfObsItem items[GF_MAX_OBS_ITEMS];
+} GfObservationArgs;
+
+/* ------------------------------------------------------------------------------------------
+ * Entity helpers — EntityManager.get_projected_gravity / get_linear_velocity /
+ * get_angular_velocity as standalone calls (entity_manager.py:130-146; utils.py:13-55).
+ * ---------------------------------------------------------------------------------------- */
+enum { GF_ROT_PROJ_GRAVITY = 0, GF_ROT_LIN_VEL = 1, GF_ROT_ANG_VEL = 2 };
+typedef struct GfRotateArgs {
+    int32_t num_envs;
+    int32_t what;         /* GF_ROT_* */
+    GfEntityView entity;
+    float* out;           /* [N,3] */
+} GfRotateArgs;
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic scene tick — stands in for Genesis' scene.step() in benchmarks and parity tests
+ * (SURVEY.md §7 step 5).  Deterministic, integer-Philox driven, f32 ops in a fixed order so the
+ * HIP kernel, the C oracle and the numpy model used to drive the reference agree bit for bit.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct GfSynthSceneArgs {
+    int32_t num_envs;
+    int32_t num_dofs;
+    int32_t num_contacts;     /* C (0: no contact generation) */
+    int32_t num_scene_links;
+    float dt;
+    float joint_rate;         /* first-order tracking gain [1/s] */
+    float ang_noise;          /* rad/s per tick */
+    float lin_noise;          /* m/s per tick */
+    float height_target;
+    float contact_prob;       /* per slot */
+    float contact_force;      /* force scale */
+    float _padf;
+    const float* targets;     /* [N,D] PD targets written by phase A */
+    float* pos;               /* [N,3] in/out */
+    float* quat;              /* [N,4] in/out */
+    float* lin_vel;           /* [N,3] in/out */
+    float* ang_vel;           /* [N,3] in/out */
+    float* dof_pos;           /* [N,D] in/out */
+    float* dof_vel;           /* [N,D] out    */
+    float* contact_force_out; /* [N,C,3] or NULL */
+    float* contact_pos_out;   /* [N,C,3] */
+    int32_t* link_a_out;      /* [N,C] */
+    int32_t* link_b_out;      /* [N,C] */
+    float* links_quat_out;    /* [N,num_scene_links,4] */
+    float* links_vel_out;     /* [N,num_scene_links,3] or NULL */
+    uint64_t seed;
+    uint64_t tick;
+} GfSynthSceneArgs;
+
+/* ------------------------------------------------------------------------------------------
+ * Entry points.  `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream).
+ * ---------------------------------------------------------------------------------------- */
+int gf_abi_version(void);
+const char* gf_build_info(void);
+const char* gf_error_string(int code);
+
+int gf_stats_clear(GfStepStats* stats, void* stream);            /* zero the per-step stats block */
+
+int gf_action_step(const GfActionArgs* a, void* stream);          /* replaces genesis_env.py:181-205 + position_action_manager.py:376-419 */
+int gf_contact_step(const GfContactArgs* a, void* stream);        /* replaces contact_manager.py:331-336 (+ contact/kernel.py:5-90) */
+int gf_termination_step(const GfTerminationArgs* a, void* stream);/* replaces termination_manager.py:151-190 */
+int gf_reward_step(const GfRewardArgs* a, void* stream);          /* replaces reward_manager.py:166-195 */
+int gf_command_step(const GfCommandArgs* a, void* stream);        /* replaces command_manager.py:152-170,290-303 */
+int gf_masked_reset(const GfResetArgs* a, void* stream);          /* replaces managed_env.py:336-366 fan-out */
+int gf_observe(const GfObservationArgs* a, void* stream);         /* replaces observation_manager.py:218-256 */
+int gf_entity_rotate(const GfRotateArgs* a, void* stream);        /* replaces entity_manager.py:130-146 */
+int gf_synth_scene_step(const GfSynthSceneArgs* a, void* stream); /* stands in for scene.step() (managed_env.py:292) */
+
+/* Optional per-phase HIP-event timing used by bench.py (events recorded on `stream`
+ * immediately around the kernel launch of the selected phase). */
+enum { GF_PHASE_ACTION = 0, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
+       GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_COUNT };
+int gf_profile_begin(int phase, int max_samples);     /* start recording event pairs for `phase` */
+int gf_profile_end(double* total_ms, int* samples);    /* sync events, return Σ elapsed + count, free them */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GF_STEP_H */

@@ -1,0 +1,681 @@
+/*
+ * gf_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C, scalar, one-env-at-a-time restatement of the per-tick manager work of the
+ * reference's ManagedEnvironment.step() (/root/reference/genesis_forge/managed_env.py:274-334).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product path (genesis-forge_amd/csrc/*.hip behind include/gf_step.h) never does.
+ *
+ * Parity status: PINNED against the reference itself — tests/golden/*.npz were generated in the
+ * build container by importing /root/reference/genesis_forge (with stub genesis/gstaichi/
+ * gymnasium/tensordict modules, tools/gen_golden.py) and recording its inputs/outputs; this
+ * oracle is checked against every one of them by tests/test_oracle_golden.py.
+ * UNPINNED sub-parts (third-party code absent from /root/reference):
+ *   - genesis.utils.geom.transform_by_quat / inv_quat (genesis-world>=0.3.4): restated from
+ *     the mathematical definition  v' = v + w*t + qv x t,  t = 2*(qv x v),  inv = conjugate;
+ *   - the Taichi kernel kernel_get_contact_forces is not executable without gstaichi: restated
+ *     from managers/contact/kernel.py:35-90 by reading, accumulation in contact-slot order;
+ *   - torch's RNG stream: draws are inputs (dense U[0,1) arrays) or Philox4x32-10.
+ *
+ * It shares the POD descriptors of include/gf_step.h (host pointers instead of device
+ * pointers); every gfo_* function mirrors the gf_* entry point of the same name.
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).  All arithmetic is
+ * f32 with one rounding per operation (no FMA contraction), in the operation order of the
+ * reference's torch expressions.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../include/gf_step.h"
+
+#define GFO_EXPORT __attribute__((visibility("default")))
+
+/* ---------------------------------------------------------------- Philox4x32-10 ---------- */
+static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                 uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* U[0,1) with 24 random bits for (env, column) of (seed, stream). */
+static inline float philox_uniform(uint64_t seed, uint64_t stream, uint32_t env, uint32_t col) {
+    uint32_t x[4];
+    philox4x32_10(env, col >> 2, (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    return (float)(x[col & 3] >> 8) * 5.9604644775390625e-8f; /* 2^-24 */
+}
+
+static inline float draw_u(const float* draws, int64_t idx, uint64_t seed, uint64_t stream, uint32_t env, uint32_t col) {
+    return draws ? draws[idx] : philox_uniform(seed, stream, env, col);
+}
+
+/* uniform_(lo, hi) as torch's uniform_real does it: x*(to-from)+from  (f32, two roundings) */
+static inline float uniform_range(float u, float lo, float hi) { return u * (hi - lo) + lo; }
+
+/* ---------------------------------------------------------------- quaternion helpers ----- */
+/* transform_by_quat(v, inv_quat(q)): rotate a world vector into the body frame
+ * (genesis_forge/utils.py:13-55; managers/entity_manager.py:130-146,195). */
+static inline void rot_inv(const float* q, const float* v, float* o) {
+    const float w = q[0], a = -q[1], b = -q[2], c = -q[3]; /* inv_quat = conjugate */
+    const float t0 = (b * v[2] - c * v[1]) * 2.0f;
+    const float t1 = (c * v[0] - a * v[2]) * 2.0f;
+    const float t2 = (a * v[1] - b * v[0]) * 2.0f;
+    o[0] = (v[0] + w * t0) + (b * t2 - c * t1);
+    o[1] = (v[1] + w * t1) + (c * t0 - a * t2);
+    o[2] = (v[2] + w * t2) + (a * t1 - b * t0);
+}
+
+static inline float norm3(const float* v) { return sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+static inline float norm2(float x, float y) { return sqrtf(x * x + y * y); }
+
+static inline void body_lin_vel(const GfEntityView* e, int64_t n, float* o) { rot_inv(e->quat + 4 * n, e->lin_vel + 3 * n, o); }
+static inline void body_ang_vel(const GfEntityView* e, int64_t n, float* o) { rot_inv(e->quat + 4 * n, e->ang_vel + 3 * n, o); }
+static inline void proj_gravity(const GfEntityView* e, int64_t n, float* o) {
+    const float g[3] = {0.0f, 0.0f, -1.0f};
+    rot_inv(e->quat + 4 * n, g, o);
+}
+
+/* ---------------------------------------------------------------- stats ------------------ */
+GFO_EXPORT int gfo_stats_clear(GfStepStats* s) {
+    if (!s) return GF_E_NULL;
+    memset(s, 0, sizeof(*s));
+    return GF_OK;
+}
+
+/* ---------------------------------------------------------------- Phase A ---------------- */
+/* genesis_env.py:181-205 (episode_length += 1; last_actions <- actions; actions <- new) then
+ * position_action_manager.py:402-414 (NaN/Inf scan, a*scale+offset, clamp) or
+ * position_within_limits.py:125-126 (clamp_(-1,1) of the manager's copy, a*scale+offset). */
+GFO_EXPORT int gfo_action_step(const GfActionArgs* a) {
+    if (!a || !a->actions_in || !a->targets || !a->scale || !a->offset) return GF_E_NULL;
+    if (a->mode == GF_ACTION_POSITION && (!a->clip_lo || !a->clip_hi)) return GF_E_NULL;
+    const int64_t N = a->num_envs, D = a->num_dofs;
+    if (N < 0 || D <= 0) return GF_E_RANGE;
+    int flags = 0;
+    if (a->episode_length)
+        for (int64_t n = 0; n < N; ++n) a->episode_length[n] += 1;
+    for (int64_t n = 0; n < N; ++n) {
+        for (int64_t d = 0; d < D; ++d) {
+            const int64_t k = n * D + d;
+            float x = a->actions_in[k];
+            if (a->env_actions) {
+                a->env_last_actions[k] = a->env_actions[k];
+                a->env_actions[k] = x;
+            }
+            if (a->check_finite && a->mode == GF_ACTION_POSITION) {
+                if (isnan(x)) flags |= 1;
+                if (isinf(x)) flags |= 2;
+            }
+            float t;
+            if (a->mode == GF_ACTION_WITHIN_LIMITS) {
+                /* torch.clamp_(-1, 1): NaN propagates */
+                if (x < -1.0f) x = -1.0f;
+                if (x > 1.0f) x = 1.0f; /* clamps the manager's private copy, the caller's tensor is untouched */
+                t = x * a->scale[d] + a->offset[d];
+            } else {
+                t = x * a->scale[d] + a->offset[d];
+                /* torch.clamp(min=lo, max=hi): min then max, NaN propagates */
+                if (t < a->clip_lo[d]) t = a->clip_lo[d];
+                if (t > a->clip_hi[d]) t = a->clip_hi[d];
+            }
+            a->targets[k] = t;
+        }
+    }
+    if (a->stats) a->stats->action_flags |= flags;
+    return GF_OK;
+}
+
+/* ---------------------------------------------------------------- Phase B2 --------------- */
+/* contact/kernel.py:35-90 + contact_manager.py:399-403 (sanitise) + :434-477 (air time). */
+GFO_EXPORT int gfo_contact_step(const GfContactArgs* a) {
+    if (!a || !a->contacts) return GF_E_NULL;
+    const int64_t N = a->num_envs, C = a->num_contacts, L = a->num_targets, W = a->num_with;
+    if (L <= 0 || L > GF_MAX_LINK_IDS || W < 0 || W > GF_MAX_LINK_IDS || C < 0) return GF_E_RANGE;
+    if (C > 0 && (!a->force || !a->position || !a->link_a || !a->link_b || !a->links_quat)) return GF_E_NULL;
+    if (a->track_air_time &&
+        (!a->last_air_time || !a->current_air_time || !a->last_contact_time || !a->current_contact_time))
+        return GF_E_NULL;
+    int flags = 0;
+    for (int64_t n = 0; n < N; ++n) {
+        float* out_f = a->contacts + n * L * 3;
+        float* out_p = a->contact_positions ? a->contact_positions + n * L * 3 : 0;
+        float* out_c = a->position_counts ? a->position_counts + n * L : 0;
+        for (int64_t t = 0; t < L; ++t) {
+            float f[3] = {0, 0, 0}, p[3] = {0, 0, 0}, cnt = 0.0f;
+            const int32_t target = a->target_link_ids[t];
+            for (int64_t c = 0; c < C; ++c) {
+                const int32_t la = a->link_a[n * C + c], lb = a->link_b[n * C + c];
+                const int is_a = la == target, is_b = lb == target;
+                if (!(is_a || is_b)) continue;
+                int include = 1;
+                if (a->has_with_filter) {
+                    include = 0;
+                    for (int64_t w = 0; w < W; ++w) {
+                        const int32_t wl = a->with_link_ids[w];
+                        if ((is_a && lb == wl) || (is_b && la == wl)) { include = 1; break; }
+                    }
+                }
+                if (!include) continue;
+                float fv[3];
+                for (int j = 0; j < 3; ++j) {
+                    float x = a->force[(n * C + c) * 3 + j];
+                    if (isnan(x) || isinf(x)) { x = 0.0f; flags |= 1; } /* nan_to_num(nan=0,posinf=0,neginf=0) */
+                    fv[j] = x;
+                    p[j] += a->position[(n * C + c) * 3 + j];
+                }
+                cnt += 1.0f;
+                float r[3];
+                if (is_b) {
+                    rot_inv(a->links_quat + ((int64_t)n * a->num_scene_links + lb) * 4, fv, r);
+                } else {
+                    const float nf[3] = {-fv[0], -fv[1], -fv[2]};
+                    rot_inv(a->links_quat + ((int64_t)n * a->num_scene_links + la) * 4, nf, r);
+                }
+                for (int j = 0; j < 3; ++j) f[j] += r[j];
+            }
+            for (int j = 0; j < 3; ++j) {
+                out_f[t * 3 + j] = f[j];
+                if (out_p) out_p[t * 3 + j] = cnt > 0.0f ? p[j] / cnt : p[j];
+            }
+            if (out_c) out_c[t] = cnt;
+            if (a->track_air_time) {
+                const int64_t k = n * L + t;
+                const float dt = a->dt;
+                const int is_contact = norm3(f) > a->air_time_threshold;
+                const float cur_air = a->current_air_time[k], cur_con = a->current_contact_time[k];
+                const int new_contact = (cur_air > 0.0f) && is_contact;
+                const int new_detach = (cur_con > 0.0f) && !is_contact;
+                if (new_contact) a->last_air_time[k] = cur_air + dt;
+                a->current_air_time[k] = !is_contact ? cur_air + dt : 0.0f;
+                if (new_detach) a->last_contact_time[k] = cur_con + dt;
+                a->current_contact_time[k] = is_contact ? cur_con + dt : 0.0f;
+            }
+        }
+    }
+    if (a->stats) a->stats->contact_flags |= flags;
+    return GF_OK;
+}
+
+/* ---------------------------------------------------------------- contact predicates ----- */
+static inline int contact_count_over(const GfContactView* v, int64_t n, float thr) {
+    int cnt = 0;
+    for (int l = 0; l < v->num_links; ++l)
+        if (norm3(v->contacts + (n * v->num_links + l) * 3) > thr) ++cnt;
+    return cnt;
+}
+
+/* ---------------------------------------------------------------- Phase B3 --------------- */
+static int eval_termination(const GfTerminationArgs* a, const GfTerm* t, int64_t n) {
+    switch (t->op) {
+        case GF_T_TIMEOUT: /* terminations.py:17-23 */
+            return a->max_episode_length ? a->episode_length[n] > a->max_episode_length[n] : 0;
+        case GF_T_BAD_ORIENTATION: { /* terminations.py:52-71; p1 = (float)radians(limit), i0 = grace */
+            const int in_grace = a->episode_length[n] <= t->i[0];
+            float g[3];
+            proj_gravity(&a->entity, n, g);
+            float m = norm2(g[0], g[1]);
+            if (m > 0.99f) m = 0.99f; /* torch.clamp(max=0.99), NaN propagates */
+            const float tilt = asinf(m);
+            return !in_grace && (tilt > t->p[1]);
+        }
+        case GF_T_BASE_HEIGHT_BELOW: /* terminations.py:93-99 */
+            return a->entity.pos[3 * n + 2] < t->p[0];
+        case GF_T_OUT_OF_BOUNDS: { /* terminations.py:121-137 */
+            const float x = a->entity.pos[3 * n], y = a->entity.pos[3 * n + 1];
+            return (x < t->p[0]) || (x > t->p[1]) || (y < t->p[2]) || (y > t->p[3]);
+        }
+        case GF_T_HAS_CONTACT: /* terminations.py:153-155 */
+            return contact_count_over(&a->contact[t->i[0]], n, t->p[0]) >= t->i[1];
+        case GF_T_CONTACT_FORCE: /* terminations.py:172 */
+            return contact_count_over(&a->contact[t->i[0]], n, t->p[0]) > 0;
+        case GF_T_CONTACT_FORCE_GRACE: { /* terminations.py:196-205 */
+            const int in_grace = a->episode_length[n] <= t->i[1];
+            return !in_grace && contact_count_over(&a->contact[t->i[0]], n, t->p[0]) > 0;
+        }
+        case GF_T_EXTERNAL:
+            return a->ext[t->i[0]][n] != 0;
+        default:
+            return 0;
+    }
+}
+
+static int check_term_table(const GfTerm* terms, int n, int is_reward) {
+    for (int k = 0; k < n; ++k) {
+        const int op = terms[k].op;
+        if (is_reward ? (op < GF_R_IS_ALIVE || op > GF_R_EXTERNAL) : (op < GF_T_TIMEOUT || op > GF_T_EXTERNAL))
+            return GF_E_OPCODE;
+    }
+    return GF_OK;
+}
+
+/* termination_manager.py:151-190 */
+GFO_EXPORT int gfo_termination_step(const GfTerminationArgs* a) {
+    if (!a || !a->terminated || !a->truncated) return GF_E_NULL;
+    if (a->num_terms < 0 || a->num_terms > GF_MAX_TERM_TERMS) return GF_E_RANGE;
+    int rc = check_term_table(a->terms, a->num_terms, 0);
+    if (rc) return rc;
+    const int64_t N = a->num_envs;
+    for (int64_t n = 0; n < N; ++n) {
+        int term = 0, trunc = 0;
+        for (int k = 0; k < a->num_terms; ++k) {
+            const int v = eval_termination(a, &a->terms[k], n);
+            if (a->terms[k].flags & GF_TERM_FLAG_TIME_OUT) trunc |= v; else term |= v;
+            if (v && a->stats) a->stats->term_fired[k] += 1;
+            if (a->term_out) a->term_out[(int64_t)k * N + n] = (uint8_t)v;
+        }
+        a->terminated[n] = (uint8_t)term;
+        a->truncated[n] = (uint8_t)trunc;
+    }
+    return GF_OK;
+}
+
+/* ---------------------------------------------------------------- Phase B4 --------------- */
+static float eval_reward(const GfRewardArgs* a, const GfTerm* t, int64_t n) {
+    const int64_t D = a->num_dofs;
+    switch (t->op) {
+        case GF_R_IS_ALIVE: return a->terminated[n] ? 0.0f : 1.0f;   /* rewards.py:36-37 */
+        case GF_R_TERMINATED: return a->terminated[n] ? 1.0f : 0.0f; /* rewards.py:45-46 */
+        case GF_R_BASE_HEIGHT: { /* rewards.py:77-90 */
+            float h = a->entity.pos[3 * n + 2];
+            if (t->flags & GF_RW_FLAG_TERRAIN) h = h - a->ext[t->i[1]][n];
+            const float target = (t->flags & GF_RW_FLAG_CMD)
+                                     ? a->command[t->i[0]].command[(int64_t)n * a->command[t->i[0]].width]
+                                     : t->p[0];
+            const float e = h - target;
+            return e * e;
+        }
+        case GF_R_DOF_SIMILAR_TO_DEFAULT: { /* rewards.py:107-109 */
+            float s = 0.0f;
+            for (int64_t d = 0; d < D; ++d) s += fabsf(a->dof_pos[n * D + d] - a->default_dof_pos[d]);
+            return s;
+        }
+        case GF_R_LIN_VEL_Z_L2: { /* rewards.py:129-135 */
+            float v[3];
+            body_lin_vel(&a->entity, n, v);
+            return v[2] * v[2];
+        }
+        case GF_R_ANG_VEL_XY_L2: { /* rewards.py:155-161 */
+            float v[3];
+            body_ang_vel(&a->entity, n, v);
+            return v[0] * v[0] + v[1] * v[1];
+        }
+        case GF_R_FLAT_ORIENTATION_L2: { /* rewards.py:184-193 */
+            float g[3];
+            proj_gravity(&a->entity, n, g);
+            return g[0] * g[0] + g[1] * g[1];
+        }
+        case GF_R_BODY_ACCEL_EXP: { /* rewards.py:219-249; state = prev (lin, ang) body-frame velocity */
+            float lv[3], av[3], la[3], aa[3];
+            body_lin_vel(&a->entity, n, lv);
+            body_ang_vel(&a->entity, n, av);
+            float* st = a->state[t->i[0]] + n * 6;
+            for (int j = 0; j < 3; ++j) {
+                if (t->flags & GF_RW_FLAG_FIRST_CALL) {
+                    la[j] = 0.0f; aa[j] = 0.0f;
+                } else {
+                    la[j] = (lv[j] - st[j]) / a->dt;
+                    aa[j] = (av[j] - st[3 + j]) / a->dt;
+                }
+                st[j] = lv[j];
+                st[3 + j] = av[j];
+            }
+            const float motion = norm3(la) + norm3(aa);
+            return 1.0f - expf((-t->p[0]) * motion);
+        }
+        case GF_R_ACTION_RATE_L2: { /* rewards.py:267-271 */
+            float s = 0.0f;
+            for (int64_t d = 0; d < D; ++d) {
+                const float e = a->last_actions[n * D + d] - a->actions[n * D + d];
+                s += e * e;
+            }
+            return s;
+        }
+        case GF_R_CMD_TRACK_LIN_VEL: { /* rewards.py:304-317 */
+            float v[3];
+            body_lin_vel(&a->entity, n, v);
+            const GfCommandView* c = &a->command[t->i[0]];
+            const float e0 = c->command[(int64_t)n * c->width] - v[0];
+            const float e1 = c->command[(int64_t)n * c->width + 1] - v[1];
+            const float err = e0 * e0 + e1 * e1;
+            return expf((-err) / t->p[0]);
+        }
+        case GF_R_CMD_TRACK_ANG_VEL: { /* rewards.py:345-358 */
+            float v[3];
+            body_ang_vel(&a->entity, n, v);
+            const GfCommandView* c = &a->command[t->i[0]];
+            const float e = c->command[(int64_t)n * c->width + t->i[1]] - v[2];
+            return expf((-(e * e)) / t->p[0]);
+        }
+        case GF_R_STAND_STILL: { /* rewards.py:379-385 */
+            float s = 0.0f;
+            for (int64_t d = 0; d < D; ++d) s += fabsf(a->dof_pos[n * D + d] - a->default_dof_pos[d]);
+            const GfCommandView* c = &a->command[t->i[0]];
+            const float m = norm2(c->command[(int64_t)n * c->width], c->command[(int64_t)n * c->width + 1]);
+            return s * ((m < t->p[0]) ? 1.0f : 0.0f);
+        }
+        case GF_R_HAS_CONTACT: /* rewards.py:408-410 */
+            return contact_count_over(&a->contact[t->i[0]], n, t->p[0]) >= t->i[1] ? 1.0f : 0.0f;
+        case GF_R_CONTACT_FORCE: { /* rewards.py:427-428 */
+            const GfContactView* v = &a->contact[t->i[0]];
+            float s = 0.0f;
+            for (int l = 0; l < v->num_links; ++l) {
+                float viol = norm3(v->contacts + (n * v->num_links + l) * 3) - t->p[0];
+                if (viol < 0.0f) viol = 0.0f; /* clip(min=0) */
+                s += viol;
+            }
+            return s;
+        }
+        case GF_R_FEET_AIR_TIME: { /* rewards.py:455-469; contact_manager.py:224-226 */
+            const GfContactView* v = &a->contact[t->i[0]];
+            float s = 0.0f;
+            for (int l = 0; l < v->num_links; ++l) {
+                const float cc = v->current_contact_time[n * v->num_links + l];
+                const float made = ((cc > 0.0f) && (cc < t->p[2])) ? 1.0f : 0.0f;
+                float air = (v->last_air_time[n * v->num_links + l] - t->p[0]) * made;
+                if ((t->flags & GF_RW_FLAG_MAX) && air > t->p[1]) air = t->p[1];
+                s += air;
+            }
+            if (t->i[1] >= 0) {
+                const GfCommandView* c = &a->command[t->i[1]];
+                const float m = norm2(c->command[(int64_t)n * c->width], c->command[(int64_t)n * c->width + 1]);
+                s = s * ((m > 0.1f) ? 1.0f : 0.0f);
+            }
+            return s;
+        }
+        case GF_R_FEET_SLIDE: { /* rewards.py:496-504 */
+            const GfContactView* v = &a->contact[t->i[0]];
+            float s = 0.0f;
+            for (int l = 0; l < v->num_links; ++l) {
+                const float c = (norm3(v->contacts + (n * v->num_links + l) * 3) > 1.0f) ? 1.0f : 0.0f;
+                s += norm3(v->link_vel + (n * v->num_links + l) * 3) * c;
+            }
+            return s;
+        }
+        case GF_R_EXTERNAL: return a->ext[t->i[0]][n];
+        default: return 0.0f;
+    }
+}
+
+/* reward_manager.py:166-195 */
+GFO_EXPORT int gfo_reward_step(const GfRewardArgs* a) {
+    if (!a) return GF_E_NULL;
+    if (a->num_terms < 0 || a->num_terms > GF_MAX_TERMS) return GF_E_RANGE;
+    int rc = check_term_table(a->terms, a->num_terms, 1);
+    if (rc) return rc;
+    const int64_t N = a->num_envs;
+    if (a->mode == GF_REWARD_MODE_EVAL) {
+        if (!a->term_out) return GF_E_NULL;
+        for (int64_t n = 0; n < N; ++n)
+            for (int k = 0; k < a->num_terms; ++k)
+                a->term_out[(int64_t)a->terms[k].row * N + n] = eval_reward(a, &a->terms[k], n);
+        return GF_OK;
+    }
+    if (!a->reward || !a->episode_seconds) return GF_E_NULL;
+    if (a->logging_enabled && !a->episode_sums) return GF_E_NULL;
+    for (int64_t n = 0; n < N; ++n) {
+        float buf = 0.0f;                       /* self._reward_buf[:] = 0.0       :177 */
+        a->episode_seconds[n] += a->dt;         /* self._episode_seconds += dt     :178 */
+        for (int k = 0; k < a->num_terms; ++k) { /* zero-weight terms are absent from the table :181-182 */
+            const float v = eval_reward(a, &a->terms[k], n) * a->terms[k].w; /* fn(...) * (weight*dt)  :185-186 */
+            buf += v;                                                        /* :189 */
+            if (a->logging_enabled) a->episode_sums[(int64_t)a->terms[k].row * N + n] += v; /* :192-193 */
+        }
+        a->reward[n] = buf;
+    }
+    return GF_OK;
+}
+
+/* ---------------------------------------------------------------- Phase B5 --------------- */
+/* command_manager.py:152-170 (step/reset) and :290-303 (resample_command) */
+GFO_EXPORT int gfo_command_step(const GfCommandArgs* a) {
+    if (!a || !a->command) return GF_E_NULL;
+    if (a->num_ranges <= 0 || a->num_ranges > GF_MAX_RANGES) return GF_E_RANGE;
+    if (a->mode == GF_CMD_STEP && (a->resample_steps <= 0 || !a->episode_length)) return a->episode_length ? GF_E_RANGE : GF_E_NULL;
+    if (a->mode == GF_CMD_MASKED && !a->mask) return GF_E_NULL;
+    const int64_t N = a->num_envs, R = a->num_ranges;
+    int count = 0;
+    for (int64_t n = 0; n < N; ++n) {
+        int go;
+        if (a->mode == GF_CMD_STEP) go = (a->episode_length[n] % a->resample_steps) == 0;
+        else if (a->mode == GF_CMD_MASKED) go = a->mask[n] || (a->mask2 && a->mask2[n]);
+        else go = 1;
+        if (!go) continue;
+        ++count;
+        for (int64_t i = 0; i < R; ++i) {
+            const float u = draw_u(a->draws, n * R + i, a->seed, a->stream, (uint32_t)n, (uint32_t)i);
+            a->command[n * R + i] = uniform_range(u, a->lo[i], a->hi[i]);
+        }
+    }
+    if (a->stats && a->mode == GF_CMD_STEP) a->stats->resample_count += count;
+    return GF_OK;
+}
+
+/* ---------------------------------------------------------------- Phase R ----------------- */
+GFO_EXPORT int gfo_masked_reset(const GfResetArgs* a) {
+    if (!a || !a->mask) return GF_E_NULL;
+    const int64_t N = a->num_envs, D = a->num_dofs;
+    if (a->num_reward_terms < 0 || a->num_reward_terms > GF_MAX_TERMS) return GF_E_RANGE;
+    if (a->num_contact < 0 || a->num_contact > GF_MAX_CONTACT_VIEWS) return GF_E_RANGE;
+    int count = 0;
+    for (int64_t n = 0; n < N; ++n) {
+        if (!(a->mask[n] || (a->mask2 && a->mask2[n]))) continue;
+        ++count;
+        /* GenesisEnv.reset  genesis_env.py:233-252 */
+        if (a->env_actions)
+            for (int64_t d = 0; d < D; ++d) { a->env_actions[n * D + d] = 0.0f; a->env_last_actions[n * D + d] = 0.0f; }
+        if (a->episode_length) a->episode_length[n] = 0;
+        if (a->max_episode_length && a->max_random_scaling > 0.0f) {
+            const float u = draw_u(a->len_draws, n, a->seed, a->stream, (uint32_t)n, 0u);
+            const float r = uniform_range(u, -1.0f, 1.0f) * a->max_random_scaling;
+            a->max_episode_length[n] = (int32_t)rintf((float)a->base_max_episode_length + r); /* torch.round = half-to-even */
+        }
+        /* RewardManager.reset  reward_manager.py:202-222 */
+        if (a->episode_seconds) {
+            if (a->reward_logging && a->episode_sums) {
+                const float secs = a->episode_seconds[n];
+                for (int t = 0; t < a->num_reward_terms; ++t) {
+                    float* v = a->episode_sums + (int64_t)t * N + n;
+                    if (a->reward_log_mask & (1u << t)) {
+                        const float per_sec = *v / secs;
+                        if (a->stats) a->stats->reward_episode_sum[t] += (double)per_sec;
+                    }
+                    *v = 0.0f;
+                }
+            }
+            a->episode_seconds[n] = 1e-10f;
+        }
+        /* ContactManager.reset  contact_manager.py:316-329 */
+        for (int m = 0; m < a->num_contact; ++m)
+            for (int s = 0; s < 4; ++s)
+                if (a->air_state[m][s])
+                    for (int l = 0; l < a->air_links[m]; ++l) a->air_state[m][s][n * a->air_links[m] + l] = 0.0f;
+        /* PositionActionManager.reset  position_action_manager.py:455-464 (scene side, synthetic scene only) */
+        if (a->scene_dof_pos) {
+            for (int64_t d = 0; d < D; ++d) {
+                float p = a->default_dof_pos[d];
+                if (a->dof_noise_scale != 0.0f) {
+                    const float u = draw_u(a->dof_draws, n * D + d, a->seed, a->stream, (uint32_t)n, (uint32_t)(4 + d));
+                    p = p + uniform_range(u, -1.0f, 1.0f) * a->dof_noise_scale;
+                }
+                a->scene_dof_pos[n * D + d] = p;
+                if (a->scene_dof_vel) a->scene_dof_vel[n * D + d] = 0.0f;
+            }
+        }
+        /* mdp.reset.position  reset.py:102-124 */
+        if (a->scene_pos) {
+            for (int j = 0; j < 3; ++j) a->scene_pos[3 * n + j] = a->reset_pos[j];
+            if (a->set_quat && a->scene_quat)
+                for (int j = 0; j < 4; ++j) a->scene_quat[4 * n + j] = a->reset_quat[j];
+            if (a->zero_velocity) {
+                if (a->scene_lin_vel) for (int j = 0; j < 3; ++j) a->scene_lin_vel[3 * n + j] = 0.0f;
+                if (a->scene_ang_vel) for (int j = 0; j < 3; ++j) a->scene_ang_vel[3 * n + j] = 0.0f;
+                if (a->scene_dof_vel) for (int64_t d = 0; d < D; ++d) a->scene_dof_vel[n * D + d] = 0.0f;
+            }
+        }
+    }
+    if (a->stats) a->stats->reset_count += count;
+    return GF_OK;
+}
+
+/* ---------------------------------------------------------------- Phase O ----------------- */
+/* observation_manager.py:218-256 */
+GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
+    if (!a || !a->obs) return GF_E_NULL;
+    if (a->num_items <= 0 || a->num_items > GF_MAX_OBS_ITEMS) return GF_E_RANGE;
+    if (a->history_len < 1 || (a->history_len > 1 && !a->prev_obs)) return a->history_len < 1 ? GF_E_RANGE : GF_E_NULL;
+    const int64_t N = a->num_envs, D = a->num_dofs, O = a->obs_width, H = a->history_len;
+    int64_t wsum = 0;
+    for (int i = 0; i < a->num_items; ++i) wsum += a->items[i].width;
+    if (wsum != O || O > GF_MAX_OBS_WIDTH) return GF_E_RANGE;
+    for (int64_t n = 0; n < N; ++n) {
+        float* row = a->obs + n * O * H;
+        int64_t col = 0;
+        for (int i = 0; i < a->num_items; ++i) {
+            const GfObsItem* it = &a->items[i];
+            float tmp[GF_MAX_OBS_WIDTH];
+            switch (it->op) {
+                case GF_O_COMMAND: {
+                    const GfCommandView* c = &a->command[it->i0];
+                    for (int j = 0; j < it->width; ++j) tmp[j] = c->command[(int64_t)n * c->width + j];
+                } break;
+                case GF_O_ANG_VEL_BODY: body_ang_vel(&a->entity, n, tmp); break;
+                case GF_O_LIN_VEL_BODY: body_lin_vel(&a->entity, n, tmp); break;
+                case GF_O_PROJ_GRAVITY: proj_gravity(&a->entity, n, tmp); break;
+                case GF_O_DOF_POS: for (int j = 0; j < it->width; ++j) tmp[j] = a->dof_pos[n * D + j]; break;
+                case GF_O_DOF_VEL: for (int j = 0; j < it->width; ++j) tmp[j] = a->dof_vel[n * D + j]; break;
+                case GF_O_DOF_FORCE: for (int j = 0; j < it->width; ++j) tmp[j] = a->dof_force[n * D + j]; break;
+                case GF_O_ACTIONS: for (int j = 0; j < it->width; ++j) tmp[j] = a->targets[n * D + j]; break;
+                case GF_O_RAW_ACTIONS: for (int j = 0; j < it->width; ++j) tmp[j] = a->env_actions[n * D + j]; break;
+                case GF_O_CONTACT_FORCE_NORM: {
+                    const GfContactView* v = &a->contact[it->i0];
+                    for (int j = 0; j < it->width; ++j) tmp[j] = norm3(v->contacts + (n * v->num_links + j) * 3);
+                } break;
+                case GF_O_EXTERNAL: for (int j = 0; j < it->width; ++j) tmp[j] = a->ext[it->i0][n * it->width + j]; break;
+                case GF_O_BASE_POS: for (int j = 0; j < 3; ++j) tmp[j] = a->entity.pos[3 * n + j]; break;
+                case GF_O_BASE_QUAT: for (int j = 0; j < 4; ++j) tmp[j] = a->entity.quat[4 * n + j]; break;
+                default: return GF_E_OPCODE;
+            }
+            for (int j = 0; j < it->width; ++j, ++col) {
+                float v = tmp[j];
+                if (it->scale != 1.0f) v = v * it->scale;             /* :242-244 */
+                if (it->noise != 0.0f) {                               /* :247-250 */
+                    const float u = draw_u(a->noise_draws, n * O + col, a->seed, a->stream, (uint32_t)n, (uint32_t)col);
+                    v = v + uniform_range(u, -1.0f, 1.0f) * it->noise;
+                }
+                row[col] = v;
+            }
+        }
+        /* history: newest first (:223-226) */
+        for (int64_t k = O; k < O * H; ++k) row[k] = a->prev_obs[n * O * H + (k - O)];
+    }
+    return GF_OK;
+}
+
+/* ---------------------------------------------------------------- entity helpers ---------- */
+GFO_EXPORT int gfo_entity_rotate(const GfRotateArgs* a) {
+    if (!a || !a->out || !a->entity.quat) return GF_E_NULL;
+    for (int64_t n = 0; n < a->num_envs; ++n) {
+        float* o = a->out + 3 * n;
+        if (a->what == GF_ROT_PROJ_GRAVITY) proj_gravity(&a->entity, n, o);
+        else if (a->what == GF_ROT_LIN_VEL) body_lin_vel(&a->entity, n, o);
+        else if (a->what == GF_ROT_ANG_VEL) body_ang_vel(&a->entity, n, o);
+        else return GF_E_RANGE;
+    }
+    return GF_OK;
+}
+
+/* ---------------------------------------------------------------- synthetic scene --------- */
+GFO_EXPORT int gfo_synth_scene_step(const GfSynthSceneArgs* a) {
+    if (!a || !a->pos || !a->quat || !a->lin_vel || !a->ang_vel || !a->dof_pos || !a->dof_vel || !a->targets) return GF_E_NULL;
+    const int64_t N = a->num_envs, D = a->num_dofs, C = a->num_contacts, NL = a->num_scene_links;
+    const float dt = a->dt;
+    for (int64_t n = 0; n < N; ++n) {
+        /* joints: first-order tracking of the PD target */
+        for (int64_t d = 0; d < D; ++d) {
+            const float err = a->targets[n * D + d] - a->dof_pos[n * D + d];
+            const float v = err * a->joint_rate;
+            a->dof_vel[n * D + d] = v;
+            a->dof_pos[n * D + d] = a->dof_pos[n * D + d] + v * dt;
+        }
+        float s[6];
+        for (int j = 0; j < 6; ++j) s[j] = philox_uniform(a->seed, a->tick, (uint32_t)n, (uint32_t)j) * 2.0f - 1.0f;
+        float* w = a->ang_vel + 3 * n;
+        float* v = a->lin_vel + 3 * n;
+        float* p = a->pos + 3 * n;
+        float* q = a->quat + 4 * n;
+        for (int j = 0; j < 3; ++j) w[j] = w[j] * 0.9f + s[j] * a->ang_noise;
+        v[0] = v[0] * 0.9f + s[3] * a->lin_noise;
+        v[1] = v[1] * 0.9f + s[4] * a->lin_noise;
+        v[2] = (v[2] * 0.9f + (a->height_target - p[2]) * 2.0f) + s[5] * a->lin_noise;
+        for (int j = 0; j < 3; ++j) p[j] = p[j] + v[j] * dt;
+        /* dq/dt = 0.5 * (0,w) (x) q  (world-frame angular velocity) */
+        const float h = 0.5f * dt;
+        const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+        const float dw = ((-(w[0] * qx)) - w[1] * qy) - w[2] * qz;
+        const float dx = (w[0] * qw + w[1] * qz) - w[2] * qy;
+        const float dy = (w[1] * qw + w[2] * qx) - w[0] * qz;
+        const float dz = (w[2] * qw + w[0] * qy) - w[1] * qx;
+        float nq[4] = {qw + dw * h, qx + dx * h, qy + dy * h, qz + dz * h};
+        const float nrm = sqrtf(((nq[0] * nq[0] + nq[1] * nq[1]) + nq[2] * nq[2]) + nq[3] * nq[3]);
+        for (int j = 0; j < 4; ++j) q[j] = nq[j] / nrm;
+        if (a->links_quat_out)
+            for (int64_t l = 0; l < NL; ++l)
+                for (int j = 0; j < 4; ++j) a->links_quat_out[(n * NL + l) * 4 + j] = q[j];
+        if (a->links_vel_out)
+            for (int64_t l = 0; l < NL; ++l)
+                for (int j = 0; j < 3; ++j)
+                    a->links_vel_out[(n * NL + l) * 3 + j] = v[j] + (float)(l % 3 == (int64_t)j ? 1 : 0) * 0.05f * w[j];
+        if (C > 0 && a->contact_force_out) {
+            for (int64_t c = 0; c < C; ++c) {
+                const uint32_t col = (uint32_t)(8 + 8 * c);
+                const float u_act = philox_uniform(a->seed, a->tick, (uint32_t)n, col);
+                const float u_link = philox_uniform(a->seed, a->tick, (uint32_t)n, col + 1);
+                const float fx = philox_uniform(a->seed, a->tick, (uint32_t)n, col + 2) * 2.0f - 1.0f;
+                const float fy = philox_uniform(a->seed, a->tick, (uint32_t)n, col + 3) * 2.0f - 1.0f;
+                const float fz = philox_uniform(a->seed, a->tick, (uint32_t)n, col + 4);
+                const int active = u_act < a->contact_prob;
+                const int64_t k = n * C + c;
+                int32_t lb = 1 + (int32_t)(u_link * (float)(NL - 1));
+                if (lb > (int32_t)NL - 1) lb = (int32_t)NL - 1;
+                a->link_a_out[k] = active ? 0 : -1;
+                a->link_b_out[k] = active ? lb : -1;
+                a->contact_force_out[k * 3 + 0] = active ? fx * a->contact_force * 0.25f : 0.0f;
+                a->contact_force_out[k * 3 + 1] = active ? fy * a->contact_force * 0.25f : 0.0f;
+                a->contact_force_out[k * 3 + 2] = active ? fz * a->contact_force : 0.0f;
+                a->contact_pos_out[k * 3 + 0] = active ? p[0] + fx * 0.2f : 0.0f;
+                a->contact_pos_out[k * 3 + 1] = active ? p[1] + fy * 0.2f : 0.0f;
+                a->contact_pos_out[k * 3 + 2] = 0.0f;
+            }
+        }
+    }
+    return GF_OK;
+}
+
+GFO_EXPORT int gfo_abi_version(void) { return GF_ABI_VERSION; }
+GFO_EXPORT int gfo_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(GfStepStats);
+        case 1: return (int)sizeof(GfActionArgs);
+        case 2: return (int)sizeof(GfContactArgs);
+        case 3: return (int)sizeof(GfTerminationArgs);
+        case 4: return (int)sizeof(GfRewardArgs);
+        case 5: return (int)sizeof(GfCommandArgs);
+        case 6: return (int)sizeof(GfResetArgs);
+        case 7: return (int)sizeof(GfObservationArgs);
+        case 8: return (int)sizeof(GfRotateArgs);
+        case 9: return (int)sizeof(GfSynthSceneArgs);
+        case 10: return (int)sizeof(GfTerm);
+        case 11: return (int)sizeof(GfObsItem);
+        default: return -1;
+    }
+}
