@@ -13,6 +13,24 @@ extern "C" {
 
 GF_EXPORT int gf_abi_version(void) { return GF_ABI_VERSION; }
 
+GF_EXPORT int gf_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(GfStepStats);
+        case 1: return (int)sizeof(GfActionArgs);
+        case 2: return (int)sizeof(GfContactArgs);
+        case 3: return (int)sizeof(GfTerminationArgs);
+        case 4: return (int)sizeof(GfRewardArgs);
+        case 5: return (int)sizeof(GfCommandArgs);
+        case 6: return (int)sizeof(GfResetArgs);
+        case 7: return (int)sizeof(GfObservationArgs);
+        case 8: return (int)sizeof(GfRotateArgs);
+        case 9: return (int)sizeof(GfSynthSceneArgs);
+        case 10: return (int)sizeof(GfTerm);
+        case 11: return (int)sizeof(GfObsItem);
+        default: return -1;
+    }
+}
+
 GF_EXPORT const char* gf_build_info(void) { return "genesis-forge_amd gf_step: gfx950 HIP, -ffp-contract=off, built " __DATE__ " " __TIME__; }
 
 GF_EXPORT const char* gf_error_string(int code) {

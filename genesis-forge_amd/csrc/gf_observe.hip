@@ -85,7 +85,12 @@ __global__ __launch_bounds__(kEnvBlock) void observe_kernel(const GfObservationA
 
     // per-env entity state, requested before anything else
     const uint32_t e = (uint32_t)n;
-    const float4 q = ldg4(gsel((needs & ON_QUAT) != 0, a.entity.quat, 4u * e));
+    // quirk: envs reset in this tick are rotated by their pre-reset quaternion (entity_manager.py:189-195)
+    const bool use_stale = a.stale_quat != nullptr;
+    const int s1 = *gsel(use_stale && a.stale_mask, a.stale_mask, e);
+    const int s2 = *gsel(use_stale && a.stale_mask2, a.stale_mask2, e);
+    const float* qsrc = (use_stale && (s1 | s2)) ? a.stale_quat : a.entity.quat;
+    const float4 q = ldg4(gsel((needs & ON_QUAT) != 0, qsrc, 4u * e));
     const GF_GLOBAL float* lp = gsel((needs & ON_LIN) != 0, a.entity.lin_vel, 3u * e);
     const GF_GLOBAL float* ap = gsel((needs & ON_ANG) != 0, a.entity.ang_vel, 3u * e);
     const V3 lin{lp[0], lp[1], lp[2]}, ang{ap[0], ap[1], ap[2]};

@@ -83,8 +83,11 @@ __global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
     }
     if (a.scene_pos) {
         for (int j = 0; j < 3; ++j) a.scene_pos[3 * n + j] = a.reset_pos[j];
-        if (a.set_quat && a.scene_quat)
-            for (int j = 0; j < 4; ++j) a.scene_quat[4 * n + j] = a.reset_quat[j];
+        if (a.set_quat && a.scene_quat) {
+            float4* qp = reinterpret_cast<float4*>(a.scene_quat) + n;
+            if (a.quat_stash) reinterpret_cast<float4*>(a.quat_stash)[n] = *qp;  // pre-reset quat for this tick's observation
+            *qp = make_float4(a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]);
+        }
         if (a.zero_velocity) {
             if (a.scene_lin_vel) for (int j = 0; j < 3; ++j) a.scene_lin_vel[3 * n + j] = 0.0f;
             if (a.scene_ang_vel) for (int j = 0; j < 3; ++j) a.scene_ang_vel[3 * n + j] = 0.0f;

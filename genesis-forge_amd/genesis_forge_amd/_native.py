@@ -1,0 +1,343 @@
+"""
+ctypes binding of the C ABI declared in ``include/gf_step.h`` (the drop-in boundary).
+
+The structures below mirror the header field for field; ``check_abi`` compares every
+``ctypes.sizeof`` with the library's own ``gf_sizeof`` so a drifted binding fails at load time,
+not with a corrupted launch.  There is no CPU fallback: if ``libgf_step.so`` (built by
+``__graft_entry__.build()`` / ``make -C genesis-forge_amd/csrc``) is missing, or no ROCm device
+is visible, every phase call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+GF_ABI_VERSION = 1
+GF_MAX_TERMS = 24
+GF_MAX_TERM_TERMS = 16
+GF_MAX_OBS_ITEMS = 24
+GF_MAX_CONTACT_VIEWS = 4
+GF_MAX_COMMAND_VIEWS = 4
+GF_MAX_EXT = 16
+GF_MAX_LINK_IDS = 32
+GF_MAX_RANGES = 8
+GF_MAX_OBS_WIDTH = 256
+
+# opcodes ------------------------------------------------------------------------------------
+GF_ACTION_POSITION, GF_ACTION_WITHIN_LIMITS = 0, 1
+
+GF_T_TIMEOUT = 1
+GF_T_BAD_ORIENTATION = 2
+GF_T_BASE_HEIGHT_BELOW = 3
+GF_T_OUT_OF_BOUNDS = 4
+GF_T_HAS_CONTACT = 5
+GF_T_CONTACT_FORCE = 6
+GF_T_CONTACT_FORCE_GRACE = 7
+GF_T_EXTERNAL = 8
+GF_TERM_FLAG_TIME_OUT = 1
+
+GF_R_IS_ALIVE = 1
+GF_R_TERMINATED = 2
+GF_R_BASE_HEIGHT = 3
+GF_R_DOF_SIMILAR_TO_DEFAULT = 4
+GF_R_LIN_VEL_Z_L2 = 5
+GF_R_ANG_VEL_XY_L2 = 6
+GF_R_FLAT_ORIENTATION_L2 = 7
+GF_R_BODY_ACCEL_EXP = 8
+GF_R_ACTION_RATE_L2 = 9
+GF_R_CMD_TRACK_LIN_VEL = 10
+GF_R_CMD_TRACK_ANG_VEL = 11
+GF_R_STAND_STILL = 12
+GF_R_HAS_CONTACT = 13
+GF_R_CONTACT_FORCE = 14
+GF_R_FEET_AIR_TIME = 15
+GF_R_FEET_SLIDE = 16
+GF_R_EXTERNAL = 17
+GF_RW_FLAG_CMD, GF_RW_FLAG_TERRAIN, GF_RW_FLAG_MAX, GF_RW_FLAG_FIRST_CALL = 1, 2, 4, 8
+GF_REWARD_MODE_STEP, GF_REWARD_MODE_EVAL = 0, 1
+
+GF_CMD_STEP, GF_CMD_MASKED, GF_CMD_ALL = 0, 1, 2
+
+GF_O_COMMAND = 1
+GF_O_ANG_VEL_BODY = 2
+GF_O_LIN_VEL_BODY = 3
+GF_O_PROJ_GRAVITY = 4
+GF_O_DOF_POS = 5
+GF_O_DOF_VEL = 6
+GF_O_DOF_FORCE = 7
+GF_O_ACTIONS = 8
+GF_O_RAW_ACTIONS = 9
+GF_O_CONTACT_FORCE_NORM = 10
+GF_O_EXTERNAL = 11
+GF_O_BASE_POS = 12
+GF_O_BASE_QUAT = 13
+
+GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
+
+(GF_PHASE_ACTION, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
+ GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_COUNT) = range(10)
+
+GF_ERRORS = {-1: "GF_E_NULL", -2: "GF_E_RANGE", -3: "GF_E_OPCODE", -4: "GF_E_SLOT", -5: "GF_E_UNSUPPORTED"}
+
+P = C.c_void_p  # every device pointer crosses the ABI as a plain address
+
+
+class GfEntityView(C.Structure):
+    _fields_ = [("pos", P), ("quat", P), ("lin_vel", P), ("ang_vel", P)]
+
+
+class GfContactView(C.Structure):
+    _fields_ = [("contacts", P), ("last_air_time", P), ("current_contact_time", P), ("link_vel", P),
+                ("num_links", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GfCommandView(C.Structure):
+    _fields_ = [("command", P), ("width", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GfTerm(C.Structure):
+    _fields_ = [("op", C.c_int32), ("flags", C.c_int32), ("w", C.c_float), ("p", C.c_float * 4),
+                ("i", C.c_int32 * 4), ("row", C.c_int32)]
+
+
+class GfStepStats(C.Structure):
+    _fields_ = [("term_fired", C.c_int32 * GF_MAX_TERM_TERMS), ("reset_count", C.c_int32),
+                ("action_flags", C.c_int32), ("contact_flags", C.c_int32), ("resample_count", C.c_int32),
+                ("_pad", C.c_int32 * 4), ("reward_episode_sum", C.c_double * GF_MAX_TERMS)]
+
+
+class GfActionArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_dofs", C.c_int32), ("mode", C.c_int32), ("check_finite", C.c_int32),
+                ("actions_in", P), ("scale", P), ("offset", P), ("clip_lo", P), ("clip_hi", P),
+                ("env_actions", P), ("env_last_actions", P), ("episode_length", P), ("targets", P), ("stats", P)]
+
+
+class GfContactArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_contacts", C.c_int32), ("num_scene_links", C.c_int32),
+                ("num_targets", C.c_int32), ("num_with", C.c_int32), ("has_with_filter", C.c_int32),
+                ("track_air_time", C.c_int32), ("_pad", C.c_int32),
+                ("force", P), ("position", P), ("link_a", P), ("link_b", P), ("links_quat", P),
+                ("target_link_ids", C.c_int32 * GF_MAX_LINK_IDS), ("with_link_ids", C.c_int32 * GF_MAX_LINK_IDS),
+                ("air_time_threshold", C.c_float), ("dt", C.c_float),
+                ("contacts", P), ("contact_positions", P), ("position_counts", P),
+                ("last_air_time", P), ("current_air_time", P), ("last_contact_time", P), ("current_contact_time", P),
+                ("stats", P)]
+
+
+class GfTerminationArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_terms", C.c_int32), ("entity", GfEntityView),
+                ("episode_length", P), ("max_episode_length", P),
+                ("contact", GfContactView * GF_MAX_CONTACT_VIEWS), ("ext", P * GF_MAX_EXT),
+                ("terminated", P), ("truncated", P), ("term_out", P), ("stats", P),
+                ("terms", GfTerm * GF_MAX_TERM_TERMS)]
+
+
+class GfRewardArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_dofs", C.c_int32), ("num_terms", C.c_int32), ("mode", C.c_int32),
+                ("dt", C.c_float), ("logging_enabled", C.c_int32), ("entity", GfEntityView),
+                ("dof_pos", P), ("default_dof_pos", P), ("actions", P), ("last_actions", P), ("terminated", P),
+                ("contact", GfContactView * GF_MAX_CONTACT_VIEWS), ("command", GfCommandView * GF_MAX_COMMAND_VIEWS),
+                ("ext", P * GF_MAX_EXT), ("state", P * 4),
+                ("reward", P), ("episode_sums", P), ("episode_seconds", P), ("term_out", P),
+                ("terms", GfTerm * GF_MAX_TERMS)]
+
+
+class GfCommandArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_ranges", C.c_int32), ("mode", C.c_int32), ("resample_steps", C.c_int32),
+                ("episode_length", P), ("mask", P), ("mask2", P), ("draws", P),
+                ("seed", C.c_uint64), ("stream", C.c_uint64),
+                ("lo", C.c_float * GF_MAX_RANGES), ("hi", C.c_float * GF_MAX_RANGES),
+                ("command", P), ("stats", P)]
+
+
+class GfResetArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_dofs", C.c_int32), ("num_reward_terms", C.c_int32), ("num_contact", C.c_int32),
+                ("mask", P), ("mask2", P),
+                ("env_actions", P), ("env_last_actions", P), ("episode_length", P), ("max_episode_length", P),
+                ("base_max_episode_length", C.c_int32), ("max_random_scaling", C.c_float), ("len_draws", P),
+                ("episode_sums", P), ("episode_seconds", P), ("reward_log_mask", C.c_uint32), ("reward_logging", C.c_int32),
+                ("air_state", (P * 4) * GF_MAX_CONTACT_VIEWS), ("air_links", C.c_int32 * GF_MAX_CONTACT_VIEWS),
+                ("scene_dof_pos", P), ("scene_dof_vel", P), ("default_dof_pos", P), ("dof_noise_scale", C.c_float),
+                ("dof_draws", P), ("scene_pos", P), ("scene_quat", P), ("quat_stash", P), ("scene_lin_vel", P), ("scene_ang_vel", P),
+                ("reset_pos", C.c_float * 3), ("reset_quat", C.c_float * 4), ("set_quat", C.c_int32), ("zero_velocity", C.c_int32),
+                ("seed", C.c_uint64), ("stream", C.c_uint64), ("stats", P)]
+
+
+class GfObsItem(C.Structure):
+    _fields_ = [("op", C.c_int32), ("width", C.c_int32), ("i0", C.c_int32), ("i1", C.c_int32),
+                ("scale", C.c_float), ("noise", C.c_float)]
+
+
+class GfObservationArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_dofs", C.c_int32), ("num_items", C.c_int32), ("obs_width", C.c_int32),
+                ("history_len", C.c_int32), ("_pad", C.c_int32), ("entity", GfEntityView),
+                ("dof_pos", P), ("dof_vel", P), ("dof_force", P), ("targets", P), ("env_actions", P),
+                ("contact", GfContactView * GF_MAX_CONTACT_VIEWS), ("command", GfCommandView * GF_MAX_COMMAND_VIEWS),
+                ("ext", P * GF_MAX_EXT), ("noise_draws", P), ("seed", C.c_uint64), ("stream", C.c_uint64),
+                ("stale_quat", P), ("stale_mask", P), ("stale_mask2", P), ("prev_obs", P), ("obs", P), ("items", GfObsItem * GF_MAX_OBS_ITEMS)]
+
+
+class GfRotateArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("what", C.c_int32), ("entity", GfEntityView), ("out", P)]
+
+
+class GfSynthSceneArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_dofs", C.c_int32), ("num_contacts", C.c_int32), ("num_scene_links", C.c_int32),
+                ("dt", C.c_float), ("joint_rate", C.c_float), ("ang_noise", C.c_float), ("lin_noise", C.c_float),
+                ("height_target", C.c_float), ("contact_prob", C.c_float), ("contact_force", C.c_float), ("_padf", C.c_float),
+                ("targets", P), ("pos", P), ("quat", P), ("lin_vel", P), ("ang_vel", P), ("dof_pos", P), ("dof_vel", P),
+                ("contact_force_out", P), ("contact_pos_out", P), ("link_a_out", P), ("link_b_out", P),
+                ("links_quat_out", P), ("links_vel_out", P), ("seed", C.c_uint64), ("tick", C.c_uint64)]
+
+
+ABI_STRUCTS = [GfStepStats, GfActionArgs, GfContactArgs, GfTerminationArgs, GfRewardArgs, GfCommandArgs,
+               GfResetArgs, GfObservationArgs, GfRotateArgs, GfSynthSceneArgs, GfTerm, GfObsItem]
+
+PHASE_FUNCS = {
+    "action_step": GfActionArgs,
+    "contact_step": GfContactArgs,
+    "termination_step": GfTerminationArgs,
+    "reward_step": GfRewardArgs,
+    "command_step": GfCommandArgs,
+    "masked_reset": GfResetArgs,
+    "observe": GfObservationArgs,
+    "entity_rotate": GfRotateArgs,
+    "synth_scene_step": GfSynthSceneArgs,
+}
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libgf_step.so")
+
+
+class GfError(RuntimeError):
+    """Raised when a native phase call returns a non-zero status (include/gf_step.h error convention)."""
+
+
+def check_abi(lib, prefix: str = "gf_") -> None:
+    sizeof = getattr(lib, prefix + "sizeof")
+    sizeof.restype = C.c_int
+    sizeof.argtypes = [C.c_int]
+    ver = getattr(lib, prefix + "abi_version")
+    ver.restype = C.c_int
+    if ver() != GF_ABI_VERSION:
+        raise GfError(f"ABI version mismatch: library {ver()} vs binding {GF_ABI_VERSION}")
+    for idx, st in enumerate(ABI_STRUCTS):
+        n = sizeof(idx)
+        if n != C.sizeof(st):
+            raise GfError(f"ABI drift: sizeof({st.__name__}) is {n} in the library, {C.sizeof(st)} in the binding")
+
+
+def data_ptr(t) -> Optional[int]:
+    """Address of a tensor's storage (None stays NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+class Backend:
+    """What the managers call.  One implementation ships: :class:`HipBackend`."""
+
+    name = "abstract"
+    device_type = "cuda"
+
+    def call(self, fn: str, args) -> None:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def stats_clear(self, stats_ptr: int) -> None:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def check_tensor(self, t, what: str = "tensor") -> None:
+        if t is None:
+            return
+        if t.device.type != self.device_type:
+            raise GfError(f"{what} lives on {t.device}, but the {self.name} backend needs {self.device_type} tensors")
+        if not t.is_contiguous():
+            raise GfError(f"{what} must be contiguous")
+
+
+class HipBackend(Backend):
+    """ctypes front of libgf_step.so; launches on torch's current HIP stream."""
+
+    name = "hip"
+    device_type = "cuda"
+
+    def __init__(self, path: Optional[str] = None):
+        path = path or lib_path()
+        if not os.path.exists(path):
+            raise GfError(
+                f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C genesis-forge_amd/csrc).  genesis_forge_amd has no CPU fallback.")
+        import torch  # plumbing only: makes sure torch's HIP runtime is the one in the process
+
+        self._torch = torch
+        self.lib = C.CDLL(path)
+        check_abi(self.lib, "gf_")
+        self._fn = {}
+        for name, st in PHASE_FUNCS.items():
+            f = getattr(self.lib, "gf_" + name)
+            f.restype = C.c_int
+            f.argtypes = [C.POINTER(st), C.c_void_p]
+            self._fn[name] = f
+        self.lib.gf_stats_clear.restype = C.c_int
+        self.lib.gf_stats_clear.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.gf_error_string.restype = C.c_char_p
+        self.lib.gf_error_string.argtypes = [C.c_int]
+        self.lib.gf_build_info.restype = C.c_char_p
+        self.lib.gf_profile_begin.restype = C.c_int
+        self.lib.gf_profile_begin.argtypes = [C.c_int, C.c_int]
+        self.lib.gf_profile_end.restype = C.c_int
+        self.lib.gf_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
+
+    def _stream(self) -> int:
+        torch = self._torch
+        if not torch.cuda.is_available():
+            raise GfError("no ROCm device visible: genesis_forge_amd runs its manager phases as HIP kernels only")
+        return torch.cuda.current_stream().cuda_stream
+
+    def _raise(self, fn: str, rc: int):
+        msg = self.lib.gf_error_string(rc).decode()
+        raise GfError(f"gf_{fn} failed: {GF_ERRORS.get(rc, rc)} ({msg})")
+
+    def call(self, fn: str, args) -> None:
+        rc = self._fn[fn](C.byref(args), self._stream())
+        if rc != 0:
+            self._raise(fn, rc)
+
+    def stats_clear(self, stats_ptr: int) -> None:
+        rc = self.lib.gf_stats_clear(stats_ptr, self._stream())
+        if rc != 0:
+            self._raise("stats_clear", rc)
+
+    def profile_begin(self, phase: int, max_samples: int) -> None:
+        rc = self.lib.gf_profile_begin(phase, max_samples)
+        if rc != 0:
+            self._raise("profile_begin", rc)
+
+    def profile_end(self):
+        tot, cnt = C.c_double(0.0), C.c_int(0)
+        rc = self.lib.gf_profile_end(C.byref(tot), C.byref(cnt))
+        if rc != 0:
+            self._raise("profile_end", rc)
+        return tot.value, cnt.value
+
+    def build_info(self) -> str:
+        return self.lib.gf_build_info().decode()
+
+
+_backend: Optional[Backend] = None
+
+
+def get_backend() -> Backend:
+    """The process-wide backend; created on first use.  Raises if the HIP library is not built."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend(b: Optional[Backend]) -> None:
+    """Replace the backend (tests inject an oracle-backed one; ``None`` resets to lazy HIP)."""
+    global _backend
+    _backend = b

@@ -1,0 +1,184 @@
+"""
+Per-step logging statistics without per-step host syncs.
+
+The reference produces its ``extras["episode"]`` scalars with blocking calls every step
+(``nonzero()`` per termination term, termination_manager.py:178; ``.item()`` per reward term on
+reset, reward_manager.py:215).  Here the kernels accumulate into one small device block
+(``GfStepStats``); at the end of a step it is copied asynchronously into a pinned host ring slot
+and an event is recorded.  ``extras["episode"]`` is a :class:`LazyEpisodeLog` that only waits for
+that event if somebody actually reads it.  At world_size > 1 the block is summed over ranks with a
+single all-reduce (RCCL over xGMI) before it is interpreted — the only collective of the path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+STATS_BYTES = C.sizeof(nat.GfStepStats)
+_RING = 64
+
+
+class StatsSnapshot:
+    """One step's statistics; ``wait()`` returns a host GfStepStats once the copy has landed."""
+
+    __slots__ = ("_host", "_event", "_value", "_reduce")
+
+    def __init__(self, host: torch.Tensor, event, reduce: Optional[Callable] = None):
+        self._host = host
+        self._event = event
+        self._value = None
+        self._reduce = reduce
+
+    def wait(self) -> nat.GfStepStats:
+        if self._value is None:
+            if self._event is not None:
+                self._event.synchronize()
+            buf = self._host.numpy().tobytes()
+            st = nat.GfStepStats.from_buffer_copy(buf)
+            if self._reduce is not None:
+                st = self._reduce(st)
+            self._value = st
+            self._host = None
+            self._event = None
+        return self._value
+
+
+class StepStats:
+    """Owns the device stats block and the pinned read-back ring."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.dev = torch.zeros(STATS_BYTES, dtype=torch.uint8, device=device)
+        pin = device.type == "cuda"
+        self._ring = [torch.zeros(STATS_BYTES, dtype=torch.uint8, pin_memory=pin) for _ in range(_RING)]
+        self._live: list[Optional[StatsSnapshot]] = [None] * _RING
+        self._slot = 0
+        self.reduce: Optional[Callable] = None  # set by distributed.attach()
+
+    @property
+    def ptr(self) -> int:
+        return self.dev.data_ptr()
+
+    def clear(self, backend: nat.Backend) -> None:
+        backend.stats_clear(self.ptr)
+
+    def snapshot(self) -> StatsSnapshot:
+        """Enqueue the device->host copy of this step's block; never blocks."""
+        i = self._slot
+        self._slot = (i + 1) % _RING
+        old = self._live[i]
+        if old is not None and old._value is None:
+            old.wait()  # ring wrapped around an unread snapshot: its copy finished long ago
+        host = self._ring[i]
+        if self.device.type == "cuda":
+            host.copy_(self.dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host = self.dev.clone()
+            ev = None
+        snap = StatsSnapshot(host, ev, self.reduce)
+        self._live[i] = snap
+        return snap
+
+
+class LazyEpisodeLog(dict):
+    """``extras["episode"]``: a dict whose manager-produced entries appear on first read.
+
+    Producers register ``fill(stats, out_dict)`` callbacks; the first read waits for the step's
+    snapshot, runs them once, and from then on this is a plain dict.  Keys written directly
+    (custom managers do ``extras["episode"][k] = v``) are kept as they are.
+    """
+
+    def __init__(self):
+        super().__init__()
+        self._snap: Optional[StatsSnapshot] = None
+        self._fillers: list[Callable] = []
+
+    def attach(self, snap: StatsSnapshot) -> None:
+        self._snap = snap
+
+    def add_filler(self, fn: Callable) -> None:
+        self._fillers.append(fn)
+
+    def materialize(self) -> "LazyEpisodeLog":
+        if self._fillers:
+            fillers, self._fillers = self._fillers, []
+            if self._snap is not None:
+                st = self._snap.wait()
+                tmp: dict = {}
+                for fn in fillers:
+                    fn(st, tmp)
+                for k, v in tmp.items():
+                    if not dict.__contains__(self, k):
+                        dict.__setitem__(self, k, v)
+        return self
+
+    # every read path materialises first
+    def __getitem__(self, k):
+        return dict.__getitem__(self.materialize(), k)
+
+    def __contains__(self, k):
+        return dict.__contains__(self.materialize(), k)
+
+    def __iter__(self):
+        return dict.__iter__(self.materialize())
+
+    def __len__(self):
+        return dict.__len__(self.materialize())
+
+    def __repr__(self):
+        return dict.__repr__(self.materialize())
+
+    def __eq__(self, other):
+        return dict.__eq__(self.materialize(), other)
+
+    def keys(self):
+        return dict.keys(self.materialize())
+
+    def values(self):
+        return dict.values(self.materialize())
+
+    def items(self):
+        return dict.items(self.materialize())
+
+    def get(self, k, default=None):
+        return dict.get(self.materialize(), k, default)
+
+    def copy(self):
+        return dict(self.materialize())
+
+
+_NT = nat.GF_MAX_TERM_TERMS
+STATS_VECTOR_LEN = _NT + 5 + nat.GF_MAX_TERMS
+
+
+def stats_to_vector(st: nat.GfStepStats) -> np.ndarray:
+    """Flatten to f64 for the cross-rank sum (counts are exact in f64; flag bits become counts)."""
+    v = np.zeros(STATS_VECTOR_LEN, dtype=np.float64)
+    v[:_NT] = list(st.term_fired)
+    v[_NT] = st.reset_count
+    v[_NT + 1] = st.action_flags & 1
+    v[_NT + 2] = (st.action_flags >> 1) & 1
+    v[_NT + 3] = st.contact_flags & 1
+    v[_NT + 4] = st.resample_count
+    v[_NT + 5:] = list(st.reward_episode_sum)
+    return v
+
+
+def vector_to_stats(v: np.ndarray) -> nat.GfStepStats:
+    st = nat.GfStepStats()
+    for k in range(_NT):
+        st.term_fired[k] = int(round(v[k]))
+    st.reset_count = int(round(v[_NT]))
+    st.action_flags = (1 if v[_NT + 1] > 0 else 0) | (2 if v[_NT + 2] > 0 else 0)
+    st.contact_flags = 1 if v[_NT + 3] > 0 else 0
+    st.resample_count = int(round(v[_NT + 4]))
+    for t in range(nat.GF_MAX_TERMS):
+        st.reward_episode_sum[t] = float(v[_NT + 5 + t])
+    return st

@@ -1,0 +1,411 @@
+"""
+Action managers — API mirror of genesis_forge/managers/action/{base.py, position_action_manager.py,
+position_within_limits.py}; the per-step math runs in ``gf_action_step`` (Phase A, one launch).
+
+What stays Python (config time only): regex joint selection → ``dofs_idx`` (position_action_manager.py:
+300-309), the ``DofValue`` pattern tables → per-DOF tensors (:311-374, :470-513), PD gain upload on reset.
+What became one kernel: NaN/Inf scan, ``a*scale+offset``, ``clamp``, and — when driven by
+``ManagedEnvironment.step`` — the env bookkeeping of genesis_env.py:196-203 as well.
+"""
+from __future__ import annotations
+
+import re
+from typing import Any, Callable, Optional, TypeVar
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from .. import gs
+from ..spaces import Box
+from .base import BaseManager
+
+T = TypeVar("T")
+DofValue = Any  # scalar or {joint-name regex: value}
+
+
+def _tag(t: torch.Tensor, src) -> torch.Tensor:
+    """Provenance tag read by ObservationManager.build() to fuse getter lambdas (see observation_manager.py)."""
+    t._gf_src = src
+    return t
+
+
+def _ensure_dof_pattern(value):
+    """Scalar → ``{".*": value}`` (position_action_manager.py:18-40)."""
+    if value is None:
+        return None
+    if isinstance(value, dict):
+        return value
+    return {".*": value}
+
+
+class BaseActionManager(BaseManager):
+    """Base for managers that handle actions (action/base.py:9-102).  ``delay_step`` is accepted and, as in
+    the reference (quirk q3: the FIFO is never primed), has no effect."""
+
+    def __init__(self, env, delay_step: int = 0):
+        super().__init__(env, type="action")
+        self._raw_actions = None
+        self._actions = None
+        self._delay_step = delay_step
+        self._action_delay_buffer: list = []
+
+    @property
+    def num_actions(self) -> int:
+        return 0
+
+    @property
+    def action_space(self):
+        return Box(low=-np.inf, high=np.inf, shape=(self.num_actions,), dtype=np.float32)
+
+    @property
+    def actions(self) -> torch.Tensor:
+        if self._actions is None:
+            return torch.zeros((self.env.num_envs, self.num_actions))
+        return self._actions
+
+    @property
+    def raw_actions(self) -> torch.Tensor:
+        if self._raw_actions is None:
+            return torch.zeros((self.env.num_envs, self.num_actions))
+        return self._raw_actions
+
+    def step(self, actions: torch.Tensor) -> torch.Tensor:
+        self._raw_actions = actions
+        return actions
+
+    def reset(self, envs_idx):
+        pass
+
+    def get_actions(self) -> torch.Tensor:
+        if self._actions is None:
+            return torch.zeros((self.env.num_envs, self.num_actions))
+        return self._actions
+
+
+class PositionActionManager(BaseActionManager):
+    """Converts actions to DOF position targets (ctor args as position_action_manager.py:148-167)."""
+
+    _mode = nat.GF_ACTION_POSITION
+    _fused_reset = True
+
+    def __init__(
+        self,
+        env,
+        joint_names: list[str] | str = ".*",
+        default_pos: DofValue = {".*": 0.0},
+        scale: DofValue = 1.0,
+        clip: DofValue = None,
+        offset: DofValue = 0.0,
+        use_default_offset: bool = True,
+        pd_kp: DofValue = None,
+        pd_kv: DofValue = None,
+        max_force: DofValue = None,
+        damping: DofValue = None,
+        stiffness: DofValue = None,
+        frictionloss: DofValue = None,
+        noise_scale: float = 0.0,
+        action_handler: Callable[[torch.Tensor], None] = None,
+        quiet_action_errors: bool = False,
+        delay_step: int = 0,
+    ):
+        super().__init__(env, delay_step)
+        self._default_pos_cfg = _ensure_dof_pattern(default_pos)
+        self._offset_cfg = _ensure_dof_pattern(offset)
+        self._scale_cfg = _ensure_dof_pattern(scale)
+        self._clip_cfg = _ensure_dof_pattern(clip)
+        self._pd_kp_cfg = _ensure_dof_pattern(pd_kp)
+        self._pd_kv_cfg = _ensure_dof_pattern(pd_kv)
+        self._max_force_cfg = _ensure_dof_pattern(max_force)
+        self._damping_cfg = _ensure_dof_pattern(damping)
+        self._stiffness_cfg = _ensure_dof_pattern(stiffness)
+        self._frictionloss_cfg = _ensure_dof_pattern(frictionloss)
+        self._quiet_action_errors = quiet_action_errors
+        self._enabled_dof: Optional[dict] = None
+        self._noise_scale = noise_scale
+        self._use_default_offset = use_default_offset
+        self._default_dofs_pos: Optional[torch.Tensor] = None
+        self._warned = 0
+
+        if use_default_offset and offset != 0.0:
+            raise ValueError("Cannot set both use_default_offset and offset")
+        if isinstance(joint_names, str):
+            self._joint_name_cfg = [joint_names]
+        elif isinstance(joint_names, list):
+            self._joint_name_cfg = joint_names
+        else:
+            raise TypeError(f"Invalid joint_names type: {type(joint_names)}")
+
+    # -- properties ---------------------------------------------------------------------------------
+    @property
+    def action_space(self):
+        return Box(low=-np.inf, high=np.inf, shape=(self.num_actions,), dtype=np.float32)
+
+    @property
+    def num_actions(self) -> int:
+        assert self._enabled_dof is not None, (
+            "PositionalActionManager not initialized. You may need to add <PositionalActionManager>.reset() in your environment's reset method.")
+        return len(self._enabled_dof)
+
+    @property
+    def dofs_idx(self) -> list[int]:
+        return list(self._enabled_dof.values())
+
+    @property
+    def default_dofs_pos(self) -> torch.Tensor:
+        return self._default_dofs_pos
+
+    # -- DOF getters (position_action_manager.py:243-289) ---------------------------------------------
+    def _scene_dofs(self, what: str) -> torch.Tensor:
+        """[N,D] f32 contiguous state of the controlled DOFs; zero-copy on the synthetic scene."""
+        robot = self.env.robot
+        if hasattr(robot, "gf_dofs"):
+            return robot.gf_dofs(what, self.dofs_idx)
+        t = getattr(robot, "get_dofs_" + what)(self.dofs_idx)
+        return t.to(torch.float32).contiguous()
+
+    def get_dofs_position(self, noise: float = 0.0):
+        pos = self.env.robot.get_dofs_position(self.dofs_idx)
+        if noise > 0.0:
+            return self._add_random_noise(pos, noise)
+        return _tag(pos, ("dof_pos", self))
+
+    def get_dofs_velocity(self, noise: float = 0.0, clip: tuple[float, float] = None):
+        vel = self.env.robot.get_dofs_velocity(self.dofs_idx)
+        if noise > 0.0:
+            vel = self._add_random_noise(vel, noise)
+        if clip is not None:
+            vel = vel.clamp(**clip)
+        if noise > 0.0 or clip is not None:
+            return vel
+        return _tag(vel, ("dof_vel", self))
+
+    def get_dofs_force(self, noise: float = 0.0, clip_to_max_force: bool = False):
+        force = self.env.robot.get_dofs_force(self.dofs_idx)
+        if noise > 0.0:
+            force = self._add_random_noise(force, noise)
+        clipped = clip_to_max_force and self._force_range is not None
+        if clipped:
+            force = force.clamp(self._force_range[0], self._force_range[1])
+        if noise > 0.0 or clipped:
+            return force
+        return _tag(force, ("dof_force", self))
+
+    def get_actions(self) -> torch.Tensor:
+        """The processed actions == clamped PD targets (quirk q1, position_action_manager.py:385-387)."""
+        if self._actions is None:
+            return torch.zeros((self.env.num_envs, self.num_actions))
+        return _tag(self._actions, ("actions", self))
+
+    # -- build --------------------------------------------------------------------------------------
+    def build(self):
+        """Resolve joints and per-DOF constants (position_action_manager.py:295-374)."""
+        self._enabled_dof = dict()
+        for joint in self.env.robot.joints:
+            if joint.type != gs.JOINT_TYPE.REVOLUTE:
+                continue
+            for pattern in self._joint_name_cfg:
+                if re.match(f"^{pattern}$", joint.name):
+                    self._enabled_dof[joint.name] = joint.dof_start
+                    break
+        D = self.num_actions
+        N = self.env.num_envs
+
+        if self._default_pos_cfg is not None:
+            self._default_vec = self._get_dof_value_tensor(self._default_pos_cfg)
+        else:
+            self._default_vec = torch.zeros(D, device=gs.device)
+        self._default_dofs_pos = self._default_vec.unsqueeze(0).expand(N, -1)
+
+        lower_limit, upper_limit = self.env.robot.get_dofs_limit(self.dofs_idx)
+        self._scale_values = None
+        self._kp_values = self._kv_values = self._damping_values = self._stiffness_values = self._frictionloss_values = None
+        self._clip_values = torch.stack([lower_limit.to(gs.tc_float), upper_limit.to(gs.tc_float)], dim=1)
+        if self._scale_cfg is not None:
+            self._scale_values = self._get_dof_value_tensor(self._scale_cfg)
+        if self._clip_cfg is not None:
+            self._clip_values = self._get_dof_value_tensor(self._clip_cfg, output=[list(map(float, r)) for r in self._clip_values.tolist()])
+        if self._pd_kp_cfg is not None:
+            self._kp_values = self._get_dof_value_tensor(self._pd_kp_cfg)
+        if self._pd_kv_cfg is not None:
+            self._kv_values = self._get_dof_value_tensor(self._pd_kv_cfg)
+        if self._damping_cfg is not None:
+            self._damping_values = self._get_dof_value_tensor(self._damping_cfg)
+        if self._stiffness_cfg is not None:
+            self._stiffness_values = self._get_dof_value_tensor(self._stiffness_cfg)
+        if self._frictionloss_cfg is not None:
+            self._frictionloss_values = self._get_dof_value_tensor(self._frictionloss_cfg)
+        if self._use_default_offset:
+            self._offset_values = self._default_dofs_pos
+            self._offset_vec = self._default_vec
+        else:
+            offset = self._offset_cfg if self._offset_cfg is not None else {".*": 0.0}
+            self._offset_vec = self._get_dof_value_tensor(offset)
+            self._offset_values = self._offset_vec
+
+        self._force_range = None
+        if self._max_force_cfg is not None:
+            max_force = self._get_dof_value_array(self._max_force_cfg)
+            lo, hi = [0.0] * D, [0.0] * D
+            for i, value in enumerate(max_force):
+                if isinstance(max_force[0], (list, tuple)):
+                    lo[i], hi[i] = value[0], value[1]
+                else:
+                    lo[i], hi[i] = -value, value
+            self._force_range = (torch.tensor(lo, device=gs.device), torch.tensor(hi, device=gs.device))
+
+        self._build_native()
+
+    def _build_native(self):
+        """Per-DOF constant vectors of Phase A and the persistent target buffer."""
+        D, N = self.num_actions, self.env.num_envs
+        scale = self._scale_values if self._scale_values is not None else torch.ones(D, device=gs.device)
+        self._k_scale = scale.to(gs.tc_float).contiguous()
+        self._k_offset = self._offset_vec.to(gs.tc_float).contiguous()
+        self._k_lo = self._clip_values[:, 0].contiguous()
+        self._k_hi = self._clip_values[:, 1].contiguous()
+        self._k_default = self._default_vec.to(gs.tc_float).contiguous()
+        self._actions = torch.zeros((N, D), device=gs.device, dtype=gs.tc_float)
+        self._args = nat.GfActionArgs()
+
+    # -- step ---------------------------------------------------------------------------------------
+    def step(self, actions: torch.Tensor, _fuse_env: bool = False) -> torch.Tensor:
+        """Phase A (position_action_manager.py:376-419).  With ``_fuse_env`` the same launch also performs
+        GenesisEnv.step's bookkeeping (genesis_env.py:196-203)."""
+        if not self.enabled:
+            return
+        env = self.env
+        if actions.dtype != torch.float32 or not actions.is_contiguous():
+            actions = actions.to(torch.float32).contiguous()
+        self._raw_actions = actions
+        a = self._args
+        a.num_envs, a.num_dofs, a.mode = env.num_envs, self.num_actions, self._mode
+        a.check_finite = 0 if self._quiet_action_errors else 1
+        a.actions_in = actions.data_ptr()
+        a.scale, a.offset = self._k_scale.data_ptr(), self._k_offset.data_ptr()
+        a.clip_lo, a.clip_hi = self._k_lo.data_ptr(), self._k_hi.data_ptr()
+        if _fuse_env:
+            env._ensure_action_buffers(actions)
+            a.env_actions, a.env_last_actions = env._actions.data_ptr(), env._last_actions.data_ptr()
+            a.episode_length = env.episode_length.data_ptr()
+        else:
+            a.env_actions = a.env_last_actions = a.episode_length = None
+        a.targets = self._actions.data_ptr()
+        a.stats = env.stats.ptr if not self._quiet_action_errors else None
+        env.backend.call("action_step", a)
+        if not self._quiet_action_errors:
+            self._watch_flags()
+        # Set target positions (position_action_manager.py:417)
+        env.robot.control_dofs_position(self._actions, self.dofs_idx)
+        return self._actions
+
+    def handle_actions(self, actions: torch.Tensor) -> torch.Tensor:
+        """Kept for API compatibility: processes ``actions`` through Phase A and returns the targets."""
+        return self.step(actions)
+
+    def _watch_flags(self):
+        """The reference prints on NaN/Inf actions after two blocking ``.any()`` calls per step
+        (position_action_manager.py:402-406); here the flag word rides along in the lazily read stats block."""
+        log = self.env.extras.get(self.env.extras_logging_key)
+        if hasattr(log, "add_filler"):
+            def _report(st, out, self=self):
+                if st.action_flags & 1:
+                    print("ERROR: NaN actions received!")
+                if st.action_flags & 2:
+                    print("ERROR: Infinite actions received!")
+            log.add_filler(_report)
+
+    # -- reset --------------------------------------------------------------------------------------
+    def _upload_gains(self, envs_idx):
+        robot = self.env.robot
+        if self._kp_values is not None:
+            robot.set_dofs_kp(self._add_random_noise(self._kp_values, self._noise_scale), self.dofs_idx, envs_idx)
+        if self._kv_values is not None:
+            robot.set_dofs_kv(self._add_random_noise(self._kv_values, self._noise_scale), self.dofs_idx, envs_idx)
+        if self._damping_values is not None:
+            robot.set_dofs_damping(self._add_random_noise(self._damping_values, self._noise_scale), self.dofs_idx, envs_idx)
+        if self._stiffness_values is not None:
+            robot.set_dofs_stiffness(self._add_random_noise(self._stiffness_values, self._noise_scale), self.dofs_idx, envs_idx)
+        if self._frictionloss_values is not None:
+            robot.set_dofs_frictionloss(self._add_random_noise(self._frictionloss_values, self._noise_scale), self.dofs_idx, envs_idx)
+        if self._force_range is not None:
+            lower = self._add_random_noise(self._force_range[0], self._noise_scale)
+            upper = self._add_random_noise(self._force_range[1], self._noise_scale)
+            robot.set_dofs_force_range(lower, upper, self.dofs_idx, envs_idx)
+
+    def reset(self, envs_idx: list[int] = None):
+        """position_action_manager.py:421-464 with an explicit index list (public API / real Genesis)."""
+        if not self.enabled:
+            return
+        if envs_idx is None:
+            envs_idx = torch.arange(self.env.num_envs, device=gs.device)
+        self._upload_gains(envs_idx)
+        position = self._add_random_noise(self._default_dofs_pos[envs_idx], self._noise_scale)
+        self.env.robot.set_dofs_position(position=position, dofs_idx_local=self.dofs_idx, envs_idx=envs_idx)
+
+    def _can_fuse_reset(self) -> bool:
+        return hasattr(self.env.robot, "gf_masked_dofs")
+
+    def _fill_reset(self, a: nat.GfResetArgs) -> None:
+        """Scene-side section of the fused reset: dof_pos <- default (+noise), dof_vel <- 0.  PD gains are
+        per-env constants unless ``noise_scale`` is set; they are uploaded once at the first reset."""
+        robot = self.env.robot
+        if not getattr(self, "_gains_uploaded", False) or self._noise_scale != 0.0:
+            self._upload_gains(None)
+            self._gains_uploaded = True
+        pos, vel = robot.gf_masked_dofs(self.dofs_idx)
+        a.num_dofs = self.num_actions
+        a.scene_dof_pos, a.scene_dof_vel = pos.data_ptr(), vel.data_ptr()
+        a.default_dof_pos = self._k_default.data_ptr()
+        a.dof_noise_scale = float(self._noise_scale)
+        d = self.env.take_draws("dof_reset")
+        self._keep = d
+        a.dof_draws = None if d is None else d.data_ptr()
+
+    # -- helpers (position_action_manager.py:470-525) -------------------------------------------------
+    def _get_dof_value_array(self, values, default_value=0.0, output=None):
+        is_set = [False] * self.num_actions
+        if output is None:
+            output = [default_value] * self.num_actions
+        for pattern, value in values.items():
+            found = False
+            for i, name in enumerate(self._enabled_dof.keys()):
+                if not is_set[i] and re.match(f"^{pattern}$", name):
+                    is_set[i] = True
+                    output[i] = list(value) if isinstance(value, (tuple, list)) else value
+                    found = True
+            if not found:
+                raise RuntimeError(f"Joint DOF '{pattern}' not found.")
+        return output
+
+    def _get_dof_value_tensor(self, values, default_value=0.0, output=None) -> torch.Tensor:
+        values = self._get_dof_value_array(values, default_value, output)
+        return torch.tensor(values, device=gs.device, dtype=gs.tc_float)
+
+    def _add_random_noise(self, values: torch.Tensor, noise_scale: float = 0.0) -> torch.Tensor:
+        if noise_scale == 0.0:
+            return values
+        return values + torch.empty_like(values).uniform_(-1, 1) * noise_scale
+
+
+class PositionWithinLimitsActionManager(PositionActionManager):
+    """Actions in [-1, 1] mapped onto the joint limits (position_within_limits.py:9-131):
+    ``clamp(a, -1, 1) * (hi-lo)/2 + (hi+lo)/2``."""
+
+    _mode = nat.GF_ACTION_WITHIN_LIMITS
+
+    def __init__(self, env, joint_names=".*", default_pos={".*": 0.0}, pd_kp=None, pd_kv=None, max_force=None, damping=None,
+                 stiffness=None, frictionloss=None, noise_scale: float = 0.0, action_handler=None,
+                 quiet_action_errors: bool = False, delay_step: int = 0):
+        super().__init__(env, joint_names=joint_names, default_pos=default_pos, pd_kp=pd_kp, pd_kv=pd_kv, max_force=max_force,
+                         damping=damping, stiffness=stiffness, frictionloss=frictionloss, noise_scale=noise_scale,
+                         action_handler=action_handler, quiet_action_errors=quiet_action_errors, delay_step=delay_step)
+
+    def _build_native(self):
+        super()._build_native()
+        lower, upper = self.env.robot.get_dofs_limit(self.dofs_idx)
+        lower, upper = lower.to(gs.tc_float), upper.to(gs.tc_float)
+        self._offset = ((upper + lower) * 0.5).unsqueeze(0).expand(self.env.num_envs, -1)
+        self._scale = ((upper - lower) * 0.5).unsqueeze(0).expand(self.env.num_envs, -1)
+        self._k_offset = ((upper + lower) * 0.5).contiguous()
+        self._k_scale = ((upper - lower) * 0.5).contiguous()

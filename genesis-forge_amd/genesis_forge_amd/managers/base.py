@@ -1,0 +1,37 @@
+"""BaseManager — registration + lifecycle (mirror of genesis_forge/managers/base.py:4-43)."""
+from __future__ import annotations
+
+from typing import Literal
+
+ManagerType = Literal["action", "reward", "termination", "contact", "terrain", "entity", "command", "observation"]
+
+
+class BaseManager:
+    """The base class used to define the interface for all other managers (base.py:16-43)."""
+
+    def __init__(self, env, type: ManagerType, enabled: bool = True):
+        self.env = env
+        self.enabled = True  # sic: the reference ignores the argument (base.py:28)
+        self.type = type
+        if hasattr(env, "add_manager"):
+            env.add_manager(type, self)
+
+    def build(self):
+        """Called when the scene is built"""
+
+    def step(self):
+        """Called when the environment is stepped"""
+
+    def reset(self, envs_idx: list[int] | None = None):
+        """One or more environments have been reset"""
+
+    # -- fused-reset protocol (no reference counterpart) ---------------------------------------------
+    #: managers whose ``reset`` can be expressed as a section of ``gf_masked_reset`` set this to True and
+    #: implement ``_fill_reset``; everything else gets ``reset(envs_idx)`` with a compacted index list.
+    _fused_reset = False
+
+    def _fill_reset(self, args) -> None:
+        pass
+
+    def _after_fused_reset(self, mask, mask2) -> None:
+        """Follow-up launches that cannot live in the fused call (e.g. command resampling)."""

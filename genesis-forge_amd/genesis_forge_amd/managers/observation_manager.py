@@ -1,0 +1,219 @@
+"""
+ObservationManager — API mirror of genesis_forge/managers/observation_manager.py.
+
+``get_observations`` (:218-256: per item fn → in-place scale → uniform noise → cat, then the history
+list pop/insert/cat) is one ``gf_observe`` launch that writes the final ``[N, O*H]`` tensor.
+
+How opaque getter lambdas get fused: the example configs write observation items as
+``lambda env: self.robot_manager.get_angular_velocity()``.  At ``build()`` every item fn is called
+once (the reference does the same trial observation to size the space, :182-216).  Tensors returned by
+the library's getters carry a provenance tag; if an item's result *is* such a tagged tensor the item
+is compiled to the matching opcode and its Python fn is never called again.  Anything else (a lambda
+that post-processes, user manager methods) stays an EXTERNAL item evaluated by Python each step.
+Pass ``fused=False`` to force the EXTERNAL path for every item.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Optional, TypedDict
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from .. import gs
+from ..spaces import Box
+from ._program import _Slots, _col
+from .base import BaseManager
+from .config import ObservationConfigItem
+
+
+class ObservationConfig(TypedDict):
+    fn: Callable[..., torch.Tensor]
+    params: dict[str, Any]
+    scale: float
+    noise: float
+
+
+_SRC_OPS = {
+    "ang_vel": nat.GF_O_ANG_VEL_BODY, "lin_vel": nat.GF_O_LIN_VEL_BODY, "grav": nat.GF_O_PROJ_GRAVITY,
+    "dof_pos": nat.GF_O_DOF_POS, "dof_vel": nat.GF_O_DOF_VEL, "dof_force": nat.GF_O_DOF_FORCE,
+    "actions": nat.GF_O_ACTIONS, "raw_actions": nat.GF_O_RAW_ACTIONS, "cmd": nat.GF_O_COMMAND,
+    "contact_norm": nat.GF_O_CONTACT_FORCE_NORM,
+}
+
+_OBS_RING = 3  # returned tensors stay valid for two further calls (rollout storages copy one step late)
+
+
+class ObservationManager(BaseManager):
+    """Generates an observation tensor from a dict of items (ctor as observation_manager.py:134-156)."""
+
+    def __init__(self, env, cfg: dict[str, ObservationConfig], name: str = "policy", history_len: int | None = None,
+                 noise: float | None = None, fused: bool = True):
+        super().__init__(env, "observation")
+        self._name = name
+        self.noise = noise
+        self._observation_size = 1
+        self._observation_space = None
+        self._fused = fused
+        if history_len is not None and history_len < 1:
+            raise ValueError("history_len must be greater than 0")
+        self._history_len = history_len if history_len is not None else 1
+        if len(cfg) > nat.GF_MAX_OBS_ITEMS:
+            raise ValueError(f"ObservationManager supports at most {nat.GF_MAX_OBS_ITEMS} items")
+        self.cfg: dict[str, ObservationConfigItem] = {}
+        for item_name, c in cfg.items():
+            self.cfg[item_name] = ObservationConfigItem(c, env, on_dirty=self._mark_dirty)
+        self._dirty = True
+        self._plan: list = []
+        self._args = nat.GfObservationArgs()
+        self._bufs: list[torch.Tensor] = []
+        self._cur = 0
+
+    def _mark_dirty(self):
+        self._dirty = True
+
+    @property
+    def name(self) -> str:
+        return self._name
+
+    @property
+    def observation_space(self):
+        return self._observation_space
+
+    # -- build ----------------------------------------------------------------------------------------
+    def build(self):
+        """Trial observation → item plan, observation space, history buffers (observation_manager.py:182-216)."""
+        if not self.enabled:
+            self._observation_size = 1
+            self._observation_space = Box(low=-np.inf, high=np.inf, shape=(1,), dtype=np.float32)
+            return
+        env = self.env
+        self._plan = []
+        width = 0
+        for name, cfg in self.cfg.items():
+            cfg.build()
+            assert callable(cfg.fn), f"Observation function {name} is not callable"
+            value = self._call_item(name, cfg)
+            src = getattr(value, "_gf_src", None) if self._fused else None
+            w = int(value.shape[-1]) if value.dim() > 1 else 1
+            self._plan.append((name, cfg, src, w))
+            width += w
+        if width >= nat.GF_MAX_OBS_WIDTH:
+            raise ValueError(f"observation frame wider than {nat.GF_MAX_OBS_WIDTH - 1}")
+        self._frame = width
+        self._observation_size = width * self._history_len
+        self._observation_space = Box(low=-np.inf, high=np.inf, shape=(self._observation_size,), dtype=np.float32)
+        self._bufs = [torch.zeros((env.num_envs, self._observation_size), device=gs.device, dtype=gs.tc_float) for _ in range(_OBS_RING)]
+        self._cur = 0
+        self._dirty = True
+
+    def _call_item(self, name, cfg) -> torch.Tensor:
+        try:
+            return cfg.fn(env=self.env, **cfg.params)
+        except Exception as e:  # observation_manager.py:253-255
+            print(f"Error generating observation for '{name}'")
+            raise e
+
+    def _compile(self):
+        a = self._args
+        self._slots = _Slots(self.env)
+        self._entity = None
+        self._entity_mgr = None
+        self._am = None
+        n = 0
+        for name, cfg, src, w in self._plan:
+            it = a.items[n]
+            it.width = w
+            scale = cfg.scale
+            it.scale = 1.0 if scale is None else float(scale)
+            noise = cfg.noise or self.noise
+            it.noise = 0.0 if noise is None else float(noise)
+            kind = src[0] if src is not None else None
+            owner = src[1] if src is not None else None
+            fused = kind in _SRC_OPS
+            if fused and kind in ("ang_vel", "lin_vel", "grav"):
+                ent = owner.entity
+                if self._entity is None:
+                    self._entity = ent
+                    self._entity_mgr = owner
+                fused = ent is self._entity
+            if fused and kind in ("dof_pos", "dof_vel", "dof_force", "actions"):
+                if self._am is None:
+                    self._am = owner
+                fused = owner is self._am
+            if fused:
+                it.op = _SRC_OPS[kind]
+                if kind == "cmd":
+                    it.i0 = self._slots.cmd(owner)
+                elif kind == "contact_norm":
+                    it.i0 = self._slots.contact(owner, False)
+            else:
+                it.op = nat.GF_O_EXTERNAL
+                it.i0 = self._slots.ext(lambda name=name, cfg=cfg: self._call_item(name, cfg))
+                it.i1 = w
+            n += 1
+        a.num_items = n
+        a.obs_width = self._frame
+        a.history_len = self._history_len
+        a.num_envs = self.env.num_envs
+        self._dirty = False
+
+    # -- public ---------------------------------------------------------------------------------------
+    def get_observations(self) -> torch.Tensor:
+        """observation_manager.py:218-226 → one launch."""
+        env = self.env
+        if not self.enabled:
+            return torch.zeros((env.num_envs, self._observation_size))
+        if self._dirty:
+            self._compile()
+        a = self._args
+        keep: list = []
+        if self._entity is not None:
+            env.entity_views(self._entity).fill(a.entity)
+            st = self._entity_mgr.stale()
+            if st is not None:
+                keep.extend(st)
+                a.stale_quat = st[0].data_ptr()
+                a.stale_mask = st[1].data_ptr()
+                a.stale_mask2 = None if st[2] is None else st[2].data_ptr()
+            else:
+                a.stale_quat = a.stale_mask = a.stale_mask2 = None
+        if self._am is not None:
+            am = self._am
+            a.num_dofs = am.num_actions
+            ops = {a.items[k].op for k in range(a.num_items)}
+            if nat.GF_O_DOF_POS in ops:
+                t = am._scene_dofs("position"); keep.append(t); a.dof_pos = t.data_ptr()
+            if nat.GF_O_DOF_VEL in ops:
+                t = am._scene_dofs("velocity"); keep.append(t); a.dof_vel = t.data_ptr()
+            if nat.GF_O_DOF_FORCE in ops:
+                t = am._scene_dofs("force"); keep.append(t); a.dof_force = t.data_ptr()
+            a.targets = am._actions.data_ptr()
+        if env.actions is not None:
+            a.env_actions = env.actions.data_ptr()
+        # ext columns are [N, w]
+        n = env.num_envs
+        for k, src in enumerate(self._slots.cmds):
+            t = src.command
+            t = _col(t.unsqueeze(-1) if t.dim() == 1 else t, n, torch.float32)
+            keep.append(t)
+            a.command[k].command, a.command[k].width = t.data_ptr(), t.shape[1]
+        for k, (mgr, lv) in enumerate(self._slots.contacts):
+            keep.extend(mgr.view(a.contact[k], need_link_vel=False))
+        for k, prov in enumerate(self._slots.exts):
+            t = prov()
+            t = _col(t.unsqueeze(-1) if t.dim() == 1 else t, n, torch.float32)
+            keep.append(t)
+            a.ext[k] = t.data_ptr()
+        draws = env.take_draws(f"obs:{self._name}")
+        keep.append(draws)
+        a.noise_draws = None if draws is None else draws.data_ptr()
+        a.seed, a.stream = env._rng_seed, env.next_stream()
+        prev = self._bufs[self._cur]
+        self._cur = (self._cur + 1) % _OBS_RING
+        out = self._bufs[self._cur]
+        a.prev_obs = prev.data_ptr() if self._history_len > 1 else None
+        a.obs = out.data_ptr()
+        env.backend.call("observe", a)
+        self._keep = keep
+        return out

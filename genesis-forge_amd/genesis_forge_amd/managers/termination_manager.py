@@ -1,0 +1,109 @@
+"""
+TerminationManager — API mirror of genesis_forge/managers/termination_manager.py.
+
+``step`` (:151-190) is one ``gf_termination_step`` launch producing the persistent
+``terminated`` / ``truncated`` masks; the per-term "fired" counts behind the
+``"Terminations / <name>"`` log entries (:178-182, one ``nonzero()`` sync per term in the reference)
+are counted on device and read lazily.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Optional, TypedDict
+
+import torch
+
+from .. import _native as nat
+from .. import gs
+from ._program import TerminationProgram, spec_of
+from .base import BaseManager
+from .config import TerminationConfigItem
+
+
+class TerminationConfig(TypedDict):
+    fn: Callable[..., torch.Tensor]
+    params: dict[str, Any]
+    time_out: bool
+
+
+class TerminationManager(BaseManager):
+    """Calculates termination / truncation signals (ctor as termination_manager.py:96-118)."""
+
+    def __init__(self, env, term_cfg: dict[str, TerminationConfig], logging_enabled: bool = True, logging_tag: str = "Terminations"):
+        super().__init__(env, type="termination")
+        self.logging_enabled = logging_enabled
+        self.logging_tag = logging_tag
+        if len(term_cfg) > nat.GF_MAX_TERM_TERMS:
+            raise ValueError(f"TerminationManager supports at most {nat.GF_MAX_TERM_TERMS} terms")
+        self.term_cfg: dict[str, TerminationConfigItem] = {}
+        for name, cfg in term_cfg.items():
+            self.term_cfg[name] = TerminationConfigItem(cfg, env, on_dirty=self._mark_dirty)
+        self._terminated_buf = torch.zeros(env.num_envs, device=gs.device, dtype=torch.bool)
+        self._truncated_buf = torch.zeros_like(self._terminated_buf)
+        self._program: Optional[TerminationProgram] = None
+        self._dirty = True
+
+    def _mark_dirty(self):
+        self._dirty = True
+
+    @property
+    def dones(self) -> torch.Tensor:
+        return self._terminated_buf | self._truncated_buf
+
+    @property
+    def terminated(self) -> torch.Tensor:
+        return self._terminated_buf
+
+    @property
+    def truncated(self) -> torch.Tensor:
+        return self._truncated_buf
+
+    def build(self):
+        for cfg in self.term_cfg.values():
+            cfg.build()
+
+    def _compile(self):
+        env = self.env
+        prog = TerminationProgram(env)
+        for name, item in self.term_cfg.items():
+            fn, params = item.fn, item.params
+
+            def fallback(fn=fn, params=params, name=name):
+                try:
+                    return fn(env, **params)
+                except Exception as e:  # termination_manager.py:184-186
+                    print(f"Error calculating termination for '{name}'")
+                    raise e
+
+            prog.add(spec_of(fn, env, params), fallback, bool(item.time_out))
+        prog.args.terminated = self._terminated_buf.data_ptr()
+        prog.args.truncated = self._truncated_buf.data_ptr()
+        self._program = prog
+        self._dirty = False
+
+    def step(self) -> tuple[torch.Tensor, torch.Tensor]:
+        """termination_manager.py:151-190"""
+        if not self.enabled:
+            return self._terminated_buf, self._truncated_buf
+        env = self.env
+        if self._dirty:
+            self._compile()
+        self._program.args.stats = env.stats.ptr if self.logging_enabled else None
+        self._program.launch()
+        if self.logging_enabled:
+            log = env.extras[env.extras_logging_key]
+            names = list(self.term_cfg.keys())
+            tag = self.logging_tag
+
+            def fill(st, out, names=names, tag=tag, n=self._global_envs()):
+                for k, name in enumerate(names):
+                    if st.term_fired[k] > 0:  # key only present when the term fired (quirk q8)
+                        out[f"{tag} / {name}"] = torch.tensor(st.term_fired[k] / n, dtype=torch.float32)
+
+            if hasattr(log, "add_filler"):
+                log.add_filler(fill)
+        env.extras["terminations"] = self._terminated_buf
+        env.extras["time_outs"] = self._truncated_buf
+        return self._terminated_buf, self._truncated_buf
+
+    def _global_envs(self) -> int:
+        return getattr(self.env, "global_num_envs", self.env.num_envs)

@@ -1,0 +1,89 @@
+"""
+Entity reset functions — same names and arguments as genesis_forge/mdp/reset.py.
+
+``position`` (reset.py:67-124), used by every BASELINE config except rough_terrain, is absorbed into
+the fused masked reset when the scene exposes masked setters; called directly it behaves like the
+reference (index-list scatter through the entity's setters).  The others call straight into the
+entity's setters — there is no per-env math to fuse.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Literal
+
+import torch
+
+from .. import gs
+from ..managers.config import ResetMdpFnClass
+
+
+def zero_all_dofs_velocity(env, entity, envs_idx):
+    entity.zero_all_dofs_velocity(envs_idx)
+
+
+def xyz_to_quat(xyz: torch.Tensor) -> torch.Tensor:
+    """Euler xyz (radians, extrinsic x-y-z) → quaternion (w,x,y,z); stands in for genesis.utils.geom.xyz_to_quat."""
+    hx, hy, hz = xyz[..., 0] * 0.5, xyz[..., 1] * 0.5, xyz[..., 2] * 0.5
+    cx, sx, cy, sy, cz, sz = torch.cos(hx), torch.sin(hx), torch.cos(hy), torch.sin(hy), torch.cos(hz), torch.sin(hz)
+    return torch.stack([cx * cy * cz + sx * sy * sz, sx * cy * cz - cx * sy * sz, cx * sy * cz + sx * cy * sz,
+                        cx * cy * sz - sx * sy * cz], dim=-1)
+
+
+def set_rotation(env, entity, envs_idx, x=0, y=0, z=0):
+    """Absolute or randomised euler rotation (reset.py:33-64)."""
+    angle_buffer = torch.zeros((len(envs_idx), 3), device=gs.device)
+    for k, v in enumerate((x, y, z)):
+        if isinstance(v, tuple):
+            angle_buffer[:, k].uniform_(*v)
+        elif v:
+            angle_buffer[:, k] = v
+    entity.set_quat(xyz_to_quat(angle_buffer), envs_idx=envs_idx)
+
+
+class position(ResetMdpFnClass):
+    """Reset the entity to a fixed position and (optional) rotation (reset.py:67-124)."""
+
+    def __init__(self, env, entity, position, quat=None, zero_velocity: bool = True):
+        self.env = env
+        self.zero_velocity = zero_velocity
+        self.reset_pos = torch.tensor(position, device=gs.device, dtype=gs.tc_float)
+        self._pos_buffer = torch.zeros((env.num_envs, 3), device=gs.device, dtype=gs.tc_float)
+        self.reset_quat = None
+        self._quat_buffer = None
+        if quat is not None:
+            self.reset_quat = torch.tensor(quat, device=gs.device, dtype=gs.tc_float)
+            self._quat_buffer = torch.zeros((env.num_envs, 4), device=gs.device, dtype=gs.tc_float)
+
+    def __call__(self, env, entity, envs_idx, position=None, quat=None, zero_velocity: bool = True):
+        self._pos_buffer[envs_idx] = self.reset_pos
+        entity.set_pos(self._pos_buffer[envs_idx], envs_idx=envs_idx, zero_velocity=self.zero_velocity)
+        if self.reset_quat is not None:
+            self._quat_buffer[envs_idx] = self.reset_quat.reshape(1, -1)
+            entity.set_quat(self._quat_buffer[envs_idx], envs_idx=envs_idx, zero_velocity=self.zero_velocity)
+
+
+class randomize_terrain_position(ResetMdpFnClass):
+    """Random position on the terrain (reset.py:127-226), via TerrainManager.generate_random_env_pos."""
+
+    def __init__(self, env, entity, terrain_manager, height_offset: float = 0.1e-3, subterrain=None,
+                 rotation: dict | None = {"z": (0, 2 * math.pi)}, zero_velocity: bool = True):
+        self.env = env
+        self.zero_velocity = zero_velocity
+
+    def __call__(self, env, entity, envs_idx, terrain_manager, height_offset: float = 0.1e-3, subterrain=None,
+                 rotation: dict | None = {"z": (0, 2 * math.pi)}, zero_velocity: bool = True):
+        sub = subterrain() if callable(subterrain) else subterrain
+        pos = terrain_manager.generate_random_env_pos(envs_idx=envs_idx, subterrain=sub, height_offset=height_offset)
+        entity.set_pos(pos, envs_idx=envs_idx, zero_velocity=self.zero_velocity)
+        if rotation is not None:
+            set_rotation(env, entity, envs_idx, **rotation)
+
+
+def randomize_link_mass_shift(env, entity, envs_idx, link_name: str, add_mass_range: tuple[float, float]):
+    """Random mass shift of matching links (reset.py:229-284)."""
+    from ..utils import links_by_name_pattern
+    links = links_by_name_pattern(entity, link_name)
+    if not links:
+        return
+    shift = torch.empty(len(envs_idx), len(links), device=gs.device).uniform_(*add_mass_range)
+    entity.set_mass_shift(shift, links_idx_local=[l.idx_local for l in links], envs_idx=envs_idx)

@@ -304,6 +304,7 @@ typedef struct GfResetArgs {
     const float* dof_draws;     /* [N,D] U[0,1) or NULL → Philox (only read when noise_scale != 0) */
     float* scene_pos;           /* [N,3] ← reset_pos    (mdp.reset.position) */
     float* scene_quat;          /* [N,4] ← reset_quat   */
+    float* quat_stash;          /* [N,4] optional: receives the pre-reset quat of every reset env (see GfObservationArgs.stale_quat) */
     float* scene_lin_vel;       /* [N,3] ← 0 when zero_velocity */
     float* scene_ang_vel;       /* [N,3] ← 0 when zero_velocity */
     float reset_pos[3];
@@ -363,6 +364,13 @@ typedef struct GfObservationArgs {
     const float* noise_draws; /* [N,O] U[0,1) or NULL → Philox */
     uint64_t seed;
     uint64_t stream;
+    /* The reference's EntityManager caches base_quat at entity.step() and does not refresh it after the reset
+     * that follows in the same tick (entity_manager.py:163-167,189-195): body-frame items of envs that were just
+     * reset are rotated by their PRE-reset quaternion.  stale_quat (written by gf_masked_reset.quat_stash) supplies
+     * it for envs whose stale_mask|stale_mask2 byte is set; NULL disables. */
+    const float* stale_quat;  /* [N,4] */
+    const uint8_t* stale_mask;
+    const uint8_t* stale_mask2;
     const float* prev_obs;    /* [N,O*H] previous output (history shift source); NULL when H==1 */
     float* obs;               /* [N,O*H] out, newest frame first (observation_manager.py:224-226) */
     GfObsItem items[GF_MAX_OBS_ITEMS];
@@ -419,6 +427,7 @@ typedef struct GfSynthSceneArgs {
  * Entry points.  `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream).
  * ---------------------------------------------------------------------------------------- */
 int gf_abi_version(void);
+int gf_sizeof(int which);   /* sizeof of the ABI structs, in header order (0 = GfStepStats … 11 = GfObsItem): binding self-check */
 const char* gf_build_info(void);
 const char* gf_error_string(int code);
 

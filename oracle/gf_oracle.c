@@ -514,8 +514,11 @@ GFO_EXPORT int gfo_masked_reset(const GfResetArgs* a) {
         /* mdp.reset.position  reset.py:102-124 */
         if (a->scene_pos) {
             for (int j = 0; j < 3; ++j) a->scene_pos[3 * n + j] = a->reset_pos[j];
-            if (a->set_quat && a->scene_quat)
+            if (a->set_quat && a->scene_quat) {
+                if (a->quat_stash)
+                    for (int j = 0; j < 4; ++j) a->quat_stash[4 * n + j] = a->scene_quat[4 * n + j];
                 for (int j = 0; j < 4; ++j) a->scene_quat[4 * n + j] = a->reset_quat[j];
+            }
             if (a->zero_velocity) {
                 if (a->scene_lin_vel) for (int j = 0; j < 3; ++j) a->scene_lin_vel[3 * n + j] = 0.0f;
                 if (a->scene_ang_vel) for (int j = 0; j < 3; ++j) a->scene_ang_vel[3 * n + j] = 0.0f;
@@ -540,6 +543,10 @@ GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
     for (int64_t n = 0; n < N; ++n) {
         float* row = a->obs + n * O * H;
         int64_t col = 0;
+        /* entity_manager.py:189-195: quaternion cached before the reset of this tick */
+        GfEntityView ent = a->entity;
+        const int stale = a->stale_quat && ((a->stale_mask && a->stale_mask[n]) || (a->stale_mask2 && a->stale_mask2[n]));
+        if (stale) ent.quat = a->stale_quat;
         for (int i = 0; i < a->num_items; ++i) {
             const GfObsItem* it = &a->items[i];
             float tmp[GF_MAX_OBS_WIDTH];
@@ -548,9 +555,9 @@ GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
                     const GfCommandView* c = &a->command[it->i0];
                     for (int j = 0; j < it->width; ++j) tmp[j] = c->command[(int64_t)n * c->width + j];
                 } break;
-                case GF_O_ANG_VEL_BODY: body_ang_vel(&a->entity, n, tmp); break;
-                case GF_O_LIN_VEL_BODY: body_lin_vel(&a->entity, n, tmp); break;
-                case GF_O_PROJ_GRAVITY: proj_gravity(&a->entity, n, tmp); break;
+                case GF_O_ANG_VEL_BODY: body_ang_vel(&ent, n, tmp); break;
+                case GF_O_LIN_VEL_BODY: body_lin_vel(&ent, n, tmp); break;
+                case GF_O_PROJ_GRAVITY: proj_gravity(&ent, n, tmp); break;
                 case GF_O_DOF_POS: for (int j = 0; j < it->width; ++j) tmp[j] = a->dof_pos[n * D + j]; break;
                 case GF_O_DOF_VEL: for (int j = 0; j < it->width; ++j) tmp[j] = a->dof_vel[n * D + j]; break;
                 case GF_O_DOF_FORCE: for (int j = 0; j < it->width; ++j) tmp[j] = a->dof_force[n * D + j]; break;

@@ -1,0 +1,83 @@
+"""Task configs used by tests and bench.py, written in the reference's style
+(cf. examples/command_direction/environment.py:84-247): same managers, cfg dicts, weights."""
+import torch
+
+from genesis_forge_amd import ManagedEnvironment
+from genesis_forge_amd.managers import (ContactManager, EntityManager, ObservationManager, PositionActionManager, RewardManager,
+                                        TerminationManager, VelocityCommandManager)
+from genesis_forge_amd.mdp import reset, rewards, terminations, observations
+from genesis_forge_amd.scene import SyntheticScene, morphs
+
+INITIAL_BODY_POSITION = [0.0, 0.0, 0.4]
+INITIAL_QUAT = [1.0, 0.0, 0.0, 0.0]
+
+
+class Go2CommandDirectionEnv(ManagedEnvironment):
+    """BASELINE config 2: Go2 12-DOF, 6 rewards, 2 terminations, velocity command, 7 observation items (O=48)."""
+
+    def __init__(self, num_envs=1, dt=1 / 50, max_episode_length_s=20, scene_kwargs=None, obs_noise=False, fused_obs=True,
+                 contacts=False, history=None, cmd_resample_s=5.0):
+        super().__init__(num_envs=num_envs, dt=dt, max_episode_length_sec=max_episode_length_s, max_episode_random_scaling=0.1)
+        kw = dict(scene_kwargs or {})
+        if contacts:
+            kw.setdefault("max_collision_pairs", 12)
+        self._contacts, self._history, self._cmd_resample_s = contacts, history, cmd_resample_s
+        self.scene = SyntheticScene(dt=self.dt, substeps=2, **kw)
+        self.terrain = self.scene.add_entity(morphs.Plane())
+        self.robot = self.scene.add_entity(morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=INITIAL_BODY_POSITION, quat=INITIAL_QUAT))
+        self._obs_noise = obs_noise
+        self._fused_obs = fused_obs
+
+    def config(self):
+        self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={
+            "position": {"fn": reset.position, "params": {"position": INITIAL_BODY_POSITION, "quat": INITIAL_QUAT, "zero_velocity": True}}})
+        self.action_manager = PositionActionManager(
+            self, joint_names=["FL_.*_joint", "FR_.*_joint", "RL_.*_joint", "RR_.*_joint"],
+            default_pos={".*_hip_joint": 0.0, "FL_thigh_joint": 0.8, "FR_thigh_joint": 0.8, "RL_thigh_joint": 1.0, "RR_thigh_joint": 1.0,
+                         ".*_calf_joint": -1.5},
+            scale=0.25, use_default_offset=True, pd_kp=20, pd_kv=0.5)
+        self.velocity_command = VelocityCommandManager(
+            self, range={"lin_vel_x": [-1.0, 1.0], "lin_vel_y": [-1.0, 1.0], "ang_vel_z": [-1.0, 1.0]}, standing_probability=0.02,
+            resample_time_sec=self._cmd_resample_s)
+        rcfg = {
+            "base_height_target": {"weight": -50.0, "fn": rewards.base_height, "params": {"target_height": 0.3, "entity_attr": "robot"}},
+            "tracking_lin_vel": {"weight": 1.0, "fn": rewards.command_tracking_lin_vel,
+                                 "params": {"vel_cmd_manager": self.velocity_command, "entity_manager": self.robot_manager}},
+            "tracking_ang_vel": {"weight": 0.5, "fn": rewards.command_tracking_ang_vel,
+                                 "params": {"vel_cmd_manager": self.velocity_command, "entity_manager": self.robot_manager}},
+            "lin_vel_z": {"weight": -1.0, "fn": rewards.lin_vel_z_l2, "params": {"entity_manager": self.robot_manager}},
+            "action_rate": {"weight": -0.005, "fn": rewards.action_rate_l2},
+            "similar_to_default": {"weight": -0.1, "fn": rewards.dof_similar_to_default, "params": {"action_manager": self.action_manager}},
+        }
+        tcfg = {
+            "timeout": {"fn": terminations.timeout, "time_out": True},
+            "fall_over": {"fn": terminations.bad_orientation, "params": {"limit_angle": 10.0, "entity_manager": self.robot_manager}},
+        }
+        if self._contacts:
+            self.foot_contacts = ContactManager(self, link_names=[".*_foot"], track_air_time=True, air_time_contact_threshold=5.0)
+            self.body_contacts = ContactManager(self, link_names=[".*_thigh", "base"])
+            rcfg["foot_air_time"] = {"weight": 2.5, "fn": rewards.feet_air_time,
+                                     "params": {"contact_manager": self.foot_contacts, "time_threshold": 0.05,
+                                                "vel_cmd_manager": self.velocity_command}}
+            rcfg["undesired_contacts"] = {"weight": -1.0, "fn": rewards.has_contact,
+                                          "params": {"contact_manager": self.body_contacts, "threshold": 5.0}}
+            rcfg["ang_vel_xy"] = {"weight": -0.05, "fn": rewards.ang_vel_xy_l2, "params": {"entity_manager": self.robot_manager}}
+            rcfg["flat_orientation"] = {"weight": -2.5, "fn": rewards.flat_orientation_l2, "params": {"entity_manager": self.robot_manager}}
+            rcfg["terminated"] = {"weight": -100.0, "fn": rewards.terminated}
+            rcfg["zero_weight"] = {"weight": 0.0, "fn": rewards.is_alive}
+            tcfg["body_contact"] = {"fn": terminations.contact_force, "params": {"contact_manager": self.body_contacts, "threshold": 30.0}}
+        self.reward_manager = RewardManager(self, logging_enabled=True, cfg=rcfg)
+        self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg=tcfg)
+        noise = 0.01 if self._obs_noise else None
+        ocfg = {
+            "velocity_cmd": {"fn": self.velocity_command.observation},
+            "angle_velocity": {"fn": lambda env: self.robot_manager.get_angular_velocity(), "noise": noise},
+            "linear_velocity": {"fn": lambda env: self.robot_manager.get_linear_velocity()},
+            "projected_gravity": {"fn": lambda env: self.robot_manager.get_projected_gravity()},
+            "dof_position": {"fn": lambda env: self.action_manager.get_dofs_position()},
+            "dof_velocity": {"fn": lambda env: self.action_manager.get_dofs_velocity(), "scale": 0.05},
+            "actions": {"fn": lambda env: self.action_manager.get_actions()},
+        }
+        if self._contacts:
+            ocfg["foot_force"] = {"fn": observations.contact_force, "params": {"contact_manager": self.foot_contacts}, "scale": 0.1}
+        self.observation_manager = ObservationManager(self, fused=self._fused_obs, cfg=ocfg, history_len=self._history)

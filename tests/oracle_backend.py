@@ -1,0 +1,34 @@
+"""Test-only backend: routes the package's phase calls to the CPU oracle (host pointers).
+Lives under tests/ on purpose — the product package never imports anything from oracle/."""
+import ctypes as C
+
+from genesis_forge_amd import _native as nat
+
+
+class OracleBackend(nat.Backend):
+    name = "oracle"
+    device_type = "cpu"
+
+    def __init__(self, path: str):
+        self.lib = C.CDLL(path)
+        nat.check_abi(self.lib, "gfo_")
+        self._fn = {}
+        for name, st in nat.PHASE_FUNCS.items():
+            f = getattr(self.lib, "gfo_" + name)
+            f.restype = C.c_int
+            f.argtypes = [C.POINTER(st)]
+            self._fn[name] = f
+        self.lib.gfo_stats_clear.restype = C.c_int
+        self.lib.gfo_stats_clear.argtypes = [C.c_void_p]
+        self.calls = []
+
+    def call(self, fn, args):
+        self.calls.append(fn)
+        rc = self._fn[fn](C.byref(args))
+        if rc != 0:
+            raise nat.GfError(f"gfo_{fn} failed: {nat.GF_ERRORS.get(rc, rc)}")
+
+    def stats_clear(self, stats_ptr):
+        rc = self.lib.gfo_stats_clear(stats_ptr)
+        if rc != 0:
+            raise nat.GfError(f"gfo_stats_clear failed: {rc}")

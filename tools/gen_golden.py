@@ -1,0 +1,508 @@
+#!/usr/bin/env python3
+"""
+Generate tests/golden/*.npz by running the REFERENCE (/root/reference/genesis_forge, imported with the
+stubs of tools/ref_stubs.py) and recording its inputs and outputs.  Runs only in the build container
+(the reference never travels); the fixtures are data and are committed.
+
+The reference drives the same synthetic scene the package uses (through its Genesis-style public API,
+stepped by the CPU oracle), its uniform_ calls are served from Philox draws (tests/philox.py) that the
+tests feed to the kernels in parity mode, so a fixture pins the reference's manager logic — phase
+order, which envs resample/reset, weights, op order — not torch's RNG stream.
+
+Usage: python tools/gen_golden.py            (rewrites every fixture)
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402
+
+my_scene = ref_stubs.install()
+
+import philox  # noqa: E402  (tests/)
+from oracle_backend import OracleBackend  # noqa: E402  (tests/)
+from genesis_forge_amd import _native as nat  # noqa: E402
+
+nat.set_backend(OracleBackend(os.path.join(ROOT, "oracle", "libgf_oracle.so")))
+
+import genesis_forge as ref  # noqa: E402  — the reference
+from genesis_forge.managers import (ContactManager, EntityManager, ObservationManager, PositionActionManager,  # noqa: E402
+                                    PositionWithinLimitsActionManager, RewardManager, TerminationManager, VelocityCommandManager,
+                                    CommandManager)
+from genesis_forge.mdp import reset, rewards, terminations, observations  # noqa: E402
+
+assert ref.__file__.startswith("/root/reference"), ref.__file__
+GOLD = os.path.join(ROOT, "tests", "golden")
+SEED = 20251017
+
+# ------------------------------------------------------------------------------------------------
+# uniform_ interception: the reference's draws come from dense Philox arrays chosen by context
+# ------------------------------------------------------------------------------------------------
+CTX = {"mode": None}
+_orig_uniform = torch.Tensor.uniform_
+
+
+def _patched_uniform(self, lo=0.0, hi=1.0):
+    mode = CTX["mode"]
+    if mode is None:
+        raise RuntimeError("uniform_ outside a known context")
+    lo32, hi32 = np.float32(lo), np.float32(hi)
+    if mode == "len":       # genesis_env.py:249
+        u = CTX["u"][CTX["ids"], 0]
+    elif mode == "cmd":     # command_manager.py:302 — i-th call fills range i
+        u = CTX["u"][CTX["ids"], CTX["i"]]
+        CTX["i"] += 1
+    elif mode == "obs":     # observation_manager.py:249 — next noisy item's columns
+        c0, w = CTX["cols"].pop(0)
+        u = CTX["u"][:, c0:c0 + w]
+    else:
+        raise RuntimeError(mode)
+    val = (u.astype(np.float32) * np.float32(hi32 - lo32) + lo32).astype(np.float32)
+    self.copy_(torch.from_numpy(np.ascontiguousarray(val)).reshape(self.shape))
+    return self
+
+
+torch.Tensor.uniform_ = _patched_uniform
+
+
+class Draws:
+    """Per-step dense draws, shared convention with tests (philox.draws)."""
+
+    def __init__(self, n, n_ranges, obs_width):
+        self.n, self.r, self.o = n, n_ranges, obs_width
+        self.step = 0
+
+    def get(self, kind, cols):
+        return philox.draws(SEED, self.step, kind, self.n, cols)
+
+
+def _ids_np(ids, n):
+    if ids is None:
+        return np.arange(n)
+    return np.asarray(torch.as_tensor(ids).cpu().numpy(), dtype=np.int64)
+
+
+_HOLD = {"draws": None, "installed": False}
+
+
+class _DrawsProxy:
+    def get(self, kind, cols):
+        return _HOLD["draws"].get(kind, cols)
+
+
+def install_contexts(env, draws_obj: Draws):
+    """Wrap the reference methods that consume RNG so the patched uniform_ knows what is being drawn."""
+    _HOLD["draws"] = draws_obj
+    if _HOLD["installed"]:
+        return
+    _HOLD["installed"] = True
+    draws = _DrawsProxy()
+    from genesis_forge import genesis_env as ge
+    from genesis_forge.managers.command import command_manager as cm
+    from genesis_forge.managers import observation_manager as om
+
+    orig_reset = ge.GenesisEnv.reset
+
+    def reset_wrap(self, envs_idx=None):
+        CTX.update(mode="len", ids=_ids_np(envs_idx, self.num_envs), u=draws.get(2, 1))
+        try:
+            return orig_reset(self, envs_idx)
+        finally:
+            CTX["mode"] = None
+
+    ge.GenesisEnv.reset = reset_wrap
+
+    orig_resample = cm.CommandManager.resample_command
+
+    def resample_wrap(self, env_ids):
+        kind = 0 if CTX.get("cmd_phase") == "step" else 1
+        CTX.update(mode="cmd", ids=_ids_np(env_ids, self.env.num_envs), i=0, u=draws.get(kind, self._command.shape[1]))
+        try:
+            return orig_resample(self, env_ids)
+        finally:
+            CTX["mode"] = None
+
+    cm.CommandManager.resample_command = resample_wrap
+
+    orig_step = cm.CommandManager.step
+
+    def step_wrap(self):
+        CTX["cmd_phase"] = "step"
+        try:
+            return orig_step(self)
+        finally:
+            CTX["cmd_phase"] = None
+
+    cm.CommandManager.step = step_wrap
+
+    orig_perform = om.ObservationManager._perform_observation
+
+    def perform_wrap(self):
+        cols, c = [], 0
+        for name, cfg in self.cfg.items():
+            w = OBS_WIDTHS[(self.name, name)]
+            noise = cfg.noise or self.noise
+            if noise is not None and noise != 0.0:
+                cols.append((c, w))
+            c += w
+        CTX.update(mode="obs", cols=cols, u=draws.get(3, c))
+        try:
+            return orig_perform(self)
+        finally:
+            CTX["mode"] = None
+
+    om.ObservationManager._perform_observation = perform_wrap
+
+
+OBS_WIDTHS = {}
+
+INITIAL_BODY_POSITION = [0.0, 0.0, 0.4]
+INITIAL_QUAT = [1.0, 0.0, 0.0, 0.0]
+GO2_DEFAULT = {".*_hip_joint": 0.0, "FL_thigh_joint": 0.8, "FR_thigh_joint": 0.8, "RL_thigh_joint": 1.0, "RR_thigh_joint": 1.0,
+               ".*_calf_joint": -1.5}
+GO2_JOINTS = ["FL_.*_joint", "FR_.*_joint", "RL_.*_joint", "RR_.*_joint"]
+
+
+class RefGo2Env(ref.ManagedEnvironment):
+    """Reference ManagedEnvironment on the synthetic scene; manager cfg mirrors the command_direction example's values."""
+
+    def __init__(self, num_envs, episode_s=20, scene_kwargs=None, contacts=False, obs_noise=True, history=None, variant="cmd"):
+        super().__init__(num_envs=num_envs, dt=1 / 50, max_episode_length_sec=episode_s, max_episode_random_scaling=0.1)
+        kw = dict(scene_kwargs or {})
+        if contacts:
+            kw.setdefault("max_collision_pairs", 12)
+        self.scene = my_scene.SyntheticScene(dt=self.dt, substeps=2, **kw)
+        self.terrain = self.scene.add_entity(my_scene.morphs.Plane())
+        self.robot = self.scene.add_entity(my_scene.morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=INITIAL_BODY_POSITION, quat=INITIAL_QUAT))
+        self._contacts, self._obs_noise, self._history, self._variant = contacts, obs_noise, history, variant
+
+    def config(self):
+        self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={
+            "position": {"fn": reset.position, "params": {"position": INITIAL_BODY_POSITION, "quat": INITIAL_QUAT, "zero_velocity": True}}})
+        self.action_manager = PositionActionManager(self, joint_names=GO2_JOINTS, default_pos=GO2_DEFAULT, scale=0.25,
+                                                    use_default_offset=True, pd_kp=20, pd_kv=0.5)
+        self.velocity_command = VelocityCommandManager(
+            self, range={"lin_vel_x": [-1.0, 1.0], "lin_vel_y": [-1.0, 1.0], "ang_vel_z": [-1.0, 1.0]}, standing_probability=0.02,
+            resample_time_sec=CMD_RESAMPLE_S)
+        rcfg = {
+            "base_height_target": {"weight": -50.0, "fn": rewards.base_height, "params": {"target_height": 0.3, "entity_attr": "robot"}},
+            "tracking_lin_vel": {"weight": 1.0, "fn": rewards.command_tracking_lin_vel,
+                                 "params": {"vel_cmd_manager": self.velocity_command, "entity_manager": self.robot_manager}},
+            "tracking_ang_vel": {"weight": 0.5, "fn": rewards.command_tracking_ang_vel,
+                                 "params": {"vel_cmd_manager": self.velocity_command, "entity_manager": self.robot_manager}},
+            "lin_vel_z": {"weight": -1.0, "fn": rewards.lin_vel_z_l2, "params": {"entity_manager": self.robot_manager}},
+            "action_rate": {"weight": -0.005, "fn": rewards.action_rate_l2},
+            "similar_to_default": {"weight": -0.1, "fn": rewards.dof_similar_to_default, "params": {"action_manager": self.action_manager}},
+        }
+        tcfg = {
+            "timeout": {"fn": terminations.timeout, "time_out": True},
+            "fall_over": {"fn": terminations.bad_orientation, "params": {"limit_angle": 10.0, "entity_manager": self.robot_manager}},
+        }
+        if self._contacts:
+            self.foot_contacts = ContactManager(self, link_names=[".*_foot"], track_air_time=True, air_time_contact_threshold=5.0)
+            self.body_contacts = ContactManager(self, link_names=[".*_thigh", "base"])
+            rcfg["foot_air_time"] = {"weight": 2.5, "fn": rewards.feet_air_time,
+                                     "params": {"contact_manager": self.foot_contacts, "time_threshold": 0.05,
+                                                "vel_cmd_manager": self.velocity_command}}
+            rcfg["undesired_contacts"] = {"weight": -1.0, "fn": rewards.has_contact,
+                                          "params": {"contact_manager": self.body_contacts, "threshold": 5.0}}
+            rcfg["ang_vel_xy"] = {"weight": -0.05, "fn": rewards.ang_vel_xy_l2, "params": {"entity_manager": self.robot_manager}}
+            rcfg["flat_orientation"] = {"weight": -2.5, "fn": rewards.flat_orientation_l2, "params": {"entity_manager": self.robot_manager}}
+            rcfg["terminated"] = {"weight": -100.0, "fn": rewards.terminated}
+            rcfg["zero_weight"] = {"weight": 0.0, "fn": rewards.is_alive}
+            tcfg["body_contact"] = {"fn": terminations.contact_force, "params": {"contact_manager": self.body_contacts, "threshold": 30.0}}
+        RewardManager(self, logging_enabled=True, cfg=rcfg)
+        self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg=tcfg)
+        noise = 0.01 if self._obs_noise else None
+        ocfg = {
+            "velocity_cmd": {"fn": self.velocity_command.observation},
+            "angle_velocity": {"fn": lambda env: self.robot_manager.get_angular_velocity(), "noise": noise},
+            "linear_velocity": {"fn": lambda env: self.robot_manager.get_linear_velocity()},
+            "projected_gravity": {"fn": lambda env: self.robot_manager.get_projected_gravity()},
+            "dof_position": {"fn": lambda env: self.action_manager.get_dofs_position()},
+            "dof_velocity": {"fn": lambda env: self.action_manager.get_dofs_velocity(), "scale": 0.05},
+            "actions": {"fn": lambda env: self.action_manager.get_actions()},
+        }
+        widths = [3, 3, 3, 3, 12, 12, 12]
+        if self._contacts:
+            ocfg["foot_force"] = {"fn": observations.contact_force, "params": {"contact_manager": self.foot_contacts}, "scale": 0.1}
+            widths.append(4)
+        for (k, w) in zip(ocfg.keys(), widths):
+            OBS_WIDTHS[("policy", k)] = w
+        ObservationManager(self, cfg=ocfg, history_len=self._history)
+
+
+CMD_RESAMPLE_S = 1.0
+
+
+def episode_scalars(extras):
+    return {k: float(v) for k, v in extras["episode"].items()}
+
+
+def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2):
+    torch.manual_seed(0)
+    env = RefGo2Env(n, episode_s=episode_s, scene_kwargs=scene_kwargs, contacts=contacts, history=history)
+    obs_w = 48 + (4 if contacts else 0)
+    draws = Draws(n, 3, obs_w)
+    install_contexts(env, draws)
+    draws.step = 0
+    env.build()
+    obs0, _ = env.reset()
+    rng = np.random.RandomState(7)
+    rec = {k: [] for k in ("actions", "obs", "reward", "terminated", "truncated", "command", "episode_length", "max_episode_length")}
+    logs = []
+    for t in range(steps):
+        draws.step = t + 1
+        act = rng.standard_normal((n, 12)).astype(np.float32)
+        if t == 5:
+            act[0, 0] = 1e9  # clip path
+        obs, rew, term, trunc, extras = env.step(torch.from_numpy(act))
+        rec["actions"].append(act)
+        rec["obs"].append(obs.numpy().copy())
+        rec["reward"].append(rew.numpy().copy())
+        rec["terminated"].append(term.numpy().copy())
+        rec["truncated"].append(trunc.numpy().copy())
+        rec["command"].append(env.velocity_command._command.numpy().copy())
+        rec["episode_length"].append(env.episode_length.numpy().copy())
+        rec["max_episode_length"].append(env.max_episode_length.numpy().copy())
+        logs.append(episode_scalars(extras))
+    keys = sorted({k for d in logs for k in d})
+    log_arr = np.full((steps, len(keys)), np.nan, dtype=np.float64)
+    for t, d in enumerate(logs):
+        for j, k in enumerate(keys):
+            if k in d:
+                log_arr[t, j] = d[k]
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(obs0=obs0.numpy().copy(), log_keys=np.array(keys), log_values=log_arr, seed=np.int64(SEED), n=np.int64(n),
+               steps=np.int64(steps), contacts=np.int64(contacts), history=np.int64(history or 1), episode_s=np.float64(episode_s),
+               cmd_resample_s=np.float64(CMD_RESAMPLE_S), scene_kwargs=np.array(repr(scene_kwargs)))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "steps", steps, "terminated", int(out["terminated"].sum()), "truncated", int(out["truncated"].sum()),
+          "log keys", len(keys))
+
+
+# ------------------------------------------------------------------------------------------------
+# Unit fixtures: every mdp.rewards / mdp.terminations term on random states
+# ------------------------------------------------------------------------------------------------
+def random_state(env, rng, n):
+    r = env.robot
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    r.pos[:] = torch.tensor([0.0, 0.0, 0.35]) + 0.05 * f(n, 3)
+    q = torch.tensor([1.0, 0.0, 0.0, 0.0]) + 0.1 * f(n, 4)
+    r.quat[:] = q / q.norm(dim=-1, keepdim=True)
+    r.lin_vel[:] = f(n, 3)
+    r.ang_vel[:] = f(n, 3)
+    r.dof_pos[:] = env.action_manager.default_dofs_pos + 0.3 * f(n, 12)
+    r.dof_vel[:] = 2.0 * f(n, 12)
+    r.links_vel = f(n, r.n_links, 3)
+    env.velocity_command._command[:] = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32))
+    env.velocity_command._command[: n // 8, :2] *= 0.05  # some near-zero commands
+    env._actions = f(n, 12)
+    env._last_actions = f(n, 12)
+    env.episode_length[:] = torch.from_numpy(rng.randint(0, 1100, n).astype(np.int32))
+    env.max_episode_length[:] = torch.from_numpy(rng.randint(900, 1100, n).astype(np.int32))
+    for cm_ in env.managers["contact"]:
+        L = cm_.contacts.shape[1]
+        cm_.contacts[:] = 6.0 * f(n, L, 3) * torch.from_numpy((rng.uniform(size=(n, L, 1)) < 0.6).astype(np.float32))
+        if cm_.last_air_time is not None:
+            cm_.last_air_time[:] = torch.from_numpy(rng.uniform(0, 0.6, (n, L)).astype(np.float32))
+            cct = rng.uniform(0, 0.1, (n, L)).astype(np.float32)
+            cct[rng.uniform(size=(n, L)) < 0.3] = np.float32(0.02)  # exactly dt: "just made contact"
+            cct[rng.uniform(size=(n, L)) < 0.3] = 0.0
+            cm_.current_contact_time[:] = torch.from_numpy(cct)
+    for em in env.managers["entity"]:
+        em.step()
+    env.extras["terminations"] = torch.from_numpy(rng.uniform(size=n) < 0.2)
+
+
+def state_dict(env):
+    r = env.robot
+    d = dict(pos=r.pos, quat=r.quat, lin_vel=r.lin_vel, ang_vel=r.ang_vel, dof_pos=r.dof_pos, dof_vel=r.dof_vel, links_vel=r.links_vel,
+             command=env.velocity_command._command, actions=env._actions, last_actions=env._last_actions,
+             episode_length=env.episode_length, max_episode_length=env.max_episode_length, terminations=env.extras["terminations"])
+    for k, cm_ in enumerate(env.managers["contact"]):
+        d[f"contacts{k}"] = cm_.contacts
+        if cm_.last_air_time is not None:
+            d[f"last_air{k}"] = cm_.last_air_time
+            d[f"cur_contact{k}"] = cm_.current_contact_time
+    return {k: v.numpy().copy() for k, v in d.items()}
+
+
+def gen_terms():
+    n = 257
+    env = RefGo2Env(n, contacts=True, obs_noise=False)
+    env.build()
+    rng = np.random.RandomState(11)
+    random_state(env, rng, n)
+    out = {"in_" + k: v for k, v in state_dict(env).items()}
+    em, am, vc = env.robot_manager, env.action_manager, env.velocity_command
+    foot, body = env.foot_contacts, env.body_contacts
+    explicit_cmd = torch.from_numpy(rng.uniform(-1, 1, (n, 2)).astype(np.float32))
+    explicit_ang = torch.from_numpy(rng.uniform(-1, 1, (n,)).astype(np.float32))
+    out["in_explicit_cmd"], out["in_explicit_ang"] = explicit_cmd.numpy(), explicit_ang.numpy()
+    bacc = rewards.body_acceleration_exp(env, entity_manager=em)
+    R = {
+        "is_alive": rewards.is_alive(env),
+        "terminated": rewards.terminated(env),
+        "base_height": rewards.base_height(env, target_height=0.3),
+        "dof_similar_to_default": rewards.dof_similar_to_default(env, action_manager=am),
+        "lin_vel_z_l2": rewards.lin_vel_z_l2(env, entity_manager=em),
+        "lin_vel_z_l2_attr": rewards.lin_vel_z_l2(env, entity_attr="robot"),
+        "ang_vel_xy_l2": rewards.ang_vel_xy_l2(env, entity_manager=em),
+        "flat_orientation_l2": rewards.flat_orientation_l2(env, entity_manager=em),
+        "body_acceleration_exp_first": bacc(env, entity_manager=em),
+        "action_rate_l2": rewards.action_rate_l2(env),
+        "command_tracking_lin_vel": rewards.command_tracking_lin_vel(env, vel_cmd_manager=vc, entity_manager=em),
+        "command_tracking_lin_vel_explicit": rewards.command_tracking_lin_vel(env, command=explicit_cmd, entity_manager=em, sensitivity=0.5),
+        "command_tracking_ang_vel": rewards.command_tracking_ang_vel(env, vel_cmd_manager=vc, entity_manager=em),
+        "command_tracking_ang_vel_explicit": rewards.command_tracking_ang_vel(env, commanded_ang_vel=explicit_ang, entity_manager=em),
+        "stand_still": rewards.stand_still_joint_deviation_l1(env, vel_cmd_manager=vc, action_manager=am),
+        "has_contact": rewards.has_contact(env, contact_manager=body, threshold=5.0, min_contacts=2),
+        "contact_force": rewards.contact_force(env, contact_manager=body, threshold=2.0),
+        "feet_air_time": rewards.feet_air_time(env, contact_manager=foot, time_threshold=0.2, vel_cmd_manager=vc),
+        "feet_air_time_max": rewards.feet_air_time(env, contact_manager=foot, time_threshold=0.2, time_threshold_max=0.5),
+        "feet_slide": rewards.feet_slide(env, contact_manager=foot),
+    }
+    # second call of the stateful term with a new state
+    prev = state_dict(env)
+    random_state(env, rng, n)
+    out.update({"in2_" + k: v for k, v in state_dict(env).items()})
+    R["body_acceleration_exp_second"] = bacc(env, entity_manager=em, sensitivity=0.1)
+    # restore first state for terminations
+    T = {}
+    for ang in (10.0, 20.0, 30.0, 40.0):
+        T[f"bad_orientation_{int(ang)}"] = terminations.bad_orientation(env, limit_angle=ang, entity_manager=em)
+    T["bad_orientation_grace"] = terminations.bad_orientation(env, limit_angle=10.0, entity_manager=em, grace_steps=500)
+    T["timeout"] = terminations.timeout(env)
+    T["base_height_below"] = terminations.base_height_below_minimum(env, minimum_height=0.33, entity_manager=em)
+    T["has_contact"] = terminations.has_contact(env, contact_manager=body, threshold=5.0, min_contacts=2)
+    T["contact_force"] = terminations.contact_force(env, contact_manager=body, threshold=8.0)
+    T["contact_force_grace"] = terminations.contact_force_with_grace_period(env, contact_manager=body, threshold=8.0, grace_steps=400)
+
+    class _TM:
+        def get_bounds(self, sub=None):
+            return (-0.1, 0.1, -0.08, 0.12)
+
+    T["out_of_bounds"] = terminations.out_of_bounds(env, terrain_manager=_TM(), border_margin=0.03)
+    for k, v in R.items():
+        out["rew_" + k] = v.detach().numpy().astype(np.float32)
+    for k, v in T.items():
+        out["term_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(GOLD, "terms_go2.npz"), **out)
+    print("terms_go2:", len(R), "reward outputs,", len(T), "termination outputs")
+
+
+def gen_orientation_sweep():
+    """Dense sweep of quaternions whose tilt sits within a few ulps of each threshold."""
+    env = RefGo2Env(8, obs_noise=False)
+    env.build()
+    quats, masks, angs = [], [], []
+    for ang in (10.0, 20.0, 30.0, 40.0, 85.0):
+        thr = math.radians(ang) if ang < 82 else math.asin(0.99)
+        base = np.float32(min(thr, math.asin(0.99)))
+        tilt = base + np.arange(-600, 601, dtype=np.float64) * 2e-8
+        # rotation about x by tilt: q = (cos(t/2), sin(t/2), 0, 0) → |g_xy| = sin(tilt)
+        for axis in (1, 2):
+            q = np.zeros((tilt.size, 4), dtype=np.float64)
+            q[:, 0] = np.cos(tilt / 2)
+            q[:, axis] = np.sin(tilt / 2)
+            q32 = q.astype(np.float32)
+            n = q32.shape[0]
+            env2 = env
+            res = []
+            for s in range(0, n, 8):
+                chunk = q32[s:s + 8]
+                m = chunk.shape[0]
+                env2.robot.quat[:m] = torch.from_numpy(chunk)
+                env2.robot_manager.step()
+                env2.episode_length[:] = 5
+                r = terminations.bad_orientation(env2, limit_angle=ang, entity_manager=env2.robot_manager)
+                res.append(r.numpy()[:m].copy())
+            quats.append(q32)
+            masks.append(np.concatenate(res))
+            angs.append(np.full(n, ang, dtype=np.float32))
+    np.savez_compressed(os.path.join(GOLD, "orientation_sweep.npz"), quat=np.concatenate(quats), mask=np.concatenate(masks),
+                        limit=np.concatenate(angs))
+    print("orientation_sweep:", sum(m.size for m in masks), "cases,", int(sum(m.sum() for m in masks)), "fired")
+
+
+def gen_action():
+    n = 65
+    out = {}
+    for cls, key in ((PositionActionManager, "position"), (PositionWithinLimitsActionManager, "within")):
+        class E(ref.ManagedEnvironment):
+            def __init__(self):
+                super().__init__(num_envs=n, dt=1 / 50, max_episode_length_sec=20)
+                self.scene = my_scene.SyntheticScene(dt=self.dt)
+                self.terrain = self.scene.add_entity(my_scene.morphs.Plane())
+                self.robot = self.scene.add_entity(my_scene.morphs.URDF(file="go2"))
+
+            def config(self):
+                if cls is PositionActionManager:
+                    self.am = cls(self, joint_names=GO2_JOINTS, default_pos=GO2_DEFAULT, scale={".*_hip_joint": 0.5, ".*": 0.25},
+                                  clip={".*_calf_joint": (-2.0, -1.0)}, quiet_action_errors=True)
+                else:
+                    self.am = cls(self, joint_names=GO2_JOINTS, default_pos=GO2_DEFAULT, quiet_action_errors=True)
+
+        env = E()
+        env.build()
+        env.reset()
+        rng = np.random.RandomState(3)
+        acts, targets, env_actions, env_last, eplen = [], [], [], [], []
+        for t in range(3):
+            a = (3.0 * rng.standard_normal((n, 12))).astype(np.float32)
+            if t == 1:
+                a[0, 0], a[1, 1], a[2, 2], a[3, 3] = np.nan, np.inf, -np.inf, 1e30
+            env.step(torch.from_numpy(a.copy()))
+            acts.append(a)
+            targets.append(env.am.get_actions().numpy().copy())
+            env_actions.append(env.actions.numpy().copy())
+            env_last.append(env.last_actions.numpy().copy())
+            eplen.append(env.episode_length.numpy().copy())
+        out.update({f"{key}_actions": np.stack(acts), f"{key}_targets": np.stack(targets), f"{key}_env_actions": np.stack(env_actions),
+                    f"{key}_env_last": np.stack(env_last), f"{key}_episode_length": np.stack(eplen)})
+    np.savez_compressed(os.path.join(GOLD, "action.npz"), **out)
+    print("action: ok")
+
+
+def gen_air_time():
+    """ContactManager._calculate_air_time over a scripted contact sequence (contact_manager.py:434-477)."""
+    n = 33
+    env = RefGo2Env(n, contacts=True, obs_noise=False)
+    env.build()
+    cm_ = env.foot_contacts
+    rng = np.random.RandomState(5)
+    seq, states = [], []
+    for t in range(14):
+        c = (8.0 * rng.standard_normal((n, 4, 3)) * (rng.uniform(size=(n, 4, 1)) < 0.5)).astype(np.float32)
+        cm_.contacts[:] = torch.from_numpy(c)
+        cm_._calculate_air_time()
+        seq.append(c)
+        states.append(np.stack([cm_.last_air_time.numpy(), cm_.current_air_time.numpy(), cm_.last_contact_time.numpy(),
+                                cm_.current_contact_time.numpy()]).copy())
+        if t == 9:
+            cm_.reset(torch.tensor([0, 5, 7]))
+            states[-1] = np.stack([cm_.last_air_time.numpy(), cm_.current_air_time.numpy(), cm_.last_contact_time.numpy(),
+                                   cm_.current_contact_time.numpy()]).copy()
+    made = cm_.has_made_contact(env.dt).numpy()
+    np.savez_compressed(os.path.join(GOLD, "air_time.npz"), contacts=np.stack(seq), states=np.stack(states), made_contact=made,
+                        threshold=np.float32(5.0), dt=np.float64(env.scene.dt), reset_step=np.int64(9), reset_ids=np.array([0, 5, 7]))
+    print("air_time: ok")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    gen_terms()
+    gen_orientation_sweep()
+    gen_action()
+    gen_air_time()
+    run_trajectory("traj_go2_cmd", n=12, steps=260, contacts=False, history=None,
+                   scene_kwargs=dict(ang_noise=0.35, lin_noise=0.05, seed=99))
+    run_trajectory("traj_go2_contacts_hist", n=10, steps=160, contacts=True, history=3,
+                   scene_kwargs=dict(ang_noise=0.3, lin_noise=0.05, seed=5, contact_prob=0.3, contact_force=30.0))
