@@ -26,22 +26,22 @@ _RING = 64
 class StatsSnapshot:
     """One step's statistics; ``wait()`` returns a host GfStepStats once the copy has landed."""
 
-    __slots__ = ("_host", "_event", "_value", "_reduce")
+    __slots__ = ("_host", "_event", "_value", "_is_vector")
 
-    def __init__(self, host: torch.Tensor, event, reduce: Optional[Callable] = None):
+    def __init__(self, host: torch.Tensor, event, is_vector: bool = False):
         self._host = host
         self._event = event
         self._value = None
-        self._reduce = reduce
+        self._is_vector = is_vector
 
     def wait(self) -> nat.GfStepStats:
         if self._value is None:
             if self._event is not None:
                 self._event.synchronize()
-            buf = self._host.numpy().tobytes()
-            st = nat.GfStepStats.from_buffer_copy(buf)
-            if self._reduce is not None:
-                st = self._reduce(st)
+            if self._is_vector:  # cross-rank reduced f64 vector
+                st = vector_to_stats(self._host.numpy().copy())
+            else:
+                st = nat.GfStepStats.from_buffer_copy(self._host.numpy().tobytes())
             self._value = st
             self._host = None
             self._event = None
@@ -58,7 +58,8 @@ class StepStats:
         self._ring = [torch.zeros(STATS_BYTES, dtype=torch.uint8, pin_memory=pin) for _ in range(_RING)]
         self._live: list[Optional[StatsSnapshot]] = [None] * _RING
         self._slot = 0
-        self.reduce: Optional[Callable] = None  # set by distributed.attach()
+        self.group = None       # torch.distributed process group (distributed.attach); None = single process
+        self._vring = None
 
     @property
     def ptr(self) -> int:
@@ -74,6 +75,10 @@ class StepStats:
         old = self._live[i]
         if old is not None and old._value is None:
             old.wait()  # ring wrapped around an unread snapshot: its copy finished long ago
+        if self.group is not None:
+            snap = self._snapshot_reduced(i)
+            self._live[i] = snap
+            return snap
         host = self._ring[i]
         if self.device.type == "cuda":
             host.copy_(self.dev, non_blocking=True)
@@ -82,9 +87,38 @@ class StepStats:
         else:
             host = self.dev.clone()
             ev = None
-        snap = StatsSnapshot(host, ev, self.reduce)
+        snap = StatsSnapshot(host, ev)
         self._live[i] = snap
         return snap
+
+    def pack_vector(self) -> torch.Tensor:
+        """The stats block as one f64 vector on the device (layout of ``stats_to_vector``): the all-reduce payload."""
+        ints = self.dev[:80].view(torch.int32)
+        f64 = self.dev[96:96 + 8 * nat.GF_MAX_TERMS].view(torch.float64)
+        flags = ints[_NT + 1]
+        head = torch.stack([ints[_NT], flags & 1, (flags >> 1) & 1, ints[_NT + 2] & 1, ints[_NT + 3]]).to(torch.float64)
+        return torch.cat([ints[:_NT].to(torch.float64), head, f64])
+
+    def _snapshot_reduced(self, i: int) -> StatsSnapshot:
+        """Sum the block over the ranks of ``self.group`` — the single collective of the path (RCCL over xGMI on
+        GPUs; ~350 B, latency bound), enqueued asynchronously behind this step's kernels — then copy it out."""
+        import torch.distributed as dist
+
+        vec = self.pack_vector()
+        if self._vring is None:
+            pin = self.device.type == "cuda"
+            self._vring = [torch.zeros(STATS_VECTOR_LEN, dtype=torch.float64, pin_memory=pin) for _ in range(_RING)]
+        if self.device.type == "cuda":
+            work = dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work.wait()  # stream-level dependency only: the host does not block
+            host = self._vring[i]
+            host.copy_(vec, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
+            host, ev = vec.clone(), None
+        return StatsSnapshot(host, ev, is_vector=True)
 
 
 class LazyEpisodeLog(dict):

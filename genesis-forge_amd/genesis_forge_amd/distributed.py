@@ -1,0 +1,55 @@
+"""
+Multi-GPU: env sharding + the one collective of the path.
+
+One process per GPU (``torch.distributed``, backend ``nccl`` == RCCL on ROCm, xGMI inside a node).
+Every manager buffer is indexed by env and no term reads another env's data, so rank ``r`` of ``R``
+simply owns a contiguous shard of envs with its own scene and RNG stream; rewards, observations and
+done masks stay sharded and are consumed by the local policy replica.  The only cross-env values are
+the logging / curriculum scalars (per-term episode means, termination fractions, reset counts): the
+per-step statistics block is summed over ranks with a single all-reduce (~350 B, latency bound,
+issued asynchronously behind the step's kernels), so every rank sees identical global values and
+takes identical curriculum decisions.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard(global_num_envs: int, rank: int, world_size: int) -> tuple[int, int]:
+    """(first env, env count) of ``rank``'s contiguous shard; the first ``global % world`` ranks get one extra."""
+    base, rem = divmod(global_num_envs, world_size)
+    count = base + (1 if rank < rem else 0)
+    start = rank * base + min(rank, rem)
+    return start, count
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple[int, int]:
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def attach(env, group=None, global_num_envs: Optional[int] = None) -> None:
+    """Make ``env``'s logging statistics global: sums over the ranks of ``group`` (default group if None).
+    ``env.num_envs`` stays the local shard size; ``env.global_num_envs`` is the denominator of fractions."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        env.global_num_envs = env.num_envs if global_num_envs is None else global_num_envs
+        return
+    env.stats.group = group if group is not None else dist.group.WORLD
+    if global_num_envs is None:
+        n = torch.tensor([env.num_envs], dtype=torch.int64, device=env.stats.device)
+        dist.all_reduce(n, group=group)
+        global_num_envs = int(n.item())
+    env.global_num_envs = global_num_envs
+    env.seed(env._rng_seed + 0x9E3779B97F4A7C15 * (dist.get_rank(group) + 1))  # independent Philox stream per rank
