@@ -141,13 +141,17 @@ class EntityManager(BaseManager):
             pos, quat, lin, ang = self.entity.gf_masked_base()
             a.scene_pos, a.scene_quat = pos.data_ptr(), quat.data_ptr()
             a.scene_lin_vel, a.scene_ang_vel = lin.data_ptr(), ang.data_ptr()
+            host = getattr(fn, "_gf_host_pose", None)
+            if host is None:  # read the fixed pose back once; never per step (a device->host copy is a sync)
+                host = (fn.reset_pos.tolist(), None if fn.reset_quat is None else fn.reset_quat.tolist())
+                fn._gf_host_pose = host
             for j in range(3):
-                a.reset_pos[j] = float(fn.reset_pos[j])
+                a.reset_pos[j] = host[0][j]
             a.set_quat = 0
-            if fn.reset_quat is not None:
+            if host[1] is not None:
                 a.set_quat = 1
                 a.quat_stash = self._stash.data_ptr()
                 self._stash_armed = True
                 for j in range(4):
-                    a.reset_quat[j] = float(fn.reset_quat[j])
+                    a.reset_quat[j] = host[1][j]
             a.zero_velocity = 1 if fn.zero_velocity else 0

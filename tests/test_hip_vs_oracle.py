@@ -59,7 +59,8 @@ def test_pipeline_hip_equals_oracle(hip_backend, oracle_lib_path, n, contacts, h
             assert torch.allclose(a[k], b[k], atol=1e-5, rtol=0, equal_nan=True), f"float state {k} differs at step {t}: {(a[k] - b[k]).abs().max()}"
         assert set(la) == set(lb), f"log keys differ at step {t}"
         for key in la:
-            assert abs(la[key] - lb[key]) <= 1e-5 + 1e-5 * abs(lb[key]), (t, key, la[key], lb[key])
+            same_nan = np.isnan(la[key]) and np.isnan(lb[key])  # the NaN action injected at step 3 poisons env 0's sums
+            assert same_nan or abs(la[key] - lb[key]) <= 1e-5 + 1e-5 * abs(lb[key]), (t, key, la[key], lb[key])
         resets += int(a[2].sum() + a[3].sum())
     if n >= 63:
         assert resets > 0
