@@ -53,6 +53,50 @@ GF_EXPORT int gf_stats_clear(GfStepStats* stats, void* stream) {
     return GF_OK;
 }
 
+GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed_index) {
+    if (!ops || num_ops < 0) return GF_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < num_ops; ++i) {
+        int rc = GF_OK;
+        const void* a = ops[i].args;
+        switch (ops[i].phase) {
+            case GF_PHASE_ACTION: rc = gf_action_step((const GfActionArgs*)a, stream); break;
+            case GF_PHASE_CONTACT: rc = gf_contact_step((const GfContactArgs*)a, stream); break;
+            case GF_PHASE_TERMINATION: rc = gf_termination_step((const GfTerminationArgs*)a, stream); break;
+            case GF_PHASE_REWARD: rc = gf_reward_step((const GfRewardArgs*)a, stream); break;
+            case GF_PHASE_COMMAND: rc = gf_command_step((const GfCommandArgs*)a, stream); break;
+            case GF_PHASE_RESET: rc = gf_masked_reset((const GfResetArgs*)a, stream); break;
+            case GF_PHASE_OBSERVE: rc = gf_observe((const GfObservationArgs*)a, stream); break;
+            case GF_PHASE_ROTATE: rc = gf_entity_rotate((const GfRotateArgs*)a, stream); break;
+            case GF_PHASE_SCENE: rc = gf_synth_scene_step((const GfSynthSceneArgs*)a, stream); break;
+            case GF_OP_STATS_CLEAR: rc = gf_stats_clear((GfStepStats*)const_cast<void*>(a), stream); break;
+            case GF_OP_STATS_COPY: {
+                const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
+                if (!c || !c->src || !c->dst) { rc = GF_E_NULL; break; }
+                hipError_t e = hipMemcpyAsync(c->dst, c->src, sizeof(GfStepStats), hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess && c->event) e = hipEventRecord((hipEvent_t)c->event, s);
+                rc = (int)e;
+            } break;
+            default: rc = GF_E_OPCODE; break;
+        }
+        if (rc != GF_OK) {
+            if (failed_index) *failed_index = i;
+            return rc;
+        }
+    }
+    return GF_OK;
+}
+
+GF_EXPORT void* gf_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return (void*)e;
+}
+
+GF_EXPORT int gf_event_destroy(void* event) { return event ? (int)hipEventDestroy((hipEvent_t)event) : GF_OK; }
+
+GF_EXPORT int gf_event_synchronize(void* event) { return event ? (int)hipEventSynchronize((hipEvent_t)event) : GF_OK; }
+
 GF_EXPORT int gf_profile_begin(int phase, int max_samples) {
     if (phase < 0 || phase >= GF_PHASE_COUNT || max_samples <= 0) return GF_E_RANGE;
     gf::Profiler& p = gf::g_prof;

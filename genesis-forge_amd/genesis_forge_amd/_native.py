@@ -191,6 +191,16 @@ class GfSynthSceneArgs(C.Structure):
                 ("links_quat_out", P), ("links_vel_out", P), ("seed", C.c_uint64), ("tick", C.c_uint64)]
 
 
+class GfOp(C.Structure):
+    _fields_ = [("phase", C.c_int32), ("_pad", C.c_int32), ("args", P)]
+
+
+class GfStatsCopyArgs(C.Structure):
+    _fields_ = [("src", P), ("dst", P), ("event", P)]
+
+
+GF_OP_STATS_CLEAR, GF_OP_STATS_COPY = 100, 101
+
 ABI_STRUCTS = [GfStepStats, GfActionArgs, GfContactArgs, GfTerminationArgs, GfRewardArgs, GfCommandArgs,
                GfResetArgs, GfObservationArgs, GfRotateArgs, GfSynthSceneArgs, GfTerm, GfObsItem]
 
@@ -204,6 +214,13 @@ PHASE_FUNCS = {
     "observe": GfObservationArgs,
     "entity_rotate": GfRotateArgs,
     "synth_scene_step": GfSynthSceneArgs,
+}
+
+
+PHASE_OF_FN = {
+    "action_step": GF_PHASE_ACTION, "contact_step": GF_PHASE_CONTACT, "termination_step": GF_PHASE_TERMINATION,
+    "reward_step": GF_PHASE_REWARD, "command_step": GF_PHASE_COMMAND, "masked_reset": GF_PHASE_RESET,
+    "observe": GF_PHASE_OBSERVE, "entity_rotate": GF_PHASE_ROTATE, "synth_scene_step": GF_PHASE_SCENE,
 }
 
 
@@ -242,11 +259,22 @@ class Backend:
     name = "abstract"
     device_type = "cuda"
 
-    def call(self, fn: str, args) -> None:  # pragma: no cover - interface
+    tracer = None  # set by _trace.StepTrace while it records a step
+
+    def call(self, fn: str, args, owner=None) -> None:  # pragma: no cover - interface
         raise NotImplementedError
 
     def stats_clear(self, stats_ptr: int) -> None:  # pragma: no cover - interface
         raise NotImplementedError
+
+    def run_ops(self, ops, n: int) -> None:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def event_create(self):
+        return None
+
+    def event_synchronize(self, ev) -> None:
+        pass
 
     def check_tensor(self, t, what: str = "tensor") -> None:
         if t is None:
@@ -285,6 +313,11 @@ class HipBackend(Backend):
         self.lib.gf_error_string.restype = C.c_char_p
         self.lib.gf_error_string.argtypes = [C.c_int]
         self.lib.gf_build_info.restype = C.c_char_p
+        self.lib.gf_run_ops.restype = C.c_int
+        self.lib.gf_run_ops.argtypes = [C.POINTER(GfOp), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        self.lib.gf_event_create.restype = C.c_void_p
+        self.lib.gf_event_synchronize.restype = C.c_int
+        self.lib.gf_event_synchronize.argtypes = [C.c_void_p]
         self.lib.gf_profile_begin.restype = C.c_int
         self.lib.gf_profile_begin.argtypes = [C.c_int, C.c_int]
         self.lib.gf_profile_end.restype = C.c_int
@@ -300,10 +333,29 @@ class HipBackend(Backend):
         msg = self.lib.gf_error_string(rc).decode()
         raise GfError(f"gf_{fn} failed: {GF_ERRORS.get(rc, rc)} ({msg})")
 
-    def call(self, fn: str, args) -> None:
+    def call(self, fn: str, args, owner=None) -> None:
+        if self.tracer is not None:
+            self.tracer.record(fn, args, owner)
         rc = self._fn[fn](C.byref(args), self._stream())
         if rc != 0:
             self._raise(fn, rc)
+
+    def run_ops(self, ops, n: int) -> None:
+        failed = C.c_int(-1)
+        rc = self.lib.gf_run_ops(ops, n, self._stream(), C.byref(failed))
+        if rc != 0:
+            self._raise(f"run_ops[op {failed.value}]", rc)
+
+    def event_create(self):
+        ev = self.lib.gf_event_create()
+        if not ev:
+            raise GfError("gf_event_create failed")
+        return ev
+
+    def event_synchronize(self, ev) -> None:
+        rc = self.lib.gf_event_synchronize(ev)
+        if rc != 0:
+            self._raise("event_synchronize", rc)
 
     def stats_clear(self, stats_ptr: int) -> None:
         rc = self.lib.gf_stats_clear(stats_ptr, self._stream())

@@ -26,17 +26,20 @@ _RING = 64
 class StatsSnapshot:
     """One step's statistics; ``wait()`` returns a host GfStepStats once the copy has landed."""
 
-    __slots__ = ("_host", "_event", "_value", "_is_vector")
+    __slots__ = ("_host", "_event", "_value", "_is_vector", "_native")
 
-    def __init__(self, host: torch.Tensor, event, is_vector: bool = False):
+    def __init__(self, host: torch.Tensor, event, is_vector: bool = False, native=None):
         self._host = host
         self._event = event
         self._value = None
         self._is_vector = is_vector
+        self._native = native  # (backend, native event handle) for snapshots taken by a recorded step
 
     def wait(self) -> nat.GfStepStats:
         if self._value is None:
-            if self._event is not None:
+            if self._native is not None:
+                self._native[0].event_synchronize(self._native[1])
+            elif self._event is not None:
                 self._event.synchronize()
             if self._is_vector:  # cross-rank reduced f64 vector
                 st = vector_to_stats(self._host.numpy().copy())
@@ -88,6 +91,25 @@ class StepStats:
             host = self.dev.clone()
             ev = None
         snap = StatsSnapshot(host, ev)
+        self._live[i] = snap
+        return snap
+
+    def ensure_native_events(self, backend) -> None:
+        if getattr(self, "_events", None) is None:
+            self._events = [backend.event_create() for _ in range(_RING)]
+
+    def native_slot(self, copy_args, backend) -> StatsSnapshot:
+        """Point a recorded step's GF_OP_STATS_COPY at the next ring slot; returns the snapshot it will fill."""
+        i = self._slot
+        self._slot = (i + 1) % _RING
+        old = self._live[i]
+        if old is not None and old._value is None:
+            old.wait()
+        host = self._ring[i]
+        copy_args.dst = host.data_ptr()
+        ev = self._events[i]
+        copy_args.event = ev
+        snap = StatsSnapshot(host, None, native=(backend, ev) if ev is not None else None)
         self._live[i] = snap
         return snap
 

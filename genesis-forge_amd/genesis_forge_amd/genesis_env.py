@@ -97,6 +97,10 @@ class GenesisEnv:
         self._rng_stream = 0           # every stochastic native call takes a fresh stream id
         self._draws: dict = {}         # parity mode: {"name": tensor of U[0,1)} consumed by the next call
         self._done_mask: Optional[torch.Tensor] = None
+        self._trace = None
+        self._trace_epoch = 0
+        self._recorder = None
+        self._last_signature = None
 
     """
     Properties (genesis_env.py:95-148)
@@ -151,6 +155,13 @@ class GenesisEnv:
     def seed(self, seed: int) -> None:
         """Seed of the in-kernel Philox generator (command resampling, reset jitter, observation noise)."""
         self._rng_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.invalidate_trace()
+
+    def invalidate_trace(self) -> None:
+        """Drop the recorded step (something its frozen descriptors depend on has changed)."""
+        self._trace = None
+        self._trace_epoch += 1
+        self._last_signature = None
 
     def next_stream(self) -> int:
         self._rng_stream += 1
@@ -162,6 +173,7 @@ class GenesisEnv:
         ``obs:<name>`` [N,O]."""
         for k, v in draws.items():
             self._draws[k] = None if v is None else _f32c(v.to(gs.device))
+        self.invalidate_trace()
 
     def take_draws(self, key: str) -> Optional[torch.Tensor]:
         return self._draws.pop(key, None)

@@ -17,11 +17,14 @@ terminal state, observations from the post-reset state.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Any, Optional
 
 import torch
 
 from . import _native as nat
+from . import _trace
 from . import gs
 from ._stats import LazyEpisodeLog
 from .genesis_env import GenesisEnv
@@ -45,11 +48,16 @@ except Exception:
         return ObservationDict()
 
 
-def _most_derived_reset_is_ours(m: BaseManager) -> bool:
+def _most_derived_is_ours(m, method: str) -> bool:
+    """True when the most-derived implementation of ``method`` on ``m`` comes from this package (not a user subclass)."""
     for klass in type(m).__mro__:
-        if "reset" in klass.__dict__:
+        if method in klass.__dict__:
             return klass.__module__.startswith(__package__ + ".")
     return True
+
+
+def _most_derived_reset_is_ours(m: BaseManager) -> bool:
+    return _most_derived_is_ours(m, "reset")
 
 
 class ManagedEnvironment(GenesisEnv):
@@ -66,6 +74,9 @@ class ManagedEnvironment(GenesisEnv):
         self._reward_buf = torch.zeros((self.num_envs,), device=gs.device, dtype=gs.tc_float)
         self._terminated_buf = torch.zeros((self.num_envs,), device=gs.device, dtype=gs.tc_bool)
         self._truncated_buf = torch.zeros((self.num_envs,), device=gs.device, dtype=gs.tc_bool)
+        self._reset_args = nat.GfResetArgs()
+        #: record the step and replay it through gf_run_ops when possible (see _trace.py); GF_NO_TRACE=1 disables
+        self.trace_enabled = os.environ.get("GF_NO_TRACE", "0") != "1"
 
     # -- spaces (managed_env.py:156-194) ------------------------------------------------------------
     @property
@@ -102,6 +113,7 @@ class ManagedEnvironment(GenesisEnv):
             self.managers[manager_type] = manager
         else:
             raise ValueError(f"Manager type '{manager_type}' already has a manager, and an environment cannot have multiple {manager_type} managers.")
+        self.invalidate_trace()
 
     def _all_managers(self) -> list:
         out = []
@@ -142,6 +154,48 @@ class ManagedEnvironment(GenesisEnv):
 
     def step(self, actions: torch.Tensor):
         """managed_env.py:274-334"""
+        if actions.dtype != torch.float32 or not actions.is_contiguous():
+            actions = actions.to(torch.float32).contiguous()
+        tr = self._trace
+        if tr is not None:
+            if tr.epoch == self._trace_epoch and not self._draws:
+                return tr.replay(actions)
+            self._trace = None
+        if not self.trace_enabled or self._draws:
+            return self._step_ordinary(actions)
+        rec = _trace.Recorder()
+        backend = self.backend
+        backend.tracer = rec
+        epoch = self._trace_epoch
+        try:
+            out = self._step_ordinary(actions)
+        finally:
+            backend.tracer = None
+        if epoch == self._trace_epoch:  # nothing was invalidated while the step ran
+            sig = rec.signature()
+            if sig == self._last_signature and _trace.traceable(self):
+                self._trace = _trace.StepTrace(self, rec.calls)
+            self._last_signature = sig
+        return out
+
+    def _begin_step_light(self) -> None:
+        """_begin_step without the statistics clear (a recorded step carries it as its first op)."""
+        self._extras = {self.extras_logging_key: LazyEpisodeLog(), "observations": _obs_dict()}
+        self.step_count += 1
+
+    def _finish_step_light(self, snap) -> None:
+        self._extras[self.extras_logging_key].attach(snap)
+        rm = self.managers["reward"]
+        if rm is not None:
+            rm._note_snapshot(snap)
+
+    def _after_masked_reset_traced(self) -> None:
+        tm = self.managers["termination"]
+        for em in self.managers["entity"]:
+            em._after_fused_reset(tm._terminated_buf, tm._truncated_buf)
+        self.invalidate_views()
+
+    def _step_ordinary(self, actions: torch.Tensor):
         self._begin_step()
         self.extras["observations"] = _obs_dict()
 
@@ -209,7 +263,8 @@ class ManagedEnvironment(GenesisEnv):
                 pass  # no-op reset (termination / observation managers)
             else:
                 indexed.append(m)
-        a = nat.GfResetArgs()
+        a = self._reset_args  # persistent descriptor: a recorded step replays it in place
+        C.memset(C.byref(a), 0, C.sizeof(a))
         a.mask = mask.data_ptr()
         a.mask2 = None if mask2 is None else mask2.data_ptr()
         self._fill_env_reset(a)
@@ -217,7 +272,7 @@ class ManagedEnvironment(GenesisEnv):
             m._fill_reset(a)
         a.stats = self.stats.ptr
         self._keep_reset = (mask, mask2)
-        self.backend.call("masked_reset", a)
+        self.backend.call("masked_reset", a, owner=self)
         for m in fused:
             m._after_fused_reset(mask, mask2)
         if indexed:

@@ -210,7 +210,7 @@ class RewardProgram:
             keep.append(t)
             a.terminated = t.data_ptr()
         self.slots.bind(a, torch.float32, keep)
-        env.backend.call("reward_step", a)
+        env.backend.call("reward_step", a, owner=self)
         for fn in self.after:
             fn()
         self._keep = keep
@@ -262,7 +262,7 @@ class TerminationProgram:
         a.episode_length = env.episode_length.data_ptr()
         a.max_episode_length = None if env.max_episode_length is None else env.max_episode_length.data_ptr()
         self.slots.bind(a, torch.bool, keep)
-        env.backend.call("termination_step", a)
+        env.backend.call("termination_step", a, owner=self)
         self._keep = keep
 
 

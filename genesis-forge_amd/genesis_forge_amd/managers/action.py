@@ -292,7 +292,7 @@ class PositionActionManager(BaseActionManager):
             a.env_actions = a.env_last_actions = a.episode_length = None
         a.targets = self._actions.data_ptr()
         a.stats = env.stats.ptr if not self._quiet_action_errors else None
-        env.backend.call("action_step", a)
+        env.backend.call("action_step", a, owner=self)
         if not self._quiet_action_errors:
             self._watch_flags()
         # Set target positions (position_action_manager.py:417)

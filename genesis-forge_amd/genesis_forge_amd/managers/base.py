@@ -11,10 +11,20 @@ class BaseManager:
 
     def __init__(self, env, type: ManagerType, enabled: bool = True):
         self.env = env
-        self.enabled = True  # sic: the reference ignores the argument (base.py:28)
+        self._enabled = True  # sic: the reference ignores the argument (base.py:28)
         self.type = type
         if hasattr(env, "add_manager"):
             env.add_manager(type, self)
+
+    @property
+    def enabled(self) -> bool:
+        return self._enabled
+
+    @enabled.setter
+    def enabled(self, v: bool):
+        self._enabled = v
+        if hasattr(self.env, "invalidate_trace"):
+            self.env.invalidate_trace()
 
     def build(self):
         """Called when the scene is built"""

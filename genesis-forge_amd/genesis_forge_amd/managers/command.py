@@ -43,7 +43,7 @@ class CommandManager(BaseManager):
         self._range_idx = {}
         if isinstance(range, dict):
             self._range_idx = {key: i for i, key in enumerate(range.keys())}
-        self._args = nat.GfCommandArgs()
+        self._args_by_mode = {m: nat.GfCommandArgs() for m in (nat.GF_CMD_STEP, nat.GF_CMD_MASKED, nat.GF_CMD_ALL)}
         self._index = len(env.managers["command"]) - 1 if hasattr(env, "managers") else 0
 
     # -- properties (command_manager.py:87-130) -------------------------------------------------------
@@ -93,7 +93,7 @@ class CommandManager(BaseManager):
 
     def _launch(self, mode: int, mask=None, mask2=None, draws_key: Optional[str] = None) -> None:
         env = self.env
-        a = self._args
+        a = self._args_by_mode[mode]
         a.num_envs, a.num_ranges, a.mode = env.num_envs, self._command.shape[1], mode
         a.resample_steps = self._resample_steps
         a.episode_length = env.episode_length.data_ptr()
@@ -107,7 +107,7 @@ class CommandManager(BaseManager):
             a.lo[i], a.hi[i] = float(r[0]), float(r[1])
         a.command = self._command.data_ptr()
         a.stats = env.stats.ptr if mode == nat.GF_CMD_STEP else None
-        env.backend.call("command_step", a)
+        env.backend.call("command_step", a, owner=self)
 
     def step(self):
         """Resample where ``episode_length % resample_steps == 0`` (command_manager.py:152-162)."""
@@ -138,6 +138,19 @@ class CommandManager(BaseManager):
     def use_external_controller(self, controller: Callable[[int], torch.Tensor]):
         """Bypass the internal generator with ``controller(step_count) -> [N, R]`` (command_manager.py:176-207)."""
         self._external_controller = controller
+        self.env.invalidate_trace()
+
+    def _trace_patch(self, args):
+        """Per-step refresh of a recorded command launch: ranges are re-read (curricula mutate them,
+        command_manager.py:293-298) and the Philox stream id advances exactly as in the unrecorded path."""
+        env = self.env
+
+        def patch(_actions, a=args, env=env, self=self):
+            for i, r in enumerate(self._ranges()):
+                a.lo[i], a.hi[i] = float(r[0]), float(r[1])
+            a.stream = env.next_stream()
+
+        return patch
 
     def use_gamepad(self, gamepad, range_axis):
         """Map gamepad axes onto the command ranges (command_manager.py:209-288).  The HID reader itself is

@@ -153,7 +153,7 @@ class ContactManager(BaseManager):
             a.last_air_time, a.current_air_time = self.last_air_time.data_ptr(), self.current_air_time.data_ptr()
             a.last_contact_time, a.current_contact_time = self.last_contact_time.data_ptr(), self.current_contact_time.data_ptr()
         a.stats = env.stats.ptr
-        env.backend.call("contact_step", a)
+        env.backend.call("contact_step", a, owner=self)
 
     def view(self, v: nat.GfContactView, need_link_vel: bool = False) -> tuple:
         """Fill a GfContactView for term kernels; returns tensors to keep alive."""

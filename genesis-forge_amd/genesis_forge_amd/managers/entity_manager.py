@@ -43,6 +43,7 @@ class EntityManager(BaseManager):
         self._stash = torch.zeros(N, 4, device=gs.device, dtype=gs.tc_float)
         self._stale_masks = None
         self._stale_tick = -1
+        self._stash_armed = False
 
     # -- properties -----------------------------------------------------------------------------------
     def stale(self):
@@ -85,7 +86,7 @@ class EntityManager(BaseManager):
         a.num_envs, a.what = env.num_envs, what
         self._views().fill(a.entity)
         a.out = out.data_ptr()
-        env.backend.call("entity_rotate", a)
+        env.backend.call("entity_rotate", a, owner=None)
         return _tag(out, (tag, self))
 
     def get_projected_gravity(self) -> torch.Tensor:
@@ -130,9 +131,12 @@ class EntityManager(BaseManager):
         return len(items) <= 1 and all(isinstance(c.fn, reset_mdp.position) for c in items)
 
     def _after_fused_reset(self, mask, mask2) -> None:
-        if getattr(self, "_stash_armed", False):
+        if getattr(self, "_stash_armed", False) or getattr(self, "_stash_always", False):
             self._stale_masks = (mask, mask2)
             self._stale_tick = self.env._tick + 1  # the views cache is invalidated right after the reset
+            self._stash_always = self._stash_always if hasattr(self, "_stash_always") else False
+            if self._stash_armed:
+                self._stash_always = True  # a recorded step replays the same descriptor (quat_stash stays set)
             self._stash_armed = False
 
     def _fill_reset(self, a: nat.GfResetArgs) -> None:

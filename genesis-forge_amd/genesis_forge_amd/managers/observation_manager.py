@@ -71,6 +71,8 @@ class ObservationManager(BaseManager):
 
     def _mark_dirty(self):
         self._dirty = True
+        if hasattr(self.env, "invalidate_trace"):
+            self.env.invalidate_trace()
 
     @property
     def name(self) -> str:
@@ -209,11 +211,29 @@ class ObservationManager(BaseManager):
         keep.append(draws)
         a.noise_draws = None if draws is None else draws.data_ptr()
         a.seed, a.stream = env._rng_seed, env.next_stream()
+        out = self._rotate_ring(a)
+        env.backend.call("observe", a, owner=self)
+        self._keep = keep
+        return out
+
+    def _rotate_ring(self, a) -> torch.Tensor:
         prev = self._bufs[self._cur]
         self._cur = (self._cur + 1) % _OBS_RING
         out = self._bufs[self._cur]
         a.prev_obs = prev.data_ptr() if self._history_len > 1 else None
         a.obs = out.data_ptr()
-        env.backend.call("observe", a)
-        self._keep = keep
         return out
+
+    def _traceable(self) -> bool:
+        return self.enabled and not self._dirty and len(self._slots.exts) == 0 and all(
+            not hasattr(s, "_external_controller") or s._external_controller is None for s in self._slots.cmds)
+
+    def _trace_patch(self, args):
+        env = self.env
+
+        def patch(_actions, a=args, env=env, self=self):
+            a.stream = env.next_stream()
+            out = self._rotate_ring(a)
+            env.extras["observations"][self._name] = out
+
+        return patch

@@ -55,6 +55,8 @@ class RewardManager(BaseManager):
 
     def _mark_dirty(self):
         self._dirty = True
+        if hasattr(self.env, "invalidate_trace"):
+            self.env.invalidate_trace()
 
     @property
     def rewards(self) -> torch.Tensor:
@@ -105,6 +107,7 @@ class RewardManager(BaseManager):
         a.reward = self._reward_buf.data_ptr()
         a.episode_sums = self._episode_sums.data_ptr()
         a.episode_seconds = self._episode_seconds.data_ptr()
+        prog.manager = self
         self._program = prog
         self._dirty = False
 

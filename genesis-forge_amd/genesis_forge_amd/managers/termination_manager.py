@@ -44,6 +44,8 @@ class TerminationManager(BaseManager):
 
     def _mark_dirty(self):
         self._dirty = True
+        if hasattr(self.env, "invalidate_trace"):
+            self.env.invalidate_trace()
 
     @property
     def dones(self) -> torch.Tensor:
@@ -87,8 +89,14 @@ class TerminationManager(BaseManager):
         env = self.env
         if self._dirty:
             self._compile()
+        self._program.manager = self
         self._program.args.stats = env.stats.ptr if self.logging_enabled else None
         self._program.launch()
+        return self._publish()
+
+    def _publish(self):
+        """Post-launch bookkeeping: log filler and the extras keys (termination_manager.py:178-190)."""
+        env = self.env
         if self.logging_enabled:
             log = env.extras[env.extras_logging_key]
             names = list(self.term_cfg.keys())

@@ -321,6 +321,7 @@ class SyntheticScene:
         self.collider = _Collider(self)
         self._args = nat.GfSynthSceneArgs()
         self.is_built = False
+        self.gf_static_buffers = True  # every state tensor is allocated once at build(): a step can be recorded
 
     # -- construction ---------------------------------------------------------------------------------
     def add_entity(self, morph=None, model: Optional[RobotModel] = None, **kw):
@@ -389,7 +390,7 @@ class SyntheticScene:
             a.links_quat_out = self.links_quat.data_ptr()
             a.links_vel_out = self.links_vel_all.data_ptr()
         a.seed, a.tick = self.seed, self.tick
-        nat.get_backend().call("synth_scene_step", a)
+        nat.get_backend().call("synth_scene_step", a, owner=self)
         if self.n_contacts > 0:
             s = r.links[0].idx
             r.links_vel = self.links_vel_all[:, s:s + r.n_links]

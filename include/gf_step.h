@@ -443,6 +443,31 @@ int gf_observe(const GfObservationArgs* a, void* stream);         /* replaces ob
 int gf_entity_rotate(const GfRotateArgs* a, void* stream);        /* replaces entity_manager.py:130-146 */
 int gf_synth_scene_step(const GfSynthSceneArgs* a, void* stream); /* stands in for scene.step() (managed_env.py:292) */
 
+/* ------------------------------------------------------------------------------------------
+ * Recorded step: the fixed launch sequence of one ManagedEnvironment.step() replayed with a single
+ * call.  The host records the (phase, descriptor) pairs of one ordinary step, keeps the descriptors
+ * alive, patches the few per-step fields (action pointer, RNG stream ids, observation ring slots) in
+ * place and replays — the phase order of managed_env.py:274-334 without per-launch host work.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct GfOp {
+    int32_t phase;      /* GF_PHASE_* or GF_OP_* */
+    int32_t _pad;
+    const void* args;   /* the phase's descriptor (GfActionArgs*, …) */
+} GfOp;
+
+enum { GF_OP_STATS_CLEAR = 100, GF_OP_STATS_COPY = 101 };
+
+typedef struct GfStatsCopyArgs {
+    const GfStepStats* src;   /* device */
+    void* dst;                /* pinned host, sizeof(GfStepStats) */
+    void* event;              /* from gf_event_create(); recorded after the copy; may be NULL */
+} GfStatsCopyArgs;
+
+int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed_index);
+void* gf_event_create(void);
+int gf_event_destroy(void* event);
+int gf_event_synchronize(void* event);   /* blocks the host until the event has completed */
+
 /* Optional per-phase HIP-event timing used by bench.py (events recorded on `stream`
  * immediately around the kernel launch of the selected phase). */
 enum { GF_PHASE_ACTION = 0, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,

@@ -668,6 +668,38 @@ GFO_EXPORT int gfo_synth_scene_step(const GfSynthSceneArgs* a) {
     return GF_OK;
 }
 
+/* host twin of gf_run_ops (the recorded-step replay), so the trace/replay host logic is testable on CPU */
+GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
+    if (!ops || num_ops < 0) return GF_E_NULL;
+    for (int i = 0; i < num_ops; ++i) {
+        int rc = GF_OK;
+        const void* a = ops[i].args;
+        switch (ops[i].phase) {
+            case GF_PHASE_ACTION: rc = gfo_action_step((const GfActionArgs*)a); break;
+            case GF_PHASE_CONTACT: rc = gfo_contact_step((const GfContactArgs*)a); break;
+            case GF_PHASE_TERMINATION: rc = gfo_termination_step((const GfTerminationArgs*)a); break;
+            case GF_PHASE_REWARD: rc = gfo_reward_step((const GfRewardArgs*)a); break;
+            case GF_PHASE_COMMAND: rc = gfo_command_step((const GfCommandArgs*)a); break;
+            case GF_PHASE_RESET: rc = gfo_masked_reset((const GfResetArgs*)a); break;
+            case GF_PHASE_OBSERVE: rc = gfo_observe((const GfObservationArgs*)a); break;
+            case GF_PHASE_ROTATE: rc = gfo_entity_rotate((const GfRotateArgs*)a); break;
+            case GF_PHASE_SCENE: rc = gfo_synth_scene_step((const GfSynthSceneArgs*)a); break;
+            case GF_OP_STATS_CLEAR: rc = gfo_stats_clear((GfStepStats*)a); break;
+            case GF_OP_STATS_COPY: {
+                const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
+                if (!c || !c->src || !c->dst) { rc = GF_E_NULL; break; }
+                memcpy(c->dst, c->src, sizeof(GfStepStats));
+            } break;
+            default: rc = GF_E_OPCODE; break;
+        }
+        if (rc != GF_OK) {
+            if (failed_index) *failed_index = i;
+            return rc;
+        }
+    }
+    return GF_OK;
+}
+
 GFO_EXPORT int gfo_abi_version(void) { return GF_ABI_VERSION; }
 GFO_EXPORT int gfo_sizeof(int which) {
     switch (which) {

@@ -20,10 +20,15 @@ class OracleBackend(nat.Backend):
             self._fn[name] = f
         self.lib.gfo_stats_clear.restype = C.c_int
         self.lib.gfo_stats_clear.argtypes = [C.c_void_p]
+        self.lib.gfo_run_ops.restype = C.c_int
+        self.lib.gfo_run_ops.argtypes = [C.POINTER(nat.GfOp), C.c_int, C.POINTER(C.c_int)]
         self.calls = []
+        self.replays = 0
 
-    def call(self, fn, args):
+    def call(self, fn, args, owner=None):
         self.calls.append(fn)
+        if self.tracer is not None:
+            self.tracer.record(fn, args, owner)
         rc = self._fn[fn](C.byref(args))
         if rc != 0:
             raise nat.GfError(f"gfo_{fn} failed: {nat.GF_ERRORS.get(rc, rc)}")
@@ -32,3 +37,10 @@ class OracleBackend(nat.Backend):
         rc = self.lib.gfo_stats_clear(stats_ptr)
         if rc != 0:
             raise nat.GfError(f"gfo_stats_clear failed: {rc}")
+
+    def run_ops(self, ops, n):
+        self.replays += 1
+        failed = C.c_int(-1)
+        rc = self.lib.gfo_run_ops(ops, n, C.byref(failed))
+        if rc != 0:
+            raise nat.GfError(f"gfo_run_ops failed at op {failed.value}: {nat.GF_ERRORS.get(rc, rc)}")

@@ -1,0 +1,81 @@
+"""The recorded step (genesis_forge_amd/_trace.py) must be indistinguishable from the ordinary path."""
+import pytest
+import torch
+
+from envs import Go2CommandDirectionEnv
+
+
+def _run(dev, trace, n=70, steps=50, mutate_at=None):
+    env = Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, contacts=True, history=2, obs_noise=True,
+                                 scene_kwargs=dict(ang_noise=0.3, seed=3))
+    env.trace_enabled = trace
+    env.build()
+    env.seed(5)
+    env.reset()
+    g = torch.Generator().manual_seed(0)
+    outs = []
+    for t in range(steps):
+        if mutate_at is not None and t == mutate_at:
+            env.reward_manager.cfg["action_rate"].weight = -0.5          # curriculum-style mutation
+            env.velocity_command.range["lin_vel_x"][1] = 3.0              # in-place range edit (no setter involved)
+            env.reward_manager.cfg["base_height_target"].params["target_height"] = 0.33
+        o, r, te, tr, ex = env.step(torch.randn(n, 12, generator=g).to(dev))
+        outs.append((o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone(), {k: float(v) for k, v in ex["episode"].items()},
+                     env.velocity_command._command.cpu().clone()))
+    return outs, env
+
+
+def _same(a, b):
+    for t, (x, y) in enumerate(zip(a, b)):
+        for k in (0, 1, 2, 3, 5):
+            assert torch.equal(x[k], y[k]), f"output {k} differs at step {t}"
+        assert x[4] == y[4], f"log differs at step {t}: {x[4]} vs {y[4]}"
+
+
+def test_traced_step_equals_ordinary_cpu(oracle_backend):
+    a, _ = _run("cpu", False)
+    before = oracle_backend.replays
+    b, env = _run("cpu", True)
+    assert oracle_backend.replays - before >= 45, "the step was not recorded"
+    _same(a, b)
+
+
+def test_trace_invalidated_by_mutation_cpu(oracle_backend):
+    a, _ = _run("cpu", False, mutate_at=20)
+    b, env = _run("cpu", True, mutate_at=20)
+    _same(a, b)
+    assert env._trace is not None, "trace should have been re-recorded after the mutation"
+
+
+def test_parity_draws_disable_trace(oracle_backend):
+    env = Go2CommandDirectionEnv(num_envs=8)
+    env.build()
+    env.reset()
+    for _ in range(4):
+        env.step(torch.zeros(8, 12))
+    assert env._trace is not None
+    env.set_draws(**{"command:0": torch.rand(8, 3)})
+    assert env._trace is None
+    env.step(torch.zeros(8, 12))
+    assert env._trace is None  # the step that consumed draws ran the ordinary path and is not a recording candidate twice yet
+
+
+def test_user_override_is_never_traced(oracle_backend):
+    class MyEnv(Go2CommandDirectionEnv):
+        def reset(self, env_ids=None):
+            return super().reset(env_ids)
+
+    env = MyEnv(num_envs=8)
+    env.build()
+    env.reset()
+    for _ in range(5):
+        env.step(torch.zeros(8, 12))
+    assert env._trace is None
+
+
+@pytest.mark.gpu
+def test_traced_step_equals_ordinary_hip(hip_backend):
+    a, _ = _run("cuda", False, n=1000)
+    b, env = _run("cuda", True, n=1000)
+    assert env._trace is not None
+    _same(a, b)
