@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kEnvBlock) void command_kernel(const GfCommandArgs 
     const int R = a.num_ranges;
     float* row = a.command + n * R;
     for (int i = 0; i < R; ++i) {
-        const float u = draw_u(a.draws, n * R + i, a.seed, a.stream, (uint32_t)n, (uint32_t)i);
+        const float u = draw_u(a.draws, n * R + i, a.seed, a.stream, (uint32_t)n + a.env_offset, (uint32_t)i);
         row[i] = uniform_range(u, a.lo[i], a.hi[i]);
     }
 }

@@ -36,7 +36,7 @@ struct TileCtx {
 __device__ __forceinline__ float finish(const GfObservationArgs& a, const GfObsItem& it, float v, int64_t n, int col) {
     if (it.scale != 1.0f) v = v * it.scale;  // observation_manager.py:242-244
     if (it.noise != 0.0f) {                  // observation_manager.py:247-250
-        const float u = draw_u(a.noise_draws, n * a.obs_width + col, a.seed, a.stream, (uint32_t)n, (uint32_t)col);
+        const float u = draw_u(a.noise_draws, n * a.obs_width + col, a.seed, a.stream, (uint32_t)n + a.env_offset, (uint32_t)col);
         v = v + uniform_range(u, -1.0f, 1.0f) * it.noise;
     }
     return v;

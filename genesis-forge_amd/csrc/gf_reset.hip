@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
     }
     if (a.episode_length) a.episode_length[n] = 0;
     if (a.max_episode_length && a.max_random_scaling > 0.0f) {
-        const float u = draw_u(a.len_draws, n, a.seed, a.stream, (uint32_t)n, 0u);
+        const float u = draw_u(a.len_draws, n, a.seed, a.stream, (uint32_t)n + a.env_offset, 0u);
         const float r = uniform_range(u, -1.0f, 1.0f) * a.max_random_scaling;
         a.max_episode_length[n] = (int32_t)rintf((float)a.base_max_episode_length + r);  // torch.round: half-to-even
     }
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
         for (int d = 0; d < D; ++d) {
             float p = a.default_dof_pos[d];
             if (a.dof_noise_scale != 0.0f) {
-                const float u = draw_u(a.dof_draws, n * D + d, a.seed, a.stream, (uint32_t)n, (uint32_t)(4 + d));
+                const float u = draw_u(a.dof_draws, n * D + d, a.seed, a.stream, (uint32_t)n + a.env_offset, (uint32_t)(4 + d));
                 p = p + uniform_range(u, -1.0f, 1.0f) * a.dof_noise_scale;
             }
             a.scene_dof_pos[n * D + d] = p;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSce
     }
     float s[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) s[j] = philox_uniform(a.seed, a.tick, (uint32_t)n, (uint32_t)j) * 2.0f - 1.0f;
+    for (int j = 0; j < 6; ++j) s[j] = philox_uniform(a.seed, a.tick, (uint32_t)n + a.env_offset, (uint32_t)j) * 2.0f - 1.0f;
     float* wp = a.ang_vel + 3 * n;
     float* vp = a.lin_vel + 3 * n;
     float* pp = a.pos + 3 * n;
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSce
         for (int c = 0; c < C; ++c) {
             const uint32_t col = (uint32_t)(8 + 8 * c);
             // columns col..col+3 share one Philox block, col+4 starts the next
-            const U4 r0 = philox4x32_10((uint32_t)n, col >> 2, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-            const U4 r1 = philox4x32_10((uint32_t)n, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            const U4 r0 = philox4x32_10((uint32_t)n + a.env_offset, col >> 2, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            const U4 r1 = philox4x32_10((uint32_t)n + a.env_offset, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
             const float u_act = u24_to_unit(r0.x), u_link = u24_to_unit(r0.y);
             const float fx = u24_to_unit(r0.z) * 2.0f - 1.0f, fy = u24_to_unit(r0.w) * 2.0f - 1.0f, fz = u24_to_unit(r1.x);
             const bool active = u_act < a.contact_prob;

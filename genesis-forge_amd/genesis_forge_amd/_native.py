@@ -146,7 +146,7 @@ class GfRewardArgs(C.Structure):
 class GfCommandArgs(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_ranges", C.c_int32), ("mode", C.c_int32), ("resample_steps", C.c_int32),
                 ("episode_length", P), ("mask", P), ("mask2", P), ("draws", P),
-                ("seed", C.c_uint64), ("stream", C.c_uint64),
+                ("seed", C.c_uint64), ("stream", C.c_uint64), ("env_offset", C.c_uint32), ("_pad2", C.c_uint32),
                 ("lo", C.c_float * GF_MAX_RANGES), ("hi", C.c_float * GF_MAX_RANGES),
                 ("command", P), ("stats", P)]
 
@@ -161,7 +161,7 @@ class GfResetArgs(C.Structure):
                 ("scene_dof_pos", P), ("scene_dof_vel", P), ("default_dof_pos", P), ("dof_noise_scale", C.c_float),
                 ("dof_draws", P), ("scene_pos", P), ("scene_quat", P), ("quat_stash", P), ("scene_lin_vel", P), ("scene_ang_vel", P),
                 ("reset_pos", C.c_float * 3), ("reset_quat", C.c_float * 4), ("set_quat", C.c_int32), ("zero_velocity", C.c_int32),
-                ("seed", C.c_uint64), ("stream", C.c_uint64), ("stats", P)]
+                ("seed", C.c_uint64), ("stream", C.c_uint64), ("env_offset", C.c_uint32), ("_pad2", C.c_uint32), ("stats", P)]
 
 
 class GfObsItem(C.Structure):
@@ -175,7 +175,7 @@ class GfObservationArgs(C.Structure):
                 ("dof_pos", P), ("dof_vel", P), ("dof_force", P), ("targets", P), ("env_actions", P),
                 ("contact", GfContactView * GF_MAX_CONTACT_VIEWS), ("command", GfCommandView * GF_MAX_COMMAND_VIEWS),
                 ("ext", P * GF_MAX_EXT), ("noise_draws", P), ("seed", C.c_uint64), ("stream", C.c_uint64),
-                ("stale_quat", P), ("stale_mask", P), ("stale_mask2", P), ("prev_obs", P), ("obs", P), ("items", GfObsItem * GF_MAX_OBS_ITEMS)]
+                ("env_offset", C.c_uint32), ("_pad2", C.c_uint32), ("stale_quat", P), ("stale_mask", P), ("stale_mask2", P), ("prev_obs", P), ("obs", P), ("items", GfObsItem * GF_MAX_OBS_ITEMS)]
 
 
 class GfRotateArgs(C.Structure):
@@ -188,7 +188,8 @@ class GfSynthSceneArgs(C.Structure):
                 ("height_target", C.c_float), ("contact_prob", C.c_float), ("contact_force", C.c_float), ("_padf", C.c_float),
                 ("targets", P), ("pos", P), ("quat", P), ("lin_vel", P), ("ang_vel", P), ("dof_pos", P), ("dof_vel", P),
                 ("contact_force_out", P), ("contact_pos_out", P), ("link_a_out", P), ("link_b_out", P),
-                ("links_quat_out", P), ("links_vel_out", P), ("seed", C.c_uint64), ("tick", C.c_uint64)]
+                ("links_quat_out", P), ("links_vel_out", P), ("seed", C.c_uint64), ("tick", C.c_uint64),
+                ("env_offset", C.c_uint32), ("_pad2", C.c_uint32)]
 
 
 class GfOp(C.Structure):

@@ -52,4 +52,12 @@ def attach(env, group=None, global_num_envs: Optional[int] = None) -> None:
         dist.all_reduce(n, group=group)
         global_num_envs = int(n.item())
     env.global_num_envs = global_num_envs
-    env.seed(env._rng_seed + 0x9E3779B97F4A7C15 * (dist.get_rank(group) + 1))  # independent Philox stream per rank
+    # Philox is keyed by the GLOBAL env id: the sharded run reproduces the unsharded one env for env
+    counts = torch.zeros(dist.get_world_size(group), dtype=torch.int64, device=env.stats.device)
+    counts[dist.get_rank(group)] = env.num_envs
+    dist.all_reduce(counts, group=group)
+    offset = int(counts[: dist.get_rank(group)].sum().item())
+    env.env_offset = offset
+    if hasattr(env.scene, "env_offset"):
+        env.scene.env_offset = offset
+    env.invalidate_trace()

@@ -94,6 +94,7 @@ class GenesisEnv:
         self._tick = 0                 # bumps whenever scene state may have changed (views cache key)
         self._views_cache: dict = {}
         self._rng_seed = 0x5EED
+        self.env_offset = 0            # global index of local env 0 when envs are sharded over ranks (distributed.attach)
         self._rng_stream = 0           # every stochastic native call takes a fresh stream id
         self._draws: dict = {}         # parity mode: {"name": tensor of U[0,1)} consumed by the next call
         self._done_mask: Optional[torch.Tensor] = None
@@ -292,6 +293,7 @@ class GenesisEnv:
             a.len_draws = None if d is None else d.data_ptr()
         a.seed = self._rng_seed
         a.stream = self.next_stream()
+        a.env_offset = self.env_offset
 
     def _reset_masked(self, mask: torch.Tensor, mask2: Optional[torch.Tensor] = None) -> None:
         a = nat.GfResetArgs()

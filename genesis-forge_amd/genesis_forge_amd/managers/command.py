@@ -102,7 +102,7 @@ class CommandManager(BaseManager):
         draws = env.take_draws(draws_key) if draws_key else None
         self._keep = (draws, mask, mask2)
         a.draws = None if draws is None else draws.data_ptr()
-        a.seed, a.stream = env._rng_seed, env.next_stream()
+        a.seed, a.stream, a.env_offset = env._rng_seed, env.next_stream(), env.env_offset
         for i, r in enumerate(self._ranges()):  # re-read every call: curricula change ranges (:293-298)
             a.lo[i], a.hi[i] = float(r[0]), float(r[1])
         a.command = self._command.data_ptr()

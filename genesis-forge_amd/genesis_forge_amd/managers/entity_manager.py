@@ -84,9 +84,11 @@ class EntityManager(BaseManager):
         out = torch.empty(env.num_envs, 3, device=gs.device, dtype=gs.tc_float)
         a = self._rot_args
         a.num_envs, a.what = env.num_envs, what
-        self._views().fill(a.entity)
+        v = self._views()
+        v.fill(a.entity)
         a.out = out.data_ptr()
         env.backend.call("entity_rotate", a, owner=None)
+        self._keep_views = v  # the stale-quat composition is a temporary: keep it alive past the launch
         return _tag(out, (tag, self))
 
     def get_projected_gravity(self) -> torch.Tensor:

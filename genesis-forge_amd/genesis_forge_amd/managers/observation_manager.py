@@ -210,7 +210,7 @@ class ObservationManager(BaseManager):
         draws = env.take_draws(f"obs:{self._name}")
         keep.append(draws)
         a.noise_draws = None if draws is None else draws.data_ptr()
-        a.seed, a.stream = env._rng_seed, env.next_stream()
+        a.seed, a.stream, a.env_offset = env._rng_seed, env.next_stream(), env.env_offset
         out = self._rotate_ring(a)
         env.backend.call("observe", a, owner=self)
         self._keep = keep

@@ -321,6 +321,7 @@ class SyntheticScene:
         self.collider = _Collider(self)
         self._args = nat.GfSynthSceneArgs()
         self.is_built = False
+        self.env_offset = 0  # global index of local env 0 (env sharding)
         self.gf_static_buffers = True  # every state tensor is allocated once at build(): a step can be recorded
 
     # -- construction ---------------------------------------------------------------------------------
@@ -389,7 +390,7 @@ class SyntheticScene:
             a.link_a_out, a.link_b_out = self.link_a.data_ptr(), self.link_b.data_ptr()
             a.links_quat_out = self.links_quat.data_ptr()
             a.links_vel_out = self.links_vel_all.data_ptr()
-        a.seed, a.tick = self.seed, self.tick
+        a.seed, a.tick, a.env_offset = self.seed, self.tick, self.env_offset
         nat.get_backend().call("synth_scene_step", a, owner=self)
         if self.n_contacts > 0:
             s = r.links[0].idx

@@ -259,6 +259,8 @@ typedef struct GfCommandArgs {
     const float* draws;       /* [N,R] U[0,1) or NULL → Philox */
     uint64_t seed;
     uint64_t stream;          /* distinct per (manager, call) so draws never repeat */
+    uint32_t env_offset;      /* global index of local env 0 (env sharding): Philox is keyed by the GLOBAL env id */
+    uint32_t _pad2;
     float lo[GF_MAX_RANGES];
     float hi[GF_MAX_RANGES];
     float* command;           /* [N,R] in/out */
@@ -313,6 +315,8 @@ typedef struct GfResetArgs {
     int32_t zero_velocity;
     uint64_t seed;
     uint64_t stream;
+    uint32_t env_offset;        /* global index of local env 0 */
+    uint32_t _pad2;
     GfStepStats* stats;         /* may be NULL */
 } GfResetArgs;
 
@@ -364,6 +368,8 @@ typedef struct GfObservationArgs {
     const float* noise_draws; /* [N,O] U[0,1) or NULL → Philox */
     uint64_t seed;
     uint64_t stream;
+    uint32_t env_offset;      /* global index of local env 0 */
+    uint32_t _pad2;
     /* The reference's EntityManager caches base_quat at entity.step() and does not refresh it after the reset
      * that follows in the same tick (entity_manager.py:163-167,189-195): body-frame items of envs that were just
      * reset are rotated by their PRE-reset quaternion.  stale_quat (written by gf_masked_reset.quat_stash) supplies
@@ -421,6 +427,8 @@ typedef struct GfSynthSceneArgs {
     float* links_vel_out;     /* [N,num_scene_links,3] or NULL */
     uint64_t seed;
     uint64_t tick;
+    uint32_t env_offset;      /* global index of local env 0 */
+    uint32_t _pad2;
 } GfSynthSceneArgs;
 
 /* ------------------------------------------------------------------------------------------

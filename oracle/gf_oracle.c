@@ -452,7 +452,7 @@ GFO_EXPORT int gfo_command_step(const GfCommandArgs* a) {
         if (!go) continue;
         ++count;
         for (int64_t i = 0; i < R; ++i) {
-            const float u = draw_u(a->draws, n * R + i, a->seed, a->stream, (uint32_t)n, (uint32_t)i);
+            const float u = draw_u(a->draws, n * R + i, a->seed, a->stream, (uint32_t)n + a->env_offset, (uint32_t)i);
             a->command[n * R + i] = uniform_range(u, a->lo[i], a->hi[i]);
         }
     }
@@ -475,7 +475,7 @@ GFO_EXPORT int gfo_masked_reset(const GfResetArgs* a) {
             for (int64_t d = 0; d < D; ++d) { a->env_actions[n * D + d] = 0.0f; a->env_last_actions[n * D + d] = 0.0f; }
         if (a->episode_length) a->episode_length[n] = 0;
         if (a->max_episode_length && a->max_random_scaling > 0.0f) {
-            const float u = draw_u(a->len_draws, n, a->seed, a->stream, (uint32_t)n, 0u);
+            const float u = draw_u(a->len_draws, n, a->seed, a->stream, (uint32_t)n + a->env_offset, 0u);
             const float r = uniform_range(u, -1.0f, 1.0f) * a->max_random_scaling;
             a->max_episode_length[n] = (int32_t)rintf((float)a->base_max_episode_length + r); /* torch.round = half-to-even */
         }
@@ -504,7 +504,7 @@ GFO_EXPORT int gfo_masked_reset(const GfResetArgs* a) {
             for (int64_t d = 0; d < D; ++d) {
                 float p = a->default_dof_pos[d];
                 if (a->dof_noise_scale != 0.0f) {
-                    const float u = draw_u(a->dof_draws, n * D + d, a->seed, a->stream, (uint32_t)n, (uint32_t)(4 + d));
+                    const float u = draw_u(a->dof_draws, n * D + d, a->seed, a->stream, (uint32_t)n + a->env_offset, (uint32_t)(4 + d));
                     p = p + uniform_range(u, -1.0f, 1.0f) * a->dof_noise_scale;
                 }
                 a->scene_dof_pos[n * D + d] = p;
@@ -576,7 +576,7 @@ GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
                 float v = tmp[j];
                 if (it->scale != 1.0f) v = v * it->scale;             /* :242-244 */
                 if (it->noise != 0.0f) {                               /* :247-250 */
-                    const float u = draw_u(a->noise_draws, n * O + col, a->seed, a->stream, (uint32_t)n, (uint32_t)col);
+                    const float u = draw_u(a->noise_draws, n * O + col, a->seed, a->stream, (uint32_t)n + a->env_offset, (uint32_t)col);
                     v = v + uniform_range(u, -1.0f, 1.0f) * it->noise;
                 }
                 row[col] = v;
@@ -615,7 +615,7 @@ GFO_EXPORT int gfo_synth_scene_step(const GfSynthSceneArgs* a) {
             a->dof_pos[n * D + d] = a->dof_pos[n * D + d] + v * dt;
         }
         float s[6];
-        for (int j = 0; j < 6; ++j) s[j] = philox_uniform(a->seed, a->tick, (uint32_t)n, (uint32_t)j) * 2.0f - 1.0f;
+        for (int j = 0; j < 6; ++j) s[j] = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, (uint32_t)j) * 2.0f - 1.0f;
         float* w = a->ang_vel + 3 * n;
         float* v = a->lin_vel + 3 * n;
         float* p = a->pos + 3 * n;
@@ -645,11 +645,11 @@ GFO_EXPORT int gfo_synth_scene_step(const GfSynthSceneArgs* a) {
         if (C > 0 && a->contact_force_out) {
             for (int64_t c = 0; c < C; ++c) {
                 const uint32_t col = (uint32_t)(8 + 8 * c);
-                const float u_act = philox_uniform(a->seed, a->tick, (uint32_t)n, col);
-                const float u_link = philox_uniform(a->seed, a->tick, (uint32_t)n, col + 1);
-                const float fx = philox_uniform(a->seed, a->tick, (uint32_t)n, col + 2) * 2.0f - 1.0f;
-                const float fy = philox_uniform(a->seed, a->tick, (uint32_t)n, col + 3) * 2.0f - 1.0f;
-                const float fz = philox_uniform(a->seed, a->tick, (uint32_t)n, col + 4);
+                const float u_act = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col);
+                const float u_link = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 1);
+                const float fx = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 2) * 2.0f - 1.0f;
+                const float fy = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 3) * 2.0f - 1.0f;
+                const float fz = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 4);
                 const int active = u_act < a->contact_prob;
                 const int64_t k = n * C + c;
                 int32_t lb = 1 + (int32_t)(u_link * (float)(NL - 1));

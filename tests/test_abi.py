@@ -1,0 +1,60 @@
+"""The drop-in boundary: libgf_step.so loads without a GPU and exports every entry point include/gf_step.h declares,
+with struct layouts identical to the ctypes binding and to the oracle's host twins."""
+import ctypes
+import os
+import re
+
+from genesis_forge_amd import _native as nat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "gf_step.h")).read()
+    body = src[src.index("Entry points"):]
+    return sorted(set(re.findall(r"\b(gf_[a-z_]+)\s*\(", body)))
+
+
+def test_header_declares_all_phases():
+    names = _declared()
+    for fn in nat.PHASE_FUNCS:
+        assert "gf_" + fn in names
+    assert {"gf_run_ops", "gf_stats_clear", "gf_abi_version", "gf_sizeof", "gf_error_string", "gf_profile_begin", "gf_profile_end",
+            "gf_event_create", "gf_event_synchronize", "gf_event_destroy", "gf_build_info"} <= set(names)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(nat.lib_path())
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} is declared in include/gf_step.h but not exported by libgf_step.so"
+    nat.check_abi(lib, "gf_")
+    lib.gf_error_string.restype = ctypes.c_char_p
+    assert lib.gf_error_string(-3) == b"unknown opcode in term table"
+
+
+def test_oracle_twin_layouts(oracle_lib_path):
+    olib = ctypes.CDLL(oracle_lib_path)
+    nat.check_abi(olib, "gfo_")
+    for fn in nat.PHASE_FUNCS:
+        assert hasattr(olib, "gfo_" + fn)
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "genesis-forge_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(base, f)).read()
+                assert "libgf_oracle" not in text and "gfo_" not in text, f"{f} references the oracle"
+
+
+def test_no_gpu_means_loud_failure():
+    import pytest
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    b = nat.HipBackend()
+    a = nat.GfRotateArgs()
+    with pytest.raises(nat.GfError, match="no ROCm device"):
+        b.call("entity_rotate", a)

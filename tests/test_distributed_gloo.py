@@ -1,0 +1,63 @@
+"""Env sharding + the single logging all-reduce, world_size 2 over gloo on CPU.
+
+Property: a run sharded over ranks reproduces the unsharded run env for env (Philox is keyed by the global
+env id) and every rank reports the same, global, log values."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from _dist_worker import run_shard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_sharded_run_equals_unsharded(oracle_lib_path):
+    n_global, steps, sizes = 70, 40, [33, 37]
+    with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
+        ctx = mp.get_context("spawn")
+        p = ctx.Process(target=run_shard, args=(0, 1, _free_port(), d1, n_global, steps, [n_global]))
+        p.start(); p.join(240)
+        assert p.exitcode == 0
+        port = _free_port()
+        procs = [ctx.Process(target=run_shard, args=(r, 2, port, d2, n_global, steps, sizes)) for r in range(2)]
+        for q in procs:
+            q.start()
+        for q in procs:
+            q.join(240)
+            assert q.exitcode == 0
+        full = torch.load(os.path.join(d1, "rank0.pt"))
+        shards = [torch.load(os.path.join(d2, f"rank{r}.pt")) for r in range(2)]
+    assert all(s["traced"] for s in shards), "the sharded env should still record its step"
+    for t in range(steps):
+        ref = full["outs"][t]
+        for k in range(4):
+            cat = torch.cat([s["outs"][t][k] for s in shards])
+            assert torch.equal(cat, ref[k]), f"per-env output {k} differs from the unsharded run at step {t}"
+        logs = [s["outs"][t][4] for s in shards]
+        assert logs[0].keys() == logs[1].keys() == ref[4].keys(), f"log keys differ at step {t}"
+        for key, want in ref[4].items():
+            for lg in logs:
+                assert abs(lg[key] - want) <= 1e-6 + 1e-6 * abs(want), (t, key, lg[key], want)
+
+
+def test_shard_partition():
+    from genesis_forge_amd.distributed import shard
+
+    for n, w in [(65536, 8), (70, 3), (5, 8), (8192, 4)]:
+        parts = [shard(n, r, w) for r in range(w)]
+        assert sum(c for _, c in parts) == n
+        pos = 0
+        for s, c in parts:
+            assert s == pos
+            pos += c
