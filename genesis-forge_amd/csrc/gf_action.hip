@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void action_kernel(const GfActionArgs a, const
     if (a.stats && a.check_finite) {
         const unsigned long long nan_m = __ballot(flags & 1);
         const unsigned long long inf_m = __ballot(flags & 2);
-        if ((nan_m | inf_m) && (threadIdx.x & (GF_WAVE - 1)) == 0) atomicOr(&a.stats->action_flags, (nan_m ? 1 : 0) | (inf_m ? 2 : 0));
+        if ((nan_m | inf_m) && (threadIdx.x & (GF_WAVE - 1)) == 0) atomicOr(&stats_shard(a.stats)->action_flags, (nan_m ? 1 : 0) | (inf_m ? 2 : 0));
     }
 }
 

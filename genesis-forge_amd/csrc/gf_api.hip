@@ -49,7 +49,7 @@ GF_EXPORT const char* gf_error_string(int code) {
 
 GF_EXPORT int gf_stats_clear(GfStepStats* stats, void* stream) {
     if (!stats) return GF_E_NULL;
-    GF_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(GfStepStats), (hipStream_t)stream));
+    GF_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(GfStepStats) * GF_STATS_SHARDS, (hipStream_t)stream));
     return GF_OK;
 }
 
@@ -73,7 +73,7 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
             case GF_OP_STATS_COPY: {
                 const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
                 if (!c || !c->src || !c->dst) { rc = GF_E_NULL; break; }
-                hipError_t e = hipMemcpyAsync(c->dst, c->src, sizeof(GfStepStats), hipMemcpyDeviceToHost, s);
+                hipError_t e = hipMemcpyAsync(c->dst, c->src, sizeof(GfStepStats) * GF_STATS_SHARDS, hipMemcpyDeviceToHost, s);
                 if (e == hipSuccess && c->event) e = hipEventRecord((hipEvent_t)c->event, s);
                 rc = (int)e;
             } break;

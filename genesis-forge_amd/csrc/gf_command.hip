@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kEnvBlock) void command_kernel(const GfCommandArgs 
     }
     if (a.stats && a.mode == GF_CMD_STEP) {
         const unsigned long long m = __ballot(go);
-        if (m && threadIdx.x == 0) atomicAdd(&a.stats->resample_count, popc64(m));
+        if (m && threadIdx.x == 0) atomicAdd(&stats_shard(a.stats)->resample_count, popc64(m));
     }
     if (!go) return;
     const int R = a.num_ranges;

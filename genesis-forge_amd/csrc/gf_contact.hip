@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kEnvBlock) void contact_kernel(const GfContactArgs 
     }
     if (a.stats) {
         const unsigned long long m = __ballot(flag);
-        if (m && threadIdx.x == 0) atomicOr(&a.stats->contact_flags, 1);
+        if (m && threadIdx.x == 0) atomicOr(&stats_shard(a.stats)->contact_flags, 1);
     }
 }
 

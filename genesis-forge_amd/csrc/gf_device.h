@@ -127,6 +127,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
 
+// this workgroup's statistics shard (see GF_STATS_SHARDS in gf_step.h)
+__device__ __forceinline__ GfStepStats* stats_shard(GfStepStats* s) { return s + (blockIdx.x % GF_STATS_SHARDS); }
+
 // contact predicates shared by termination / reward terms
 __device__ __forceinline__ int contact_count_over(const GfContactView& v, int64_t n, float thr) {
     int cnt = 0;

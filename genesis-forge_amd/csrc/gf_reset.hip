@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
     const int64_t N = a.num_envs;
     const int D = a.num_dofs;
 
-    if (a.stats && threadIdx.x == 0) atomicAdd(&a.stats->reset_count, popc64(wave_go));
+    if (a.stats && threadIdx.x == 0) atomicAdd(&stats_shard(a.stats)->reset_count, popc64(wave_go));
 
     // ---- RewardManager.reset: needs every lane for the wave reduction --------------------------
     if (a.episode_seconds) {
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
                     const float per_sec = go ? (*v / secs) : 0.0f;  // value[envs_idx] /= episode_seconds
                     if (a.stats) {
                         const double s = wave_sum((double)per_sec);
-                        if (threadIdx.x == 0) atomicAdd(&a.stats->reward_episode_sum[t], s);
+                        if (threadIdx.x == 0) unsafeAtomicAdd(&stats_shard(a.stats)->reward_episode_sum[t], s);  // native global_atomic_add_f64
                     }
                 }
                 if (go) *v = 0.0f;

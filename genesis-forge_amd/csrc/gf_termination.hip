@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kEnvBlock) void termination_kernel(const GfTerminat
         if (a.term_out && live) a.term_out[(int64_t)k * a.num_envs + n] = (uint8_t)v;
         if (a.stats) {
             const unsigned long long hit = __ballot(v);
-            if (hit && threadIdx.x == 0) atomicAdd(&a.stats->term_fired[k], popc64(hit));
+            if (hit && threadIdx.x == 0) atomicAdd(&stats_shard(a.stats)->term_fired[k], popc64(hit));
         }
     }
     if (live) {

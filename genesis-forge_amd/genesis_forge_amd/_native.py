@@ -23,6 +23,7 @@ GF_MAX_EXT = 16
 GF_MAX_LINK_IDS = 32
 GF_MAX_RANGES = 8
 GF_MAX_OBS_WIDTH = 256
+GF_STATS_SHARDS = 64
 
 # opcodes ------------------------------------------------------------------------------------
 GF_ACTION_POSITION, GF_ACTION_WITHIN_LIMITS = 0, 1

@@ -19,8 +19,31 @@ import torch
 
 from . import _native as nat
 
-STATS_BYTES = C.sizeof(nat.GfStepStats)
+BLOCK_BYTES = C.sizeof(nat.GfStepStats)
+STATS_BYTES = BLOCK_BYTES * nat.GF_STATS_SHARDS  # the device block is GF_STATS_SHARDS shards (see gf_step.h)
 _RING = 64
+_INTS = BLOCK_BYTES // 4
+
+
+def sum_shards(buf: bytes) -> nat.GfStepStats:
+    """Fold the shards of one statistics read-back: counts and sums add, flag words OR."""
+    raw = np.frombuffer(buf, dtype=np.uint8).reshape(nat.GF_STATS_SHARDS, BLOCK_BYTES)
+    ints = raw[:, :96].copy().view(np.int32)                       # term_fired[16], reset, action_flags, contact_flags, resample, pad[4]
+    f64 = raw[:, 96:96 + 8 * nat.GF_MAX_TERMS].copy().view(np.float64)
+    st = nat.GfStepStats()
+    tot = ints.sum(axis=0, dtype=np.int64)
+    for k in range(nat.GF_MAX_TERM_TERMS):
+        st.term_fired[k] = int(tot[k])
+    o = nat.GF_MAX_TERM_TERMS
+    st.reset_count = int(tot[o])
+    st.action_flags = int(np.bitwise_or.reduce(ints[:, o + 1]))
+    st.contact_flags = int(np.bitwise_or.reduce(ints[:, o + 2]))
+    st.resample_count = int(tot[o + 3])
+    sums = f64.sum(axis=0)
+    for t in range(nat.GF_MAX_TERMS):
+        st.reward_episode_sum[t] = float(sums[t])
+    return st
+
 
 
 class StatsSnapshot:
@@ -44,7 +67,7 @@ class StatsSnapshot:
             if self._is_vector:  # cross-rank reduced f64 vector
                 st = vector_to_stats(self._host.numpy().copy())
             else:
-                st = nat.GfStepStats.from_buffer_copy(self._host.numpy().tobytes())
+                st = sum_shards(self._host.numpy().tobytes())
             self._value = st
             self._host = None
             self._event = None
@@ -115,11 +138,13 @@ class StepStats:
 
     def pack_vector(self) -> torch.Tensor:
         """The stats block as one f64 vector on the device (layout of ``stats_to_vector``): the all-reduce payload."""
-        ints = self.dev[:80].view(torch.int32)
-        f64 = self.dev[96:96 + 8 * nat.GF_MAX_TERMS].view(torch.float64)
-        flags = ints[_NT + 1]
-        head = torch.stack([ints[_NT], flags & 1, (flags >> 1) & 1, ints[_NT + 2] & 1, ints[_NT + 3]]).to(torch.float64)
-        return torch.cat([ints[:_NT].to(torch.float64), head, f64])
+        blocks = self.dev.view(nat.GF_STATS_SHARDS, BLOCK_BYTES)
+        ints = blocks[:, :96].contiguous().view(torch.int32)
+        f64 = blocks[:, 96:96 + 8 * nat.GF_MAX_TERMS].contiguous().view(torch.float64).sum(dim=0)
+        tot = ints.sum(dim=0)
+        flags = ints[:, _NT + 1]
+        head = torch.stack([tot[_NT], (flags & 1).max(), ((flags >> 1) & 1).max(), (ints[:, _NT + 2] & 1).max(), tot[_NT + 3]]).to(torch.float64)
+        return torch.cat([tot[:_NT].to(torch.float64), head, f64])
 
     def _snapshot_reduced(self, i: int) -> StatsSnapshot:
         """Sum the block over the ranks of ``self.group`` — the single collective of the path (RCCL over xGMI on

@@ -90,8 +90,12 @@ typedef struct GfTerm {
 } GfTerm;           /* 48 bytes */
 
 /* Per-step scalar statistics, accumulated on device, read back lazily by the host.
- * These are the only cross-env reductions of the path; at world_size>1 this
- * block (cast to f64) is the payload of the single RCCL all-reduce. */
+ * These are the only cross-env reductions of the path; at world_size>1 the
+ * summed block (cast to f64) is the payload of the single RCCL all-reduce.
+ * Every `stats` pointer of this ABI addresses an array of GF_STATS_SHARDS blocks: workgroup b
+ * accumulates into shard b % GF_STATS_SHARDS (1 024 waves adding to ONE word serialise at ≈ 88
+ * atomics/µs; sharding removes that), and the reader sums the shards (flags: bitwise OR). */
+#define GF_STATS_SHARDS 64
 typedef struct GfStepStats {
     int32_t term_fired[GF_MAX_TERM_TERMS]; /* #envs for which termination term k fired (termination_manager.py:178-182) */
     int32_t reset_count;                   /* #envs reset this step (managed_env.py:308-323) */
@@ -439,7 +443,7 @@ int gf_sizeof(int which);   /* sizeof of the ABI structs, in header order (0 = G
 const char* gf_build_info(void);
 const char* gf_error_string(int code);
 
-int gf_stats_clear(GfStepStats* stats, void* stream);            /* zero the per-step stats block */
+int gf_stats_clear(GfStepStats* stats, void* stream);            /* zero all GF_STATS_SHARDS blocks */
 
 int gf_action_step(const GfActionArgs* a, void* stream);          /* replaces genesis_env.py:181-205 + position_action_manager.py:376-419 */
 int gf_contact_step(const GfContactArgs* a, void* stream);        /* replaces contact_manager.py:331-336 (+ contact/kernel.py:5-90) */
@@ -466,8 +470,8 @@ typedef struct GfOp {
 enum { GF_OP_STATS_CLEAR = 100, GF_OP_STATS_COPY = 101 };
 
 typedef struct GfStatsCopyArgs {
-    const GfStepStats* src;   /* device */
-    void* dst;                /* pinned host, sizeof(GfStepStats) */
+    const GfStepStats* src;   /* device, GF_STATS_SHARDS blocks */
+    void* dst;                /* pinned host, GF_STATS_SHARDS * sizeof(GfStepStats) */
     void* event;              /* from gf_event_create(); recorded after the copy; may be NULL */
 } GfStatsCopyArgs;
 

@@ -88,7 +88,7 @@ static inline void proj_gravity(const GfEntityView* e, int64_t n, float* o) {
 /* ---------------------------------------------------------------- stats ------------------ */
 GFO_EXPORT int gfo_stats_clear(GfStepStats* s) {
     if (!s) return GF_E_NULL;
-    memset(s, 0, sizeof(*s));
+    memset(s, 0, sizeof(*s) * GF_STATS_SHARDS); /* the oracle itself only ever uses shard 0 */
     return GF_OK;
 }
 
@@ -688,7 +688,7 @@ GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
             case GF_OP_STATS_COPY: {
                 const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
                 if (!c || !c->src || !c->dst) { rc = GF_E_NULL; break; }
-                memcpy(c->dst, c->src, sizeof(GfStepStats));
+                memcpy(c->dst, c->src, sizeof(GfStepStats) * GF_STATS_SHARDS);
             } break;
             default: rc = GF_E_OPCODE; break;
         }
