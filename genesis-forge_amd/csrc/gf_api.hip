@@ -70,6 +70,7 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
             case GF_PHASE_ROTATE: rc = gf_entity_rotate((const GfRotateArgs*)a, stream); break;
             case GF_PHASE_SCENE: rc = gf_synth_scene_step((const GfSynthSceneArgs*)a, stream); break;
             case GF_OP_STATS_CLEAR: rc = gf_stats_clear((GfStepStats*)const_cast<void*>(a), stream); break;
+            case GF_OP_POST_PHYSICS: rc = gf_post_physics_step((const GfPostRefs*)a, stream); break;
             case GF_OP_STATS_COPY: {
                 const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
                 if (!c || !c->src || !c->dst) { rc = GF_E_NULL; break; }

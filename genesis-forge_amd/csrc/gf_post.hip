@@ -1,0 +1,831 @@
+// gf_post.hip — fused post-physics step: termination → reward → command.step → reset of done envs →
+// command.reset → observations (managed_env.py:303-326) as ONE launch.
+//
+// Every phase after scene.step() is per-env work over the same state, so one lane carries its env through
+// all of them with that state in registers:
+//   * pos / quat / lin / ang / the [N,D] rows / commands / episode_length are loaded ONCE, up front, all
+//     loads in flight together (straight-line load stream, zero-pad redirection, pinned kernarg pointers —
+//     see gf_reward.hip);
+//   * termination masks, the reward fold and the per-term episode sums (LDS-DMA prefetched) are evaluated by
+//     the shared term bodies of gf_terms.h — the same code the per-phase kernels run;
+//   * the reset of done envs is applied to the registers as well as to memory, so the observation that
+//     follows needs no reload: it reads post-reset dof_pos / dof_vel / velocities / commands from registers,
+//     and — reproducing the reference's stale EntityManager cache (entity_manager.py:163-167,189-195) — the
+//     PRE-reset quaternion;
+//   * the reward manager's reset (sum/seconds → log, sum ← 0) is folded into the sum update itself, which
+//     removes a whole read-modify-write pass over the [T,N] sums;
+//   * each wave assembles its [64, O] observation tile in LDS and streams it out with coalesced stores.
+// Semantics are, by construction, those of calling the phase entry points in sequence (the oracle twin does
+// exactly that); tests compare the two paths bit for bit.
+// Algorithmic traffic, Go2 command config: R 13·4 + 5 rows·48 + cmd 12 + ep/max 8 + secs 4 + sums 24 = 340,
+// W masks 2 + reward 4 + sums 24 + secs 4 + obs 192 = 226  →  566 B/env.
+#include "gf_launch.h"
+#include "gf_terms.h"
+
+namespace gf {
+
+constexpr int kPostMaxTerm = 8;
+constexpr int kPostMaxReward = 16;
+constexpr int kPostMaxItems = 12;
+constexpr int kPostMaxRanges = 4;
+
+struct PostCmd {
+    float* command;
+    int32_t width;
+    int32_t resample_steps;
+    uint64_t stream_step;
+    uint64_t stream_reset;
+    float lo[kPostMaxRanges];
+    float hi[kPostMaxRanges];
+};
+
+struct PostObs {
+    float* obs;
+    const float* prev;
+    uint64_t stream;
+    int32_t num_items;
+    int32_t width;
+    int32_t history;
+    int32_t _pad;
+    GfObsItem items[kPostMaxItems];
+};
+
+struct GfPostArgs {
+    int32_t num_envs, num_dofs, num_term, num_rew;
+    uint32_t needs;
+    int32_t n_cmd, n_obs, logging;
+    float dt;
+    int32_t reward_rows;
+    uint32_t reward_log_mask;
+    uint32_t uncovered_rows;   // rows of episode_sums no active term owns (zero weight): still zeroed on reset
+    uint64_t seed;
+    uint32_t env_offset;
+    int32_t has_maxlen;
+    // state
+    float *pos, *quat, *lin_vel, *ang_vel;       // entity views (writable: scene-side reset)
+    float *dof_pos, *dof_vel;
+    const float *dof_force, *targets, *default_dof_pos;
+    float *env_actions, *env_last_actions;
+    int32_t *episode_length, *max_episode_length;
+    uint8_t *terminated, *truncated;
+    float *reward, *episode_sums, *episode_seconds;
+    GfStepStats* stats;
+    float* quat_stash;
+    // views shared by every phase (slot indices in the copied terms/items are remapped onto these)
+    GfContactView contact[GF_MAX_CONTACT_VIEWS];
+    GfCommandView command[GF_MAX_COMMAND_VIEWS];
+    int32_t cmd_of_view[GF_MAX_COMMAND_VIEWS];   // index into cmds[] of the manager that owns the view's buffer, or -1
+    const float* ext[1];
+    float* state[4];
+    // reset
+    int32_t scene_reset, set_quat, zero_velocity, reset_env /* bit0: actions rows, bit1: episode_length */, reset_dofs;
+    int32_t base_max_episode_length;
+    float max_random_scaling, dof_noise_scale;
+    float reset_pos[3], reset_quat[4];
+    uint64_t stream_reset;
+    float* air_state[GF_MAX_CONTACT_VIEWS][4];
+    int32_t air_links[GF_MAX_CONTACT_VIEWS];
+    int32_t n_air;
+    int32_t _pad0;
+    GfTerm tterms[kPostMaxTerm];
+    GfTerm rterms[kPostMaxReward];
+    PostCmd cmds[GF_POST_MAX_CMD];
+    PostObs obs[GF_POST_MAX_OBS];
+};
+static_assert(sizeof(GfPostArgs) <= 4096, "GfPostArgs must fit the 4 KB kernarg segment");
+
+enum : uint32_t {
+    PN_POS = 1, PN_QUAT = 2, PN_LIN = 4, PN_ANG = 8, PN_DOFPOS = 16, PN_DOFVEL = 32, PN_TARGETS = 64, PN_ACTIONS = 128, PN_LAST = 256,
+    PN_EPLEN = 512, PN_MAXLEN = 1024, PN_DOFDEV = 2048, PN_ACTRATE = 4096, PN_DOFFORCE = 8192,
+};
+
+__device__ __forceinline__ float obs_finish(const GfPostArgs& a, const PostObs& ob, const GfObsItem& it, float v, uint32_t genv, int64_t n, int col) {
+    if (it.scale != 1.0f) v = v * it.scale;
+    if (it.noise != 0.0f) {
+        const float u = philox_uniform(a.seed, ob.stream, genv, (uint32_t)col);
+        v = v + uniform_range(u, -1.0f, 1.0f) * it.noise;
+    }
+    return v;
+}
+
+// one [D] row of registers → the lane's observation tile row (separate call per source keeps every index static)
+template <int DV>
+__device__ __forceinline__ void put_row(const GfPostArgs& a, const PostObs& ob, const GfObsItem& it, const float4 (&r)[DV], float* row, uint32_t genv,
+                                        int64_t n, int col) {
+#pragma unroll
+    for (int c = 0; c < DV; ++c) {
+        row[col + 4 * c + 0] = obs_finish(a, ob, it, r[c].x, genv, n, col + 4 * c + 0);
+        row[col + 4 * c + 1] = obs_finish(a, ob, it, r[c].y, genv, n, col + 4 * c + 1);
+        row[col + 4 * c + 2] = obs_finish(a, ob, it, r[c].z, genv, n, col + 4 * c + 2);
+        row[col + 4 * c + 3] = obs_finish(a, ob, it, r[c].w, genv, n, col + 4 * c + 3);
+    }
+}
+
+template <int DV>
+__global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lds_sums = lds;                                   // [num_rew][64]
+    float* tile = lds + kPostMaxReward * kEnvBlock;          // [64][O+1]
+
+    const int lane = threadIdx.x;
+    const int64_t N = a.num_envs;
+    const int64_t n0 = (int64_t)blockIdx.x * kEnvBlock;
+    const int64_t n_raw = n0 + lane;
+    const bool live = n_raw < N;
+    const int64_t n = live ? n_raw : N - 1;
+    const uint32_t e = (uint32_t)n;
+    const uint32_t genv = e + a.env_offset;
+    const int D = a.num_dofs;
+    const uint32_t needs = a.needs;
+    constexpr int R = DV;
+
+    // ---- 0. episode-sum columns: global -> LDS without VGPRs or waits ------------------------------------
+    const bool logging = a.logging != 0;
+    if (logging)
+        for (int k = 0; k < a.num_rew; ++k)
+            __builtin_amdgcn_global_load_lds(a.episode_sums + (int64_t)a.rterms[k].row * N + n, lds_sums + k * kEnvBlock, 4, 0, 0);
+
+    // ---- 1. all per-env inputs, one straight-line burst ------------------------------------------------------
+    const float *k_pos = a.pos, *k_quat = a.quat, *k_lin = a.lin_vel, *k_ang = a.ang_vel, *k_dof = a.dof_pos, *k_dvel = a.dof_vel;
+    const float *k_tgt = a.targets, *k_act = a.env_actions, *k_last = a.env_last_actions, *k_def = a.default_dof_pos, *k_secs = a.episode_seconds;
+    const int32_t *k_ep = a.episode_length, *k_max = a.max_episode_length;
+    asm volatile("" : "+s"(k_pos), "+s"(k_quat), "+s"(k_lin), "+s"(k_ang), "+s"(k_dof), "+s"(k_dvel));
+    asm volatile("" : "+s"(k_tgt), "+s"(k_act), "+s"(k_last), "+s"(k_def), "+s"(k_secs), "+s"(k_ep), "+s"(k_max));
+
+    const float4 q = ldg4(gsel((needs & PN_QUAT) != 0, k_quat, 4u * e));
+    const GF_GLOBAL float* pp = gsel((needs & PN_POS) != 0, k_pos, 3u * e);
+    const GF_GLOBAL float* lp = gsel((needs & PN_LIN) != 0, k_lin, 3u * e);
+    const GF_GLOBAL float* ap = gsel((needs & PN_ANG) != 0, k_ang, 3u * e);
+    V3 pos{pp[0], pp[1], pp[2]}, lin{lp[0], lp[1], lp[2]}, ang{ap[0], ap[1], ap[2]};
+    const int ep_len = *gsel((needs & PN_EPLEN) != 0, k_ep, e);
+    const int max_len = *gsel((needs & PN_MAXLEN) != 0, k_max, e);
+    const float secs_in = *gsel(a.num_rew >= 0 && k_secs != nullptr, k_secs, e);
+
+    const uint32_t ro = e * (uint32_t)D;
+    float4 r_pos[R], r_vel[R], r_tgt[R], r_act[R], r_last[R], r_def[R];
+    {
+        const GF_GLOBAL float* p0 = gsel((needs & PN_DOFPOS) != 0, k_dof, ro);
+        const GF_GLOBAL float* p1 = gsel((needs & PN_DOFVEL) != 0, k_dvel, ro);
+        const GF_GLOBAL float* p2 = gsel((needs & PN_TARGETS) != 0, k_tgt, ro);
+        const GF_GLOBAL float* p3 = gsel((needs & PN_ACTIONS) != 0, k_act, ro);
+        const GF_GLOBAL float* p4 = gsel((needs & PN_LAST) != 0, k_last, ro);
+        const GF_GLOBAL float* p5 = gsel(k_def != nullptr, k_def, 0u);
+#pragma unroll
+        for (int c = 0; c < DV; ++c) {
+            r_pos[c] = ldg4(p0 + 4 * c); r_vel[c] = ldg4(p1 + 4 * c); r_tgt[c] = ldg4(p2 + 4 * c);
+            r_act[c] = ldg4(p3 + 4 * c); r_last[c] = ldg4(p4 + 4 * c); r_def[c] = ldg4(p5 + 4 * c);
+        }
+    }
+    // command rows of the stepped managers (≤ 2 managers × ≤ 4 ranges)
+    float cmd[GF_POST_MAX_CMD][kPostMaxRanges];
+#pragma unroll
+    for (int c = 0; c < GF_POST_MAX_CMD; ++c) {
+        const bool on = c < a.n_cmd;
+        const uint32_t w = on ? (uint32_t)a.cmds[c].width : 0u;
+        const GF_GLOBAL float* cp = gsel(on, on ? a.cmds[c].command : nullptr, e * w);
+#pragma unroll
+        for (int j = 0; j < kPostMaxRanges; ++j) cmd[c][j] = cp[(uint32_t)j < w ? j : 0];
+    }
+
+    // ---- 2. derived per-env quantities (pre-reset) ----------------------------------------------------------------
+    const V3 blin = rot_inv(q, lin), bang = rot_inv(q, ang), grav = rot_inv(q, V3{0.f, 0.f, -1.f});
+    float dof_dev = 0.f, act_rate = 0.f;
+#pragma unroll
+    for (int c = 0; c < DV; ++c) {
+        dof_dev += fabsf(r_pos[c].x - r_def[c].x);
+        dof_dev += fabsf(r_pos[c].y - r_def[c].y);
+        dof_dev += fabsf(r_pos[c].z - r_def[c].z);
+        dof_dev += fabsf(r_pos[c].w - r_def[c].w);
+    }
+#pragma unroll
+    for (int c = 0; c < DV; ++c) {
+        float d;
+        d = r_last[c].x - r_act[c].x; act_rate += d * d;
+        d = r_last[c].y - r_act[c].y; act_rate += d * d;
+        d = r_last[c].z - r_act[c].z; act_rate += d * d;
+        d = r_last[c].w - r_act[c].w; act_rate += d * d;
+    }
+    GfStepStats* shard = a.stats ? stats_shard(a.stats) : nullptr;
+
+    // ---- 3. termination (termination_manager.py:151-190) ---------------------------------------------------------------
+    TermRegs tr;
+    tr.ep_len = ep_len; tr.max_len = max_len; tr.has_maxlen = a.has_maxlen != 0; tr.pos = pos; tr.m = n;
+    tr.tilt_sin = clamp_max(norm2(grav.x, grav.y), 0.99f);
+    int term = 0, trunc = 0;
+    for (int k = 0; k < a.num_term; ++k) {
+        const GfTerm& t = a.tterms[k];
+        int v = eval_termination_term(t, a, tr, (uint32_t)a.has_maxlen);
+        v = live ? v : 0;
+        if (t.flags & GF_TERM_FLAG_TIME_OUT) trunc |= v; else term |= v;
+        if (shard) {
+            const unsigned long long hit = __ballot(v);
+            if (hit && lane == 0) atomicAdd(&shard->term_fired[k], popc64(hit));
+        }
+    }
+    if (live) {
+        a.terminated[n_raw] = (uint8_t)term;
+        a.truncated[n_raw] = (uint8_t)trunc;
+    }
+    const bool done = live && (term | trunc);
+    const unsigned long long done_mask = __ballot(done);
+    if (shard && done_mask && lane == 0) atomicAdd(&shard->reset_count, popc64(done_mask));
+
+    // ---- 4. reward (reward_manager.py:166-195) with the manager's reset (:197-222) folded into the sum update -----------
+    if (a.num_rew >= 0 && a.reward) {
+        RewardRegs rr;
+        rr.pos = pos; rr.blin = blin; rr.bang = bang; rr.grav = grav; rr.dof_dev = dof_dev; rr.act_rate = act_rate; rr.terminated = term;
+        rr.n = n; rr.live = live;
+        const int c0 = a.cmd_of_view[0];
+        if (c0 >= 0) {
+            rr.cmd0[0] = c0 == 0 ? cmd[0][0] : cmd[1][0];
+            rr.cmd0[1] = c0 == 0 ? cmd[0][1] : cmd[1][1];
+            rr.cmd0[2] = c0 == 0 ? cmd[0][2] : cmd[1][2];
+        } else {
+            const bool nv = a.command[0].command != nullptr;
+            const uint32_t w = nv ? (uint32_t)a.command[0].width : 0u;
+            const GF_GLOBAL float* cp = gsel(nv, a.command[0].command, e * w);
+            rr.cmd0[0] = cp[0]; rr.cmd0[1] = cp[w > 1 ? 1 : 0]; rr.cmd0[2] = cp[w > 2 ? 2 : 0];
+        }
+        const float secs_new = secs_in + a.dt;
+        if (logging) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float buf = 0.f;
+        const bool log_reset = logging && done_mask != 0;
+        for (int k = 0; k < a.num_rew; ++k) {
+            const GfTerm& t = a.rterms[k];
+            float v = eval_reward_term(t, a, rr);
+            v = v * t.w;
+            buf += v;
+            if (logging) {
+                float s = lds_sums[k * kEnvBlock + lane] + v;
+                if (log_reset) {
+                    // RewardManager.reset: value /= seconds; mean → log; value ← 0 (zero-weight rows are not logged)
+                    const float per_sec = done ? s / secs_new : 0.f;
+                    if (shard && (a.reward_log_mask & (1u << t.row))) {
+                        if (popc64(done_mask) > 4) {
+                            const double w = wave_sum((double)per_sec);
+                            if (lane == 0) unsafeAtomicAdd(&shard->reward_episode_sum[t.row], w);
+                        } else if (done) {
+                            unsafeAtomicAdd(&shard->reward_episode_sum[t.row], (double)per_sec);
+                        }
+                    }
+                    if (done) s = 0.f;
+                }
+                if (live) a.episode_sums[(int64_t)t.row * N + n_raw] = s;
+            }
+        }
+        if (live) {
+            a.reward[n_raw] = buf;
+            a.episode_seconds[n_raw] = done ? 1e-10f : secs_new;
+        }
+        if (done && logging)
+            for (int row = 0; row < a.reward_rows; ++row)
+                if (a.uncovered_rows & (1u << row)) a.episode_sums[(int64_t)row * N + n_raw] = 0.f;
+    }
+
+    // ---- 5. command.step: resample where episode_length % resample_steps == 0 (command_manager.py:152-162) --------------
+    bool cmd_dirty[GF_POST_MAX_CMD] = {false, false};
+#pragma unroll
+    for (int c = 0; c < GF_POST_MAX_CMD; ++c) {
+        if (c < a.n_cmd) {
+            const PostCmd& cm = a.cmds[c];
+            const bool go = live && (ep_len % cm.resample_steps) == 0;
+            if (shard) {
+                const unsigned long long m = __ballot(go);
+                if (m && lane == 0) atomicAdd(&shard->resample_count, popc64(m));
+            }
+            if (go) {
+#pragma unroll
+                for (int j = 0; j < kPostMaxRanges; ++j)
+                    if (j < cm.width) cmd[c][j] = uniform_range(philox_uniform(a.seed, cm.stream_step, genv, (uint32_t)j), cm.lo[j], cm.hi[j]);
+                cmd_dirty[c] = true;
+            }
+        }
+    }
+
+    // ---- 6. reset of done envs (managed_env.py:336-366), applied to memory AND to the registers the observation reads ----
+    float4 o_act[R];  // raw actions as the observation sees them
+#pragma unroll
+    for (int c = 0; c < DV; ++c) o_act[c] = r_act[c];
+    if (done) {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((a.reset_env & 1) && a.env_actions) {
+            float4* ra = reinterpret_cast<float4*>(a.env_actions + n * D);
+            float4* rl = reinterpret_cast<float4*>(a.env_last_actions + n * D);
+#pragma unroll
+            for (int c = 0; c < DV; ++c) { ra[c] = z4; rl[c] = z4; o_act[c] = z4; }
+        }
+        if (a.reset_env & 2) a.episode_length[n] = 0;
+        if (a.max_episode_length && a.max_random_scaling > 0.0f) {
+            const float u = philox_uniform(a.seed, a.stream_reset, genv, 0u);
+            const float rnd = uniform_range(u, -1.0f, 1.0f) * a.max_random_scaling;
+            a.max_episode_length[n] = (int32_t)rintf((float)a.base_max_episode_length + rnd);
+        }
+        for (int m = 0; m < a.n_air; ++m) {
+            const int L = a.air_links[m];
+            for (int s = 0; s < 4; ++s) {
+                float* p = a.air_state[m][s];
+                if (p)
+                    for (int l = 0; l < L; ++l) p[n * L + l] = 0.0f;
+            }
+        }
+        if (a.reset_dofs) {
+            float4* dp = reinterpret_cast<float4*>(a.dof_pos + n * D);
+            float4* dv = reinterpret_cast<float4*>(a.dof_vel + n * D);
+#pragma unroll
+            for (int c = 0; c < DV; ++c) {
+                float4 p = r_def[c];
+                if (a.dof_noise_scale != 0.0f) {
+                    p.x = p.x + uniform_range(philox_uniform(a.seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 0)), -1.0f, 1.0f) * a.dof_noise_scale;
+                    p.y = p.y + uniform_range(philox_uniform(a.seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 1)), -1.0f, 1.0f) * a.dof_noise_scale;
+                    p.z = p.z + uniform_range(philox_uniform(a.seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 2)), -1.0f, 1.0f) * a.dof_noise_scale;
+                    p.w = p.w + uniform_range(philox_uniform(a.seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 3)), -1.0f, 1.0f) * a.dof_noise_scale;
+                }
+                r_pos[c] = p;
+                dp[c] = p;
+                if (a.dof_vel) { dv[c] = z4; r_vel[c] = z4; }
+            }
+        }
+        if (a.scene_reset) {
+            float* wp = a.pos + 3 * n;
+            wp[0] = a.reset_pos[0]; wp[1] = a.reset_pos[1]; wp[2] = a.reset_pos[2];
+            if (a.set_quat) {
+                if (a.quat_stash) reinterpret_cast<float4*>(a.quat_stash)[n] = q;
+                reinterpret_cast<float4*>(a.quat)[n] = make_float4(a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]);
+            }
+            if (a.zero_velocity) {
+                float* wl = a.lin_vel + 3 * n;
+                float* wa = a.ang_vel + 3 * n;
+                wl[0] = 0.f; wl[1] = 0.f; wl[2] = 0.f;
+                wa[0] = 0.f; wa[1] = 0.f; wa[2] = 0.f;
+                lin = V3{0.f, 0.f, 0.f};
+                ang = V3{0.f, 0.f, 0.f};
+                if (a.dof_vel) {
+                    float4* dv = reinterpret_cast<float4*>(a.dof_vel + n * D);
+#pragma unroll
+                    for (int c = 0; c < DV; ++c) { dv[c] = z4; r_vel[c] = z4; }
+                }
+            }
+        }
+    }
+
+    // ---- 7. command.reset for done envs (command_manager.py:164-170) + write back changed commands ------------------------
+#pragma unroll
+    for (int c = 0; c < GF_POST_MAX_CMD; ++c) {
+        if (c < a.n_cmd) {
+            const PostCmd& cm = a.cmds[c];
+            if (done) {
+#pragma unroll
+                for (int j = 0; j < kPostMaxRanges; ++j)
+                    if (j < cm.width) cmd[c][j] = uniform_range(philox_uniform(a.seed, cm.stream_reset, genv, (uint32_t)j), cm.lo[j], cm.hi[j]);
+                cmd_dirty[c] = true;
+            }
+            if (cmd_dirty[c] && live) {
+                float* row = cm.command + n * cm.width;
+#pragma unroll
+                for (int j = 0; j < kPostMaxRanges; ++j)
+                    if (j < cm.width) row[j] = cmd[c][j];
+            }
+        }
+    }
+
+    // ---- 8. observations (observation_manager.py:218-256): post-reset state, pre-reset quaternion ------------------------
+    const V3 o_lin = rot_inv(q, lin), o_ang = rot_inv(q, ang);
+    for (int m = 0; m < a.n_obs; ++m) {
+        const PostObs& ob = a.obs[m];
+        const int O = ob.width, S = O + 1, H = ob.history;
+        float* row = tile + lane * S;
+        int col = 0;
+        for (int i = 0; i < ob.num_items; ++i) {
+            const GfObsItem& it = ob.items[i];
+            switch (it.op) {
+                case GF_O_COMMAND: {
+                    const int owner = a.cmd_of_view[it.i0];
+                    if (owner >= 0) {
+#pragma unroll
+                        for (int j = 0; j < kPostMaxRanges; ++j)
+                            if (j < it.width) row[col + j] = obs_finish(a, ob, it, owner == 0 ? cmd[0][j] : cmd[1][j], genv, n, col + j);
+                    } else {
+                        const GfCommandView& cv = a.command[it.i0];
+                        for (int j = 0; j < it.width; ++j) row[col + j] = obs_finish(a, ob, it, cv.command[n * cv.width + j], genv, n, col + j);
+                    }
+                } break;
+                case GF_O_ANG_VEL_BODY:
+                case GF_O_LIN_VEL_BODY:
+                case GF_O_PROJ_GRAVITY: {
+                    const V3 v = it.op == GF_O_ANG_VEL_BODY ? o_ang : (it.op == GF_O_LIN_VEL_BODY ? o_lin : grav);
+                    row[col + 0] = obs_finish(a, ob, it, v.x, genv, n, col + 0);
+                    row[col + 1] = obs_finish(a, ob, it, v.y, genv, n, col + 1);
+                    row[col + 2] = obs_finish(a, ob, it, v.z, genv, n, col + 2);
+                } break;
+                case GF_O_DOF_POS: put_row<DV>(a, ob, it, r_pos, row, genv, n, col); break;
+                case GF_O_DOF_VEL: put_row<DV>(a, ob, it, r_vel, row, genv, n, col); break;
+                case GF_O_ACTIONS: put_row<DV>(a, ob, it, r_tgt, row, genv, n, col); break;
+                case GF_O_RAW_ACTIONS: put_row<DV>(a, ob, it, o_act, row, genv, n, col); break;
+                case GF_O_DOF_FORCE: {
+                    const float* r = a.dof_force + n * D;
+                    for (int j = 0; j < it.width; ++j) row[col + j] = obs_finish(a, ob, it, r[j], genv, n, col + j);
+                } break;
+                case GF_O_CONTACT_FORCE_NORM: {
+                    const GfContactView& cv = a.contact[it.i0];
+                    const float* r = cv.contacts + n * cv.num_links * 3;
+                    for (int l = 0; l < it.width; ++l) row[col + l] = obs_finish(a, ob, it, norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]), genv, n, col + l);
+                } break;
+                default: break;
+            }
+            col += it.width;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const int rows = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
+        const int64_t OH = (int64_t)O * H;
+        float* out = ob.obs + n0 * OH;
+        if ((O & 3) == 0) {
+            const int o4 = O >> 2;
+            for (int i = lane; i < rows * o4; i += GF_WAVE) {
+                const int rw = i / o4, c4 = i - rw * o4;
+                const float* r = tile + rw * S + c4 * 4;
+                reinterpret_cast<float4*>(out + rw * OH)[c4] = make_float4(r[0], r[1], r[2], r[3]);
+            }
+            if (H > 1) {
+                const int h4 = (O * (H - 1)) >> 2;
+                const float* prev = ob.prev + n0 * OH;
+                for (int i = lane; i < rows * h4; i += GF_WAVE) {
+                    const int rw = i / h4, j = i - rw * h4;
+                    reinterpret_cast<float4*>(out + rw * OH + O)[j] = reinterpret_cast<const float4*>(prev + rw * OH)[j];
+                }
+            }
+        } else {
+            for (int i = lane; i < rows * O; i += GF_WAVE) {
+                const int rw = i / O, cc = i - rw * O;
+                out[rw * OH + cc] = tile[rw * S + cc];
+            }
+            if (H > 1) {
+                const int hw = O * (H - 1);
+                const float* prev = ob.prev + n0 * OH;
+                for (int i = lane; i < rows * hw; i += GF_WAVE) {
+                    const int rw = i / hw, j = i - rw * hw;
+                    out[rw * OH + O + j] = prev[rw * OH + j];
+                }
+            }
+        }
+        // the tile is reused by the next observation manager
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Host side: validate that the per-phase descriptors describe one fusable step and pack them.
+// ------------------------------------------------------------------------------------------------------------
+static int cmd_slot_of_reward_op(int op) {
+    switch (op) {
+        case GF_R_CMD_TRACK_LIN_VEL:
+        case GF_R_CMD_TRACK_ANG_VEL:
+        case GF_R_STAND_STILL: return 0;
+        case GF_R_FEET_AIR_TIME: return 1;
+        default: return -1;
+    }
+}
+static bool reward_op_has_contact(int op) { return op == GF_R_HAS_CONTACT || op == GF_R_CONTACT_FORCE || op == GF_R_FEET_AIR_TIME || op == GF_R_FEET_SLIDE; }
+static bool term_op_has_contact(int op) { return op == GF_T_HAS_CONTACT || op == GF_T_CONTACT_FORCE || op == GF_T_CONTACT_FORCE_GRACE; }
+
+struct Packer {
+    GfPostArgs a{};
+    int n_contact = 0, n_view = 0;
+
+    int contact_slot(const GfContactView& v) {
+        for (int k = 0; k < n_contact; ++k)
+            if (a.contact[k].contacts == v.contacts) {
+                if (!a.contact[k].link_vel) a.contact[k].link_vel = v.link_vel;
+                return k;
+            }
+        if (n_contact >= GF_MAX_CONTACT_VIEWS) return -1;
+        a.contact[n_contact] = v;
+        return n_contact++;
+    }
+    int view_slot(const GfCommandView& v) {
+        for (int k = 0; k < n_view; ++k)
+            if (a.command[k].command == v.command) return k;
+        if (n_view >= GF_MAX_COMMAND_VIEWS) return -1;
+        a.command[n_view] = v;
+        a.cmd_of_view[n_view] = -1;
+        for (int c = 0; c < a.n_cmd; ++c)
+            if (a.cmds[c].command == v.command) a.cmd_of_view[n_view] = c;
+        return n_view++;
+    }
+};
+
+static bool same_entity(const GfEntityView& x, const GfEntityView& y) {
+    auto ok = [](const float* p, const float* q) { return !p || !q || p == q; };
+    return ok(x.pos, y.pos) && ok(x.quat, y.quat) && ok(x.lin_vel, y.lin_vel) && ok(x.ang_vel, y.ang_vel);
+}
+static void merge_entity(GfPostArgs& a, const GfEntityView& v) {
+    if (v.pos) a.pos = const_cast<float*>(v.pos);
+    if (v.quat) a.quat = const_cast<float*>(v.quat);
+    if (v.lin_vel) a.lin_vel = const_cast<float*>(v.lin_vel);
+    if (v.ang_vel) a.ang_vel = const_cast<float*>(v.ang_vel);
+}
+
+#define UNSUP(cond)                          \
+    do {                                     \
+        if (cond) return GF_E_UNSUPPORTED;   \
+    } while (0)
+
+static int pack(const GfPostRefs* r, Packer& pk) {
+    if (!r || !r->termination || !r->reset) return GF_E_NULL;
+    GfPostArgs& a = pk.a;
+    const GfTerminationArgs& T = *r->termination;
+    const GfResetArgs& RS = *r->reset;
+    const GfRewardArgs* RW = r->reward;
+    const int N = T.num_envs;
+    UNSUP(N <= 0 || T.num_terms > kPostMaxTerm || T.term_out);
+    UNSUP(r->num_command < 0 || r->num_command > GF_POST_MAX_CMD || r->num_observe < 0 || r->num_observe > GF_POST_MAX_OBS);
+    UNSUP(RS.num_envs != N || RS.mask != T.terminated || RS.mask2 != T.truncated);
+    UNSUP(RS.len_draws || RS.dof_draws);
+    a.num_envs = N;
+    a.terminated = T.terminated; a.truncated = T.truncated; a.stats = T.stats ? T.stats : RS.stats;
+    UNSUP(RS.stats && T.stats && RS.stats != T.stats);
+    a.episode_length = const_cast<int32_t*>(T.episode_length);
+    a.max_episode_length = const_cast<int32_t*>(T.max_episode_length);
+    a.has_maxlen = T.max_episode_length != nullptr;
+    merge_entity(a, T.entity);
+    uint32_t needs = 0;
+    int D = RS.num_dofs;
+
+    // commands first (views map onto them)
+    a.n_cmd = r->num_command;
+    for (int c = 0; c < a.n_cmd; ++c) {
+        const GfCommandArgs* s = r->command_step[c];
+        const GfCommandArgs* m = r->command_reset[c];
+        UNSUP(!s || !m || s->mode != GF_CMD_STEP || m->mode != GF_CMD_MASKED || s->command != m->command || s->num_ranges != m->num_ranges);
+        UNSUP(s->num_envs != N || m->num_envs != N || s->num_ranges > kPostMaxRanges || s->draws || m->draws || s->resample_steps <= 0);
+        UNSUP(m->mask != T.terminated || m->mask2 != T.truncated || s->episode_length != T.episode_length);
+        UNSUP(s->seed != RS.seed || m->seed != RS.seed || s->env_offset != RS.env_offset || m->env_offset != RS.env_offset);
+        UNSUP(s->stats && a.stats && s->stats != a.stats);
+        PostCmd& pc = a.cmds[c];
+        pc.command = s->command; pc.width = s->num_ranges; pc.resample_steps = s->resample_steps;
+        pc.stream_step = s->stream; pc.stream_reset = m->stream;
+        for (int j = 0; j < s->num_ranges; ++j) {
+            UNSUP(s->lo[j] != m->lo[j] || s->hi[j] != m->hi[j]);
+            pc.lo[j] = s->lo[j]; pc.hi[j] = s->hi[j];
+        }
+        needs |= PN_EPLEN;
+    }
+    a.seed = RS.seed; a.env_offset = RS.env_offset; a.stream_reset = RS.stream;
+
+    // termination terms
+    a.num_term = T.num_terms;
+    for (int k = 0; k < T.num_terms; ++k) {
+        GfTerm t = T.terms[k];
+        switch (t.op) {
+            case GF_T_TIMEOUT: if (T.max_episode_length) needs |= PN_EPLEN | PN_MAXLEN; break;
+            case GF_T_BAD_ORIENTATION: needs |= PN_QUAT | PN_EPLEN; break;
+            case GF_T_BASE_HEIGHT_BELOW:
+            case GF_T_OUT_OF_BOUNDS: needs |= PN_POS; break;
+            case GF_T_CONTACT_FORCE_GRACE: needs |= PN_EPLEN;  // fallthrough
+            case GF_T_HAS_CONTACT:
+            case GF_T_CONTACT_FORCE: break;
+            default: return GF_E_UNSUPPORTED;  // EXTERNAL columns cannot be fused
+        }
+        if (term_op_has_contact(t.op)) {
+            UNSUP(t.i[0] < 0 || t.i[0] >= GF_MAX_CONTACT_VIEWS || !T.contact[t.i[0]].contacts);
+            const int s = pk.contact_slot(T.contact[t.i[0]]);
+            UNSUP(s < 0);
+            t.i[0] = s;
+        }
+        a.tterms[k] = t;
+    }
+
+    // reward
+    a.num_rew = -1;
+    if (RW) {
+        UNSUP(RW->num_envs != N || RW->mode != GF_REWARD_MODE_STEP || RW->num_terms > kPostMaxReward || !RW->reward || !RW->episode_seconds);
+        UNSUP(!same_entity(T.entity, RW->entity));
+        merge_entity(a, RW->entity);
+        a.num_rew = RW->num_terms;
+        a.reward = RW->reward; a.episode_sums = RW->episode_sums; a.episode_seconds = RW->episode_seconds;
+        a.logging = RW->logging_enabled && RW->episode_sums;
+        a.dt = RW->dt;
+        for (int s = 0; s < 4; ++s) a.state[s] = RW->state[s];
+        // view 0 first so the kernel's preloaded cmd0 refers to it
+        if (RW->command[0].command) UNSUP(pk.view_slot(RW->command[0]) != 0);
+        uint32_t covered = 0;
+        for (int k = 0; k < RW->num_terms; ++k) {
+            GfTerm t = RW->terms[k];
+            UNSUP(t.row < 0 || t.row >= 24);
+            covered |= 1u << t.row;
+            switch (t.op) {
+                case GF_R_IS_ALIVE:
+                case GF_R_TERMINATED: UNSUP(RW->terminated != T.terminated); break;
+                case GF_R_BASE_HEIGHT: needs |= PN_POS; UNSUP(t.flags & GF_RW_FLAG_TERRAIN); break;
+                case GF_R_DOF_SIMILAR_TO_DEFAULT:
+                case GF_R_STAND_STILL: needs |= PN_DOFPOS | PN_DOFDEV; break;
+                case GF_R_LIN_VEL_Z_L2: needs |= PN_QUAT | PN_LIN; break;
+                case GF_R_ANG_VEL_XY_L2: needs |= PN_QUAT | PN_ANG; break;
+                case GF_R_FLAT_ORIENTATION_L2: needs |= PN_QUAT; break;
+                case GF_R_BODY_ACCEL_EXP: needs |= PN_QUAT | PN_LIN | PN_ANG; UNSUP(t.i[0] < 0 || t.i[0] >= 4 || !RW->state[t.i[0]]); break;
+                case GF_R_ACTION_RATE_L2: needs |= PN_ACTIONS | PN_LAST | PN_ACTRATE; break;
+                case GF_R_CMD_TRACK_LIN_VEL: needs |= PN_QUAT | PN_LIN; break;
+                case GF_R_CMD_TRACK_ANG_VEL: needs |= PN_QUAT | PN_ANG; break;
+                case GF_R_HAS_CONTACT:
+                case GF_R_CONTACT_FORCE:
+                case GF_R_FEET_AIR_TIME:
+                case GF_R_FEET_SLIDE: break;
+                default: return GF_E_UNSUPPORTED;
+            }
+            if (t.op == GF_R_BASE_HEIGHT && (t.flags & GF_RW_FLAG_CMD)) {
+                UNSUP(t.i[0] < 0 || t.i[0] >= GF_MAX_COMMAND_VIEWS || !RW->command[t.i[0]].command);
+                const int s = pk.view_slot(RW->command[t.i[0]]);
+                UNSUP(s < 0 || pk.a.cmd_of_view[s] >= 0);  // a resampled buffer as height target: keep the unfused path
+                t.i[0] = s;
+            }
+            const int cs = cmd_slot_of_reward_op(t.op);
+            if (cs >= 0 && t.i[cs] >= 0) {
+                UNSUP(t.i[cs] >= GF_MAX_COMMAND_VIEWS || !RW->command[t.i[cs]].command);
+                const int s = pk.view_slot(RW->command[t.i[cs]]);
+                UNSUP(s < 0);
+                // terms read view 0 from registers and any other view from memory: a non-zero view must not be resampled this step
+                UNSUP(s != 0 && pk.a.cmd_of_view[s] >= 0);
+                t.i[cs] = s;
+            }
+            if (reward_op_has_contact(t.op)) {
+                UNSUP(t.i[0] < 0 || t.i[0] >= GF_MAX_CONTACT_VIEWS || !RW->contact[t.i[0]].contacts);
+                const int s = pk.contact_slot(RW->contact[t.i[0]]);
+                UNSUP(s < 0);
+                t.i[0] = s;
+            }
+            a.rterms[k] = t;
+        }
+        if (needs & (PN_DOFPOS | PN_DOFDEV)) {
+            UNSUP(!RW->dof_pos || !RW->default_dof_pos);
+            a.dof_pos = const_cast<float*>(RW->dof_pos);
+            a.default_dof_pos = RW->default_dof_pos;
+            D = RW->num_dofs;
+        }
+        if (needs & PN_ACTIONS) {
+            UNSUP(!RW->actions || !RW->last_actions);
+            a.env_actions = const_cast<float*>(RW->actions);
+            a.env_last_actions = const_cast<float*>(RW->last_actions);
+            D = RW->num_dofs;
+        }
+        // reward-manager reset section must address the same buffers
+        UNSUP(RS.episode_seconds && RS.episode_seconds != RW->episode_seconds);
+        UNSUP(RS.episode_sums && RS.episode_sums != RW->episode_sums);
+        UNSUP(!RS.episode_seconds);  // the fused kernel always resets the seconds of done envs
+        UNSUP((RS.reward_logging != 0) != (a.logging != 0));
+        a.reward_rows = RS.num_reward_terms;
+        a.reward_log_mask = RS.reward_log_mask;
+        a.uncovered_rows = 0;
+        for (int row = 0; row < RS.num_reward_terms; ++row)
+            if (!(covered & (1u << row))) a.uncovered_rows |= 1u << row;
+    } else {
+        UNSUP(RS.episode_seconds || RS.episode_sums);
+    }
+
+    // reset sections
+    a.reset_env = (RS.env_actions != nullptr ? 1 : 0) | (RS.episode_length != nullptr ? 2 : 0);
+    if (RS.env_actions) {
+        UNSUP(a.env_actions && a.env_actions != RS.env_actions);
+        UNSUP(!RS.env_last_actions || (a.env_last_actions && a.env_last_actions != RS.env_last_actions));
+        a.env_actions = RS.env_actions; a.env_last_actions = RS.env_last_actions;
+    }
+    UNSUP(RS.episode_length && RS.episode_length != T.episode_length);
+    UNSUP(RS.max_episode_length && T.max_episode_length && RS.max_episode_length != T.max_episode_length);
+    if (RS.max_episode_length) a.max_episode_length = RS.max_episode_length;
+    a.base_max_episode_length = RS.base_max_episode_length;
+    a.max_random_scaling = RS.max_episode_length ? RS.max_random_scaling : 0.0f;
+    a.n_air = RS.num_contact;
+    for (int m = 0; m < RS.num_contact; ++m) {
+        a.air_links[m] = RS.air_links[m];
+        for (int s = 0; s < 4; ++s) a.air_state[m][s] = RS.air_state[m][s];
+    }
+    a.reset_dofs = RS.scene_dof_pos != nullptr;
+    if (RS.scene_dof_pos) {
+        UNSUP(a.dof_pos && a.dof_pos != RS.scene_dof_pos);
+        UNSUP(!RS.default_dof_pos || (a.default_dof_pos && a.default_dof_pos != RS.default_dof_pos));
+        a.dof_pos = RS.scene_dof_pos; a.default_dof_pos = RS.default_dof_pos; a.dof_vel = RS.scene_dof_vel;
+        a.dof_noise_scale = RS.dof_noise_scale;
+    }
+    a.scene_reset = RS.scene_pos != nullptr;
+    if (RS.scene_pos) {
+        GfEntityView ev{RS.scene_pos, RS.set_quat ? RS.scene_quat : nullptr, RS.zero_velocity ? RS.scene_lin_vel : nullptr,
+                        RS.zero_velocity ? RS.scene_ang_vel : nullptr};
+        GfEntityView cur{a.pos, a.quat, a.lin_vel, a.ang_vel};
+        UNSUP(!same_entity(cur, ev));
+        UNSUP(RS.set_quat && !RS.scene_quat);
+        UNSUP(RS.zero_velocity && (!RS.scene_lin_vel || !RS.scene_ang_vel));
+        merge_entity(a, ev);
+        a.set_quat = RS.set_quat; a.zero_velocity = RS.zero_velocity; a.quat_stash = RS.quat_stash;
+        for (int j = 0; j < 3; ++j) a.reset_pos[j] = RS.reset_pos[j];
+        for (int j = 0; j < 4; ++j) a.reset_quat[j] = RS.reset_quat[j];
+        if (RS.zero_velocity && RS.scene_dof_vel) {
+            UNSUP(a.dof_vel && a.dof_vel != RS.scene_dof_vel);
+            a.dof_vel = RS.scene_dof_vel;
+        }
+    }
+
+    // observations
+    a.n_obs = r->num_observe;
+    int omax = 0;
+    for (int m = 0; m < a.n_obs; ++m) {
+        const GfObservationArgs* ob = r->observe[m];
+        UNSUP(!ob || ob->num_envs != N || ob->num_items > kPostMaxItems || ob->noise_draws || !ob->obs);
+        UNSUP(ob->seed != RS.seed || ob->env_offset != RS.env_offset);
+        UNSUP(ob->history_len > 1 && !ob->prev_obs);
+        UNSUP((reinterpret_cast<uintptr_t>(ob->obs) & 15u) || (ob->prev_obs && (reinterpret_cast<uintptr_t>(ob->prev_obs) & 15u)));
+        GfEntityView cur{a.pos, a.quat, a.lin_vel, a.ang_vel};
+        PostObs& po = a.obs[m];
+        po.obs = ob->obs; po.prev = ob->history_len > 1 ? ob->prev_obs : nullptr; po.stream = ob->stream;
+        po.num_items = ob->num_items; po.width = ob->obs_width; po.history = ob->history_len;
+        omax = ob->obs_width > omax ? ob->obs_width : omax;
+        bool uses_entity = false;
+        for (int i = 0; i < ob->num_items; ++i) {
+            GfObsItem it = ob->items[i];
+            switch (it.op) {
+                case GF_O_COMMAND: {
+                    UNSUP(it.i0 < 0 || it.i0 >= GF_MAX_COMMAND_VIEWS || !ob->command[it.i0].command || it.width != ob->command[it.i0].width);
+                    const int s = pk.view_slot(ob->command[it.i0]);
+                    UNSUP(s < 0 || it.width > kPostMaxRanges);
+                    it.i0 = s;
+                } break;
+                case GF_O_ANG_VEL_BODY: needs |= PN_QUAT | PN_ANG; uses_entity = true; break;
+                case GF_O_LIN_VEL_BODY: needs |= PN_QUAT | PN_LIN; uses_entity = true; break;
+                case GF_O_PROJ_GRAVITY: needs |= PN_QUAT; uses_entity = true; break;
+                case GF_O_DOF_POS: needs |= PN_DOFPOS; UNSUP(!ob->dof_pos || (a.dof_pos && a.dof_pos != ob->dof_pos)); a.dof_pos = const_cast<float*>(ob->dof_pos); D = ob->num_dofs; break;
+                case GF_O_DOF_VEL: needs |= PN_DOFVEL; UNSUP(!ob->dof_vel || (a.dof_vel && a.dof_vel != ob->dof_vel)); a.dof_vel = const_cast<float*>(ob->dof_vel); D = ob->num_dofs; break;
+                case GF_O_DOF_FORCE: UNSUP(!ob->dof_force || (a.dof_force && a.dof_force != ob->dof_force)); a.dof_force = ob->dof_force; D = ob->num_dofs; break;
+                case GF_O_ACTIONS: needs |= PN_TARGETS; UNSUP(!ob->targets || (a.targets && a.targets != ob->targets)); a.targets = ob->targets; D = ob->num_dofs; break;
+                case GF_O_RAW_ACTIONS: needs |= PN_ACTIONS; UNSUP(!ob->env_actions || (a.env_actions && a.env_actions != ob->env_actions)); a.env_actions = const_cast<float*>(ob->env_actions); D = ob->num_dofs; break;
+                case GF_O_CONTACT_FORCE_NORM: {
+                    UNSUP(it.i0 < 0 || it.i0 >= GF_MAX_CONTACT_VIEWS || !ob->contact[it.i0].contacts || it.width != ob->contact[it.i0].num_links);
+                    const int s = pk.contact_slot(ob->contact[it.i0]);
+                    UNSUP(s < 0);
+                    it.i0 = s;
+                } break;
+                default: return GF_E_UNSUPPORTED;
+            }
+            if (it.op == GF_O_DOF_POS || it.op == GF_O_DOF_VEL || it.op == GF_O_ACTIONS || it.op == GF_O_RAW_ACTIONS || it.op == GF_O_DOF_FORCE)
+                UNSUP(it.width != ob->num_dofs);
+            po.items[i] = it;
+        }
+        if (uses_entity) {
+            UNSUP(!same_entity(cur, ob->entity));
+            merge_entity(a, ob->entity);
+            // stale quaternion source must be this step's reset (or absent when the reset does not touch quat)
+            if (a.scene_reset && a.set_quat) UNSUP(ob->stale_quat != a.quat_stash || ob->stale_mask != T.terminated || ob->stale_mask2 != T.truncated);
+            else UNSUP(ob->stale_quat != nullptr);
+        }
+    }
+    UNSUP(omax >= GF_MAX_OBS_WIDTH);
+
+    // everything the kernel dereferences must exist, be float4-aligned and agree on D
+    a.num_dofs = D;
+    a.needs = needs;
+    UNSUP((needs & PN_QUAT) && !a.quat);
+    UNSUP((needs & PN_POS) && !a.pos);
+    UNSUP((needs & PN_LIN) && !a.lin_vel);
+    UNSUP((needs & PN_ANG) && !a.ang_vel);
+    UNSUP((needs & PN_EPLEN) && !a.episode_length);
+    UNSUP((needs & (PN_DOFPOS | PN_DOFVEL | PN_TARGETS | PN_ACTIONS | PN_LAST)) && (D != 12 && D != 28));
+    UNSUP((a.reset_dofs || (a.reset_env & 1)) && (D != 12 && D != 28));
+    UNSUP((needs & PN_DOFPOS) && !a.dof_pos);
+    UNSUP((needs & PN_DOFVEL) && !a.dof_vel);
+    UNSUP((needs & PN_TARGETS) && !a.targets);
+    UNSUP((needs & PN_ACTIONS) && !a.env_actions);
+    UNSUP((needs & PN_LAST) && !a.env_last_actions);
+    UNSUP((needs & PN_DOFDEV) && !a.default_dof_pos);
+    const void* al[] = {a.quat, a.dof_pos, a.dof_vel, a.targets, a.env_actions, a.env_last_actions, a.default_dof_pos, a.quat_stash};
+    for (const void* p : al) UNSUP(reinterpret_cast<uintptr_t>(p) & 15u);
+    UNSUP((int64_t)N * (D > 4 ? D : 4) * 4 >= (int64_t)1 << 32);
+    return GF_OK;
+}
+
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_post_physics_check(const GfPostRefs* r) {
+    gf::Packer pk;
+    return gf::pack(r, pk);
+}
+
+extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const GfPostRefs* r, void* stream) {
+    gf::Packer pk;
+    const int rc = gf::pack(r, pk);
+    if (rc) return rc;
+    const gf::GfPostArgs& a = pk.a;
+    int omax = 0;
+    for (int m = 0; m < a.n_obs; ++m) omax = a.obs[m].width > omax ? a.obs[m].width : omax;
+    const size_t lds = ((size_t)gf::kPostMaxReward * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = gf::env_grid(a.num_envs);
+    gf::PhaseScope scope(GF_PHASE_POST, s);
+    if (a.num_dofs == 28) gf::post_kernel<7><<<grid, gf::kEnvBlock, lds, s>>>(a);
+    else gf::post_kernel<3><<<grid, gf::kEnvBlock, lds, s>>>(a);
+    return gf::launch_status();
+}

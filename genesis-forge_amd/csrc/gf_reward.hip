@@ -24,6 +24,7 @@
 // dof_pos 48 + actions 48 + last_actions 48 + cmd 12 = 208;  RW episode_sums 8T = 48;  RW secs 8;
 // W reward 4  →  268 B/env  (SURVEY.md §8d).
 #include "gf_launch.h"
+#include "gf_terms.h"
 
 namespace gf {
 
@@ -130,116 +131,15 @@ __global__ __launch_bounds__(kEnvBlock) void reward_kernel(const GfRewardArgs a,
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- 4. term loop (wave-uniform control flow) ----------------------------------------------
+    // ---- 4. term loop (wave-uniform control flow); term bodies live in gf_terms.h ---------------
+    RewardRegs rr;
+    rr.pos = pos; rr.blin = blin; rr.bang = bang; rr.grav = grav; rr.dof_dev = dof_dev; rr.act_rate = act_rate;
+    rr.terminated = terminated; rr.cmd0[0] = cmd0[0]; rr.cmd0[1] = cmd0[1]; rr.cmd0[2] = cmd0[2]; rr.n = n; rr.live = live;
     float buf = 0.f;
     for (int k = 0; k < T; ++k) {
         const GfTerm& t = a.terms[k];
         float v = 0.f;
-        switch (t.op) {
-            case GF_R_IS_ALIVE: v = terminated ? 0.f : 1.f; break;
-            case GF_R_TERMINATED: v = terminated ? 1.f : 0.f; break;
-            case GF_R_BASE_HEIGHT: {
-                float h = pos.z;
-                if (t.flags & GF_RW_FLAG_TERRAIN) h = h - a.ext[t.i[1]][n];
-                const float target = (t.flags & GF_RW_FLAG_CMD) ? a.command[t.i[0]].command[n * a.command[t.i[0]].width] : t.p[0];
-                const float e = h - target;
-                v = e * e;
-            } break;
-            case GF_R_DOF_SIMILAR_TO_DEFAULT: v = dof_dev; break;
-            case GF_R_LIN_VEL_Z_L2: v = blin.z * blin.z; break;
-            case GF_R_ANG_VEL_XY_L2: v = bang.x * bang.x + bang.y * bang.y; break;
-            case GF_R_FLAT_ORIENTATION_L2: v = grav.x * grav.x + grav.y * grav.y; break;
-            case GF_R_BODY_ACCEL_EXP: {
-                float* st = a.state[t.i[0]] + n * 6;
-                V3 la{0, 0, 0}, aa{0, 0, 0};
-                if (!(t.flags & GF_RW_FLAG_FIRST_CALL)) {
-                    la = V3{(blin.x - st[0]) / a.dt, (blin.y - st[1]) / a.dt, (blin.z - st[2]) / a.dt};
-                    aa = V3{(bang.x - st[3]) / a.dt, (bang.y - st[4]) / a.dt, (bang.z - st[5]) / a.dt};
-                }
-                if (live) {
-                    st[0] = blin.x; st[1] = blin.y; st[2] = blin.z;
-                    st[3] = bang.x; st[4] = bang.y; st[5] = bang.z;
-                }
-                const float motion = norm3(la.x, la.y, la.z) + norm3(aa.x, aa.y, aa.z);
-                v = 1.0f - expf((-t.p[0]) * motion);
-            } break;
-            case GF_R_ACTION_RATE_L2: v = act_rate; break;
-            case GF_R_CMD_TRACK_LIN_VEL: {
-                float c0 = cmd0[0], c1 = cmd0[1];
-                if (t.i[0] != 0) {
-                    const GfCommandView& c = a.command[t.i[0]];
-                    c0 = c.command[n * c.width];
-                    c1 = c.command[n * c.width + 1];
-                }
-                const float e0 = c0 - blin.x;
-                const float e1 = c1 - blin.y;
-                const float err = e0 * e0 + e1 * e1;
-                v = expf((-err) / t.p[0]);
-            } break;
-            case GF_R_CMD_TRACK_ANG_VEL: {
-                float cz;
-                if (t.i[0] == 0 && t.i[1] < 3) {
-                    cz = t.i[1] == 0 ? cmd0[0] : (t.i[1] == 1 ? cmd0[1] : cmd0[2]);
-                } else {
-                    const GfCommandView& c = a.command[t.i[0]];
-                    cz = c.command[n * c.width + t.i[1]];
-                }
-                const float e = cz - bang.z;
-                v = expf((-(e * e)) / t.p[0]);
-            } break;
-            case GF_R_STAND_STILL: {
-                float c0 = cmd0[0], c1 = cmd0[1];
-                if (t.i[0] != 0) {
-                    const GfCommandView& c = a.command[t.i[0]];
-                    c0 = c.command[n * c.width];
-                    c1 = c.command[n * c.width + 1];
-                }
-                const float m = norm2(c0, c1);
-                v = dof_dev * ((m < t.p[0]) ? 1.f : 0.f);
-            } break;
-            case GF_R_HAS_CONTACT: v = contact_count_over(a.contact[t.i[0]], n, t.p[0]) >= t.i[1] ? 1.f : 0.f; break;
-            case GF_R_CONTACT_FORCE: {
-                const GfContactView& cv = a.contact[t.i[0]];
-                const float* r = cv.contacts + n * cv.num_links * 3;
-                float s = 0.f;
-                for (int l = 0; l < cv.num_links; ++l) s += clamp_min(norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]) - t.p[0], 0.f);
-                v = s;
-            } break;
-            case GF_R_FEET_AIR_TIME: {
-                const GfContactView& cv = a.contact[t.i[0]];
-                float s = 0.f;
-                for (int l = 0; l < cv.num_links; ++l) {
-                    const float cc = cv.current_contact_time[n * cv.num_links + l];
-                    const float made = ((cc > 0.f) && (cc < t.p[2])) ? 1.f : 0.f;
-                    float air = (cv.last_air_time[n * cv.num_links + l] - t.p[0]) * made;
-                    if (t.flags & GF_RW_FLAG_MAX) air = clamp_max(air, t.p[1]);
-                    s += air;
-                }
-                if (t.i[1] >= 0) {
-                    float c0 = cmd0[0], c1 = cmd0[1];
-                    if (t.i[1] != 0) {
-                        const GfCommandView& c = a.command[t.i[1]];
-                        c0 = c.command[n * c.width];
-                        c1 = c.command[n * c.width + 1];
-                    }
-                    s = s * ((norm2(c0, c1) > 0.1f) ? 1.f : 0.f);
-                }
-                v = s;
-            } break;
-            case GF_R_FEET_SLIDE: {
-                const GfContactView& cv = a.contact[t.i[0]];
-                const float* r = cv.contacts + n * cv.num_links * 3;
-                const float* lv = cv.link_vel + n * cv.num_links * 3;
-                float s = 0.f;
-                for (int l = 0; l < cv.num_links; ++l) {
-                    const float c = norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]) > 1.0f ? 1.f : 0.f;
-                    s += norm3(lv[3 * l], lv[3 * l + 1], lv[3 * l + 2]) * c;
-                }
-                v = s;
-            } break;
-            case GF_R_EXTERNAL: v = a.ext[t.i[0]][n]; break;
-            default: break;
-        }
+        v = eval_reward_term(t, a, rr);
         if (!step_mode) {
             if (live) a.term_out[(int64_t)t.row * N + n_raw] = v;
             continue;

@@ -10,6 +10,7 @@
 // wave ballot + one integer atomic per wave that has a hit (integer adds: order independent).
 // Algorithmic traffic (K=2: timeout + bad_orientation): R quat 16 + ep_len 4 + max_len 4, W 2 masks.
 #include "gf_launch.h"
+#include "gf_terms.h"
 
 namespace gf {
 
@@ -35,42 +36,14 @@ __global__ __launch_bounds__(kEnvBlock) void termination_kernel(const GfTerminat
         tilt_sin = clamp_max(norm2(g.x, g.y), 0.99f);  // torch.clamp(max=0.99), NaN propagates
     }
 
+    TermRegs tr;
+    tr.ep_len = ep_len; tr.max_len = max_len; tr.has_maxlen = (needs & NEED_MAXLEN) != 0; tr.tilt_sin = tilt_sin; tr.pos = pos; tr.m = m;
     int term = 0, trunc = 0;
     const int K = a.num_terms;
     for (int k = 0; k < K; ++k) {
         const GfTerm& t = a.terms[k];
         int v = 0;
-        switch (t.op) {
-            case GF_T_TIMEOUT:
-                v = (needs & NEED_MAXLEN) ? (ep_len > max_len) : 0;
-                break;
-            case GF_T_BAD_ORIENTATION:
-                // asin is monotone: asin(x) > radians(limit)  <=>  x > p0, where the host found p0 as
-                // the largest f32 with asin(p0) <= (float)radians(limit) (same libm/torch asin as the
-                // reference), so no device asinf can flip a mask.
-                v = !(ep_len <= t.i[0]) && (tilt_sin > t.p[0]);
-                break;
-            case GF_T_BASE_HEIGHT_BELOW:
-                v = pos.z < t.p[0];
-                break;
-            case GF_T_OUT_OF_BOUNDS:
-                v = (pos.x < t.p[0]) || (pos.x > t.p[1]) || (pos.y < t.p[2]) || (pos.y > t.p[3]);
-                break;
-            case GF_T_HAS_CONTACT:
-                v = contact_count_over(a.contact[t.i[0]], m, t.p[0]) >= t.i[1];
-                break;
-            case GF_T_CONTACT_FORCE:
-                v = contact_count_over(a.contact[t.i[0]], m, t.p[0]) > 0;
-                break;
-            case GF_T_CONTACT_FORCE_GRACE:
-                v = !(ep_len <= t.i[1]) && (contact_count_over(a.contact[t.i[0]], m, t.p[0]) > 0);
-                break;
-            case GF_T_EXTERNAL:
-                v = a.ext[t.i[0]][m] != 0;
-                break;
-            default:
-                break;
-        }
+        v = eval_termination_term(t, a, tr, needs & NEED_MAXLEN);
         v = live ? v : 0;
         if (t.flags & GF_TERM_FLAG_TIME_OUT) trunc |= v; else term |= v;
         if (a.term_out && live) a.term_out[(int64_t)k * a.num_envs + n] = (uint8_t)v;

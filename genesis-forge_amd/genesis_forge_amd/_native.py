@@ -77,7 +77,7 @@ GF_O_BASE_QUAT = 13
 GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
 
 (GF_PHASE_ACTION, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
- GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_COUNT) = range(10)
+ GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_COUNT) = range(11)
 
 GF_ERRORS = {-1: "GF_E_NULL", -2: "GF_E_RANGE", -3: "GF_E_OPCODE", -4: "GF_E_SLOT", -5: "GF_E_UNSUPPORTED"}
 
@@ -201,7 +201,13 @@ class GfStatsCopyArgs(C.Structure):
     _fields_ = [("src", P), ("dst", P), ("event", P)]
 
 
-GF_OP_STATS_CLEAR, GF_OP_STATS_COPY = 100, 101
+GF_OP_STATS_CLEAR, GF_OP_STATS_COPY, GF_OP_POST_PHYSICS = 100, 101, 102
+GF_POST_MAX_CMD, GF_POST_MAX_OBS = 2, 2
+
+
+class GfPostRefs(C.Structure):
+    _fields_ = [("termination", P), ("reward", P), ("reset", P), ("num_command", C.c_int32), ("num_observe", C.c_int32),
+                ("command_step", P * GF_POST_MAX_CMD), ("command_reset", P * GF_POST_MAX_CMD), ("observe", P * GF_POST_MAX_OBS)]
 
 ABI_STRUCTS = [GfStepStats, GfActionArgs, GfContactArgs, GfTerminationArgs, GfRewardArgs, GfCommandArgs,
                GfResetArgs, GfObservationArgs, GfRotateArgs, GfSynthSceneArgs, GfTerm, GfObsItem]
@@ -278,6 +284,10 @@ class Backend:
     def event_synchronize(self, ev) -> None:
         pass
 
+    def post_check(self, refs) -> bool:
+        """True when gf_post_physics_step can fuse the phases ``refs`` points at."""
+        return False
+
     def check_tensor(self, t, what: str = "tensor") -> None:
         if t is None:
             return
@@ -317,6 +327,8 @@ class HipBackend(Backend):
         self.lib.gf_build_info.restype = C.c_char_p
         self.lib.gf_run_ops.restype = C.c_int
         self.lib.gf_run_ops.argtypes = [C.POINTER(GfOp), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        self.lib.gf_post_physics_check.restype = C.c_int
+        self.lib.gf_post_physics_check.argtypes = [C.POINTER(GfPostRefs)]
         self.lib.gf_event_create.restype = C.c_void_p
         self.lib.gf_event_synchronize.restype = C.c_int
         self.lib.gf_event_synchronize.argtypes = [C.c_void_p]
@@ -347,6 +359,9 @@ class HipBackend(Backend):
         rc = self.lib.gf_run_ops(ops, n, self._stream(), C.byref(failed))
         if rc != 0:
             self._raise(f"run_ops[op {failed.value}]", rc)
+
+    def post_check(self, refs) -> bool:
+        return self.lib.gf_post_physics_check(C.byref(refs)) == 0
 
     def event_create(self):
         ev = self.lib.gf_event_create()

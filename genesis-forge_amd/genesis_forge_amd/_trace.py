@@ -52,10 +52,17 @@ class StepTrace:
         k = 0
         self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_CLEAR, stats.ptr
         k += 1
-        for fn, args, owner in calls:
-            self.ops[k].phase = nat.PHASE_OF_FN[fn]
-            self.ops[k].args = C.addressof(args)
-            k += 1
+        self.post_refs = self._fuse_post(calls) if env.fuse_post_physics else None
+        first_post = self._post_start(calls) if self.post_refs is not None else len(calls)
+        for idx, (fn, args, owner) in enumerate(calls):
+            if idx < first_post:
+                self.ops[k].phase = nat.PHASE_OF_FN[fn]
+                self.ops[k].args = C.addressof(args)
+                k += 1
+            elif idx == first_post:
+                self.ops[k].phase = nat.GF_OP_POST_PHYSICS
+                self.ops[k].args = C.addressof(self.post_refs)
+                k += 1
             self._hooks(fn, args, owner)
         self.use_native_copy = stats.group is None
         if self.use_native_copy:
@@ -65,6 +72,57 @@ class StepTrace:
             k += 1
             stats.ensure_native_events(self.backend)
         self.n_ops = k
+
+    # -- fused post-physics launch -----------------------------------------------------------------------
+    @staticmethod
+    def _post_start(calls) -> int:
+        for i, (fn, _, _) in enumerate(calls):
+            if fn == "termination_step":
+                return i
+        return len(calls)
+
+    def _fuse_post(self, calls):
+        """If the tail of the step is [termination, reward?, command.step*, reset, command.reset*, observe*], describe it
+        to gf_post_physics_step (one launch) — provided the library agrees the combination is fusable."""
+        i = self._post_start(calls)
+        tail = calls[i:]
+        fns = [c[0] for c in tail]
+        if not fns or fns[0] != "termination_step":
+            return None
+        refs = nat.GfPostRefs()
+        refs.termination = C.addressof(tail[0][1])
+        j = 1
+        if j < len(fns) and fns[j] == "reward_step":
+            refs.reward = C.addressof(tail[j][1])
+            j += 1
+        steps = []
+        while j < len(fns) and fns[j] == "command_step" and tail[j][1].mode == nat.GF_CMD_STEP:
+            steps.append(tail[j])
+            j += 1
+        if j >= len(fns) or fns[j] != "masked_reset":
+            return None
+        refs.reset = C.addressof(tail[j][1])
+        j += 1
+        resets = []
+        while j < len(fns) and fns[j] == "command_step" and tail[j][1].mode == nat.GF_CMD_MASKED:
+            resets.append(tail[j])
+            j += 1
+        obs = []
+        while j < len(fns) and fns[j] == "observe":
+            obs.append(tail[j])
+            j += 1
+        if j != len(fns) or len(steps) != len(resets) or len(steps) > nat.GF_POST_MAX_CMD or len(obs) > nat.GF_POST_MAX_OBS:
+            return None
+        for s, r in zip(steps, resets):
+            if s[2] is not r[2]:
+                return None
+        refs.num_command, refs.num_observe = len(steps), len(obs)
+        for c, (s, r) in enumerate(zip(steps, resets)):
+            refs.command_step[c] = C.addressof(s[1])
+            refs.command_reset[c] = C.addressof(r[1])
+        for m, o in enumerate(obs):
+            refs.observe[m] = C.addressof(o[1])
+        return refs if self.backend.post_check(refs) else None
 
     # -- per-phase hooks ----------------------------------------------------------------------------
     def _hooks(self, fn, args, owner):

@@ -77,6 +77,8 @@ class ManagedEnvironment(GenesisEnv):
         self._reset_args = nat.GfResetArgs()
         #: record the step and replay it through gf_run_ops when possible (see _trace.py); GF_NO_TRACE=1 disables
         self.trace_enabled = os.environ.get("GF_NO_TRACE", "0") != "1"
+        #: replace the recorded post-physics phases by the fused gf_post_physics_step launch; GF_NO_FUSE=1 disables
+        self.fuse_post_physics = os.environ.get("GF_NO_FUSE", "0") != "1"
 
     # -- spaces (managed_env.py:156-194) ------------------------------------------------------------
     @property

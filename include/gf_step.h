@@ -456,6 +456,35 @@ int gf_entity_rotate(const GfRotateArgs* a, void* stream);        /* replaces en
 int gf_synth_scene_step(const GfSynthSceneArgs* a, void* stream); /* stands in for scene.step() (managed_env.py:292) */
 
 /* ------------------------------------------------------------------------------------------
+ * Fused post-physics step: everything ManagedEnvironment.step() does after scene.step() and the
+ * contact managers — termination → reward → command.step → reset of done envs → command.reset →
+ * observations (managed_env.py:303-326) — as ONE launch.  All of it is per-env work on the same
+ * state (pos/quat/vel/ang, the [N,D] rows, commands), so one lane carries an env through every phase
+ * with that state in registers: 566 B/env of traffic instead of 268 + 26 + 4 + 388 + the reset's
+ * re-reads, one launch instead of six.  The descriptors are the per-phase ones (so the semantics are by
+ * definition those of calling the phases in sequence — which is what the oracle twin does); the call
+ * packs them into one kernarg block.  Returns GF_E_UNSUPPORTED when the combination cannot be fused
+ * (Python-evaluated terms, parity-mode draws, D not a built variant, phases reading different
+ * buffers, more than 2 command / observation managers …): the caller then runs the phases one by one.
+ * ---------------------------------------------------------------------------------------- */
+#define GF_POST_MAX_CMD 2
+#define GF_POST_MAX_OBS 2
+
+typedef struct GfPostRefs {
+    const GfTerminationArgs* termination;                 /* required */
+    const GfRewardArgs* reward;                           /* may be NULL */
+    const GfResetArgs* reset;                             /* required; mask/mask2 must be termination's outputs */
+    int32_t num_command;
+    int32_t num_observe;
+    const GfCommandArgs* command_step[GF_POST_MAX_CMD];   /* mode GF_CMD_STEP  */
+    const GfCommandArgs* command_reset[GF_POST_MAX_CMD];  /* mode GF_CMD_MASKED on the same masks, same buffers */
+    const GfObservationArgs* observe[GF_POST_MAX_OBS];
+} GfPostRefs;
+
+int gf_post_physics_check(const GfPostRefs* r);               /* GF_OK if gf_post_physics_step can fuse this combination */
+int gf_post_physics_step(const GfPostRefs* r, void* stream);  /* replaces managed_env.py:303-326 in one launch */
+
+/* ------------------------------------------------------------------------------------------
  * Recorded step: the fixed launch sequence of one ManagedEnvironment.step() replayed with a single
  * call.  The host records the (phase, descriptor) pairs of one ordinary step, keeps the descriptors
  * alive, patches the few per-step fields (action pointer, RNG stream ids, observation ring slots) in
@@ -467,7 +496,7 @@ typedef struct GfOp {
     const void* args;   /* the phase's descriptor (GfActionArgs*, …) */
 } GfOp;
 
-enum { GF_OP_STATS_CLEAR = 100, GF_OP_STATS_COPY = 101 };
+enum { GF_OP_STATS_CLEAR = 100, GF_OP_STATS_COPY = 101, GF_OP_POST_PHYSICS = 102 /* args = GfPostRefs* */ };
 
 typedef struct GfStatsCopyArgs {
     const GfStepStats* src;   /* device, GF_STATS_SHARDS blocks */
@@ -483,7 +512,7 @@ int gf_event_synchronize(void* event);   /* blocks the host until the event has 
 /* Optional per-phase HIP-event timing used by bench.py (events recorded on `stream`
  * immediately around the kernel launch of the selected phase). */
 enum { GF_PHASE_ACTION = 0, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
-       GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_COUNT };
+       GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_COUNT };
 int gf_profile_begin(int phase, int max_samples);     /* start recording event pairs for `phase` */
 int gf_profile_end(double* total_ms, int* samples);    /* sync events, return Σ elapsed + count, free them */
 

@@ -668,6 +668,24 @@ GFO_EXPORT int gfo_synth_scene_step(const GfSynthSceneArgs* a) {
     return GF_OK;
 }
 
+/* Host twin of gf_post_physics_step: BY DEFINITION the phases in the reference's order (managed_env.py:303-326). */
+GFO_EXPORT int gfo_post_physics_check(const GfPostRefs* r) { return (r && r->termination && r->reset) ? GF_OK : GF_E_NULL; }
+
+GFO_EXPORT int gfo_post_physics_step(const GfPostRefs* r) {
+    if (!r || !r->termination || !r->reset) return GF_E_NULL;
+    int rc = gfo_termination_step(r->termination);
+    if (rc) return rc;
+    if (r->reward && (rc = gfo_reward_step(r->reward))) return rc;
+    for (int c = 0; c < r->num_command; ++c)
+        if ((rc = gfo_command_step(r->command_step[c]))) return rc;
+    if ((rc = gfo_masked_reset(r->reset))) return rc;
+    for (int c = 0; c < r->num_command; ++c)
+        if ((rc = gfo_command_step(r->command_reset[c]))) return rc;
+    for (int o = 0; o < r->num_observe; ++o)
+        if ((rc = gfo_observe(r->observe[o]))) return rc;
+    return GF_OK;
+}
+
 /* host twin of gf_run_ops (the recorded-step replay), so the trace/replay host logic is testable on CPU */
 GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
     if (!ops || num_ops < 0) return GF_E_NULL;
@@ -685,6 +703,7 @@ GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
             case GF_PHASE_ROTATE: rc = gfo_entity_rotate((const GfRotateArgs*)a); break;
             case GF_PHASE_SCENE: rc = gfo_synth_scene_step((const GfSynthSceneArgs*)a); break;
             case GF_OP_STATS_CLEAR: rc = gfo_stats_clear((GfStepStats*)a); break;
+            case GF_OP_POST_PHYSICS: rc = gfo_post_physics_step((const GfPostRefs*)a); break;
             case GF_OP_STATS_COPY: {
                 const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
                 if (!c || !c->src || !c->dst) { rc = GF_E_NULL; break; }

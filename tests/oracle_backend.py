@@ -38,6 +38,9 @@ class OracleBackend(nat.Backend):
         if rc != 0:
             raise nat.GfError(f"gfo_stats_clear failed: {rc}")
 
+    def post_check(self, refs):
+        return self.lib.gfo_post_physics_check(C.byref(refs)) == 0
+
     def run_ops(self, ops, n):
         self.replays += 1
         failed = C.c_int(-1)

@@ -78,4 +78,33 @@ def test_traced_step_equals_ordinary_hip(hip_backend):
     a, _ = _run("cuda", False, n=1000)
     b, env = _run("cuda", True, n=1000)
     assert env._trace is not None
+    assert env._trace.post_refs is not None, "the post-physics phases should have been fused into one launch"
     _same(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 65, 4096])
+def test_fused_post_physics_equals_phase_by_phase_hip(hip_backend, n):
+    """gf_post_physics_step (one launch) against the same recorded step replayed phase by phase."""
+    outs = []
+    for fuse in (False, True):
+        env = Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, obs_noise=True, scene_kwargs=dict(ang_noise=0.3, seed=11))
+        env.fuse_post_physics = fuse
+        env.build()
+        env.seed(77)
+        env.reset()
+        g = torch.Generator().manual_seed(3)
+        seq = []
+        for t in range(80):
+            o, r, te, tr, ex = env.step(torch.randn(n, 12, generator=g).to("cuda"))
+            seq.append((o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone(), {k: float(v) for k, v in ex["episode"].items()},
+                        env.velocity_command._command.cpu().clone(), env.episode_length.cpu().clone(), env.max_episode_length.cpu().clone(),
+                        env.reward_manager._episode_sums.cpu().clone(), env.robot.dof_pos.cpu().clone(), env.robot.quat.cpu().clone()))
+        assert env._trace is not None and (env._trace.post_refs is not None) == fuse
+        outs.append(seq)
+    for t, (x, y) in enumerate(zip(*outs)):
+        for k in (0, 1, 2, 3, 5, 6, 7, 8, 9, 10):
+            assert torch.equal(x[k], y[k]), f"output {k} differs at step {t}"
+        assert x[4].keys() == y[4].keys()
+        for key in x[4]:
+            assert abs(x[4][key] - y[4][key]) <= 1e-6 + 1e-6 * abs(y[4][key]), (t, key)

@@ -168,6 +168,15 @@ int main(int argc, char** argv) {
     time_loop("gf_observe", iters, 388.0 * Nd, [&] { chk(gf_observe(&oa, 0), "observe"); });
     GfOp ops_[8] = {{GF_PHASE_ACTION, 0, &aa}, {GF_PHASE_SCENE, 0, &sa}, {GF_PHASE_TERMINATION, 0, &ta}, {GF_PHASE_REWARD, 0, &ra},
                     {GF_PHASE_COMMAND, 0, &ca}, {GF_PHASE_RESET, 0, &rs}, {GF_PHASE_COMMAND, 0, &cr}, {GF_PHASE_OBSERVE, 0, &oa}};
+    GfPostRefs pr{};
+    pr.termination = &ta; pr.reward = &ra; pr.reset = &rs; pr.num_command = 1; pr.num_observe = 1;
+    pr.command_step[0] = &ca; pr.command_reset[0] = &cr; pr.observe[0] = &oa;
+    cr.seed = rs.seed; ca.seed = rs.seed; oa.seed = rs.seed;
+    {
+        const int rc = gf_post_physics_check(&pr);
+        printf("gf_post_physics_check: %d (%s)\n", rc, gf_error_string(rc));
+        if (rc == 0) time_loop("gf_post_physics_step", iters, 566.0 * Nd, [&] { chk(gf_post_physics_step(&pr, 0), "post"); });
+    }
     int failed = -1;
     time_loop("full step (8 ops)", iters, 806.0 * Nd, [&] { sa.tick++; chk(gf_run_ops(ops_, 8, 0, &failed), "run_ops"); });
     return 0;
