@@ -35,6 +35,13 @@ __device__ __forceinline__ const GF_GLOBAL T* gsel(bool need, const T* p, uint32
     return base + (need ? elem_off : 0u);
 }
 
+// explicit global-memory views of pointers whose address space the compiler cannot infer (descriptor fields read
+// back from LDS): keeps loads/stores on the global_* path instead of flat_* (which also ties up lgkmcnt)
+template <typename T>
+__device__ __forceinline__ GF_GLOBAL T* G(T* p) { return (GF_GLOBAL T*)p; }
+template <typename T>
+__device__ __forceinline__ const GF_GLOBAL T* G(const T* p) { return (const GF_GLOBAL T*)p; }
+
 // 16-byte global load through an address_space(1) pointer (float4 is a class type and cannot bind
 // to a non-generic address space; the ext-vector can).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -133,7 +140,7 @@ __device__ __forceinline__ GfStepStats* stats_shard(GfStepStats* s) { return s +
 // contact predicates shared by termination / reward terms
 __device__ __forceinline__ int contact_count_over(const GfContactView& v, int64_t n, float thr) {
     int cnt = 0;
-    const float* r = v.contacts + n * v.num_links * 3;
+    const GF_GLOBAL float* r = G(v.contacts) + n * v.num_links * 3;
     for (int l = 0; l < v.num_links; ++l) cnt += norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]) > thr ? 1 : 0;
     return cnt;
 }

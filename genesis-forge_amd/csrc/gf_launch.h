@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "gf_device.h"
+#include "gf_prefetch.h"
 
 namespace gf {
 

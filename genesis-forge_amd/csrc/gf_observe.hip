@@ -72,6 +72,7 @@ __device__ __forceinline__ void copy_rows(const TileCtx& c, const GfObsItem& it,
 
 template <int V>
 __global__ __launch_bounds__(kEnvBlock) void observe_kernel(const GfObservationArgs a, const uint32_t needs) {
+    prefetch_args<GfObservationArgs>();
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int lane = threadIdx.x;
     const int64_t n0 = (int64_t)blockIdx.x * kEnvBlock;

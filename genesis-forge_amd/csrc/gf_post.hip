@@ -22,6 +22,23 @@
 #include "gf_launch.h"
 #include "gf_terms.h"
 
+// Diagnostic build only (tools/stamp_post.hip, -DGF_STAMPS): lane 0 of one workgroup records the 100 MHz wall
+// clock at the phase boundaries into a buffer of its own; no product build contains a stamp.
+#ifdef GF_STAMPS
+extern "C" unsigned long long* gf_debug_stamps;  // host variable set by the tool
+#define GF_STAMP(i)                                                                                          \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (a.stamps && blockIdx.x == a.stamp_block && threadIdx.x == 0) {                                   \
+            a.stamps[i] = __builtin_amdgcn_s_memrealtime();                                                  \
+            a.stamps[16 + i] = __builtin_amdgcn_s_memtime();                                                 \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+#else
+#define GF_STAMP(i)
+#endif
+
 namespace gf {
 
 constexpr int kPostMaxTerm = 8;
@@ -50,7 +67,7 @@ struct PostObs {
     GfObsItem items[kPostMaxItems];
 };
 
-struct GfPostArgs {
+struct alignas(16) GfPostArgs {
     int32_t num_envs, num_dofs, num_term, num_rew;
     uint32_t needs;
     int32_t n_cmd, n_obs, logging;
@@ -91,6 +108,10 @@ struct GfPostArgs {
     GfTerm rterms[kPostMaxReward];
     PostCmd cmds[GF_POST_MAX_CMD];
     PostObs obs[GF_POST_MAX_OBS];
+#ifdef GF_STAMPS
+    unsigned long long* stamps;
+    uint32_t stamp_block;
+#endif
 };
 static_assert(sizeof(GfPostArgs) <= 4096, "GfPostArgs must fit the 4 KB kernarg segment");
 
@@ -99,58 +120,98 @@ enum : uint32_t {
     PN_EPLEN = 512, PN_MAXLEN = 1024, PN_DOFDEV = 2048, PN_ACTRATE = 4096, PN_DOFFORCE = 8192,
 };
 
-__device__ __forceinline__ float obs_finish(const GfPostArgs& a, const PostObs& ob, const GfObsItem& it, float v, uint32_t genv, int64_t n, int col) {
-    if (it.scale != 1.0f) v = v * it.scale;
-    if (it.noise != 0.0f) {
-        const float u = philox_uniform(a.seed, ob.stream, genv, (uint32_t)col);
-        v = v + uniform_range(u, -1.0f, 1.0f) * it.noise;
+// scale / noise of one observation element (observation_manager.py:242-250); everything it needs arrives by value
+struct ObsFin {
+    float scale, noise;
+    uint64_t seed, stream;
+    uint32_t genv;
+};
+__device__ __forceinline__ float obs_finish(const ObsFin& f, float v, int col) {
+    if (f.scale != 1.0f) v = v * f.scale;
+    if (f.noise != 0.0f) {
+        const float u = philox_uniform(f.seed, f.stream, f.genv, (uint32_t)col);
+        v = v + uniform_range(u, -1.0f, 1.0f) * f.noise;
     }
     return v;
 }
 
 // one [D] row of registers → the lane's observation tile row (separate call per source keeps every index static)
 template <int DV>
-__device__ __forceinline__ void put_row(const GfPostArgs& a, const PostObs& ob, const GfObsItem& it, const float4 (&r)[DV], float* row, uint32_t genv,
-                                        int64_t n, int col) {
+__device__ __forceinline__ void put_row(const ObsFin& f, const float4 (&r)[DV], float* row, int col) {
 #pragma unroll
     for (int c = 0; c < DV; ++c) {
-        row[col + 4 * c + 0] = obs_finish(a, ob, it, r[c].x, genv, n, col + 4 * c + 0);
-        row[col + 4 * c + 1] = obs_finish(a, ob, it, r[c].y, genv, n, col + 4 * c + 1);
-        row[col + 4 * c + 2] = obs_finish(a, ob, it, r[c].z, genv, n, col + 4 * c + 2);
-        row[col + 4 * c + 3] = obs_finish(a, ob, it, r[c].w, genv, n, col + 4 * c + 3);
+        row[col + 4 * c + 0] = obs_finish(f, r[c].x, col + 4 * c + 0);
+        row[col + 4 * c + 1] = obs_finish(f, r[c].y, col + 4 * c + 1);
+        row[col + 4 * c + 2] = obs_finish(f, r[c].z, col + 4 * c + 2);
+        row[col + 4 * c + 3] = obs_finish(f, r[c].w, col + 4 * c + 3);
+    }
+}
+
+// wave-uniform value that lives in a VGPR (read from the LDS-staged descriptor) → SGPR
+template <typename T>
+__device__ __forceinline__ T uni(T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "uni: 4- or 8-byte types");
+    if constexpr (sizeof(T) == 4) {
+        uint32_t u = __builtin_bit_cast(uint32_t, v);
+        u = __builtin_amdgcn_readfirstlane(u);
+        return __builtin_bit_cast(T, u);
+    } else {
+        uint64_t u = __builtin_bit_cast(uint64_t, v);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        u = ((uint64_t)hi << 32) | lo;
+        return __builtin_bit_cast(T, u);
     }
 }
 
 template <int DV>
-__global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
+__global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) {
+    // The 2.7 KB descriptor is staged into LDS once, with vector loads (all 42 lines in flight together), and every
+    // later field read is a ds_read.  Reading it in place would cost one dependent, uncached scalar load per term /
+    // item / field group: the kernarg block is rewritten by the host for every launch and lives in memory the scalar
+    // cache does not keep, and in-kernel stamps showed ≈ 0.35 µs per table row — more than the arithmetic of the row.
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lds_sums = lds;                                   // [num_rew][64]
-    float* tile = lds + kPostMaxReward * kEnvBlock;          // [64][O+1]
+    constexpr int kArgVec = (int)(sizeof(GfPostArgs) / 16);
+    {
+        const auto* src = (const __attribute__((address_space(4))) f32x4*)__builtin_amdgcn_kernarg_segment_ptr();
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < kArgVec; i += kEnvBlock) dst[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const GfPostArgs& a = *reinterpret_cast<const GfPostArgs*>(lds);
+    GF_STAMP(1);
+    float* lds_sums = lds + kArgVec * 4;                     // [num_rew][64]
+    float* tile = lds_sums + kPostMaxReward * kEnvBlock;     // [64][O+1]
 
     const int lane = threadIdx.x;
-    const int64_t N = a.num_envs;
+    const int64_t N = uni(a.num_envs);
     const int64_t n0 = (int64_t)blockIdx.x * kEnvBlock;
     const int64_t n_raw = n0 + lane;
     const bool live = n_raw < N;
     const int64_t n = live ? n_raw : N - 1;
     const uint32_t e = (uint32_t)n;
-    const uint32_t genv = e + a.env_offset;
-    const int D = a.num_dofs;
-    const uint32_t needs = a.needs;
+    const uint32_t genv = e + uni(a.env_offset);
+    const int D = uni(a.num_dofs);
+    const uint32_t needs = uni(a.needs);
+    const int n_term = uni(a.num_term), n_rew = uni(a.num_rew), n_cmd = uni(a.n_cmd), n_obs = uni(a.n_obs);
+    const uint64_t seed = uni(a.seed);
     constexpr int R = DV;
 
     // ---- 0. episode-sum columns: global -> LDS without VGPRs or waits ------------------------------------
-    const bool logging = a.logging != 0;
+    const bool logging = uni(a.logging) != 0;
+    float* const k_sums = uni(a.episode_sums);
     if (logging)
-        for (int k = 0; k < a.num_rew; ++k)
-            __builtin_amdgcn_global_load_lds(a.episode_sums + (int64_t)a.rterms[k].row * N + n, lds_sums + k * kEnvBlock, 4, 0, 0);
+        for (int k = 0; k < n_rew; ++k)
+            __builtin_amdgcn_global_load_lds(k_sums + (int64_t)uni(a.rterms[k].row) * N + n, lds_sums + k * kEnvBlock, 4, 0, 0);
 
     // ---- 1. all per-env inputs, one straight-line burst ------------------------------------------------------
-    const float *k_pos = a.pos, *k_quat = a.quat, *k_lin = a.lin_vel, *k_ang = a.ang_vel, *k_dof = a.dof_pos, *k_dvel = a.dof_vel;
-    const float *k_tgt = a.targets, *k_act = a.env_actions, *k_last = a.env_last_actions, *k_def = a.default_dof_pos, *k_secs = a.episode_seconds;
-    const int32_t *k_ep = a.episode_length, *k_max = a.max_episode_length;
-    asm volatile("" : "+s"(k_pos), "+s"(k_quat), "+s"(k_lin), "+s"(k_ang), "+s"(k_dof), "+s"(k_dvel));
-    asm volatile("" : "+s"(k_tgt), "+s"(k_act), "+s"(k_last), "+s"(k_def), "+s"(k_secs), "+s"(k_ep), "+s"(k_max));
+    const float *k_pos = uni(a.pos), *k_quat = uni(a.quat), *k_lin = uni(a.lin_vel), *k_ang = uni(a.ang_vel), *k_dof = uni(a.dof_pos),
+                *k_dvel = uni(a.dof_vel);
+    const float *k_tgt = uni(a.targets), *k_act = uni(a.env_actions), *k_last = uni(a.env_last_actions), *k_def = uni(a.default_dof_pos),
+                *k_secs = uni(a.episode_seconds);
+    const int32_t *k_ep = uni(a.episode_length), *k_max = uni(a.max_episode_length);
 
     const float4 q = ldg4(gsel((needs & PN_QUAT) != 0, k_quat, 4u * e));
     const GF_GLOBAL float* pp = gsel((needs & PN_POS) != 0, k_pos, 3u * e);
@@ -159,7 +220,7 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
     V3 pos{pp[0], pp[1], pp[2]}, lin{lp[0], lp[1], lp[2]}, ang{ap[0], ap[1], ap[2]};
     const int ep_len = *gsel((needs & PN_EPLEN) != 0, k_ep, e);
     const int max_len = *gsel((needs & PN_MAXLEN) != 0, k_max, e);
-    const float secs_in = *gsel(a.num_rew >= 0 && k_secs != nullptr, k_secs, e);
+    const float secs_in = *gsel(n_rew >= 0 && k_secs != nullptr, k_secs, e);
 
     const uint32_t ro = e * (uint32_t)D;
     float4 r_pos[R], r_vel[R], r_tgt[R], r_act[R], r_last[R], r_def[R];
@@ -180,13 +241,14 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
     float cmd[GF_POST_MAX_CMD][kPostMaxRanges];
 #pragma unroll
     for (int c = 0; c < GF_POST_MAX_CMD; ++c) {
-        const bool on = c < a.n_cmd;
-        const uint32_t w = on ? (uint32_t)a.cmds[c].width : 0u;
-        const GF_GLOBAL float* cp = gsel(on, on ? a.cmds[c].command : nullptr, e * w);
+        const bool on = c < n_cmd;
+        const uint32_t w = on ? (uint32_t)uni(a.cmds[c].width) : 0u;
+        const GF_GLOBAL float* cp = gsel(on, on ? uni(a.cmds[c].command) : nullptr, e * w);
 #pragma unroll
         for (int j = 0; j < kPostMaxRanges; ++j) cmd[c][j] = cp[(uint32_t)j < w ? j : 0];
     }
 
+    GF_STAMP(2);
     // ---- 2. derived per-env quantities (pre-reset) ----------------------------------------------------------------
     const V3 blin = rot_inv(q, lin), bang = rot_inv(q, ang), grav = rot_inv(q, V3{0.f, 0.f, -1.f});
     float dof_dev = 0.f, act_rate = 0.f;
@@ -205,16 +267,19 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
         d = r_last[c].z - r_act[c].z; act_rate += d * d;
         d = r_last[c].w - r_act[c].w; act_rate += d * d;
     }
-    GfStepStats* shard = a.stats ? stats_shard(a.stats) : nullptr;
+    GfStepStats* const k_stats = uni(a.stats);
+    GfStepStats* shard = k_stats ? stats_shard(k_stats) : nullptr;
 
+    GF_STAMP(3);
     // ---- 3. termination (termination_manager.py:151-190) ---------------------------------------------------------------
     TermRegs tr;
-    tr.ep_len = ep_len; tr.max_len = max_len; tr.has_maxlen = a.has_maxlen != 0; tr.pos = pos; tr.m = n;
+    const int has_maxlen = uni(a.has_maxlen);
+    tr.ep_len = ep_len; tr.max_len = max_len; tr.has_maxlen = has_maxlen != 0; tr.pos = pos; tr.m = n;
     tr.tilt_sin = clamp_max(norm2(grav.x, grav.y), 0.99f);
     int term = 0, trunc = 0;
-    for (int k = 0; k < a.num_term; ++k) {
-        const GfTerm& t = a.tterms[k];
-        int v = eval_termination_term(t, a, tr, (uint32_t)a.has_maxlen);
+    for (int k = 0; k < n_term; ++k) {
+        const GfTerm t = a.tterms[k];
+        int v = eval_termination_term(t, a, tr, (uint32_t)has_maxlen);
         v = live ? v : 0;
         if (t.flags & GF_TERM_FLAG_TIME_OUT) trunc |= v; else term |= v;
         if (shard) {
@@ -223,38 +288,43 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
         }
     }
     if (live) {
-        a.terminated[n_raw] = (uint8_t)term;
-        a.truncated[n_raw] = (uint8_t)trunc;
+        G(uni(a.terminated))[n_raw] = (uint8_t)term;
+        G(uni(a.truncated))[n_raw] = (uint8_t)trunc;
     }
     const bool done = live && (term | trunc);
     const unsigned long long done_mask = __ballot(done);
     if (shard && done_mask && lane == 0) atomicAdd(&shard->reset_count, popc64(done_mask));
 
+    GF_STAMP(4);
     // ---- 4. reward (reward_manager.py:166-195) with the manager's reset (:197-222) folded into the sum update -----------
-    if (a.num_rew >= 0 && a.reward) {
+    float* const k_reward = uni(a.reward);
+    if (n_rew >= 0 && k_reward) {
         RewardRegs rr;
         rr.pos = pos; rr.blin = blin; rr.bang = bang; rr.grav = grav; rr.dof_dev = dof_dev; rr.act_rate = act_rate; rr.terminated = term;
         rr.n = n; rr.live = live;
-        const int c0 = a.cmd_of_view[0];
+        const int c0 = uni(a.cmd_of_view[0]);
         if (c0 >= 0) {
             rr.cmd0[0] = c0 == 0 ? cmd[0][0] : cmd[1][0];
             rr.cmd0[1] = c0 == 0 ? cmd[0][1] : cmd[1][1];
             rr.cmd0[2] = c0 == 0 ? cmd[0][2] : cmd[1][2];
         } else {
-            const bool nv = a.command[0].command != nullptr;
-            const uint32_t w = nv ? (uint32_t)a.command[0].width : 0u;
-            const GF_GLOBAL float* cp = gsel(nv, a.command[0].command, e * w);
+            const float* v0 = uni(a.command[0].command);
+            const bool nv = v0 != nullptr;
+            const uint32_t w = nv ? (uint32_t)uni(a.command[0].width) : 0u;
+            const GF_GLOBAL float* cp = gsel(nv, v0, e * w);
             rr.cmd0[0] = cp[0]; rr.cmd0[1] = cp[w > 1 ? 1 : 0]; rr.cmd0[2] = cp[w > 2 ? 2 : 0];
         }
-        const float secs_new = secs_in + a.dt;
+        const float dt = uni(a.dt);
+        const uint32_t log_mask = uni(a.reward_log_mask);
+        const float secs_new = secs_in + dt;
         if (logging) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
         float buf = 0.f;
         const bool log_reset = logging && done_mask != 0;
-        for (int k = 0; k < a.num_rew; ++k) {
-            const GfTerm& t = a.rterms[k];
+        for (int k = 0; k < n_rew; ++k) {
+            const GfTerm t = a.rterms[k];
             float v = eval_reward_term(t, a, rr);
             v = v * t.w;
             buf += v;
@@ -263,7 +333,7 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
                 if (log_reset) {
                     // RewardManager.reset: value /= seconds; mean → log; value ← 0 (zero-weight rows are not logged)
                     const float per_sec = done ? s / secs_new : 0.f;
-                    if (shard && (a.reward_log_mask & (1u << t.row))) {
+                    if (shard && (log_mask & (1u << t.row))) {
                         if (popc64(done_mask) > 4) {
                             const double w = wave_sum((double)per_sec);
                             if (lane == 0) unsafeAtomicAdd(&shard->reward_episode_sum[t.row], w);
@@ -273,25 +343,26 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
                     }
                     if (done) s = 0.f;
                 }
-                if (live) a.episode_sums[(int64_t)t.row * N + n_raw] = s;
+                if (live) G(k_sums)[(int64_t)t.row * N + n_raw] = s;
             }
         }
         if (live) {
-            a.reward[n_raw] = buf;
-            a.episode_seconds[n_raw] = done ? 1e-10f : secs_new;
+            G(k_reward)[n_raw] = buf;
+            G(const_cast<float*>(k_secs))[n_raw] = done ? 1e-10f : secs_new;
         }
         if (done && logging)
             for (int row = 0; row < a.reward_rows; ++row)
-                if (a.uncovered_rows & (1u << row)) a.episode_sums[(int64_t)row * N + n_raw] = 0.f;
+                if (a.uncovered_rows & (1u << row)) G(k_sums)[(int64_t)row * N + n_raw] = 0.f;
     }
 
+    GF_STAMP(5);
     // ---- 5. command.step: resample where episode_length % resample_steps == 0 (command_manager.py:152-162) --------------
     bool cmd_dirty[GF_POST_MAX_CMD] = {false, false};
 #pragma unroll
     for (int c = 0; c < GF_POST_MAX_CMD; ++c) {
-        if (c < a.n_cmd) {
-            const PostCmd& cm = a.cmds[c];
-            const bool go = live && (ep_len % cm.resample_steps) == 0;
+        if (c < n_cmd) {
+            const PostCmd cm = a.cmds[c];
+            const bool go = live && (ep_len % uni(cm.resample_steps)) == 0;
             if (shard) {
                 const unsigned long long m = __ballot(go);
                 if (m && lane == 0) atomicAdd(&shard->resample_count, popc64(m));
@@ -299,12 +370,13 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
             if (go) {
 #pragma unroll
                 for (int j = 0; j < kPostMaxRanges; ++j)
-                    if (j < cm.width) cmd[c][j] = uniform_range(philox_uniform(a.seed, cm.stream_step, genv, (uint32_t)j), cm.lo[j], cm.hi[j]);
+                    if (j < cm.width) cmd[c][j] = uniform_range(philox_uniform(seed, cm.stream_step, genv, (uint32_t)j), cm.lo[j], cm.hi[j]);
                 cmd_dirty[c] = true;
             }
         }
     }
 
+    GF_STAMP(6);
     // ---- 6. reset of done envs (managed_env.py:336-366), applied to memory AND to the registers the observation reads ----
     float4 o_act[R];  // raw actions as the observation sees them
 #pragma unroll
@@ -312,60 +384,60 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
     if (done) {
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((a.reset_env & 1) && a.env_actions) {
-            float4* ra = reinterpret_cast<float4*>(a.env_actions + n * D);
-            float4* rl = reinterpret_cast<float4*>(a.env_last_actions + n * D);
+            GF_GLOBAL f32x4* ra = reinterpret_cast<GF_GLOBAL f32x4*>(G(const_cast<float*>(k_act)) + n * D);
+            GF_GLOBAL f32x4* rl = reinterpret_cast<GF_GLOBAL f32x4*>(G(const_cast<float*>(k_last)) + n * D);
 #pragma unroll
-            for (int c = 0; c < DV; ++c) { ra[c] = z4; rl[c] = z4; o_act[c] = z4; }
+            for (int c = 0; c < DV; ++c) { ra[c] = f32x4{0.f, 0.f, 0.f, 0.f}; rl[c] = f32x4{0.f, 0.f, 0.f, 0.f}; o_act[c] = z4; }
         }
-        if (a.reset_env & 2) a.episode_length[n] = 0;
+        if (a.reset_env & 2) G(const_cast<int32_t*>(k_ep))[n] = 0;
         if (a.max_episode_length && a.max_random_scaling > 0.0f) {
-            const float u = philox_uniform(a.seed, a.stream_reset, genv, 0u);
+            const float u = philox_uniform(seed, a.stream_reset, genv, 0u);
             const float rnd = uniform_range(u, -1.0f, 1.0f) * a.max_random_scaling;
-            a.max_episode_length[n] = (int32_t)rintf((float)a.base_max_episode_length + rnd);
+            G(const_cast<int32_t*>(k_max))[n] = (int32_t)rintf((float)a.base_max_episode_length + rnd);
         }
         for (int m = 0; m < a.n_air; ++m) {
             const int L = a.air_links[m];
             for (int s = 0; s < 4; ++s) {
-                float* p = a.air_state[m][s];
+                GF_GLOBAL float* p = G(a.air_state[m][s]);
                 if (p)
                     for (int l = 0; l < L; ++l) p[n * L + l] = 0.0f;
             }
         }
         if (a.reset_dofs) {
-            float4* dp = reinterpret_cast<float4*>(a.dof_pos + n * D);
-            float4* dv = reinterpret_cast<float4*>(a.dof_vel + n * D);
+            GF_GLOBAL f32x4* dp = reinterpret_cast<GF_GLOBAL f32x4*>(G(const_cast<float*>(k_dof)) + n * D);
+            GF_GLOBAL f32x4* dv = reinterpret_cast<GF_GLOBAL f32x4*>(G(const_cast<float*>(k_dvel)) + n * D);
 #pragma unroll
             for (int c = 0; c < DV; ++c) {
                 float4 p = r_def[c];
                 if (a.dof_noise_scale != 0.0f) {
-                    p.x = p.x + uniform_range(philox_uniform(a.seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 0)), -1.0f, 1.0f) * a.dof_noise_scale;
-                    p.y = p.y + uniform_range(philox_uniform(a.seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 1)), -1.0f, 1.0f) * a.dof_noise_scale;
-                    p.z = p.z + uniform_range(philox_uniform(a.seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 2)), -1.0f, 1.0f) * a.dof_noise_scale;
-                    p.w = p.w + uniform_range(philox_uniform(a.seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 3)), -1.0f, 1.0f) * a.dof_noise_scale;
+                    p.x = p.x + uniform_range(philox_uniform(seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 0)), -1.0f, 1.0f) * a.dof_noise_scale;
+                    p.y = p.y + uniform_range(philox_uniform(seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 1)), -1.0f, 1.0f) * a.dof_noise_scale;
+                    p.z = p.z + uniform_range(philox_uniform(seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 2)), -1.0f, 1.0f) * a.dof_noise_scale;
+                    p.w = p.w + uniform_range(philox_uniform(seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 3)), -1.0f, 1.0f) * a.dof_noise_scale;
                 }
                 r_pos[c] = p;
-                dp[c] = p;
-                if (a.dof_vel) { dv[c] = z4; r_vel[c] = z4; }
+                dp[c] = f32x4{p.x, p.y, p.z, p.w};
+                if (k_dvel) { dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; r_vel[c] = z4; }
             }
         }
         if (a.scene_reset) {
-            float* wp = a.pos + 3 * n;
+            GF_GLOBAL float* wp = G(const_cast<float*>(k_pos)) + 3 * n;
             wp[0] = a.reset_pos[0]; wp[1] = a.reset_pos[1]; wp[2] = a.reset_pos[2];
             if (a.set_quat) {
-                if (a.quat_stash) reinterpret_cast<float4*>(a.quat_stash)[n] = q;
-                reinterpret_cast<float4*>(a.quat)[n] = make_float4(a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]);
+                if (a.quat_stash) reinterpret_cast<GF_GLOBAL f32x4*>(G(a.quat_stash))[n] = f32x4{q.x, q.y, q.z, q.w};
+                reinterpret_cast<GF_GLOBAL f32x4*>(G(const_cast<float*>(k_quat)))[n] = f32x4{a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]};
             }
             if (a.zero_velocity) {
-                float* wl = a.lin_vel + 3 * n;
-                float* wa = a.ang_vel + 3 * n;
+                GF_GLOBAL float* wl = G(const_cast<float*>(k_lin)) + 3 * n;
+                GF_GLOBAL float* wa = G(const_cast<float*>(k_ang)) + 3 * n;
                 wl[0] = 0.f; wl[1] = 0.f; wl[2] = 0.f;
                 wa[0] = 0.f; wa[1] = 0.f; wa[2] = 0.f;
                 lin = V3{0.f, 0.f, 0.f};
                 ang = V3{0.f, 0.f, 0.f};
-                if (a.dof_vel) {
-                    float4* dv = reinterpret_cast<float4*>(a.dof_vel + n * D);
+                if (k_dvel) {
+                    GF_GLOBAL f32x4* dv = reinterpret_cast<GF_GLOBAL f32x4*>(G(const_cast<float*>(k_dvel)) + n * D);
 #pragma unroll
-                    for (int c = 0; c < DV; ++c) { dv[c] = z4; r_vel[c] = z4; }
+                    for (int c = 0; c < DV; ++c) { dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; r_vel[c] = z4; }
                 }
             }
         }
@@ -374,90 +446,96 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
     // ---- 7. command.reset for done envs (command_manager.py:164-170) + write back changed commands ------------------------
 #pragma unroll
     for (int c = 0; c < GF_POST_MAX_CMD; ++c) {
-        if (c < a.n_cmd) {
-            const PostCmd& cm = a.cmds[c];
+        if (c < n_cmd) {
+            const PostCmd cm = a.cmds[c];
             if (done) {
 #pragma unroll
                 for (int j = 0; j < kPostMaxRanges; ++j)
-                    if (j < cm.width) cmd[c][j] = uniform_range(philox_uniform(a.seed, cm.stream_reset, genv, (uint32_t)j), cm.lo[j], cm.hi[j]);
+                    if (j < cm.width) cmd[c][j] = uniform_range(philox_uniform(seed, cm.stream_reset, genv, (uint32_t)j), cm.lo[j], cm.hi[j]);
                 cmd_dirty[c] = true;
             }
             if (cmd_dirty[c] && live) {
-                float* row = cm.command + n * cm.width;
+                GF_GLOBAL float* crow = G(cm.command) + n * cm.width;
 #pragma unroll
                 for (int j = 0; j < kPostMaxRanges; ++j)
-                    if (j < cm.width) row[j] = cmd[c][j];
+                    if (j < cm.width) crow[j] = cmd[c][j];
             }
         }
     }
 
+    GF_STAMP(7);
     // ---- 8. observations (observation_manager.py:218-256): post-reset state, pre-reset quaternion ------------------------
     const V3 o_lin = rot_inv(q, lin), o_ang = rot_inv(q, ang);
-    for (int m = 0; m < a.n_obs; ++m) {
+    for (int m = 0; m < n_obs; ++m) {
         const PostObs& ob = a.obs[m];
-        const int O = ob.width, S = O + 1, H = ob.history;
+        const int O = uni(ob.width), S = O + 1, H = uni(ob.history), n_items = uni(ob.num_items);
+        float* const ob_out = uni(ob.obs);
+        const float* const ob_prev = uni(ob.prev);
+        const uint64_t ob_stream = uni(ob.stream);
         float* row = tile + lane * S;
         int col = 0;
-        for (int i = 0; i < ob.num_items; ++i) {
-            const GfObsItem& it = ob.items[i];
-            switch (it.op) {
+        for (int i = 0; i < n_items; ++i) {
+            const GfObsItem it = ob.items[i];  // by value: the tile stores below must not force reloads of the item
+            const ObsFin f{it.scale, it.noise, seed, ob_stream, genv};
+            switch (uni(it.op)) {
                 case GF_O_COMMAND: {
                     const int owner = a.cmd_of_view[it.i0];
                     if (owner >= 0) {
 #pragma unroll
                         for (int j = 0; j < kPostMaxRanges; ++j)
-                            if (j < it.width) row[col + j] = obs_finish(a, ob, it, owner == 0 ? cmd[0][j] : cmd[1][j], genv, n, col + j);
+                            if (j < it.width) row[col + j] = obs_finish(f, owner == 0 ? cmd[0][j] : cmd[1][j], col + j);
                     } else {
-                        const GfCommandView& cv = a.command[it.i0];
-                        for (int j = 0; j < it.width; ++j) row[col + j] = obs_finish(a, ob, it, cv.command[n * cv.width + j], genv, n, col + j);
+                        const GfCommandView cv = a.command[it.i0];
+                        for (int j = 0; j < it.width; ++j) row[col + j] = obs_finish(f, G(cv.command)[n * cv.width + j], col + j);
                     }
                 } break;
                 case GF_O_ANG_VEL_BODY:
                 case GF_O_LIN_VEL_BODY:
                 case GF_O_PROJ_GRAVITY: {
                     const V3 v = it.op == GF_O_ANG_VEL_BODY ? o_ang : (it.op == GF_O_LIN_VEL_BODY ? o_lin : grav);
-                    row[col + 0] = obs_finish(a, ob, it, v.x, genv, n, col + 0);
-                    row[col + 1] = obs_finish(a, ob, it, v.y, genv, n, col + 1);
-                    row[col + 2] = obs_finish(a, ob, it, v.z, genv, n, col + 2);
+                    row[col + 0] = obs_finish(f, v.x, col + 0);
+                    row[col + 1] = obs_finish(f, v.y, col + 1);
+                    row[col + 2] = obs_finish(f, v.z, col + 2);
                 } break;
-                case GF_O_DOF_POS: put_row<DV>(a, ob, it, r_pos, row, genv, n, col); break;
-                case GF_O_DOF_VEL: put_row<DV>(a, ob, it, r_vel, row, genv, n, col); break;
-                case GF_O_ACTIONS: put_row<DV>(a, ob, it, r_tgt, row, genv, n, col); break;
-                case GF_O_RAW_ACTIONS: put_row<DV>(a, ob, it, o_act, row, genv, n, col); break;
+                case GF_O_DOF_POS: put_row<DV>(f, r_pos, row, col); break;
+                case GF_O_DOF_VEL: put_row<DV>(f, r_vel, row, col); break;
+                case GF_O_ACTIONS: put_row<DV>(f, r_tgt, row, col); break;
+                case GF_O_RAW_ACTIONS: put_row<DV>(f, o_act, row, col); break;
                 case GF_O_DOF_FORCE: {
-                    const float* r = a.dof_force + n * D;
-                    for (int j = 0; j < it.width; ++j) row[col + j] = obs_finish(a, ob, it, r[j], genv, n, col + j);
+                    const GF_GLOBAL float* r = G(a.dof_force) + n * D;
+                    for (int j = 0; j < it.width; ++j) row[col + j] = obs_finish(f, r[j], col + j);
                 } break;
                 case GF_O_CONTACT_FORCE_NORM: {
-                    const GfContactView& cv = a.contact[it.i0];
-                    const float* r = cv.contacts + n * cv.num_links * 3;
-                    for (int l = 0; l < it.width; ++l) row[col + l] = obs_finish(a, ob, it, norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]), genv, n, col + l);
+                    const GfContactView cv = a.contact[it.i0];
+                    const GF_GLOBAL float* r = G(cv.contacts) + n * cv.num_links * 3;
+                    for (int l = 0; l < it.width; ++l) row[col + l] = obs_finish(f, norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]), col + l);
                 } break;
                 default: break;
             }
-            col += it.width;
+            col += uni(it.width);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GF_STAMP(8);
 
         const int rows = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
         const int64_t OH = (int64_t)O * H;
-        float* out = ob.obs + n0 * OH;
+        GF_GLOBAL float* out = G(ob_out) + n0 * OH;
         if ((O & 3) == 0) {
             const int o4 = O >> 2;
             for (int i = lane; i < rows * o4; i += GF_WAVE) {
                 const int rw = i / o4, c4 = i - rw * o4;
                 const float* r = tile + rw * S + c4 * 4;
-                reinterpret_cast<float4*>(out + rw * OH)[c4] = make_float4(r[0], r[1], r[2], r[3]);
+                reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OH)[c4] = f32x4{r[0], r[1], r[2], r[3]};
             }
             if (H > 1) {
                 const int h4 = (O * (H - 1)) >> 2;
-                const float* prev = ob.prev + n0 * OH;
+                const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
                 for (int i = lane; i < rows * h4; i += GF_WAVE) {
                     const int rw = i / h4, j = i - rw * h4;
-                    reinterpret_cast<float4*>(out + rw * OH + O)[j] = reinterpret_cast<const float4*>(prev + rw * OH)[j];
+                    reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OH + O)[j] = reinterpret_cast<const GF_GLOBAL f32x4*>(prev + rw * OH)[j];
                 }
             }
         } else {
@@ -467,7 +545,7 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
             }
             if (H > 1) {
                 const int hw = O * (H - 1);
-                const float* prev = ob.prev + n0 * OH;
+                const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
                 for (int i = lane; i < rows * hw; i += GF_WAVE) {
                     const int rw = i / hw, j = i - rw * hw;
                     out[rw * OH + O + j] = prev[rw * OH + j];
@@ -479,6 +557,7 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs a) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
+    GF_STAMP(9);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -818,10 +897,14 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     gf::Packer pk;
     const int rc = gf::pack(r, pk);
     if (rc) return rc;
+#ifdef GF_STAMPS
+    pk.a.stamps = gf_debug_stamps;
+    pk.a.stamp_block = (uint32_t)(pk.a.num_envs / 64 / 2);
+#endif
     const gf::GfPostArgs& a = pk.a;
     int omax = 0;
     for (int m = 0; m < a.n_obs; ++m) omax = a.obs[m].width > omax ? a.obs[m].width : omax;
-    const size_t lds = ((size_t)gf::kPostMaxReward * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock) * sizeof(float);
+    const size_t lds = sizeof(gf::GfPostArgs) + ((size_t)gf::kPostMaxReward * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = gf::env_grid(a.num_envs);
     gf::PhaseScope scope(GF_PHASE_POST, s);

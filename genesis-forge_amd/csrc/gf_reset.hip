@@ -16,6 +16,7 @@
 namespace gf {
 
 __global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
+    prefetch_args<GfResetArgs>();
     const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
     const bool live = n < a.num_envs;
     const bool go = live && (a.mask[n] || (a.mask2 && a.mask2[n]));

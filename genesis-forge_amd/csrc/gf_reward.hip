@@ -35,6 +35,7 @@ enum : uint32_t {
 
 template <int DV>
 __global__ __launch_bounds__(kEnvBlock) void reward_kernel(const GfRewardArgs a, const uint32_t needs) {
+    prefetch_args<GfRewardArgs>();
     __shared__ float lds_sums[GF_MAX_TERMS * kEnvBlock];
 
     const int64_t N = a.num_envs;

@@ -17,6 +17,7 @@ namespace gf {
 enum : uint32_t { NEED_QUAT = 1, NEED_POS = 2, NEED_EPLEN = 4, NEED_MAXLEN = 8 };
 
 __global__ __launch_bounds__(kEnvBlock) void termination_kernel(const GfTerminationArgs a, const uint32_t needs) {
+    prefetch_args<GfTerminationArgs>();
     const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
     const bool live = n < a.num_envs;
     const int64_t m = live ? n : 0;  // clamp so every lane can take part in ballots

@@ -49,7 +49,7 @@ __device__ __forceinline__ int eval_termination_term(const GfTerm& t, const Args
             v = !(ep_len <= t.i[1]) && (contact_count_over(a.contact[t.i[0]], m, t.p[0]) > 0);
             break;
         case GF_T_EXTERNAL:
-            v = a.ext[t.i[0]][m] != 0;
+            v = G(a.ext[t.i[0]])[m] != 0;
             break;
         default:
             break;
@@ -80,8 +80,8 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
         case GF_R_TERMINATED: v = terminated ? 1.f : 0.f; break;
         case GF_R_BASE_HEIGHT: {
             float h = pos.z;
-            if (t.flags & GF_RW_FLAG_TERRAIN) h = h - a.ext[t.i[1]][n];
-            const float target = (t.flags & GF_RW_FLAG_CMD) ? a.command[t.i[0]].command[n * a.command[t.i[0]].width] : t.p[0];
+            if (t.flags & GF_RW_FLAG_TERRAIN) h = h - G(a.ext[t.i[1]])[n];
+            const float target = (t.flags & GF_RW_FLAG_CMD) ? G(a.command[t.i[0]].command)[n * a.command[t.i[0]].width] : t.p[0];
             const float e = h - target;
             v = e * e;
         } break;
@@ -90,7 +90,7 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
         case GF_R_ANG_VEL_XY_L2: v = bang.x * bang.x + bang.y * bang.y; break;
         case GF_R_FLAT_ORIENTATION_L2: v = grav.x * grav.x + grav.y * grav.y; break;
         case GF_R_BODY_ACCEL_EXP: {
-            float* st = a.state[t.i[0]] + n * 6;
+            GF_GLOBAL float* st = G(a.state[t.i[0]]) + n * 6;
             V3 la{0, 0, 0}, aa{0, 0, 0};
             if (!(t.flags & GF_RW_FLAG_FIRST_CALL)) {
                 la = V3{(blin.x - st[0]) / a.dt, (blin.y - st[1]) / a.dt, (blin.z - st[2]) / a.dt};
@@ -108,8 +108,8 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
             float c0 = cmd0[0], c1 = cmd0[1];
             if (t.i[0] != 0) {
                 const GfCommandView& c = a.command[t.i[0]];
-                c0 = c.command[n * c.width];
-                c1 = c.command[n * c.width + 1];
+                c0 = G(c.command)[n * c.width];
+                c1 = G(c.command)[n * c.width + 1];
             }
             const float e0 = c0 - blin.x;
             const float e1 = c1 - blin.y;
@@ -122,7 +122,7 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
                 cz = t.i[1] == 0 ? cmd0[0] : (t.i[1] == 1 ? cmd0[1] : cmd0[2]);
             } else {
                 const GfCommandView& c = a.command[t.i[0]];
-                cz = c.command[n * c.width + t.i[1]];
+                cz = G(c.command)[n * c.width + t.i[1]];
             }
             const float e = cz - bang.z;
             v = expf((-(e * e)) / t.p[0]);
@@ -131,8 +131,8 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
             float c0 = cmd0[0], c1 = cmd0[1];
             if (t.i[0] != 0) {
                 const GfCommandView& c = a.command[t.i[0]];
-                c0 = c.command[n * c.width];
-                c1 = c.command[n * c.width + 1];
+                c0 = G(c.command)[n * c.width];
+                c1 = G(c.command)[n * c.width + 1];
             }
             const float m = norm2(c0, c1);
             v = dof_dev * ((m < t.p[0]) ? 1.f : 0.f);
@@ -140,7 +140,7 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
         case GF_R_HAS_CONTACT: v = contact_count_over(a.contact[t.i[0]], n, t.p[0]) >= t.i[1] ? 1.f : 0.f; break;
         case GF_R_CONTACT_FORCE: {
             const GfContactView& cv = a.contact[t.i[0]];
-            const float* r = cv.contacts + n * cv.num_links * 3;
+            const GF_GLOBAL float* r = G(cv.contacts) + n * cv.num_links * 3;
             float s = 0.f;
             for (int l = 0; l < cv.num_links; ++l) s += clamp_min(norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]) - t.p[0], 0.f);
             v = s;
@@ -149,9 +149,9 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
             const GfContactView& cv = a.contact[t.i[0]];
             float s = 0.f;
             for (int l = 0; l < cv.num_links; ++l) {
-                const float cc = cv.current_contact_time[n * cv.num_links + l];
+                const float cc = G(cv.current_contact_time)[n * cv.num_links + l];
                 const float made = ((cc > 0.f) && (cc < t.p[2])) ? 1.f : 0.f;
-                float air = (cv.last_air_time[n * cv.num_links + l] - t.p[0]) * made;
+                float air = (G(cv.last_air_time)[n * cv.num_links + l] - t.p[0]) * made;
                 if (t.flags & GF_RW_FLAG_MAX) air = clamp_max(air, t.p[1]);
                 s += air;
             }
@@ -159,8 +159,8 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
                 float c0 = cmd0[0], c1 = cmd0[1];
                 if (t.i[1] != 0) {
                     const GfCommandView& c = a.command[t.i[1]];
-                    c0 = c.command[n * c.width];
-                    c1 = c.command[n * c.width + 1];
+                    c0 = G(c.command)[n * c.width];
+                    c1 = G(c.command)[n * c.width + 1];
                 }
                 s = s * ((norm2(c0, c1) > 0.1f) ? 1.f : 0.f);
             }
@@ -168,8 +168,8 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
         } break;
         case GF_R_FEET_SLIDE: {
             const GfContactView& cv = a.contact[t.i[0]];
-            const float* r = cv.contacts + n * cv.num_links * 3;
-            const float* lv = cv.link_vel + n * cv.num_links * 3;
+            const GF_GLOBAL float* r = G(cv.contacts) + n * cv.num_links * 3;
+            const GF_GLOBAL float* lv = G(cv.link_vel) + n * cv.num_links * 3;
             float s = 0.f;
             for (int l = 0; l < cv.num_links; ++l) {
                 const float c = norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]) > 1.0f ? 1.f : 0.f;
@@ -177,7 +177,7 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
             }
             v = s;
         } break;
-        case GF_R_EXTERNAL: v = a.ext[t.i[0]][n]; break;
+        case GF_R_EXTERNAL: v = G(a.ext[t.i[0]])[n]; break;
         default: break;
     }
     return v;
