@@ -68,6 +68,12 @@ __global__ __launch_bounds__(kEnvBlock) void contact_kernel(const GfContactArgs 
             a.contact_positions[3 * k + 2] = cnt > 0.f ? p2 / cnt : p2;
         }
         if (a.position_counts) a.position_counts[k] = cnt;
+        if (a.links_vel && a.link_vel_out) {  // compact per-manager copy of the tracked links' velocities (feet_slide)
+            const float* sv = a.links_vel + (n * a.num_scene_links + target) * 3;
+            a.link_vel_out[3 * k + 0] = sv[0];
+            a.link_vel_out[3 * k + 1] = sv[1];
+            a.link_vel_out[3 * k + 2] = sv[2];
+        }
         if (a.track_air_time) {  // contact_manager.py:441-477
             const float dt = a.dt;
             const bool is_contact = norm3(f0, f1, f2) > a.air_time_threshold;

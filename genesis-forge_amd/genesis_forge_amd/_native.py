@@ -118,7 +118,7 @@ class GfContactArgs(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_contacts", C.c_int32), ("num_scene_links", C.c_int32),
                 ("num_targets", C.c_int32), ("num_with", C.c_int32), ("has_with_filter", C.c_int32),
                 ("track_air_time", C.c_int32), ("_pad", C.c_int32),
-                ("force", P), ("position", P), ("link_a", P), ("link_b", P), ("links_quat", P),
+                ("force", P), ("position", P), ("link_a", P), ("link_b", P), ("links_quat", P), ("links_vel", P), ("link_vel_out", P),
                 ("target_link_ids", C.c_int32 * GF_MAX_LINK_IDS), ("with_link_ids", C.c_int32 * GF_MAX_LINK_IDS),
                 ("air_time_threshold", C.c_float), ("dt", C.c_float),
                 ("contacts", P), ("contact_positions", P), ("position_counts", P),

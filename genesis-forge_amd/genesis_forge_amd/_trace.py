@@ -201,9 +201,9 @@ def traceable(env) -> bool:
         for meth in ("step", "reset", "get_observations", "_perform_observation", "handle_actions"):
             if hasattr(m, meth) and not _most_derived_is_ours(m, meth):
                 return False
-    if tm._dirty or len(tm._program.slots.exts) > 0:
+    if tm._dirty or tm._program.slots.volatile:
         return False
-    if rm is not None and (not rm.enabled or rm._dirty or len(rm._program.slots.exts) > 0):
+    if rm is not None and (not rm.enabled or rm._dirty or rm._program.slots.volatile):
         return False
     for cm in env.managers["command"]:
         if cm._external_controller is not None or not cm.enabled:

@@ -66,6 +66,9 @@ class _Slots:
         self.contacts: list = []   # [manager, need_link_vel]
         self.exts: list = []
         self.states: list = []
+        #: True when a launch bound a per-step temporary (Python-evaluated column, link velocities fetched through a
+        #: Genesis getter, an external command controller): such a descriptor must never be frozen into a recorded step
+        self.volatile = False
 
     def cmd(self, src) -> int:
         for k, s in enumerate(self.cmds):
@@ -116,7 +119,10 @@ class _Slots:
     def bind(self, args, ext_dtype, keep: list) -> None:
         """Refresh the pointers of every slot for this launch."""
         n = self.env.num_envs
+        self.volatile = len(self.exts) > 0
         for k, src in enumerate(self.cmds):
+            if getattr(src, "_external_controller", None) is not None:
+                self.volatile = True
             t = src.command if hasattr(src, "command") else src
             if t.dim() == 1:
                 t = t.unsqueeze(-1)
@@ -126,7 +132,10 @@ class _Slots:
             args.command[k].width = t.shape[1]
         if hasattr(args, "contact"):
             for k, (mgr, lv) in enumerate(self.contacts):
-                keep.extend(mgr.view(args.contact[k], need_link_vel=lv))
+                tmp = mgr.view(args.contact[k], need_link_vel=lv)
+                if tmp:
+                    self.volatile = True  # link velocities are a fresh tensor every step
+                keep.extend(tmp)
         for k, prov in enumerate(self.exts):
             t = _col(prov(), n, ext_dtype)
             keep.append(t)

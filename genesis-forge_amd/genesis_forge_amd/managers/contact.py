@@ -86,6 +86,8 @@ class ContactManager(BaseManager):
         self.contacts = torch.zeros((N, L, 3), device=gs.device)
         self.contact_positions = torch.zeros((N, L, 3), device=gs.device)
         self._contact_position_counts = torch.zeros((N, L), device=gs.device)
+        self.link_vel = torch.zeros((N, L, 3), device=gs.device)  # velocity of each tracked link, refreshed by step()
+        self._has_link_vel = False
         if self._track_air_time:
             self.last_air_time = torch.zeros((N, L), device=gs.device)
             self.current_air_time = torch.zeros_like(self.last_air_time)
@@ -145,6 +147,17 @@ class ContactManager(BaseManager):
         a.num_scene_links = int(links_quat.shape[1])
         a.force, a.position = force.data_ptr(), position.data_ptr()
         a.link_a, a.link_b, a.links_quat = link_a.data_ptr(), link_b.data_ptr(), links_quat.data_ptr()
+        lv = c.get("links_vel") if isinstance(c, dict) else None
+        if lv is None and hasattr(solver, "get_links_vel"):
+            lv = solver.get_links_vel()
+        if lv is not None:
+            lv = lv.to(torch.float32).contiguous()
+            self._keep = self._keep + (lv,)
+            a.links_vel, a.link_vel_out = lv.data_ptr(), self.link_vel.data_ptr()
+            self._has_link_vel = True
+        else:
+            a.links_vel = a.link_vel_out = None
+            self._has_link_vel = False
         a.dt = float(env.scene.dt)
         a.contacts = self.contacts.data_ptr()
         a.contact_positions = self.contact_positions.data_ptr()
@@ -162,7 +175,9 @@ class ContactManager(BaseManager):
         v.last_air_time = None if self.last_air_time is None else self.last_air_time.data_ptr()
         v.current_contact_time = None if self.current_contact_time is None else self.current_contact_time.data_ptr()
         keep = ()
-        if need_link_vel:
+        if need_link_vel and self._has_link_vel:
+            v.link_vel = self.link_vel.data_ptr()   # persistent, filled by gf_contact_step
+        elif need_link_vel:
             robot = getattr(self.env, self._entity_attr)
             lv = robot.get_links_vel(links_idx_local=self._local_link_ids).to(torch.float32).contiguous()
             v.link_vel = lv.data_ptr()

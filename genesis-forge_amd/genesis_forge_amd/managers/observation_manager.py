@@ -225,7 +225,7 @@ class ObservationManager(BaseManager):
         return out
 
     def _traceable(self) -> bool:
-        return self.enabled and not self._dirty and len(self._slots.exts) == 0 and all(
+        return self.enabled and not self._dirty and len(self._slots.exts) == 0 and len(self._slots.contacts) >= 0 and all(
             not hasattr(s, "_external_controller") or s._external_controller is None for s in self._slots.cmds)
 
     def _trace_patch(self, args):

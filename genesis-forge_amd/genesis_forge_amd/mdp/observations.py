@@ -55,6 +55,11 @@ def entity_dofs_force(env, action_manager=None, entity_attr: str = "robot", dofs
 def current_actions(env, action_manager=None) -> torch.Tensor:
     if action_manager is not None:
         return action_manager.get_actions()
+    if env.actions is None and env.action_space is not None:
+        # called before the first reset (ObservationManager.build's trial observation): the reference would hand
+        # torch.cat a None here; allocate the buffers reset() would create
+        env._actions = torch.zeros((env.num_envs, env.action_space.shape[0]), device=gs.device, dtype=gs.tc_float)
+        env._last_actions = torch.zeros_like(env._actions)
     return _tag(env.actions, ("raw_actions", env))
 
 

@@ -371,7 +371,7 @@ class SyntheticScene:
 
     def gf_contacts(self) -> dict:
         return {"force": self.contact_force, "position": self.contact_pos, "link_a": self.link_a, "link_b": self.link_b,
-                "links_quat": self.links_quat}
+                "links_quat": self.links_quat, "links_vel": self.links_vel_all}
 
     def step(self):
         """One synthetic tick (stands in for managed_env.py:292)."""

@@ -148,6 +148,8 @@ typedef struct GfContactArgs {
     const int32_t* link_a;    /* [N,C] */
     const int32_t* link_b;    /* [N,C] */
     const float* links_quat;  /* [N,num_scene_links,4] */
+    const float* links_vel;   /* [N,num_scene_links,3] world link velocities, or NULL */
+    float* link_vel_out;      /* [N,L,3] out: velocity of each tracked link (what rewards.feet_slide reads, rewards.py:496-504), or NULL */
     int32_t target_link_ids[GF_MAX_LINK_IDS];
     int32_t with_link_ids[GF_MAX_LINK_IDS];
     float air_time_threshold; /* (float)air_time_contact_threshold */

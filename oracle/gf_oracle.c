@@ -188,6 +188,8 @@ GFO_EXPORT int gfo_contact_step(const GfContactArgs* a) {
                 if (out_p) out_p[t * 3 + j] = cnt > 0.0f ? p[j] / cnt : p[j];
             }
             if (out_c) out_c[t] = cnt;
+            if (a->links_vel && a->link_vel_out)
+                for (int j = 0; j < 3; ++j) a->link_vel_out[(n * L + t) * 3 + j] = a->links_vel[((int64_t)n * a->num_scene_links + target) * 3 + j];
             if (a->track_air_time) {
                 const int64_t k = n * L + t;
                 const float dt = a->dt;

@@ -81,3 +81,66 @@ class Go2CommandDirectionEnv(ManagedEnvironment):
         if self._contacts:
             ocfg["foot_force"] = {"fn": observations.contact_force, "params": {"contact_manager": self.foot_contacts}, "scale": 0.1}
         self.observation_manager = ObservationManager(self, fused=self._fused_obs, cfg=ocfg, history_len=self._history)
+
+
+class HumanoidGaitLikeEnv(ManagedEnvironment):
+    """Stress config for the fused post-physics kernel: synthetic 28-DOF humanoid (BASELINE config 4's size), two
+    command managers, two observation managers (policy with history, critic), three contact managers, the stateful
+    body_acceleration_exp term, PositionWithinLimitsActionManager, zero-weight and contact terms."""
+
+    def __init__(self, num_envs=1, dofs=28, dt=1 / 50, max_episode_length_s=1, scene_kwargs=None):
+        super().__init__(num_envs=num_envs, dt=dt, max_episode_length_sec=max_episode_length_s, max_episode_random_scaling=0.4)
+        from genesis_forge_amd.scene import humanoid_model
+        kw = dict(max_collision_pairs=10, ang_noise=0.3, contact_prob=0.3, seed=21)
+        kw.update(scene_kwargs or {})
+        self.scene = SyntheticScene(dt=self.dt, substeps=2, **kw)
+        self.terrain = self.scene.add_entity(morphs.Plane())
+        self.robot = self.scene.add_entity(model=humanoid_model(dofs))
+
+    def config(self):
+        from genesis_forge_amd.managers import CommandManager, PositionWithinLimitsActionManager
+        self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={
+            "position": {"fn": reset.position, "params": {"position": [0.0, 0.0, 0.55], "quat": [1.0, 0.0, 0.0, 0.0]}}})
+        self.action_manager = PositionWithinLimitsActionManager(self, joint_names=".*", default_pos={".*": 0.1}, noise_scale=0.02)
+        self.velocity_command = VelocityCommandManager(self, range={"lin_vel_x": [-1.0, 1.0], "lin_vel_y": [0.0, 0.0], "ang_vel_z": [-1.0, 1.0]},
+                                                       resample_time_sec=0.3)
+        self.height_command = CommandManager(self, range=(0.3, 0.6), resample_time_sec=0.4)
+        self.feet = ContactManager(self, link_names=[".*_faa"], track_air_time=True, air_time_contact_threshold=1.0)
+        self.torso = ContactManager(self, link_names=["torso"])
+        self.legs = ContactManager(self, link_names=[".*_kfe", ".*_hfe"], track_air_time=True)
+        self.reward_manager = RewardManager(self, cfg={
+            "lin": {"weight": 1.0, "fn": rewards.command_tracking_lin_vel, "params": {"vel_cmd_manager": self.velocity_command, "entity_manager": self.robot_manager}},
+            "ang": {"weight": 0.5, "fn": rewards.command_tracking_ang_vel, "params": {"vel_cmd_manager": self.velocity_command, "entity_manager": self.robot_manager}},
+            "accel": {"weight": -0.1, "fn": rewards.body_acceleration_exp, "params": {"entity_manager": self.robot_manager}},
+            "rate": {"weight": -0.005, "fn": rewards.action_rate_l2},
+            "pose": {"weight": -0.05, "fn": rewards.dof_similar_to_default, "params": {"action_manager": self.action_manager}},
+            "still": {"weight": -0.2, "fn": rewards.stand_still_joint_deviation_l1, "params": {"vel_cmd_manager": self.velocity_command, "action_manager": self.action_manager, "command_threshold": 0.3}},
+            "air": {"weight": 2.0, "fn": rewards.feet_air_time, "params": {"contact_manager": self.feet, "time_threshold": 0.04, "time_threshold_max": 0.5, "vel_cmd_manager": self.velocity_command}},
+            "bad_contact": {"weight": -1.0, "fn": rewards.contact_force, "params": {"contact_manager": self.legs, "threshold": 2.0}},
+            "slide": {"weight": -0.1, "fn": rewards.feet_slide, "params": {"contact_manager": self.feet}},
+            "alive": {"weight": 0.3, "fn": rewards.is_alive},
+            "off": {"weight": 0.0, "fn": rewards.flat_orientation_l2, "params": {"entity_manager": self.robot_manager}},
+            "flat": {"weight": -1.0, "fn": rewards.flat_orientation_l2, "params": {"entity_manager": self.robot_manager}},
+            "height": {"weight": -5.0, "fn": rewards.base_height, "params": {"target_height": 0.5}},
+        })
+        self.termination_manager = TerminationManager(self, term_cfg={
+            "timeout": {"fn": terminations.timeout, "time_out": True},
+            "fall": {"fn": terminations.bad_orientation, "params": {"limit_angle": 20.0, "entity_manager": self.robot_manager, "grace_steps": 3}},
+            "torso": {"fn": terminations.contact_force, "params": {"contact_manager": self.torso, "threshold": 25.0}},
+            "low": {"fn": terminations.base_height_below_minimum, "params": {"minimum_height": 0.2, "entity_manager": self.robot_manager}},
+        })
+        self.observation_manager = ObservationManager(self, name="policy", history_len=3, noise=0.01, cfg={
+            "height_cmd": {"fn": self.height_command.observation},
+            "velocity_cmd": {"fn": self.velocity_command.observation},
+            "ang": {"fn": lambda env: self.robot_manager.get_angular_velocity(), "scale": 0.25},
+            "grav": {"fn": lambda env: self.robot_manager.get_projected_gravity()},
+            "pos": {"fn": lambda env: self.action_manager.get_dofs_position()},
+            "vel": {"fn": lambda env: self.action_manager.get_dofs_velocity(), "scale": 0.05},
+            "act": {"fn": lambda env: self.action_manager.get_actions()},
+        })
+        self.critic_manager = ObservationManager(self, name="critic", cfg={
+            "feet": {"fn": observations.contact_force, "params": {"contact_manager": self.feet}, "scale": 0.1},
+            "lin": {"fn": lambda env: self.robot_manager.get_linear_velocity()},
+            "force": {"fn": observations.entity_dofs_force, "params": {"action_manager": self.action_manager}},
+            "raw": {"fn": observations.current_actions},
+        })

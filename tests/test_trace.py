@@ -108,3 +108,54 @@ def test_fused_post_physics_equals_phase_by_phase_hip(hip_backend, n):
         assert x[4].keys() == y[4].keys()
         for key in x[4]:
             assert abs(x[4][key] - y[4][key]) <= 1e-6 + 1e-6 * abs(y[4][key]), (t, key)
+
+
+def _run_humanoid(dev, mode, n, dofs, steps=50):
+    from envs import HumanoidGaitLikeEnv
+
+    env = HumanoidGaitLikeEnv(num_envs=n, dofs=dofs)
+    env.trace_enabled = mode != "ordinary"
+    env.fuse_post_physics = mode == "fused"
+    env.build()
+    env.seed(31)
+    env.reset()
+    g = torch.Generator().manual_seed(5)
+    seq = []
+    for t in range(steps):
+        o, r, te, tr, ex = env.step(torch.randn(n, dofs, generator=g).to(dev))
+        crit = ex["observations"]["critic"]
+        seq.append((o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone(), {k: float(v) for k, v in ex["episode"].items()},
+                    crit.cpu().clone(), env.velocity_command._command.cpu().clone(), env.height_command._command.cpu().clone(),
+                    env.max_episode_length.cpu().clone(), env.feet.current_air_time.cpu().clone(), env.reward_manager._episode_sums.cpu().clone()))
+    return seq, env
+
+
+def _same_h(a, b):
+    for t, (x, y) in enumerate(zip(a, b)):
+        for k in (0, 1, 2, 3, 5, 6, 7, 8, 9, 10):
+            assert torch.equal(x[k], y[k]), f"output {k} differs at step {t}"
+        assert x[4].keys() == y[4].keys(), f"log keys differ at step {t}"
+        for key in x[4]:
+            assert abs(x[4][key] - y[4][key]) <= 1e-6 + 1e-6 * abs(y[4][key]), (t, key)
+
+
+@pytest.mark.parametrize("dofs", [12, 28])
+def test_humanoid_config_traced_equals_ordinary_cpu(oracle_backend, dofs):
+    a, _ = _run_humanoid("cpu", "ordinary", 50, dofs)
+    b, env = _run_humanoid("cpu", "fused", 50, dofs)
+    assert env._trace is not None and env._trace.post_refs is not None
+    _same_h(a, b)
+    assert sum(int(x[2].sum() + x[3].sum()) for x in a) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dofs,n", [(12, 200), (28, 200), (28, 1), (12, 4097)])
+def test_humanoid_config_fused_hip(hip_backend, dofs, n):
+    """Two command managers, two observation managers, three contact managers, 13 reward terms, D=28 variant."""
+    a, _ = _run_humanoid("cuda", "ordinary", n, dofs)
+    b, env_b = _run_humanoid("cuda", "unfused", n, dofs)
+    c, env_c = _run_humanoid("cuda", "fused", n, dofs)
+    assert env_b._trace is not None and env_b._trace.post_refs is None
+    assert env_c._trace is not None and env_c._trace.post_refs is not None, "this config must take the fused kernel"
+    _same_h(a, b)
+    _same_h(a, c)
