@@ -122,17 +122,17 @@ enum : uint32_t {
 
 // scale / noise of one observation element (observation_manager.py:242-250); everything it needs arrives by value
 struct ObsFin {
-    float scale, noise;
-    uint64_t seed, stream;
-    uint32_t genv;
+    float scale;
+    bool scaled;
 };
-__device__ __forceinline__ float obs_finish(const ObsFin& f, float v, int col) {
-    if (f.scale != 1.0f) v = v * f.scale;
-    if (f.noise != 0.0f) {
-        const float u = philox_uniform(f.seed, f.stream, f.genv, (uint32_t)col);
-        v = v + uniform_range(u, -1.0f, 1.0f) * f.noise;
-    }
-    return v;
+__device__ __forceinline__ float obs_finish(const ObsFin& f, float v, int) { return f.scaled ? v * f.scale : v; }
+
+// All ≤ 4 range draws of one command resample come out of ONE Philox block (columns 0..3 share counter col>>2 == 0),
+// exactly the values philox_uniform(seed, stream, env, j) returns for j = 0..3.
+// (register-only signature: a real call, no stack, so the rarely-taken resample paths cost one Philox body in the binary)
+__device__ __noinline__ float4 draw_unit4(uint64_t seed, uint64_t stream, uint32_t genv, uint32_t block) {
+    const U4 r = philox4x32_10(genv, block, (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+    return make_float4(u24_to_unit(r.x), u24_to_unit(r.y), u24_to_unit(r.z), u24_to_unit(r.w));
 }
 
 // one [D] row of registers → the lane's observation tile row (separate call per source keeps every index static)
@@ -183,7 +183,8 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
     const GfPostArgs& a = *reinterpret_cast<const GfPostArgs*>(lds);
     GF_STAMP(1);
     float* lds_sums = lds + kArgVec * 4;                     // [num_rew][64]
-    float* tile = lds_sums + kPostMaxReward * kEnvBlock;     // [64][O+1]
+    float* lds_aux = lds_sums + kPostMaxReward * kEnvBlock;  // [16][64] per-lane scratch for rolled Philox loops (dof reset noise)
+    float* tile = lds_aux + 16 * kEnvBlock;                  // [64][O+1]
 
     const int lane = threadIdx.x;
     const int64_t N = uni(a.num_envs);
@@ -368,9 +369,12 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
                 if (m && lane == 0) atomicAdd(&shard->resample_count, popc64(m));
             }
             if (go) {
+                const float4 u4 = draw_unit4(seed, cm.stream_step, genv, 0u);
+                const float nv[kPostMaxRanges] = {uniform_range(u4.x, cm.lo[0], cm.hi[0]), uniform_range(u4.y, cm.lo[1], cm.hi[1]),
+                                                  uniform_range(u4.z, cm.lo[2], cm.hi[2]), uniform_range(u4.w, cm.lo[3], cm.hi[3])};
 #pragma unroll
                 for (int j = 0; j < kPostMaxRanges; ++j)
-                    if (j < cm.width) cmd[c][j] = uniform_range(philox_uniform(seed, cm.stream_step, genv, (uint32_t)j), cm.lo[j], cm.hi[j]);
+                    if (j < cm.width) cmd[c][j] = nv[j];
                 cmd_dirty[c] = true;
             }
         }
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
         }
         if (a.reset_env & 2) G(const_cast<int32_t*>(k_ep))[n] = 0;
         if (a.max_episode_length && a.max_random_scaling > 0.0f) {
-            const float u = philox_uniform(seed, a.stream_reset, genv, 0u);
+            const float u = draw_unit4(seed, a.stream_reset, genv, 0u).x;
             const float rnd = uniform_range(u, -1.0f, 1.0f) * a.max_random_scaling;
             G(const_cast<int32_t*>(k_max))[n] = (int32_t)rintf((float)a.base_max_episode_length + rnd);
         }
@@ -406,14 +410,28 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
         if (a.reset_dofs) {
             GF_GLOBAL f32x4* dp = reinterpret_cast<GF_GLOBAL f32x4*>(G(const_cast<float*>(k_dof)) + n * D);
             GF_GLOBAL f32x4* dv = reinterpret_cast<GF_GLOBAL f32x4*>(G(const_cast<float*>(k_dvel)) + n * D);
+            const float dof_noise = a.dof_noise_scale;
+            if (dof_noise != 0.0f) {
+                // one Philox block yields the four draws of columns 4+4c .. 4+4c+3 (they share counter (4+4c)>>2)
+#pragma nounroll
+                for (int c = 0; c < DV; ++c) {
+                    const float4 r4 = draw_unit4(seed, a.stream_reset, genv, (uint32_t)(1 + c));
+                    float* sc = lds_aux + (4 * c) * kEnvBlock + lane;
+                    sc[0 * kEnvBlock] = uniform_range(r4.x, -1.0f, 1.0f) * dof_noise;
+                    sc[1 * kEnvBlock] = uniform_range(r4.y, -1.0f, 1.0f) * dof_noise;
+                    sc[2 * kEnvBlock] = uniform_range(r4.z, -1.0f, 1.0f) * dof_noise;
+                    sc[3 * kEnvBlock] = uniform_range(r4.w, -1.0f, 1.0f) * dof_noise;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < DV; ++c) {
                 float4 p = r_def[c];
-                if (a.dof_noise_scale != 0.0f) {
-                    p.x = p.x + uniform_range(philox_uniform(seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 0)), -1.0f, 1.0f) * a.dof_noise_scale;
-                    p.y = p.y + uniform_range(philox_uniform(seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 1)), -1.0f, 1.0f) * a.dof_noise_scale;
-                    p.z = p.z + uniform_range(philox_uniform(seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 2)), -1.0f, 1.0f) * a.dof_noise_scale;
-                    p.w = p.w + uniform_range(philox_uniform(seed, a.stream_reset, genv, (uint32_t)(4 + 4 * c + 3)), -1.0f, 1.0f) * a.dof_noise_scale;
+                if (dof_noise != 0.0f) {
+                    const float* sc = lds_aux + (4 * c) * kEnvBlock + lane;
+                    p.x = p.x + sc[0 * kEnvBlock];
+                    p.y = p.y + sc[1 * kEnvBlock];
+                    p.z = p.z + sc[2 * kEnvBlock];
+                    p.w = p.w + sc[3 * kEnvBlock];
                 }
                 r_pos[c] = p;
                 dp[c] = f32x4{p.x, p.y, p.z, p.w};
@@ -449,9 +467,12 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
         if (c < n_cmd) {
             const PostCmd cm = a.cmds[c];
             if (done) {
+                const float4 u4 = draw_unit4(seed, cm.stream_reset, genv, 0u);
+                const float nv[kPostMaxRanges] = {uniform_range(u4.x, cm.lo[0], cm.hi[0]), uniform_range(u4.y, cm.lo[1], cm.hi[1]),
+                                                  uniform_range(u4.z, cm.lo[2], cm.hi[2]), uniform_range(u4.w, cm.lo[3], cm.hi[3])};
 #pragma unroll
                 for (int j = 0; j < kPostMaxRanges; ++j)
-                    if (j < cm.width) cmd[c][j] = uniform_range(philox_uniform(seed, cm.stream_reset, genv, (uint32_t)j), cm.lo[j], cm.hi[j]);
+                    if (j < cm.width) cmd[c][j] = nv[j];
                 cmd_dirty[c] = true;
             }
             if (cmd_dirty[c] && live) {
@@ -465,7 +486,9 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
 
     GF_STAMP(7);
     // ---- 8. observations (observation_manager.py:218-256): post-reset state, pre-reset quaternion ------------------------
-    const V3 o_lin = rot_inv(q, lin), o_ang = rot_inv(q, ang);
+    // a done env's velocities were zeroed above and rot_inv(q, 0) is exactly +0: no second rotation needed
+    const bool zeroed = done && a.scene_reset && a.zero_velocity;
+    const V3 o_lin = zeroed ? V3{0.f, 0.f, 0.f} : blin, o_ang = zeroed ? V3{0.f, 0.f, 0.f} : bang;
     for (int m = 0; m < n_obs; ++m) {
         const PostObs& ob = a.obs[m];
         const int O = uni(ob.width), S = O + 1, H = uni(ob.history), n_items = uni(ob.num_items);
@@ -476,7 +499,8 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
         int col = 0;
         for (int i = 0; i < n_items; ++i) {
             const GfObsItem it = ob.items[i];  // by value: the tile stores below must not force reloads of the item
-            const ObsFin f{it.scale, it.noise, seed, ob_stream, genv};
+            const float it_scale = uni(it.scale), it_noise = uni(it.noise);
+            const ObsFin f{it_scale, it_scale != 1.0f};
             switch (uni(it.op)) {
                 case GF_O_COMMAND: {
                     const int owner = a.cmd_of_view[it.i0];
@@ -512,7 +536,20 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
                 } break;
                 default: break;
             }
-            col += uni(it.width);
+            const int it_w = uni(it.width);
+            if (it_noise != 0.0f) {
+                // += uniform_(-1,1)*noise on the scaled value (observation_manager.py:247-250); kept as a rolled loop so the
+                // kernel contains ONE inlined Philox here instead of one per observation element
+#pragma nounroll
+                for (int j = 0; j < it_w; ++j) {
+                    const uint32_t cj = (uint32_t)(col + j);
+                    const float4 u4 = draw_unit4(seed, ob_stream, genv, cj >> 2);
+                    const uint32_t sel = cj & 3u;
+                    const float u = sel == 0 ? u4.x : (sel == 1 ? u4.y : (sel == 2 ? u4.z : u4.w));
+                    row[col + j] = row[col + j] + uniform_range(u, -1.0f, 1.0f) * it_noise;
+                }
+            }
+            col += it_w;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
@@ -525,10 +562,13 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
         GF_GLOBAL float* out = G(ob_out) + n0 * OH;
         if ((O & 3) == 0) {
             const int o4 = O >> 2;
+            const int qstep = GF_WAVE / o4, rstep = GF_WAVE - qstep * o4;  // wave-uniform: one division per tile, not per element
+            int rw = lane / o4, c4 = lane - rw * o4;
             for (int i = lane; i < rows * o4; i += GF_WAVE) {
-                const int rw = i / o4, c4 = i - rw * o4;
                 const float* r = tile + rw * S + c4 * 4;
                 reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OH)[c4] = f32x4{r[0], r[1], r[2], r[3]};
+                rw += qstep; c4 += rstep;
+                if (c4 >= o4) { c4 -= o4; ++rw; }
             }
             if (H > 1) {
                 const int h4 = (O * (H - 1)) >> 2;
@@ -904,7 +944,7 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     const gf::GfPostArgs& a = pk.a;
     int omax = 0;
     for (int m = 0; m < a.n_obs; ++m) omax = a.obs[m].width > omax ? a.obs[m].width : omax;
-    const size_t lds = sizeof(gf::GfPostArgs) + ((size_t)gf::kPostMaxReward * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock) * sizeof(float);
+    const size_t lds = sizeof(gf::GfPostArgs) + ((size_t)(gf::kPostMaxReward + 16) * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = gf::env_grid(a.num_envs);
     gf::PhaseScope scope(GF_PHASE_POST, s);
