@@ -30,6 +30,11 @@ __device__ __forceinline__ float action_target(float x, float s, float o, float 
 template <bool VEC4>
 __global__ __launch_bounds__(256) void action_kernel(const GfActionArgs a, const int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // zero the next step's statistics slot (nobody else touches it during this step)
+    if (a.stats_zero) {
+        constexpr int kWords = (int)(sizeof(GfStepStats) * GF_STATS_SHARDS / 4);
+        for (int64_t w = i; w < kWords; w += (int64_t)gridDim.x * blockDim.x) reinterpret_cast<uint32_t*>(a.stats_zero)[w] = 0u;
+    }
     const int D = a.num_dofs;
     const int mode = a.mode;
     int flags = 0;

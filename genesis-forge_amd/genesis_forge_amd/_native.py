@@ -111,7 +111,7 @@ class GfStepStats(C.Structure):
 class GfActionArgs(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_dofs", C.c_int32), ("mode", C.c_int32), ("check_finite", C.c_int32),
                 ("actions_in", P), ("scale", P), ("offset", P), ("clip_lo", P), ("clip_hi", P),
-                ("env_actions", P), ("env_last_actions", P), ("episode_length", P), ("targets", P), ("stats", P)]
+                ("env_actions", P), ("env_last_actions", P), ("episode_length", P), ("targets", P), ("stats", P), ("stats_zero", P)]
 
 
 class GfContactArgs(C.Structure):

@@ -74,6 +74,20 @@ class StatsSnapshot:
         return self._value
 
 
+class RingSnapshot:
+    """Statistics of one recorded step, living in a device ring slot until somebody reads them."""
+
+    __slots__ = ("_owner", "_slot", "_value")
+
+    def __init__(self, owner, slot: int):
+        self._owner, self._slot, self._value = owner, slot, None
+
+    def wait(self) -> nat.GfStepStats:
+        if self._value is None:
+            self._owner.materialize_ring()
+        return self._value
+
+
 class StepStats:
     """Owns the device stats block and the pinned read-back ring."""
 
@@ -116,6 +130,38 @@ class StepStats:
         snap = StatsSnapshot(host, ev)
         self._live[i] = snap
         return snap
+
+    # -- device ring used by recorded steps -------------------------------------------------------------
+    # A recorded step writes its statistics into slot (step % _RING) of a device-resident ring and zeroes the next
+    # slot from inside its first kernel, so it needs neither a memset nor a device→host copy (together they cost as
+    # much stream time as all the kernels of a step).  Slots are copied out in one batch only when a log entry is
+    # actually read, or just before an unread slot would be recycled.
+    def ensure_ring(self) -> None:
+        if getattr(self, "ring", None) is None:
+            self.ring = torch.zeros(_RING, STATS_BYTES, dtype=torch.uint8, device=self.device)
+            self.ring_pos = 0
+            self._ring_snaps = [None] * _RING
+
+    def ring_ptr(self, slot: int) -> int:
+        return self.ring.data_ptr() + slot * STATS_BYTES
+
+    def ring_next(self):
+        """(pointer of this step's slot, pointer of the slot to zero for the next step, snapshot)."""
+        i = self.ring_pos
+        j = (i + 1) % _RING
+        old = self._ring_snaps[j]
+        if old is not None and old._value is None:
+            self.materialize_ring()  # about to be recycled while still unread
+        snap = RingSnapshot(self, i)
+        self._ring_snaps[i] = snap
+        self.ring_pos = j
+        return self.ring_ptr(i), self.ring_ptr(j), snap
+
+    def materialize_ring(self) -> None:
+        host = self.ring.cpu().numpy()  # one blocking copy of every slot (synchronises the stream first)
+        for snap in self._ring_snaps:
+            if snap is not None and snap._value is None:
+                snap._value = sum_shards(host[snap._slot].tobytes())
 
     def ensure_native_events(self, backend) -> None:
         if getattr(self, "_events", None) is None:

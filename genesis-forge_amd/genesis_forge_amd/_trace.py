@@ -64,13 +64,16 @@ class StepTrace:
                 self.ops[k].args = C.addressof(self.post_refs)
                 k += 1
             self._hooks(fn, args, owner)
-        self.use_native_copy = stats.group is None
-        if self.use_native_copy:
-            self.copy_args = nat.GfStatsCopyArgs()
-            self.copy_args.src = stats.ptr
-            self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_COPY, C.addressof(self.copy_args)
-            k += 1
-            stats.ensure_native_events(self.backend)
+        # single process: statistics go to a device ring slot per step (no memset, no copy); with a process group the
+        # per-step all-reduce path is kept (clear op here, packed + reduced + copied by StepStats.snapshot)
+        self.use_ring = stats.group is None
+        self.stat_fields = [c[1] for c in calls if hasattr(c[1], "stats") and c[1].stats]
+        self.action_args = next(c[1] for c in calls if c[0] == "action_step")
+        if self.use_ring:
+            stats.ensure_ring()
+            for i in range(k - 1):  # drop the leading STATS_CLEAR op
+                self.ops[i].phase, self.ops[i].args = self.ops[i + 1].phase, self.ops[i + 1].args
+            k -= 1
         self.n_ops = k
 
     # -- fused post-physics launch -----------------------------------------------------------------------
@@ -167,8 +170,11 @@ class StepTrace:
         for p in self.patches:
             p(actions)
         snap = None
-        if self.use_native_copy:
-            snap = env.stats.native_slot(self.copy_args, self.backend)
+        if self.use_ring:
+            cur, nxt, snap = env.stats.ring_next()
+            for a in self.stat_fields:
+                a.stats = cur
+            self.action_args.stats_zero = nxt
         self.backend.run_ops(self.ops, self.n_ops)
         env._tick += 1  # scene advanced
         for f in self.afters:

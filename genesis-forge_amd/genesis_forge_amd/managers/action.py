@@ -292,6 +292,7 @@ class PositionActionManager(BaseActionManager):
             a.env_actions = a.env_last_actions = a.episode_length = None
         a.targets = self._actions.data_ptr()
         a.stats = env.stats.ptr if not self._quiet_action_errors else None
+        a.stats_zero = None  # only a recorded step recycles statistics ring slots
         env.backend.call("action_step", a, owner=self)
         if not self._quiet_action_errors:
             self._watch_flags()

@@ -160,8 +160,10 @@ class RewardManager(BaseManager):
         if names:
             self._pending.append((snap, names, self.env.num_envs))
             self._pending_names = None
-            if len(self._pending) > 32:
-                self._drain_pending(keep_last=16)
+            if len(self._pending) > 56:
+                # one batched read-back per ~48 steps (the statistics ring holds 64): keeps _episode_mean exact without a
+                # per-step sync
+                self._drain_pending(keep_last=8)
 
     def reset(self, envs_idx: list[int] | None = None):
         """reward_manager.py:197-222 (standalone form)."""

@@ -128,6 +128,8 @@ typedef struct GfActionArgs {
     int32_t* episode_length; /* [N] += 1 (may be NULL) */
     float* targets;          /* [N,D] out: clamped PD targets == action_manager.get_actions() */
     GfStepStats* stats;      /* may be NULL */
+    GfStepStats* stats_zero; /* optional: GF_STATS_SHARDS blocks this launch zeroes — the NEXT step's slot of a statistics
+                                ring, so a recorded step needs neither a memset nor a per-step device→host copy */
 } GfActionArgs;
 
 /* ------------------------------------------------------------------------------------------

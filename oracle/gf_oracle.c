@@ -132,6 +132,7 @@ GFO_EXPORT int gfo_action_step(const GfActionArgs* a) {
         }
     }
     if (a->stats) a->stats->action_flags |= flags;
+    if (a->stats_zero) memset(a->stats_zero, 0, sizeof(GfStepStats) * GF_STATS_SHARDS);
     return GF_OK;
 }
 

@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
     const int D = 12, T = 6, O = 48;
     printf("N=%d D=%d iters=%d\n", N, D, iters);
 
-    auto q = randn((size_t)N * 4, 0.f, 0.1f);
+    auto q = randn((size_t)N * 4, 0.f, 0.02f);  // ~2 deg tilt: a few percent of envs terminate, like the bench
     for (int n = 0; n < N; ++n) {
         q[4 * n] += 1.f;
         float s = 0;
