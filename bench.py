@@ -11,8 +11,9 @@ terms, velocity command, 48-wide observation), synthetic data.  Weak scaling: ev
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  ``roofline`` is for the fused reward kernel: algorithmic bytes per launch
-(268 B/env for this config) ÷ its average duration measured with HIP events on the launch
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel — the fused post-physics launch that
+contains the reward fold (566 algorithmic B/env for this config; 268 B/env if the step runs unfused and
+the stand-alone reward kernel is the one measured) — bytes ÷ its average duration measured with HIP events on the launch
 stream during the timed region.  ``cpu_baseline`` times the CPU oracle (oracle/, a scalar C port of the
 reference algorithm) on the host cores of the same box, on a bounded sample of the same workload.
 """
@@ -33,6 +34,16 @@ def reward_bytes_per_env(D: int, T: int, cmd_width: int) -> int:
     """Algorithmic bytes of one reward-kernel launch per env: every input read once, every output
     written once: pos 12 + quat 16 + vel 12 + ang 12 + 3 [N,D] rows + command, RW episode sums 8T, RW seconds 8, W reward 4."""
     return 4 * (13 + 3 * D + cmd_width) + 8 * T + 12
+
+
+def post_bytes_per_env(D: int, T: int, cmd_width: int, O: int, H: int = 1) -> int:
+    """Algorithmic bytes per env of the fused post-physics launch for this config (SURVEY.md §8d "fully fused post-physics
+    kernel"): read pos/quat/vel/ang 52, five [N,D] rows (dof_pos, dof_vel, targets, actions, last_actions), the command row,
+    episode_length + max_episode_length 8, episode_seconds 4, T episode sums; write 2 masks, reward 4, T sums, seconds 4 and the
+    O*H observation (plus the (H-1) history frames it re-reads).  = 566 for D=12, T=6, R=3, O=48, H=1."""
+    reads = 52 + 5 * 4 * D + 4 * cmd_width + 8 + 4 + 4 * T + 4 * O * (H - 1)
+    writes = 2 + 4 + 4 * T + 4 + 4 * O * H
+    return reads + writes
 
 
 def make_env(num_envs: int):
@@ -116,8 +127,10 @@ def main():
     for i in range(args.warmup):
         env.step(acts[i % 8])
     barrier()
+    fused = env._trace is not None and env._trace.post_refs is not None
+    prof_phase = nat.GF_PHASE_POST if fused else nat.GF_PHASE_REWARD
     if not args.no_profile:
-        backend.profile_begin(nat.GF_PHASE_REWARD, args.steps)
+        backend.profile_begin(prof_phase, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
         env.step(acts[i % 8])
@@ -138,13 +151,15 @@ def main():
     if rank == 0:
         rm = env.managers["reward"]
         T = sum(1 for c in rm.cfg.values() if c.weight != 0)
-        bytes_per_launch = reward_bytes_per_env(12, T, 3) * N
+        per_env = post_bytes_per_env(12, T, 3, 48, 1) if fused else reward_bytes_per_env(12, T, 3)
+        bytes_per_launch = per_env * N
+        kernel = "gf::post_kernel<3> (termination+reward+command+reset+observe fused)" if fused else "gf::reward_kernel<3>"
         roof = None
         if prof_n > 0:
             avg_s = prof_ms / prof_n / 1e3
             achieved = bytes_per_launch / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "kernel": "gf::reward_kernel<3>", "avg_launch_us": avg_s * 1e6, "launches": prof_n,
+                    "traffic": None, "kernel": kernel, "algorithmic_bytes_per_env": per_env, "avg_launch_us": avg_s * 1e6, "launches": prof_n,
                     "algorithmic_bytes_per_launch": bytes_per_launch}
         out = {
             "metric": "env-steps/sec", "value": world * N * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world,

@@ -120,6 +120,7 @@ extern "C" __attribute__((visibility("default"))) int gf_action_step(const GfAct
                      (!a->episode_length || al16(a->episode_length));
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_ACTION, s);
+    scope.begin_bracket();
     if (vec) {
         int64_t lanes = total >> 2;
         if (a->episode_length) {

@@ -49,6 +49,7 @@ extern "C" __attribute__((visibility("default"))) int gf_command_step(const GfCo
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_COMMAND, s);
+    scope.begin_bracket();
     gf::command_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a);
     return gf::launch_status();
 }

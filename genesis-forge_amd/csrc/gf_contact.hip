@@ -104,6 +104,7 @@ extern "C" __attribute__((visibility("default"))) int gf_contact_step(const GfCo
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_CONTACT, s);
+    scope.begin_bracket();
     gf::contact_kernel<<<gf::env_grid((int64_t)a->num_envs * a->num_targets), gf::kEnvBlock, 0, s>>>(*a);
     return gf::launch_status();
 }

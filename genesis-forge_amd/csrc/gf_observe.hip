@@ -237,6 +237,7 @@ extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObserva
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)(O + 1) * gf::kEnvBlock * sizeof(float);
     gf::PhaseScope scope(GF_PHASE_OBSERVE, s);
+    scope.begin_bracket();
     if (vec) gf::observe_kernel<4><<<gf::env_grid(a->num_envs), gf::kEnvBlock, lds, s>>>(*a, needs);
     else gf::observe_kernel<1><<<gf::env_grid(a->num_envs), gf::kEnvBlock, lds, s>>>(*a, needs);
     return gf::launch_status();

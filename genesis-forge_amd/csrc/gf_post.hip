@@ -948,7 +948,7 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = gf::env_grid(a.num_envs);
     gf::PhaseScope scope(GF_PHASE_POST, s);
-    if (a.num_dofs == 28) gf::post_kernel<7><<<grid, gf::kEnvBlock, lds, s>>>(a);
-    else gf::post_kernel<3><<<grid, gf::kEnvBlock, lds, s>>>(a);
+    if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid, gf::kEnvBlock, lds, s, a);
+    else GF_LAUNCH(scope, gf::post_kernel<3>, grid, gf::kEnvBlock, lds, s, a);
     return gf::launch_status();
 }

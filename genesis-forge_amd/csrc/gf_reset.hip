@@ -109,6 +109,7 @@ extern "C" __attribute__((visibility("default"))) int gf_masked_reset(const GfRe
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_RESET, s);
+    scope.begin_bracket();
     gf::reset_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a);
     return gf::launch_status();
 }

@@ -26,28 +26,55 @@ __global__ __launch_bounds__(kEnvBlock) void rotate_kernel(const GfRotateArgs a)
     r[0] = o.x; r[1] = o.y; r[2] = o.z;
 }
 
+template <int DV>
 __global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSceneArgs a) {
     const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
     if (n >= a.num_envs) return;
     const int D = a.num_dofs, C = a.num_contacts, NL = a.num_scene_links;
     const float dt = a.dt;
-    for (int d = 0; d < D; ++d) {
-        const float cur = a.dof_pos[n * D + d];
-        const float err = a.targets[n * D + d] - cur;
-        const float v = err * a.joint_rate;
-        a.dof_vel[n * D + d] = v;
-        a.dof_pos[n * D + d] = cur + v * dt;
-    }
-    float s[6];
+    const uint32_t genv = (uint32_t)n + a.env_offset;
+    // all loads first: joint rows as float4 (DV = D/4 when the rows are 16-byte tiles), base state, then one wait
+    float4 tg[DV > 0 ? DV : 1], dp[DV > 0 ? DV : 1];
+    if (DV > 0) {
+        const float4* t4 = reinterpret_cast<const float4*>(a.targets + n * D);
+        const float4* p4 = reinterpret_cast<const float4*>(a.dof_pos + n * D);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) s[j] = philox_uniform(a.seed, a.tick, (uint32_t)n + a.env_offset, (uint32_t)j) * 2.0f - 1.0f;
+        for (int c = 0; c < DV; ++c) { tg[c] = t4[c]; dp[c] = p4[c]; }
+    }
+    const float4 q4 = load_quat(a.quat, n);
+    const V3 w0 = load3(a.ang_vel, n), v0 = load3(a.lin_vel, n), p0 = load3(a.pos, n);
+    // six base-motion draws = Philox columns 0..5 = block 0 (x,y,z,w) + block 1 (x,y)
+    const U4 b0 = philox4x32_10(genv, 0u, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    const U4 b1 = philox4x32_10(genv, 1u, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    const float s[6] = {u24_to_unit(b0.x) * 2.0f - 1.0f, u24_to_unit(b0.y) * 2.0f - 1.0f, u24_to_unit(b0.z) * 2.0f - 1.0f,
+                        u24_to_unit(b0.w) * 2.0f - 1.0f, u24_to_unit(b1.x) * 2.0f - 1.0f, u24_to_unit(b1.y) * 2.0f - 1.0f};
+    if (DV > 0) {
+        float4* v4 = reinterpret_cast<float4*>(a.dof_vel + n * D);
+        float4* p4 = reinterpret_cast<float4*>(a.dof_pos + n * D);
+#pragma unroll
+        for (int c = 0; c < DV; ++c) {
+            float4 v, p;
+            v.x = (tg[c].x - dp[c].x) * a.joint_rate; p.x = dp[c].x + v.x * dt;
+            v.y = (tg[c].y - dp[c].y) * a.joint_rate; p.y = dp[c].y + v.y * dt;
+            v.z = (tg[c].z - dp[c].z) * a.joint_rate; p.z = dp[c].z + v.z * dt;
+            v.w = (tg[c].w - dp[c].w) * a.joint_rate; p.w = dp[c].w + v.w * dt;
+            v4[c] = v;
+            p4[c] = p;
+        }
+    } else {
+        for (int d = 0; d < D; ++d) {
+            const float cur = a.dof_pos[n * D + d];
+            const float err = a.targets[n * D + d] - cur;
+            const float v = err * a.joint_rate;
+            a.dof_vel[n * D + d] = v;
+            a.dof_pos[n * D + d] = cur + v * dt;
+        }
+    }
     float* wp = a.ang_vel + 3 * n;
     float* vp = a.lin_vel + 3 * n;
     float* pp = a.pos + 3 * n;
     float* qp = a.quat + 4 * n;
-    float w[3], v[3], p[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { w[j] = wp[j]; v[j] = vp[j]; p[j] = pp[j]; }
+    float w[3] = {w0.x, w0.y, w0.z}, v[3] = {v0.x, v0.y, v0.z}, p[3] = {p0.x, p0.y, p0.z};
 #pragma unroll
     for (int j = 0; j < 3; ++j) w[j] = w[j] * 0.9f + s[j] * a.ang_noise;
     v[0] = v[0] * 0.9f + s[3] * a.lin_noise;
@@ -56,7 +83,6 @@ __global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSce
 #pragma unroll
     for (int j = 0; j < 3; ++j) p[j] = p[j] + v[j] * dt;
     const float h = 0.5f * dt;
-    const float4 q4 = load_quat(a.quat, n);
     const float qw = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
     const float dw = ((-(w[0] * qx)) - w[1] * qy) - w[2] * qz;
     const float dx = (w[0] * qw + w[1] * qz) - w[2] * qy;
@@ -80,8 +106,8 @@ __global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSce
         for (int c = 0; c < C; ++c) {
             const uint32_t col = (uint32_t)(8 + 8 * c);
             // columns col..col+3 share one Philox block, col+4 starts the next
-            const U4 r0 = philox4x32_10((uint32_t)n + a.env_offset, col >> 2, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-            const U4 r1 = philox4x32_10((uint32_t)n + a.env_offset, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            const U4 r0 = philox4x32_10(genv, col >> 2, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            const U4 r1 = philox4x32_10(genv, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
             const float u_act = u24_to_unit(r0.x), u_link = u24_to_unit(r0.y);
             const float fx = u24_to_unit(r0.z) * 2.0f - 1.0f, fy = u24_to_unit(r0.w) * 2.0f - 1.0f, fz = u24_to_unit(r1.x);
             const bool active = u_act < a.contact_prob;
@@ -111,6 +137,7 @@ extern "C" __attribute__((visibility("default"))) int gf_entity_rotate(const GfR
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_ROTATE, s);
+    scope.begin_bracket();
     gf::rotate_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a);
     return gf::launch_status();
 }
@@ -123,6 +150,12 @@ extern "C" __attribute__((visibility("default"))) int gf_synth_scene_step(const 
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_SCENE, s);
-    gf::synth_scene_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a);
+    scope.begin_bracket();
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool rows16 = (a->num_dofs % 4 == 0) && al16(a->targets) && al16(a->dof_pos) && al16(a->dof_vel);
+    const unsigned grid = gf::env_grid(a->num_envs);
+    if (rows16 && a->num_dofs == 12) gf::synth_scene_kernel<3><<<grid, gf::kEnvBlock, 0, s>>>(*a);
+    else if (rows16 && a->num_dofs == 28) gf::synth_scene_kernel<7><<<grid, gf::kEnvBlock, 0, s>>>(*a);
+    else gf::synth_scene_kernel<0><<<grid, gf::kEnvBlock, 0, s>>>(*a);
     return gf::launch_status();
 }

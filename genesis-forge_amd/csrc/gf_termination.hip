@@ -92,6 +92,7 @@ extern "C" __attribute__((visibility("default"))) int gf_termination_step(const 
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_TERMINATION, s);
+    scope.begin_bracket();
     gf::termination_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a, needs);
     return gf::launch_status();
 }
