@@ -155,11 +155,19 @@ def main():
         bytes_per_launch = per_env * N
         kernel = "gf::post_kernel<3> (termination+reward+command+reset+observe fused)" if fused else "gf::reward_kernel<3>"
         roof = None
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if fused and os.path.exists(pmc_file):
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected in
+            # separate rocprofv3 --pmc passes over this same command and committed under profiles/ (r01_pmc_traffic.md)
+            rec = json.load(open(pmc_file)).get(str(N))
+            if rec:
+                traffic, traffic_src = rec["traffic_bytes"], "profiles/r01_pmc_traffic.md"
         if prof_n > 0:
             avg_s = prof_ms / prof_n / 1e3
             achieved = bytes_per_launch / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "kernel": kernel, "algorithmic_bytes_per_env": per_env, "avg_launch_us": avg_s * 1e6, "launches": prof_n,
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "algorithmic_bytes_per_env": per_env, "avg_launch_us": avg_s * 1e6, "launches": prof_n,
                     "algorithmic_bytes_per_launch": bytes_per_launch}
         out = {
             "metric": "env-steps/sec", "value": world * N * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
