@@ -9,6 +9,29 @@ Profiler g_prof;
 }
 
 #define GF_EXPORT __attribute__((visibility("default")))
+namespace gf {
+// one wave: lane v < GF_STATS_VECTOR_LEN folds entry v over the shards
+__global__ __launch_bounds__(64) void stats_pack_kernel(const GfStatsPackArgs a) {
+    const int v = threadIdx.x;
+    if (v >= GF_STATS_VECTOR_LEN) return;
+    double acc = 0.0;
+    for (int s = 0; s < GF_STATS_SHARDS; ++s) {
+        const GfStepStats& b = a.src[s];
+        double x;
+        if (v < GF_MAX_TERM_TERMS) x = (double)b.term_fired[v];
+        else if (v == GF_MAX_TERM_TERMS) x = (double)b.reset_count;
+        else if (v == GF_MAX_TERM_TERMS + 1) x = (double)(b.action_flags & 1);
+        else if (v == GF_MAX_TERM_TERMS + 2) x = (double)((b.action_flags >> 1) & 1);
+        else if (v == GF_MAX_TERM_TERMS + 3) x = (double)(b.contact_flags & 1);
+        else if (v == GF_MAX_TERM_TERMS + 4) x = (double)b.resample_count;
+        else x = b.reward_episode_sum[v - (GF_MAX_TERM_TERMS + 5)];
+        const bool is_flag = v > GF_MAX_TERM_TERMS && v < GF_MAX_TERM_TERMS + 4;
+        acc = is_flag ? (x > acc ? x : acc) : acc + x;
+    }
+    a.dst[v] = acc;
+}
+}  // namespace gf
+
 extern "C" {
 
 GF_EXPORT int gf_abi_version(void) { return GF_ABI_VERSION; }
@@ -53,6 +76,12 @@ GF_EXPORT int gf_stats_clear(GfStepStats* stats, void* stream) {
     return GF_OK;
 }
 
+GF_EXPORT int gf_stats_pack(const GfStatsPackArgs* a, void* stream) {
+    if (!a || !a->src || !a->dst) return GF_E_NULL;
+    gf::stats_pack_kernel<<<1, 64, 0, (hipStream_t)stream>>>(*a);
+    return gf::launch_status();
+}
+
 GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed_index) {
     if (!ops || num_ops < 0) return GF_E_NULL;
     hipStream_t s = (hipStream_t)stream;
@@ -71,6 +100,7 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
             case GF_PHASE_SCENE: rc = gf_synth_scene_step((const GfSynthSceneArgs*)a, stream); break;
             case GF_OP_STATS_CLEAR: rc = gf_stats_clear((GfStepStats*)const_cast<void*>(a), stream); break;
             case GF_OP_POST_PHYSICS: rc = gf_post_physics_step((const GfPostRefs*)a, stream); break;
+            case GF_OP_STATS_PACK: rc = gf_stats_pack((const GfStatsPackArgs*)a, stream); break;
             case GF_OP_STATS_COPY: {
                 const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
                 if (!c || !c->src || !c->dst) { rc = GF_E_NULL; break; }

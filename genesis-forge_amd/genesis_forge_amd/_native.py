@@ -201,7 +201,12 @@ class GfStatsCopyArgs(C.Structure):
     _fields_ = [("src", P), ("dst", P), ("event", P)]
 
 
-GF_OP_STATS_CLEAR, GF_OP_STATS_COPY, GF_OP_POST_PHYSICS = 100, 101, 102
+GF_OP_STATS_CLEAR, GF_OP_STATS_COPY, GF_OP_POST_PHYSICS, GF_OP_STATS_PACK = 100, 101, 102, 103
+
+
+class GfStatsPackArgs(C.Structure):
+    _fields_ = [("src", P), ("dst", P)]
+
 GF_POST_MAX_CMD, GF_POST_MAX_OBS = 2, 2
 
 

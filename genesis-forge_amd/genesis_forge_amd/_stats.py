@@ -88,6 +88,20 @@ class RingSnapshot:
         return self._value
 
 
+class VecRingSnapshot:
+    """Cross-rank reduced statistics of one recorded step: a row of the device vector ring + the pending all-reduce."""
+
+    __slots__ = ("_owner", "_slot", "_work", "_value")
+
+    def __init__(self, owner, slot: int, work):
+        self._owner, self._slot, self._work, self._value = owner, slot, work, None
+
+    def wait(self) -> nat.GfStepStats:
+        if self._value is None:
+            self._owner.materialize_vec_ring()
+        return self._value
+
+
 class StepStats:
     """Owns the device stats block and the pinned read-back ring."""
 
@@ -162,6 +176,47 @@ class StepStats:
         for snap in self._ring_snaps:
             if snap is not None and snap._value is None:
                 snap._value = sum_shards(host[snap._slot].tobytes())
+
+    # -- recorded steps with a process group: shards are folded into a row of a device f64 ring by gf_stats_pack (one op of
+    # the recorded step), that row is all-reduced asynchronously (the single collective of the path), and rows are copied
+    # out in a batch only when a log entry is read.
+    def ensure_vec_ring(self) -> None:
+        self.ensure_ring()
+        if getattr(self, "vec_ring", None) is None:
+            self.vec_ring = torch.zeros(_RING, STATS_VECTOR_LEN, dtype=torch.float64, device=self.device)
+            self._vec_snaps = [None] * _RING
+
+    def vec_ptr(self, slot: int) -> int:
+        return self.vec_ring.data_ptr() + slot * STATS_VECTOR_LEN * 8
+
+    def vec_ring_next(self):
+        """(slot index, shard-slot pointer, next shard-slot pointer, vector-row pointer) for this step."""
+        i = self.ring_pos
+        j = (i + 1) % _RING
+        old = self._vec_snaps[i]
+        if old is not None and old._value is None:
+            self.materialize_vec_ring()
+        self.ring_pos = j
+        return i, self.ring_ptr(i), self.ring_ptr(j), self.vec_ptr(i)
+
+    def vec_ring_reduce(self, slot: int) -> "VecRingSnapshot":
+        import torch.distributed as dist
+
+        row = self.vec_ring[slot]
+        work = dist.all_reduce(row, op=dist.ReduceOp.SUM, group=self.group, async_op=self.device.type == "cuda")
+        snap = VecRingSnapshot(self, slot, work)
+        self._vec_snaps[slot] = snap
+        return snap
+
+    def materialize_vec_ring(self) -> None:
+        for snap in self._vec_snaps:
+            if snap is not None and snap._value is None and snap._work is not None:
+                snap._work.wait()
+        host = self.vec_ring.cpu().numpy()
+        for snap in self._vec_snaps:
+            if snap is not None and snap._value is None:
+                snap._value = vector_to_stats(host[snap._slot])
+                snap._work = None
 
     def ensure_native_events(self, backend) -> None:
         if getattr(self, "_events", None) is None:

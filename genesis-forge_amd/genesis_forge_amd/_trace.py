@@ -69,11 +69,16 @@ class StepTrace:
         self.use_ring = stats.group is None
         self.stat_fields = [c[1] for c in calls if hasattr(c[1], "stats") and c[1].stats]
         self.action_args = next(c[1] for c in calls if c[0] == "action_step")
+        for i in range(k - 1):  # drop the leading STATS_CLEAR op: ring slots are zeroed by the previous step's action kernel
+            self.ops[i].phase, self.ops[i].args = self.ops[i + 1].phase, self.ops[i + 1].args
+        k -= 1
         if self.use_ring:
             stats.ensure_ring()
-            for i in range(k - 1):  # drop the leading STATS_CLEAR op
-                self.ops[i].phase, self.ops[i].args = self.ops[i + 1].phase, self.ops[i + 1].args
-            k -= 1
+        else:
+            stats.ensure_vec_ring()
+            self.pack_args = nat.GfStatsPackArgs()
+            self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_PACK, C.addressof(self.pack_args)
+            k += 1
         self.n_ops = k
 
     # -- fused post-physics launch -----------------------------------------------------------------------
@@ -172,15 +177,18 @@ class StepTrace:
         snap = None
         if self.use_ring:
             cur, nxt, snap = env.stats.ring_next()
-            for a in self.stat_fields:
-                a.stats = cur
-            self.action_args.stats_zero = nxt
+        else:
+            slot, cur, nxt, vec = env.stats.vec_ring_next()
+            self.pack_args.src, self.pack_args.dst = cur, vec
+        for a in self.stat_fields:
+            a.stats = cur
+        self.action_args.stats_zero = nxt
         self.backend.run_ops(self.ops, self.n_ops)
+        if not self.use_ring:
+            snap = env.stats.vec_ring_reduce(slot)  # the single collective of the path, asynchronous
         env._tick += 1  # scene advanced
         for f in self.afters:
             f()
-        if snap is None:
-            snap = env.stats.snapshot()
         env._finish_step_light(snap)
         tm, rm = env.managers["termination"], env.managers["reward"]
         obs = env.extras["observations"].get("policy") if len(env.managers["observation"]) > 0 else None

@@ -500,7 +500,18 @@ typedef struct GfOp {
     const void* args;   /* the phase's descriptor (GfActionArgs*, …) */
 } GfOp;
 
-enum { GF_OP_STATS_CLEAR = 100, GF_OP_STATS_COPY = 101, GF_OP_POST_PHYSICS = 102 /* args = GfPostRefs* */ };
+enum { GF_OP_STATS_CLEAR = 100, GF_OP_STATS_COPY = 101, GF_OP_POST_PHYSICS = 102 /* args = GfPostRefs* */,
+       GF_OP_STATS_PACK = 103 /* args = GfStatsPackArgs* */ };
+
+/* Fold the GF_STATS_SHARDS shards of one statistics block into the f64 vector that is all-reduced across ranks
+ * (layout: term_fired[GF_MAX_TERM_TERMS], reset_count, nan_flag, inf_flag, contact_flag, resample_count,
+ * reward_episode_sum[GF_MAX_TERMS]; flags fold with max, everything else adds). */
+#define GF_STATS_VECTOR_LEN (GF_MAX_TERM_TERMS + 5 + GF_MAX_TERMS)
+typedef struct GfStatsPackArgs {
+    const GfStepStats* src;   /* device, GF_STATS_SHARDS blocks */
+    double* dst;              /* device, GF_STATS_VECTOR_LEN */
+} GfStatsPackArgs;
+int gf_stats_pack(const GfStatsPackArgs* a, void* stream);
 
 typedef struct GfStatsCopyArgs {
     const GfStepStats* src;   /* device, GF_STATS_SHARDS blocks */

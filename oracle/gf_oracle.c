@@ -689,6 +689,28 @@ GFO_EXPORT int gfo_post_physics_step(const GfPostRefs* r) {
     return GF_OK;
 }
 
+GFO_EXPORT int gfo_stats_pack(const GfStatsPackArgs* a) {
+    if (!a || !a->src || !a->dst) return GF_E_NULL;
+    for (int v = 0; v < GF_STATS_VECTOR_LEN; ++v) {
+        double acc = 0.0;
+        for (int s = 0; s < GF_STATS_SHARDS; ++s) {
+            const GfStepStats* b = &a->src[s];
+            double x;
+            if (v < GF_MAX_TERM_TERMS) x = (double)b->term_fired[v];
+            else if (v == GF_MAX_TERM_TERMS) x = (double)b->reset_count;
+            else if (v == GF_MAX_TERM_TERMS + 1) x = (double)(b->action_flags & 1);
+            else if (v == GF_MAX_TERM_TERMS + 2) x = (double)((b->action_flags >> 1) & 1);
+            else if (v == GF_MAX_TERM_TERMS + 3) x = (double)(b->contact_flags & 1);
+            else if (v == GF_MAX_TERM_TERMS + 4) x = (double)b->resample_count;
+            else x = b->reward_episode_sum[v - (GF_MAX_TERM_TERMS + 5)];
+            const int is_flag = v > GF_MAX_TERM_TERMS && v < GF_MAX_TERM_TERMS + 4;
+            acc = is_flag ? (x > acc ? x : acc) : acc + x;
+        }
+        a->dst[v] = acc;
+    }
+    return GF_OK;
+}
+
 /* host twin of gf_run_ops (the recorded-step replay), so the trace/replay host logic is testable on CPU */
 GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
     if (!ops || num_ops < 0) return GF_E_NULL;
@@ -707,6 +729,7 @@ GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
             case GF_PHASE_SCENE: rc = gfo_synth_scene_step((const GfSynthSceneArgs*)a); break;
             case GF_OP_STATS_CLEAR: rc = gfo_stats_clear((GfStepStats*)a); break;
             case GF_OP_POST_PHYSICS: rc = gfo_post_physics_step((const GfPostRefs*)a); break;
+            case GF_OP_STATS_PACK: rc = gfo_stats_pack((const GfStatsPackArgs*)a); break;
             case GF_OP_STATS_COPY: {
                 const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
                 if (!c || !c->src || !c->dst) { rc = GF_E_NULL; break; }
