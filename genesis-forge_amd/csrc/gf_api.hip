@@ -14,20 +14,7 @@ namespace gf {
 __global__ __launch_bounds__(64) void stats_pack_kernel(const GfStatsPackArgs a) {
     const int v = threadIdx.x;
     if (v >= GF_STATS_VECTOR_LEN) return;
-    double acc = 0.0;
-    for (int s = 0; s < GF_STATS_SHARDS; ++s) {
-        const GfStepStats& b = a.src[s];
-        double x;
-        if (v < GF_MAX_TERM_TERMS) x = (double)b.term_fired[v];
-        else if (v == GF_MAX_TERM_TERMS) x = (double)b.reset_count;
-        else if (v == GF_MAX_TERM_TERMS + 1) x = (double)(b.action_flags & 1);
-        else if (v == GF_MAX_TERM_TERMS + 2) x = (double)((b.action_flags >> 1) & 1);
-        else if (v == GF_MAX_TERM_TERMS + 3) x = (double)(b.contact_flags & 1);
-        else if (v == GF_MAX_TERM_TERMS + 4) x = (double)b.resample_count;
-        else x = b.reward_episode_sum[v - (GF_MAX_TERM_TERMS + 5)];
-        const bool is_flag = v > GF_MAX_TERM_TERMS && v < GF_MAX_TERM_TERMS + 4;
-        acc = is_flag ? (x > acc ? x : acc) : acc + x;
-    }
+    const double acc = fold_stats_entry(a.src, v);
     a.dst[v] = acc;
 }
 }  // namespace gf

@@ -137,6 +137,25 @@ __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m)
 // this workgroup's statistics shard (see GF_STATS_SHARDS in gf_step.h)
 __device__ __forceinline__ GfStepStats* stats_shard(GfStepStats* s) { return s + (blockIdx.x % GF_STATS_SHARDS); }
 
+// entry v of the folded statistics vector (layout of gf_stats_pack): shards add, flag entries fold with max
+__device__ __forceinline__ double fold_stats_entry(const GfStepStats* src, int v) {
+    double acc = 0.0;
+    for (int s = 0; s < GF_STATS_SHARDS; ++s) {
+        const GfStepStats& b = src[s];
+        double x;
+        if (v < GF_MAX_TERM_TERMS) x = (double)b.term_fired[v];
+        else if (v == GF_MAX_TERM_TERMS) x = (double)b.reset_count;
+        else if (v == GF_MAX_TERM_TERMS + 1) x = (double)(b.action_flags & 1);
+        else if (v == GF_MAX_TERM_TERMS + 2) x = (double)((b.action_flags >> 1) & 1);
+        else if (v == GF_MAX_TERM_TERMS + 3) x = (double)(b.contact_flags & 1);
+        else if (v == GF_MAX_TERM_TERMS + 4) x = (double)b.resample_count;
+        else x = b.reward_episode_sum[v - (GF_MAX_TERM_TERMS + 5)];
+        const bool is_flag = v > GF_MAX_TERM_TERMS && v < GF_MAX_TERM_TERMS + 4;
+        acc = is_flag ? (x > acc ? x : acc) : acc + x;
+    }
+    return acc;
+}
+
 // contact predicates shared by termination / reward terms
 __device__ __forceinline__ int contact_count_over(const GfContactView& v, int64_t n, float thr) {
     int cnt = 0;

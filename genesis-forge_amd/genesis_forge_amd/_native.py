@@ -111,7 +111,8 @@ class GfStepStats(C.Structure):
 class GfActionArgs(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_dofs", C.c_int32), ("mode", C.c_int32), ("check_finite", C.c_int32),
                 ("actions_in", P), ("scale", P), ("offset", P), ("clip_lo", P), ("clip_hi", P),
-                ("env_actions", P), ("env_last_actions", P), ("episode_length", P), ("targets", P), ("stats", P), ("stats_zero", P)]
+                ("env_actions", P), ("env_last_actions", P), ("episode_length", P), ("targets", P), ("stats", P), ("stats_zero", P),
+                ("stats_fold_src", P), ("stats_fold_dst", P), ("stats_last_reset", P)]
 
 
 class GfContactArgs(C.Structure):
@@ -293,6 +294,9 @@ class Backend:
         """True when gf_post_physics_step can fuse the phases ``refs`` points at."""
         return False
 
+    def stats_pack(self, src_ptr: int, dst_ptr: int) -> None:  # pragma: no cover - interface
+        raise NotImplementedError
+
     def check_tensor(self, t, what: str = "tensor") -> None:
         if t is None:
             return
@@ -332,6 +336,8 @@ class HipBackend(Backend):
         self.lib.gf_build_info.restype = C.c_char_p
         self.lib.gf_run_ops.restype = C.c_int
         self.lib.gf_run_ops.argtypes = [C.POINTER(GfOp), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        self.lib.gf_stats_pack.restype = C.c_int
+        self.lib.gf_stats_pack.argtypes = [C.POINTER(GfStatsPackArgs), C.c_void_p]
         self.lib.gf_post_physics_check.restype = C.c_int
         self.lib.gf_post_physics_check.argtypes = [C.POINTER(GfPostRefs)]
         self.lib.gf_event_create.restype = C.c_void_p
@@ -367,6 +373,13 @@ class HipBackend(Backend):
 
     def post_check(self, refs) -> bool:
         return self.lib.gf_post_physics_check(C.byref(refs)) == 0
+
+    def stats_pack(self, src_ptr: int, dst_ptr: int) -> None:
+        a = GfStatsPackArgs()
+        a.src, a.dst = src_ptr, dst_ptr
+        rc = self.lib.gf_stats_pack(C.byref(a), self._stream())
+        if rc != 0:
+            self._raise("stats_pack", rc)
 
     def event_create(self):
         ev = self.lib.gf_event_create()

@@ -12,6 +12,7 @@ single all-reduce (RCCL over xGMI) before it is interpreted — the only collect
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Callable, Optional
 
 import numpy as np
@@ -25,24 +26,37 @@ _RING = 64
 _INTS = BLOCK_BYTES // 4
 
 
-def sum_shards(buf: bytes) -> nat.GfStepStats:
-    """Fold the shards of one statistics read-back: counts and sums add, flag words OR."""
-    raw = np.frombuffer(buf, dtype=np.uint8).reshape(nat.GF_STATS_SHARDS, BLOCK_BYTES)
-    ints = raw[:, :96].copy().view(np.int32)                       # term_fired[16], reset, action_flags, contact_flags, resample, pad[4]
-    f64 = raw[:, 96:96 + 8 * nat.GF_MAX_TERMS].copy().view(np.float64)
-    st = nat.GfStepStats()
-    tot = ints.sum(axis=0, dtype=np.int64)
-    for k in range(nat.GF_MAX_TERM_TERMS):
-        st.term_fired[k] = int(tot[k])
+class HostStats:
+    """One step's folded statistics on the host (same field names as GfStepStats)."""
+
+    __slots__ = ("term_fired", "reset_count", "action_flags", "contact_flags", "resample_count", "reward_episode_sum")
+
+    def __init__(self, term_fired, reset_count, action_flags, contact_flags, resample_count, reward_episode_sum):
+        self.term_fired, self.reset_count, self.action_flags = term_fired, reset_count, action_flags
+        self.contact_flags, self.resample_count, self.reward_episode_sum = contact_flags, resample_count, reward_episode_sum
+
+
+def fold_shards(raw: np.ndarray):
+    """Fold the shards of a batch of statistics blocks, ``raw`` = uint8 [B, GF_STATS_SHARDS * BLOCK_BYTES]: counts and
+    sums add, flag words OR.  Returns (int64 [B, 24], float64 [B, GF_MAX_TERMS]) — vectorised over the batch."""
+    blocks = raw.reshape(raw.shape[0], nat.GF_STATS_SHARDS, BLOCK_BYTES)
+    ints = np.ascontiguousarray(blocks[:, :, :96]).view(np.int32)  # term_fired[16], reset, action_flags, contact_flags, resample, pad[4]
+    f64 = np.ascontiguousarray(blocks[:, :, 96:96 + 8 * nat.GF_MAX_TERMS]).view(np.float64)
+    tot = ints.sum(axis=1, dtype=np.int64)
     o = nat.GF_MAX_TERM_TERMS
-    st.reset_count = int(tot[o])
-    st.action_flags = int(np.bitwise_or.reduce(ints[:, o + 1]))
-    st.contact_flags = int(np.bitwise_or.reduce(ints[:, o + 2]))
-    st.resample_count = int(tot[o + 3])
-    sums = f64.sum(axis=0)
-    for t in range(nat.GF_MAX_TERMS):
-        st.reward_episode_sum[t] = float(sums[t])
-    return st
+    tot[:, o + 1] = np.bitwise_or.reduce(ints[:, :, o + 1], axis=1)
+    tot[:, o + 2] = np.bitwise_or.reduce(ints[:, :, o + 2], axis=1)
+    return tot, f64.sum(axis=1)
+
+
+def host_stats(tot_row: np.ndarray, sums_row: np.ndarray) -> HostStats:
+    o = nat.GF_MAX_TERM_TERMS
+    return HostStats(tot_row[:o], int(tot_row[o]), int(tot_row[o + 1]), int(tot_row[o + 2]), int(tot_row[o + 3]), sums_row)
+
+
+def sum_shards(buf: bytes) -> HostStats:
+    tot, sums = fold_shards(np.frombuffer(buf, dtype=np.uint8).reshape(1, -1))
+    return host_stats(tot[0], sums[0])
 
 
 
@@ -58,7 +72,7 @@ class StatsSnapshot:
         self._is_vector = is_vector
         self._native = native  # (backend, native event handle) for snapshots taken by a recorded step
 
-    def wait(self) -> nat.GfStepStats:
+    def wait(self) -> HostStats:
         if self._value is None:
             if self._native is not None:
                 self._native[0].event_synchronize(self._native[1])
@@ -77,12 +91,12 @@ class StatsSnapshot:
 class RingSnapshot:
     """Statistics of one recorded step, living in a device ring slot until somebody reads them."""
 
-    __slots__ = ("_owner", "_slot", "_value")
+    __slots__ = ("_owner", "_slot", "_value", "__weakref__")
 
     def __init__(self, owner, slot: int):
         self._owner, self._slot, self._value = owner, slot, None
 
-    def wait(self) -> nat.GfStepStats:
+    def wait(self) -> HostStats:
         if self._value is None:
             self._owner.materialize_ring()
         return self._value
@@ -96,7 +110,7 @@ class VecRingSnapshot:
     def __init__(self, owner, slot: int, work):
         self._owner, self._slot, self._work, self._value = owner, slot, work, None
 
-    def wait(self) -> nat.GfStepStats:
+    def wait(self) -> HostStats:
         if self._value is None:
             self._owner.materialize_vec_ring()
         return self._value
@@ -146,48 +160,81 @@ class StepStats:
         return snap
 
     # -- device ring used by recorded steps -------------------------------------------------------------
-    # A recorded step writes its statistics into slot (step % _RING) of a device-resident ring and zeroes the next
-    # slot from inside its first kernel, so it needs neither a memset nor a device→host copy (together they cost as
-    # much stream time as all the kernels of a step).  Slots are copied out in one batch only when a log entry is
-    # actually read, or just before an unread slot would be recycled.
+    # A recorded step writes its statistics into slot (step % _RING) of a device-resident ring of shard blocks.  Its
+    # action kernel zeroes the next slot and folds the PREVIOUS slot into a 45-entry f64 row of ``vec_ring`` (and into
+    # ``last_reset`` when that step reset something), so a step carries neither a memset, nor a pack launch, nor a
+    # device→host copy — together those cost as much stream time as all the kernels of a step.  Rows are copied out,
+    # 23 KB in one batch, only when a log entry is actually read or just before an unread slot is recycled.
     def ensure_ring(self) -> None:
         if getattr(self, "ring", None) is None:
             self.ring = torch.zeros(_RING, STATS_BYTES, dtype=torch.uint8, device=self.device)
+            self.vec_ring = torch.zeros(_RING, STATS_VECTOR_LEN, dtype=torch.float64, device=self.device)
+            self.last_reset = torch.zeros(STATS_VECTOR_LEN, dtype=torch.float64, device=self.device)
             self.ring_pos = 0
+            self._ring_prev = None      # slot written by the previous recorded step (not folded yet)
             self._ring_snaps = [None] * _RING
+            self._vec_snaps = [None] * _RING
 
     def ring_ptr(self, slot: int) -> int:
         return self.ring.data_ptr() + slot * STATS_BYTES
 
+    def vec_ptr(self, slot: int) -> int:
+        return self.vec_ring.data_ptr() + slot * STATS_VECTOR_LEN * 8
+
     def ring_next(self):
-        """(pointer of this step's slot, pointer of the slot to zero for the next step, snapshot)."""
+        """(this step's slot pointer, slot pointer to zero, previous slot pointer or None, its vector row or None, snapshot)."""
         i = self.ring_pos
-        j = (i + 1) % _RING
-        old = self._ring_snaps[j]
+        ref = self._ring_snaps[i]
+        old = ref() if ref is not None else None
         if old is not None and old._value is None:
-            self.materialize_ring()  # about to be recycled while still unread
+            self.materialize_ring()  # still referenced by a live extras dict and about to be recycled unread
+        prev = self._ring_prev
         snap = RingSnapshot(self, i)
-        self._ring_snaps[i] = snap
-        self.ring_pos = j
-        return self.ring_ptr(i), self.ring_ptr(j), snap
+        self._ring_snaps[i] = weakref.ref(snap)  # weak: a log nobody kept is never copied out
+        self._ring_prev = i
+        self.ring_pos = (i + 1) % _RING
+        if prev is None:
+            return self.ring_ptr(i), self.ring_ptr(self.ring_pos), None, None, snap
+        return self.ring_ptr(i), self.ring_ptr(self.ring_pos), self.ring_ptr(prev), self.vec_ptr(prev), snap
+
+    def _fold_latest(self, backend) -> None:
+        """The newest slot has not been folded by a following step yet: fold it explicitly (one tiny launch)."""
+        if self._ring_prev is not None:
+            backend.stats_pack(self.ring_ptr(self._ring_prev), self.vec_ptr(self._ring_prev))
 
     def materialize_ring(self) -> None:
-        host = self.ring.cpu().numpy()  # one blocking copy of every slot (synchronises the stream first)
-        for snap in self._ring_snaps:
+        self._fold_latest(nat.get_backend())
+        host = self.vec_ring.cpu().numpy()  # one blocking 23 KB copy (synchronises the stream first)
+        for ref in self._ring_snaps:
+            snap = ref() if ref is not None else None
             if snap is not None and snap._value is None:
-                snap._value = sum_shards(host[snap._slot].tobytes())
+                snap._value = vector_to_stats(host[snap._slot])
+
+    def read_last_reset(self) -> Optional["HostStats"]:
+        """Statistics of the most recent recorded step that reset at least one env, or None (blocking, on demand)."""
+        if getattr(self, "ring", None) is None or self._ring_prev is None:
+            return None
+        self._fold_latest(nat.get_backend())
+        both = torch.stack([self.vec_ring[self._ring_prev], self.last_reset]).cpu().numpy()
+        for row in both:
+            if row[_NT] > 0:
+                return vector_to_stats(row)
+        return None
+
+    def end_recording(self) -> Optional["HostStats"]:
+        """Called when a recorded step is dropped: hands back the last reset statistics and forgets the unfolded slot."""
+        last = self.read_last_reset()
+        if getattr(self, "ring", None) is not None:
+            self.materialize_ring()
+            self._ring_prev = None
+            self.last_reset.zero_()
+        return last
 
     # -- recorded steps with a process group: shards are folded into a row of a device f64 ring by gf_stats_pack (one op of
     # the recorded step), that row is all-reduced asynchronously (the single collective of the path), and rows are copied
     # out in a batch only when a log entry is read.
     def ensure_vec_ring(self) -> None:
         self.ensure_ring()
-        if getattr(self, "vec_ring", None) is None:
-            self.vec_ring = torch.zeros(_RING, STATS_VECTOR_LEN, dtype=torch.float64, device=self.device)
-            self._vec_snaps = [None] * _RING
-
-    def vec_ptr(self, slot: int) -> int:
-        return self.vec_ring.data_ptr() + slot * STATS_VECTOR_LEN * 8
 
     def vec_ring_next(self):
         """(slot index, shard-slot pointer, next shard-slot pointer, vector-row pointer) for this step."""
@@ -340,7 +387,7 @@ _NT = nat.GF_MAX_TERM_TERMS
 STATS_VECTOR_LEN = _NT + 5 + nat.GF_MAX_TERMS
 
 
-def stats_to_vector(st: nat.GfStepStats) -> np.ndarray:
+def stats_to_vector(st) -> np.ndarray:
     """Flatten to f64 for the cross-rank sum (counts are exact in f64; flag bits become counts)."""
     v = np.zeros(STATS_VECTOR_LEN, dtype=np.float64)
     v[:_NT] = list(st.term_fired)
@@ -353,14 +400,6 @@ def stats_to_vector(st: nat.GfStepStats) -> np.ndarray:
     return v
 
 
-def vector_to_stats(v: np.ndarray) -> nat.GfStepStats:
-    st = nat.GfStepStats()
-    for k in range(_NT):
-        st.term_fired[k] = int(round(v[k]))
-    st.reset_count = int(round(v[_NT]))
-    st.action_flags = (1 if v[_NT + 1] > 0 else 0) | (2 if v[_NT + 2] > 0 else 0)
-    st.contact_flags = 1 if v[_NT + 3] > 0 else 0
-    st.resample_count = int(round(v[_NT + 4]))
-    for t in range(nat.GF_MAX_TERMS):
-        st.reward_episode_sum[t] = float(v[_NT + 5 + t])
-    return st
+def vector_to_stats(v: np.ndarray) -> HostStats:
+    return HostStats(np.rint(v[:_NT]).astype(np.int64), int(round(v[_NT])), (1 if v[_NT + 1] > 0 else 0) | (2 if v[_NT + 2] > 0 else 0),
+                     1 if v[_NT + 3] > 0 else 0, int(round(v[_NT + 4])), np.array(v[_NT + 5:], dtype=np.float64))

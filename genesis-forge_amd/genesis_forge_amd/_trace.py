@@ -176,7 +176,10 @@ class StepTrace:
             p(actions)
         snap = None
         if self.use_ring:
-            cur, nxt, snap = env.stats.ring_next()
+            cur, nxt, prev, prev_vec, snap = env.stats.ring_next()
+            aa = self.action_args
+            aa.stats_fold_src, aa.stats_fold_dst = prev, prev_vec
+            aa.stats_last_reset = env.stats.last_reset.data_ptr() if prev is not None else None
         else:
             slot, cur, nxt, vec = env.stats.vec_ring_next()
             self.pack_args.src, self.pack_args.dst = cur, vec
@@ -191,8 +194,9 @@ class StepTrace:
             f()
         env._finish_step_light(snap)
         tm, rm = env.managers["termination"], env.managers["reward"]
-        obs = env.extras["observations"].get("policy") if len(env.managers["observation"]) > 0 else None
-        return obs, rm._reward_buf if rm is not None else env._reward_buf, tm._terminated_buf, tm._truncated_buf, env.extras
+        extras = env._extras
+        obs = extras["observations"].get("policy") if len(env.managers["observation"]) > 0 else None
+        return obs, rm._reward_buf if rm is not None else env._reward_buf, tm._terminated_buf, tm._truncated_buf, extras
 
 
 def traceable(env) -> bool:

@@ -160,6 +160,11 @@ class GenesisEnv:
 
     def invalidate_trace(self) -> None:
         """Drop the recorded step (something its frozen descriptors depend on has changed)."""
+        if self._trace is not None and self._stats is not None and getattr(self._stats, "ring", None) is not None and self._stats.group is None:
+            last = self._stats.end_recording()
+            rm = getattr(self, "managers", {}).get("reward") if hasattr(self, "managers") else None
+            if rm is not None:
+                rm._apply_reset_stats(last)
         self._trace = None
         self._trace_epoch += 1
         self._last_signature = None

@@ -292,7 +292,7 @@ class PositionActionManager(BaseActionManager):
             a.env_actions = a.env_last_actions = a.episode_length = None
         a.targets = self._actions.data_ptr()
         a.stats = env.stats.ptr if not self._quiet_action_errors else None
-        a.stats_zero = None  # only a recorded step recycles statistics ring slots
+        a.stats_zero = a.stats_fold_src = a.stats_fold_dst = a.stats_last_reset = None  # only a recorded step uses the ring
         env.backend.call("action_step", a, owner=self)
         if not self._quiet_action_errors:
             self._watch_flags()
@@ -307,14 +307,16 @@ class PositionActionManager(BaseActionManager):
     def _watch_flags(self):
         """The reference prints on NaN/Inf actions after two blocking ``.any()`` calls per step
         (position_action_manager.py:402-406); here the flag word rides along in the lazily read stats block."""
-        log = self.env.extras.get(self.env.extras_logging_key)
+        log = self.env._extras.get(self.env.extras_logging_key)
         if hasattr(log, "add_filler"):
-            def _report(st, out, self=self):
-                if st.action_flags & 1:
-                    print("ERROR: NaN actions received!")
-                if st.action_flags & 2:
-                    print("ERROR: Infinite actions received!")
-            log.add_filler(_report)
+            log.add_filler(self._report_flags)
+
+    @staticmethod
+    def _report_flags(st, out):
+        if st.action_flags & 1:
+            print("ERROR: NaN actions received!")
+        if st.action_flags & 2:
+            print("ERROR: Infinite actions received!")
 
     # -- reset --------------------------------------------------------------------------------------
     def _upload_gains(self, envs_idx):

@@ -234,6 +234,6 @@ class ObservationManager(BaseManager):
         def patch(_actions, a=args, env=env, self=self):
             a.stream = env.next_stream()
             out = self._rotate_ring(a)
-            env.extras["observations"][self._name] = out
+            env._extras["observations"][self._name] = out
 
         return patch

@@ -8,12 +8,14 @@ on device and surface in ``extras["episode"]`` lazily (no ``.item()`` per term).
 """
 from __future__ import annotations
 
+from functools import partial
 from typing import Any, Callable, Optional, TypedDict
 
 import torch
 
 from .. import _native as nat
 from .. import gs
+from .._stats import RingSnapshot
 from ._program import RewardProgram, spec_of
 from .base import BaseManager
 from .config import RewardConfigItem
@@ -50,11 +52,14 @@ class RewardManager(BaseManager):
         self._episode_mean: dict[str, float] = dict()
         self._episode_data: dict[str, torch.Tensor] = {name: self._episode_sums[i] for i, name in enumerate(self.cfg.keys())}
         self._program: Optional[RewardProgram] = None
+        self._log_names = None
+        self._pending_names = None
         self._dirty = True
         self._pending: list = []  # snapshots with unreduced episode means (for last_episode_mean_reward)
 
     def _mark_dirty(self):
         self._dirty = True
+        self._log_names = None
         if hasattr(self.env, "invalidate_trace"):
             self.env.invalidate_trace()
 
@@ -71,10 +76,19 @@ class RewardManager(BaseManager):
         """reward_manager.py:138-153.  Reading it drains the pending statistics snapshots (the only place this
         manager ever waits for the device)."""
         self._drain_pending()
+        st = self.env.stats.read_last_reset() if self.env._trace is not None else None
+        if st is not None:  # recorded steps keep this on the device; read it on demand
+            self._apply_reset_stats(st)
         rew = self._episode_mean.get(name, 0.0)
         if before_weight:
             rew /= self.cfg[name].weight
         return rew
+
+    def _apply_reset_stats(self, st) -> None:
+        if st is not None and st.reset_count > 0:
+            for row, (name, cfg) in enumerate(self.cfg.items()):
+                if cfg.weight != 0:
+                    self._episode_mean[name] = float(st.reward_episode_sum[row] / st.reset_count)
 
     def _drain_pending(self, keep_last: int = 0):
         while len(self._pending) > keep_last:
@@ -139,24 +153,28 @@ class RewardManager(BaseManager):
     def _register_log(self):
         """Queue the "Rewards / <name>" entries for this reset event (reward_manager.py:202-216)."""
         env = self.env
-        log = env.extras[env.extras_logging_key]
-        names = [(row, name) for row, (name, cfg) in enumerate(self.cfg.items()) if cfg.weight != 0]
-        tag = self.logging_tag
-
-        def fill(st, out, names=names, tag=tag, self=self):
-            if st.reset_count > 0:
-                for row, name in names:
-                    mean = st.reward_episode_sum[row] / st.reset_count
-                    self._episode_mean[name] = float(mean)
-                    out[f"{tag} / {name}"] = torch.tensor(mean, dtype=torch.float32)
-
+        log = env._extras[env.extras_logging_key]
+        names = self._log_names
+        if names is None:  # rebuilt only after a weight / param mutation (_mark_dirty)
+            names = self._log_names = [(row, name) for row, (name, cfg) in enumerate(self.cfg.items()) if cfg.weight != 0]
         if hasattr(log, "add_filler"):
-            log.add_filler(fill)
+            log.add_filler(partial(self._fill_log, names))
         self._pending_names = names
+
+    def _fill_log(self, names, st, out):
+        if st.reset_count > 0:
+            tag = self.logging_tag
+            for row, name in names:
+                mean = st.reward_episode_sum[row] / st.reset_count
+                self._episode_mean[name] = float(mean)
+                out[f"{tag} / {name}"] = torch.tensor(mean, dtype=torch.float32)
 
     def _note_snapshot(self, snap):
         """Called by the env after the step's snapshot exists, so curricula can read means later."""
-        names = getattr(self, "_pending_names", None)
+        names = self._pending_names
+        if type(snap) is RingSnapshot:
+            self._pending_names = None  # single-process recorded step: the device keeps the last reset statistics
+            return
         if names:
             self._pending.append((snap, names, self.env.num_envs))
             self._pending_names = None

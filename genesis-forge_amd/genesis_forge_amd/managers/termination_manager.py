@@ -97,21 +97,21 @@ class TerminationManager(BaseManager):
     def _publish(self):
         """Post-launch bookkeeping: log filler and the extras keys (termination_manager.py:178-190)."""
         env = self.env
+        extras = env._extras
         if self.logging_enabled:
-            log = env.extras[env.extras_logging_key]
-            names = list(self.term_cfg.keys())
-            tag = self.logging_tag
-
-            def fill(st, out, names=names, tag=tag, n=self._global_envs()):
-                for k, name in enumerate(names):
-                    if st.term_fired[k] > 0:  # key only present when the term fired (quirk q8)
-                        out[f"{tag} / {name}"] = torch.tensor(st.term_fired[k] / n, dtype=torch.float32)
-
+            log = extras[env.extras_logging_key]
             if hasattr(log, "add_filler"):
-                log.add_filler(fill)
-        env.extras["terminations"] = self._terminated_buf
-        env.extras["time_outs"] = self._truncated_buf
+                log.add_filler(self._fill_log)
+        extras["terminations"] = self._terminated_buf
+        extras["time_outs"] = self._truncated_buf
         return self._terminated_buf, self._truncated_buf
+
+    def _fill_log(self, st, out):
+        n = self._global_envs()
+        tag = self.logging_tag
+        for k, name in enumerate(self.term_cfg.keys()):
+            if st.term_fired[k] > 0:  # key only present when the term fired (quirk q8)
+                out[f"{tag} / {name}"] = torch.tensor(st.term_fired[k] / n, dtype=torch.float32)
 
     def _global_envs(self) -> int:
         return getattr(self.env, "global_num_envs", self.env.num_envs)

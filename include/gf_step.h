@@ -130,6 +130,10 @@ typedef struct GfActionArgs {
     GfStepStats* stats;      /* may be NULL */
     GfStepStats* stats_zero; /* optional: GF_STATS_SHARDS blocks this launch zeroes — the NEXT step's slot of a statistics
                                 ring, so a recorded step needs neither a memset nor a per-step device→host copy */
+    const GfStepStats* stats_fold_src; /* optional: the PREVIOUS step's slot (complete by stream order) … */
+    double* stats_fold_dst;            /* … folded over its shards into this GF_STATS_VECTOR_LEN row (layout of gf_stats_pack) */
+    double* stats_last_reset;          /* optional: copy of the most recent folded row whose reset_count > 0
+                                          (RewardManager.last_episode_mean_reward, reward_manager.py:138-153) */
 } GfActionArgs;
 
 /* ------------------------------------------------------------------------------------------

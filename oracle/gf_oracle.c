@@ -92,6 +92,8 @@ GFO_EXPORT int gfo_stats_clear(GfStepStats* s) {
     return GF_OK;
 }
 
+int gfo_stats_pack(const GfStatsPackArgs* a);
+
 /* ---------------------------------------------------------------- Phase A ---------------- */
 /* genesis_env.py:181-205 (episode_length += 1; last_actions <- actions; actions <- new) then
  * position_action_manager.py:402-414 (NaN/Inf scan, a*scale+offset, clamp) or
@@ -133,6 +135,12 @@ GFO_EXPORT int gfo_action_step(const GfActionArgs* a) {
     }
     if (a->stats) a->stats->action_flags |= flags;
     if (a->stats_zero) memset(a->stats_zero, 0, sizeof(GfStepStats) * GF_STATS_SHARDS);
+    if (a->stats_fold_src && a->stats_fold_dst) {
+        GfStatsPackArgs pk = {a->stats_fold_src, a->stats_fold_dst};
+        gfo_stats_pack(&pk);
+        if (a->stats_last_reset && a->stats_fold_dst[GF_MAX_TERM_TERMS] > 0.0)
+            memcpy(a->stats_last_reset, a->stats_fold_dst, sizeof(double) * GF_STATS_VECTOR_LEN);
+    }
     return GF_OK;
 }
 

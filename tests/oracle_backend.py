@@ -38,6 +38,13 @@ class OracleBackend(nat.Backend):
         if rc != 0:
             raise nat.GfError(f"gfo_stats_clear failed: {rc}")
 
+    def stats_pack(self, src_ptr, dst_ptr):
+        a = nat.GfStatsPackArgs()
+        a.src, a.dst = src_ptr, dst_ptr
+        rc = self.lib.gfo_stats_pack(C.byref(a))
+        if rc != 0:
+            raise nat.GfError(f"gfo_stats_pack failed: {rc}")
+
     def post_check(self, refs):
         return self.lib.gfo_post_physics_check(C.byref(refs)) == 0
 
