@@ -36,15 +36,7 @@ __global__ __launch_bounds__(256) void action_kernel(const GfActionArgs a, const
         for (int64_t w = i; w < kWords; w += (int64_t)gridDim.x * blockDim.x) reinterpret_cast<uint32_t*>(a.stats_zero)[w] = 0u;
     }
     // fold the previous step's statistics slot (complete by stream order) into its row of the vector ring
-    if (a.stats_fold_src && a.stats_fold_dst && blockIdx.x == 0 && threadIdx.x < GF_WAVE) {
-        const int v = threadIdx.x;
-        const double resets = fold_stats_entry(a.stats_fold_src, GF_MAX_TERM_TERMS);
-        if (v < GF_STATS_VECTOR_LEN) {
-            const double acc = fold_stats_entry(a.stats_fold_src, v);
-            a.stats_fold_dst[v] = acc;
-            if (a.stats_last_reset && resets > 0.0) a.stats_last_reset[v] = acc;
-        }
-    }
+    if (a.stats_fold_src && a.stats_fold_dst && blockIdx.x == 0) fold_stats_block256(a.stats_fold_src, a.stats_fold_dst, a.stats_last_reset);
     const int D = a.num_dofs;
     const int mode = a.mode;
     int flags = 0;

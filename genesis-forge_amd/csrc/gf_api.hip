@@ -10,13 +10,7 @@ Profiler g_prof;
 
 #define GF_EXPORT __attribute__((visibility("default")))
 namespace gf {
-// one wave: lane v < GF_STATS_VECTOR_LEN folds entry v over the shards
-__global__ __launch_bounds__(64) void stats_pack_kernel(const GfStatsPackArgs a) {
-    const int v = threadIdx.x;
-    if (v >= GF_STATS_VECTOR_LEN) return;
-    const double acc = fold_stats_entry(a.src, v);
-    a.dst[v] = acc;
-}
+__global__ __launch_bounds__(256) void stats_pack_kernel(const GfStatsPackArgs a) { fold_stats_block256(a.src, a.dst, nullptr); }
 }  // namespace gf
 
 extern "C" {
@@ -65,7 +59,7 @@ GF_EXPORT int gf_stats_clear(GfStepStats* stats, void* stream) {
 
 GF_EXPORT int gf_stats_pack(const GfStatsPackArgs* a, void* stream) {
     if (!a || !a->src || !a->dst) return GF_E_NULL;
-    gf::stats_pack_kernel<<<1, 64, 0, (hipStream_t)stream>>>(*a);
+    gf::stats_pack_kernel<<<1, 256, 0, (hipStream_t)stream>>>(*a);
     return gf::launch_status();
 }
 

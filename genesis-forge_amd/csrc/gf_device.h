@@ -137,23 +137,49 @@ __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m)
 // this workgroup's statistics shard (see GF_STATS_SHARDS in gf_step.h)
 __device__ __forceinline__ GfStepStats* stats_shard(GfStepStats* s) { return s + (blockIdx.x % GF_STATS_SHARDS); }
 
-// entry v of the folded statistics vector (layout of gf_stats_pack): shards add, flag entries fold with max
-__device__ __forceinline__ double fold_stats_entry(const GfStepStats* src, int v) {
-    double acc = 0.0;
-    for (int s = 0; s < GF_STATS_SHARDS; ++s) {
-        const GfStepStats& b = src[s];
-        double x;
-        if (v < GF_MAX_TERM_TERMS) x = (double)b.term_fired[v];
-        else if (v == GF_MAX_TERM_TERMS) x = (double)b.reset_count;
-        else if (v == GF_MAX_TERM_TERMS + 1) x = (double)(b.action_flags & 1);
-        else if (v == GF_MAX_TERM_TERMS + 2) x = (double)((b.action_flags >> 1) & 1);
-        else if (v == GF_MAX_TERM_TERMS + 3) x = (double)(b.contact_flags & 1);
-        else if (v == GF_MAX_TERM_TERMS + 4) x = (double)b.resample_count;
-        else x = b.reward_episode_sum[v - (GF_MAX_TERM_TERMS + 5)];
+// Fold the GF_STATS_SHARDS shards of one statistics slot into the GF_STATS_VECTOR_LEN-entry f64 vector (layout of
+// gf_stats_pack): shards add, flag entries fold with max.  Run by ONE 256-thread workgroup: lane = shard, each of the 4
+// waves owns 12 entries; all of a lane's loads are issued together and each entry is reduced across the wave with
+// shuffles (a lane-per-entry loop over the shards would be 64 dependent memory round trips).
+__device__ __forceinline__ double stats_entry(const GfStepStats& b, int v) {
+    if (v < GF_MAX_TERM_TERMS) return (double)b.term_fired[v];
+    if (v == GF_MAX_TERM_TERMS) return (double)b.reset_count;
+    if (v == GF_MAX_TERM_TERMS + 1) return (double)(b.action_flags & 1);
+    if (v == GF_MAX_TERM_TERMS + 2) return (double)((b.action_flags >> 1) & 1);
+    if (v == GF_MAX_TERM_TERMS + 3) return (double)(b.contact_flags & 1);
+    if (v == GF_MAX_TERM_TERMS + 4) return (double)b.resample_count;
+    if (v < GF_STATS_VECTOR_LEN) return b.reward_episode_sum[v - (GF_MAX_TERM_TERMS + 5)];
+    return 0.0;
+}
+
+__device__ __forceinline__ void fold_stats_block256(const GfStepStats* src, double* dst, double* last_reset) {
+    static_assert(GF_STATS_SHARDS == GF_WAVE, "one lane per shard");
+    constexpr int kPerWave = (GF_STATS_VECTOR_LEN + 3) / 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (GF_WAVE - 1);
+    const GfStepStats& b = src[lane];
+    double x[kPerWave];
+#pragma unroll
+    for (int j = 0; j < kPerWave; ++j) x[j] = stats_entry(b, wave * kPerWave + j);
+    const double resets = wave_sum((double)b.reset_count);  // valid in lane 0
+#pragma unroll
+    for (int j = 0; j < kPerWave; ++j) {
+        const int v = wave * kPerWave + j;
         const bool is_flag = v > GF_MAX_TERM_TERMS && v < GF_MAX_TERM_TERMS + 4;
-        acc = is_flag ? (x > acc ? x : acc) : acc + x;
+        double r = x[j];
+        if (is_flag) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_down(r, off, GF_WAVE);
+                r = o > r ? o : r;
+            }
+        } else {
+            r = wave_sum(r);
+        }
+        if (lane == 0 && v < GF_STATS_VECTOR_LEN) {
+            dst[v] = r;
+            if (last_reset && resets > 0.0) last_reset[v] = r;
+        }
     }
-    return acc;
 }
 
 // contact predicates shared by termination / reward terms

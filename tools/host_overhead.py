@@ -37,7 +37,7 @@ for i in range(tr.n_ops):
 def py_only():
     env._begin_step_light()
     for p in tr.patches: p(act)
-    cur, nxt, snap = env.stats.ring_next()
+    cur, nxt, prev, prev_vec, snap = env.stats.ring_next()
     for f in tr.afters: f()
     env._finish_step_light(snap)
 print("python bookkeeping only  %.1f us" % timeit(py_only))
