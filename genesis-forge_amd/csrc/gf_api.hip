@@ -5,6 +5,7 @@
 #include "gf_launch.h"
 
 namespace gf {
+int g_options[GF_OPT_COUNT] = {1, 0, 0, 0};
 Profiler g_prof;
 }
 
@@ -16,6 +17,12 @@ __global__ __launch_bounds__(256) void stats_pack_kernel(const GfStatsPackArgs a
 extern "C" {
 
 GF_EXPORT int gf_abi_version(void) { return GF_ABI_VERSION; }
+
+GF_EXPORT int gf_set_option(int option, int value) {
+    if (option < 0 || option >= GF_OPT_COUNT) return GF_E_RANGE;
+    gf::g_options[option] = value;
+    return GF_OK;
+}
 
 GF_EXPORT int gf_sizeof(int which) {
     switch (which) {

@@ -26,6 +26,7 @@ struct Profiler {
     std::vector<hipEvent_t> events;
 };
 extern Profiler g_prof;
+extern int g_options[GF_OPT_COUNT];
 
 // RAII scope of one profiled launch.  Two modes:
 //  * bracket (default): an event pair is recorded on `stream` around the launch (≈ 3 µs of event overhead inside the pair);

@@ -79,6 +79,8 @@ GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
 (GF_PHASE_ACTION, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
  GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_COUNT) = range(11)
 
+GF_OPT_POST_VARIANT = 0  # gf_set_option: 0 = one wave per tile, 1 = four specialised waves per tile (default)
+
 GF_ERRORS = {-1: "GF_E_NULL", -2: "GF_E_RANGE", -3: "GF_E_OPCODE", -4: "GF_E_SLOT", -5: "GF_E_UNSUPPORTED"}
 
 P = C.c_void_p  # every device pointer crosses the ABI as a plain address
@@ -343,8 +345,13 @@ class HipBackend(Backend):
         self.lib.gf_event_create.restype = C.c_void_p
         self.lib.gf_event_synchronize.restype = C.c_int
         self.lib.gf_event_synchronize.argtypes = [C.c_void_p]
+        self.lib.gf_set_option.restype = C.c_int
+        self.lib.gf_set_option.argtypes = [C.c_int, C.c_int]
         self.lib.gf_profile_begin.restype = C.c_int
         self.lib.gf_profile_begin.argtypes = [C.c_int, C.c_int]
+        variant = os.environ.get("GF_POST_VARIANT")
+        if variant is not None:
+            self.set_option(GF_OPT_POST_VARIANT, int(variant))
         self.lib.gf_profile_end.restype = C.c_int
         self.lib.gf_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
@@ -396,6 +403,11 @@ class HipBackend(Backend):
         rc = self.lib.gf_stats_clear(stats_ptr, self._stream())
         if rc != 0:
             self._raise("stats_clear", rc)
+
+    def set_option(self, option: int, value: int) -> None:
+        rc = self.lib.gf_set_option(option, value)
+        if rc != 0:
+            self._raise("set_option", rc)
 
     def profile_begin(self, phase: int, max_samples: int) -> None:
         rc = self.lib.gf_profile_begin(phase, max_samples)

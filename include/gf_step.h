@@ -447,6 +447,10 @@ typedef struct GfSynthSceneArgs {
  * Entry points.  `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream).
  * ---------------------------------------------------------------------------------------- */
 int gf_abi_version(void);
+/* library-wide tuning switches (process global).  GF_OPT_POST_VARIANT: 0 = one wave per 64-env tile, 1 = four
+ * specialised waves per tile (default).  Both variants produce bit-identical results. */
+enum { GF_OPT_POST_VARIANT = 0, GF_OPT_COUNT = 4 };
+int gf_set_option(int option, int value);
 int gf_sizeof(int which);   /* sizeof of the ABI structs, in header order (0 = GfStepStats … 11 = GfObsItem): binding self-check */
 const char* gf_build_info(void);
 const char* gf_error_string(int code);

@@ -19,7 +19,7 @@ def test_header_declares_all_phases():
     names = _declared()
     for fn in nat.PHASE_FUNCS:
         assert "gf_" + fn in names
-    assert {"gf_run_ops", "gf_stats_clear", "gf_abi_version", "gf_sizeof", "gf_error_string", "gf_profile_begin", "gf_profile_end",
+    assert {"gf_run_ops", "gf_stats_clear", "gf_abi_version", "gf_sizeof", "gf_error_string", "gf_profile_begin", "gf_profile_end", "gf_set_option",
             "gf_event_create", "gf_event_synchronize", "gf_event_destroy", "gf_build_info"} <= set(names)
 
 

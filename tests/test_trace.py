@@ -82,9 +82,20 @@ def test_traced_step_equals_ordinary_hip(hip_backend):
     _same(a, b)
 
 
+@pytest.fixture
+def post_variant(hip_backend, request):
+    """Selects the fused kernel's variant (0 = one wave per tile, 1 = four specialised waves) for one test."""
+    from genesis_forge_amd import _native as nat
+
+    hip_backend.set_option(nat.GF_OPT_POST_VARIANT, request.param)
+    yield request.param
+    hip_backend.set_option(nat.GF_OPT_POST_VARIANT, 1)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("post_variant", [0, 1], indirect=True)
 @pytest.mark.parametrize("n", [1, 65, 4096])
-def test_fused_post_physics_equals_phase_by_phase_hip(hip_backend, n):
+def test_fused_post_physics_equals_phase_by_phase_hip(hip_backend, post_variant, n):
     """gf_post_physics_step (one launch) against the same recorded step replayed phase by phase."""
     outs = []
     for fuse in (False, True):
@@ -149,8 +160,9 @@ def test_humanoid_config_traced_equals_ordinary_cpu(oracle_backend, dofs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("post_variant", [0, 1], indirect=True)
 @pytest.mark.parametrize("dofs,n", [(12, 200), (28, 200), (28, 1), (12, 4097)])
-def test_humanoid_config_fused_hip(hip_backend, dofs, n):
+def test_humanoid_config_fused_hip(hip_backend, post_variant, dofs, n):
     """Two command managers, two observation managers, three contact managers, 13 reward terms, D=28 variant."""
     a, _ = _run_humanoid("cuda", "ordinary", n, dofs)
     b, env_b = _run_humanoid("cuda", "unfused", n, dofs)

@@ -175,7 +175,12 @@ int main(int argc, char** argv) {
     {
         const int rc = gf_post_physics_check(&pr);
         printf("gf_post_physics_check: %d (%s)\n", rc, gf_error_string(rc));
-        if (rc == 0) time_loop("gf_post_physics_step", iters, 566.0 * Nd, [&] { chk(gf_post_physics_step(&pr, 0), "post"); });
+        if (rc == 0) {
+            gf_set_option(GF_OPT_POST_VARIANT, 0);
+            time_loop("gf_post_physics_step (1 wave)", iters, 566.0 * Nd, [&] { chk(gf_post_physics_step(&pr, 0), "post"); });
+            gf_set_option(GF_OPT_POST_VARIANT, 1);
+            time_loop("gf_post_physics_step (4 waves)", iters, 566.0 * Nd, [&] { chk(gf_post_physics_step(&pr, 0), "post"); });
+        }
     }
     int failed = -1;
     time_loop("full step (8 ops)", iters, 806.0 * Nd, [&] { sa.tick++; chk(gf_run_ops(ops_, 8, 0, &failed), "run_ops"); });
