@@ -5,7 +5,7 @@
 #include "gf_launch.h"
 
 namespace gf {
-int g_options[GF_OPT_COUNT] = {1, 0, 0, 0};
+int g_options[GF_OPT_COUNT] = {2, 0, 0, 0};
 Profiler g_prof;
 }
 

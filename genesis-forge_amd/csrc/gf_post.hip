@@ -19,150 +19,11 @@
 // exactly that); tests compare the two paths bit for bit.
 // Algorithmic traffic, Go2 command config: R 13·4 + 5 rows·48 + cmd 12 + ep/max 8 + secs 4 + sums 24 = 340,
 // W masks 2 + reward 4 + sums 24 + secs 4 + obs 192 = 226  →  566 B/env.
-#include "gf_launch.h"
-#include "gf_terms.h"
-
-// Diagnostic build only (tools/stamp_post.hip, -DGF_STAMPS): lane 0 of one workgroup records the 100 MHz wall
-// clock at the phase boundaries into a buffer of its own; no product build contains a stamp.
-#ifdef GF_STAMPS
-extern "C" unsigned long long* gf_debug_stamps;  // host variable set by the tool
-#define GF_STAMP(i)                                                                                          \
-    do {                                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        if (a.stamps && blockIdx.x == a.stamp_block && threadIdx.x == 0) {                                   \
-            a.stamps[i] = __builtin_amdgcn_s_memrealtime();                                                  \
-            a.stamps[16 + i] = __builtin_amdgcn_s_memtime();                                                 \
-        }                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-    } while (0)
-#else
-#define GF_STAMP(i)
-#endif
+#include "gf_post_args.h"
+#include "gf_post_ws.h"
+#include "gf_post_programs.h"
 
 namespace gf {
-
-constexpr int kPostMaxTerm = 8;
-constexpr int kPostMaxReward = 16;
-constexpr int kPostAuxRows = 32;  // per-lane scratch rows: 4 per float4 chunk of a DOF row, up to D = 28
-constexpr int kPostMaxItems = 12;
-constexpr int kPostMaxRanges = 4;
-
-struct PostCmd {
-    float* command;
-    int32_t width;
-    int32_t resample_steps;
-    uint64_t stream_step;
-    uint64_t stream_reset;
-    float lo[kPostMaxRanges];
-    float hi[kPostMaxRanges];
-};
-
-struct PostObs {
-    float* obs;
-    const float* prev;
-    uint64_t stream;
-    int32_t num_items;
-    int32_t width;
-    int32_t history;
-    int32_t _pad;
-    GfObsItem items[kPostMaxItems];
-};
-
-struct alignas(16) GfPostArgs {
-    int32_t num_envs, num_dofs, num_term, num_rew;
-    uint32_t needs;
-    int32_t n_cmd, n_obs, logging;
-    float dt;
-    int32_t reward_rows;
-    uint32_t reward_log_mask;
-    uint32_t uncovered_rows;   // rows of episode_sums no active term owns (zero weight): still zeroed on reset
-    uint64_t seed;
-    uint32_t env_offset;
-    int32_t has_maxlen;
-    // state
-    float *pos, *quat, *lin_vel, *ang_vel;       // entity views (writable: scene-side reset)
-    float *dof_pos, *dof_vel;
-    const float *dof_force, *targets, *default_dof_pos;
-    float *env_actions, *env_last_actions;
-    int32_t *episode_length, *max_episode_length;
-    uint8_t *terminated, *truncated;
-    float *reward, *episode_sums, *episode_seconds;
-    GfStepStats* stats;
-    float* quat_stash;
-    // views shared by every phase (slot indices in the copied terms/items are remapped onto these)
-    GfContactView contact[GF_MAX_CONTACT_VIEWS];
-    GfCommandView command[GF_MAX_COMMAND_VIEWS];
-    int32_t cmd_of_view[GF_MAX_COMMAND_VIEWS];   // index into cmds[] of the manager that owns the view's buffer, or -1
-    const float* ext[1];
-    float* state[4];
-    // reset
-    int32_t scene_reset, set_quat, zero_velocity, reset_env /* bit0: actions rows, bit1: episode_length */, reset_dofs;
-    int32_t base_max_episode_length;
-    float max_random_scaling, dof_noise_scale;
-    float reset_pos[3], reset_quat[4];
-    uint64_t stream_reset;
-    float* air_state[GF_MAX_CONTACT_VIEWS][4];
-    int32_t air_links[GF_MAX_CONTACT_VIEWS];
-    int32_t n_air;
-    int32_t _pad0;
-    GfTerm tterms[kPostMaxTerm];
-    GfTerm rterms[kPostMaxReward];
-    PostCmd cmds[GF_POST_MAX_CMD];
-    PostObs obs[GF_POST_MAX_OBS];
-#ifdef GF_STAMPS
-    unsigned long long* stamps;
-    uint32_t stamp_block;
-#endif
-};
-static_assert(sizeof(GfPostArgs) <= 4096, "GfPostArgs must fit the 4 KB kernarg segment");
-
-enum : uint32_t {
-    PN_POS = 1, PN_QUAT = 2, PN_LIN = 4, PN_ANG = 8, PN_DOFPOS = 16, PN_DOFVEL = 32, PN_TARGETS = 64, PN_ACTIONS = 128, PN_LAST = 256,
-    PN_EPLEN = 512, PN_MAXLEN = 1024, PN_DOFDEV = 2048, PN_ACTRATE = 4096, PN_DOFFORCE = 8192,
-};
-
-// scale / noise of one observation element (observation_manager.py:242-250); everything it needs arrives by value
-struct ObsFin {
-    float scale;
-    bool scaled;
-};
-__device__ __forceinline__ float obs_finish(const ObsFin& f, float v, int) { return f.scaled ? v * f.scale : v; }
-
-// All ≤ 4 range draws of one command resample come out of ONE Philox block (columns 0..3 share counter col>>2 == 0),
-// exactly the values philox_uniform(seed, stream, env, j) returns for j = 0..3.
-// (register-only signature: a real call, no stack, so the rarely-taken resample paths cost one Philox body in the binary)
-__device__ __noinline__ float4 draw_unit4(uint64_t seed, uint64_t stream, uint32_t genv, uint32_t block) {
-    const U4 r = philox4x32_10(genv, block, (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
-    return make_float4(u24_to_unit(r.x), u24_to_unit(r.y), u24_to_unit(r.z), u24_to_unit(r.w));
-}
-
-// one [D] row of registers → the lane's observation tile row (separate call per source keeps every index static)
-template <int DV>
-__device__ __forceinline__ void put_row(const ObsFin& f, const float4 (&r)[DV], float* row, int col) {
-#pragma unroll
-    for (int c = 0; c < DV; ++c) {
-        row[col + 4 * c + 0] = obs_finish(f, r[c].x, col + 4 * c + 0);
-        row[col + 4 * c + 1] = obs_finish(f, r[c].y, col + 4 * c + 1);
-        row[col + 4 * c + 2] = obs_finish(f, r[c].z, col + 4 * c + 2);
-        row[col + 4 * c + 3] = obs_finish(f, r[c].w, col + 4 * c + 3);
-    }
-}
-
-// wave-uniform value that lives in a VGPR (read from the LDS-staged descriptor) → SGPR
-template <typename T>
-__device__ __forceinline__ T uni(T v) {
-    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "uni: 4- or 8-byte types");
-    if constexpr (sizeof(T) == 4) {
-        uint32_t u = __builtin_bit_cast(uint32_t, v);
-        u = __builtin_amdgcn_readfirstlane(u);
-        return __builtin_bit_cast(T, u);
-    } else {
-        uint64_t u = __builtin_bit_cast(uint64_t, v);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-        u = ((uint64_t)hi << 32) | lo;
-        return __builtin_bit_cast(T, u);
-    }
-}
 
 template <int DV>
 __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) {
@@ -602,477 +463,6 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Wave-specialised variant.  In-kernel stamps showed post_kernel to be ISSUE-bound on a single wave per SIMD
-// (≈ 24 000 cycles of one instruction stream, memory < 20 %): at N = 65 536 there are only 1 024 waves for 1 024 SIMDs.
-// Here a workgroup of 4 waves shares a 64-env tile (lane = env in every wave) and each wave runs a quarter of the step:
-//   wave 0  control : base state → body-frame vectors, termination terms, command.step / command.reset draws; after the
-//                     barrier: masks, commands, env-level + base-pose reset stores
-//   wave 1  reward  : [N,D] rows → Σ|dof-default|, Σ(Δaction)², episode sums (LDS-DMA); after the barrier: the term fold
-//   wave 2  obs-rows: dof_pos / dof_vel rows; after the barrier: DOF reset of done envs, dof_pos / dof_vel items
-//   wave 3  obs-misc: targets / raw-action rows; after the barrier: command, body-frame, action, contact items
-// then all 256 lanes stream the observation tile out.  What the waves exchange (masks, body-frame vectors, new commands)
-// goes through 5 KB of LDS and one s_barrier.  Every global load happens before the barrier and every store of state that
-// another wave loads happens after it, so the phases see exactly the values they see in post_kernel.  Same arithmetic,
-// same order per env: bit-identical outputs (tests/test_trace.py runs both).
-// ------------------------------------------------------------------------------------------------------------
-constexpr int kWsBlock = 4 * kEnvBlock;
-enum : int { X_TERM = 0, X_TRUNC = 1, X_DONE = 2, X_BLIN = 3, X_BANG = 6, X_GRAV = 9, X_CMD = 12, X_DIRTY = 20, X_FIELDS = 21 };
-
-template <int DV>
-__global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int kArgVec = (int)(sizeof(GfPostArgs) / 16);
-    {
-        const auto* src = (const __attribute__((address_space(4))) f32x4*)__builtin_amdgcn_kernarg_segment_ptr();
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = threadIdx.x; i < kArgVec; i += kWsBlock) dst[i] = src[i];
-    }
-    __syncthreads();
-    const GfPostArgs& a = *reinterpret_cast<const GfPostArgs*>(lds);
-    float* xch = lds + kArgVec * 4;                          // [X_FIELDS][64]
-    float* lds_sums = xch + X_FIELDS * kEnvBlock;            // [kPostMaxReward][64]
-    float* lds_aux = lds_sums + kPostMaxReward * kEnvBlock;  // [kPostAuxRows][64]
-    float* tile = lds_aux + kPostAuxRows * kEnvBlock;                  // [64][O+1]
-
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & (GF_WAVE - 1);
-    const int64_t N = uni(a.num_envs);
-    const int64_t n0 = (int64_t)blockIdx.x * kEnvBlock;
-    const int64_t n_raw = n0 + lane;
-    const bool live = n_raw < N;
-    const int64_t n = live ? n_raw : N - 1;
-    const uint32_t e = (uint32_t)n;
-    const uint32_t genv = e + uni(a.env_offset);
-    const int D = uni(a.num_dofs);
-    const uint32_t needs = uni(a.needs);
-    const int n_term = uni(a.num_term), n_rew = uni(a.num_rew), n_cmd = uni(a.n_cmd), n_obs = uni(a.n_obs);
-    const uint64_t seed = uni(a.seed);
-    constexpr int R = DV;
-    const uint32_t ro = e * (uint32_t)D;
-    GfStepStats* const k_stats = uni(a.stats);
-    GfStepStats* shard = k_stats ? stats_shard(k_stats) : nullptr;
-    const bool logging = uni(a.logging) != 0;
-    float* const k_sums = uni(a.episode_sums);
-    float* const k_reward = uni(a.reward);
-    const bool has_reward = n_rew >= 0 && k_reward != nullptr;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // ---- state that lives across the barrier, per role -------------------------------------------------------------
-    float4 q = make_float4(1.f, 0.f, 0.f, 0.f);       // wave 0
-    V3 pos{0, 0, 0};                                    // waves 0, 1
-    int ep_len = 0, term = 0, trunc = 0;                // wave 0
-    float cmd[GF_POST_MAX_CMD][kPostMaxRanges] = {};    // wave 0
-    bool cmd_dirty[GF_POST_MAX_CMD] = {false, false};   // wave 0
-    float dof_dev = 0.f, act_rate = 0.f, secs_in = 0.f; // wave 1
-    float cmd0[3] = {0.f, 0.f, 0.f};                    // wave 1
-    float4 r_a[R], r_b[R], r_c[R];                      // wave 1: dof_pos/actions/last; wave 2: dof_pos/dof_vel/default; wave 3: targets/actions
-#pragma unroll
-    for (int c = 0; c < DV; ++c) { r_a[c] = z4; r_b[c] = z4; r_c[c] = z4; }
-
-    if (wave == 0) {
-        // ---- control: loads -------------------------------------------------------------------------------------------
-        q = ldg4(gsel((needs & PN_QUAT) != 0, uni(a.quat), 4u * e));
-        const GF_GLOBAL float* pp = gsel((needs & PN_POS) != 0, uni(a.pos), 3u * e);
-        const GF_GLOBAL float* lp = gsel((needs & PN_LIN) != 0, uni(a.lin_vel), 3u * e);
-        const GF_GLOBAL float* ap = gsel((needs & PN_ANG) != 0, uni(a.ang_vel), 3u * e);
-        pos = V3{pp[0], pp[1], pp[2]};
-        const V3 lin{lp[0], lp[1], lp[2]}, ang{ap[0], ap[1], ap[2]};
-        ep_len = *gsel((needs & PN_EPLEN) != 0, uni(a.episode_length), e);
-        const int max_len = *gsel((needs & PN_MAXLEN) != 0, uni(a.max_episode_length), e);
-#pragma unroll
-        for (int c = 0; c < GF_POST_MAX_CMD; ++c) {
-            const bool on = c < n_cmd;
-            const uint32_t w = on ? (uint32_t)uni(a.cmds[c].width) : 0u;
-            const GF_GLOBAL float* cp = gsel(on, on ? uni(a.cmds[c].command) : nullptr, e * w);
-#pragma unroll
-            for (int j = 0; j < kPostMaxRanges; ++j) cmd[c][j] = cp[(uint32_t)j < w ? j : 0];
-        }
-        // ---- body-frame vectors, termination -----------------------------------------------------------------------------
-        const V3 blin = rot_inv(q, lin), bang = rot_inv(q, ang), grav = rot_inv(q, V3{0.f, 0.f, -1.f});
-        TermRegs tr;
-        const int has_maxlen = uni(a.has_maxlen);
-        tr.ep_len = ep_len; tr.max_len = max_len; tr.has_maxlen = has_maxlen != 0; tr.pos = pos; tr.m = n;
-        tr.tilt_sin = clamp_max(norm2(grav.x, grav.y), 0.99f);
-        for (int k = 0; k < n_term; ++k) {
-            const GfTerm t = a.tterms[k];
-            int v = eval_termination_term(t, a, tr, (uint32_t)has_maxlen);
-            v = live ? v : 0;
-            if (t.flags & GF_TERM_FLAG_TIME_OUT) trunc |= v; else term |= v;
-            if (shard) {
-                const unsigned long long hit = __ballot(v);
-                if (hit && lane == 0) atomicAdd(&shard->term_fired[k], popc64(hit));
-            }
-        }
-        const bool done0 = live && (term | trunc);
-        // ---- command.step then command.reset draws (values only; stores wait for the barrier) ------------------------------
-#pragma unroll
-        for (int c = 0; c < GF_POST_MAX_CMD; ++c) {
-            if (c < n_cmd) {
-                const PostCmd cm = a.cmds[c];
-                const bool go = live && (ep_len % uni(cm.resample_steps)) == 0;
-                if (shard) {
-                    const unsigned long long m = __ballot(go);
-                    if (m && lane == 0) atomicAdd(&shard->resample_count, popc64(m));
-                }
-                if (go) {
-                    const float4 u4 = draw_unit4(seed, cm.stream_step, genv, 0u);
-                    const float nv[kPostMaxRanges] = {uniform_range(u4.x, cm.lo[0], cm.hi[0]), uniform_range(u4.y, cm.lo[1], cm.hi[1]),
-                                                      uniform_range(u4.z, cm.lo[2], cm.hi[2]), uniform_range(u4.w, cm.lo[3], cm.hi[3])};
-#pragma unroll
-                    for (int j = 0; j < kPostMaxRanges; ++j)
-                        if (j < cm.width) cmd[c][j] = nv[j];
-                    cmd_dirty[c] = true;
-                }
-                if (done0) {
-                    const float4 u4 = draw_unit4(seed, cm.stream_reset, genv, 0u);
-                    const float nv[kPostMaxRanges] = {uniform_range(u4.x, cm.lo[0], cm.hi[0]), uniform_range(u4.y, cm.lo[1], cm.hi[1]),
-                                                      uniform_range(u4.z, cm.lo[2], cm.hi[2]), uniform_range(u4.w, cm.lo[3], cm.hi[3])};
-#pragma unroll
-                    for (int j = 0; j < kPostMaxRanges; ++j)
-                        if (j < cm.width) cmd[c][j] = nv[j];
-                    cmd_dirty[c] = true;
-                }
-            }
-        }
-        // ---- publish ---------------------------------------------------------------------------------------------------------
-        xch[X_TERM * kEnvBlock + lane] = (float)term;
-        xch[X_TRUNC * kEnvBlock + lane] = (float)trunc;
-        xch[X_DONE * kEnvBlock + lane] = done0 ? 1.f : 0.f;
-        xch[(X_BLIN + 0) * kEnvBlock + lane] = blin.x; xch[(X_BLIN + 1) * kEnvBlock + lane] = blin.y; xch[(X_BLIN + 2) * kEnvBlock + lane] = blin.z;
-        xch[(X_BANG + 0) * kEnvBlock + lane] = bang.x; xch[(X_BANG + 1) * kEnvBlock + lane] = bang.y; xch[(X_BANG + 2) * kEnvBlock + lane] = bang.z;
-        xch[(X_GRAV + 0) * kEnvBlock + lane] = grav.x; xch[(X_GRAV + 1) * kEnvBlock + lane] = grav.y; xch[(X_GRAV + 2) * kEnvBlock + lane] = grav.z;
-#pragma unroll
-        for (int c = 0; c < GF_POST_MAX_CMD; ++c)
-#pragma unroll
-            for (int j = 0; j < kPostMaxRanges; ++j) xch[(X_CMD + c * kPostMaxRanges + j) * kEnvBlock + lane] = cmd[c][j];
-        xch[X_DIRTY * kEnvBlock + lane] = (float)((cmd_dirty[0] ? 1 : 0) | (cmd_dirty[1] ? 2 : 0));
-    } else if (wave == 1) {
-        // ---- reward: loads + per-row reductions ------------------------------------------------------------------------------
-        if (logging)
-            for (int k = 0; k < n_rew; ++k)
-                __builtin_amdgcn_global_load_lds(k_sums + (int64_t)uni(a.rterms[k].row) * N + n, lds_sums + k * kEnvBlock, 4, 0, 0);
-        const GF_GLOBAL float* p0 = gsel((needs & PN_DOFDEV) != 0, uni(a.dof_pos), ro);
-        const GF_GLOBAL float* p1 = gsel((needs & PN_ACTRATE) != 0, uni(a.env_actions), ro);
-        const GF_GLOBAL float* p2 = gsel((needs & PN_ACTRATE) != 0, uni(a.env_last_actions), ro);
-        const GF_GLOBAL float* p3 = gsel((needs & PN_DOFDEV) != 0, uni(a.default_dof_pos), 0u);
-        float4 r_def[R];
-#pragma unroll
-        for (int c = 0; c < DV; ++c) { r_a[c] = ldg4(p0 + 4 * c); r_b[c] = ldg4(p1 + 4 * c); r_c[c] = ldg4(p2 + 4 * c); r_def[c] = ldg4(p3 + 4 * c); }
-        const GF_GLOBAL float* pp = gsel((needs & PN_POS) != 0, uni(a.pos), 3u * e);
-        pos = V3{pp[0], pp[1], pp[2]};
-        const float* k_secs = uni(a.episode_seconds);
-        secs_in = *gsel(has_reward && k_secs != nullptr, k_secs, e);
-        {   // command view 0 as it is BEFORE this step's resample (wave 0 stores new values only after the barrier)
-            const float* v0 = uni(a.command[0].command);
-            const bool nv = v0 != nullptr;
-            const uint32_t w = nv ? (uint32_t)uni(a.command[0].width) : 0u;
-            const GF_GLOBAL float* cp = gsel(nv, v0, e * w);
-            cmd0[0] = cp[0]; cmd0[1] = cp[w > 1 ? 1 : 0]; cmd0[2] = cp[w > 2 ? 2 : 0];
-        }
-#pragma unroll
-        for (int c = 0; c < DV; ++c) {
-            dof_dev += fabsf(r_a[c].x - r_def[c].x);
-            dof_dev += fabsf(r_a[c].y - r_def[c].y);
-            dof_dev += fabsf(r_a[c].z - r_def[c].z);
-            dof_dev += fabsf(r_a[c].w - r_def[c].w);
-        }
-#pragma unroll
-        for (int c = 0; c < DV; ++c) {
-            float d;
-            d = r_c[c].x - r_b[c].x; act_rate += d * d;
-            d = r_c[c].y - r_b[c].y; act_rate += d * d;
-            d = r_c[c].z - r_b[c].z; act_rate += d * d;
-            d = r_c[c].w - r_b[c].w; act_rate += d * d;
-        }
-    } else if (wave == 2) {
-        const GF_GLOBAL float* p0 = gsel((needs & PN_DOFPOS) != 0, uni(a.dof_pos), ro);
-        const GF_GLOBAL float* p1 = gsel((needs & PN_DOFVEL) != 0, uni(a.dof_vel), ro);
-        const float* k_def = uni(a.default_dof_pos);
-        const GF_GLOBAL float* p2 = gsel(k_def != nullptr, k_def, 0u);
-#pragma unroll
-        for (int c = 0; c < DV; ++c) { r_a[c] = ldg4(p0 + 4 * c); r_b[c] = ldg4(p1 + 4 * c); r_c[c] = ldg4(p2 + 4 * c); }
-    } else {
-        const GF_GLOBAL float* p0 = gsel((needs & PN_TARGETS) != 0, uni(a.targets), ro);
-        const GF_GLOBAL float* p1 = gsel((needs & PN_ACTIONS) != 0, uni(a.env_actions), ro);
-#pragma unroll
-        for (int c = 0; c < DV; ++c) { r_a[c] = ldg4(p0 + 4 * c); r_b[c] = ldg4(p1 + 4 * c); }
-    }
-    // every load above has landed (registers / LDS) before any wave starts storing state behind the barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-
-    // State that reward terms read straight from memory (commands of other views, air-time) is stored by the reward wave
-    // itself, after its term fold; without a reward manager the control wave stores it.
-    const int state_writer = has_reward ? 1 : 0;
-
-    const bool done = xch[X_DONE * kEnvBlock + lane] != 0.f;
-    const unsigned long long done_mask = __ballot(done);
-    const int scene_reset = uni(a.scene_reset), zero_velocity = uni(a.zero_velocity), reset_env = uni(a.reset_env);
-
-    if (wave == 0) {
-        // ---- control: stores --------------------------------------------------------------------------------------------------
-        if (live) {
-            G(uni(a.terminated))[n_raw] = (uint8_t)term;
-            G(uni(a.truncated))[n_raw] = (uint8_t)trunc;
-        }
-        if (shard && done_mask && lane == 0) atomicAdd(&shard->reset_count, popc64(done_mask));
-        if (done) {
-            if ((reset_env & 1) && a.env_actions) {
-                GF_GLOBAL f32x4* ra = reinterpret_cast<GF_GLOBAL f32x4*>(G(a.env_actions) + n * D);
-                GF_GLOBAL f32x4* rl = reinterpret_cast<GF_GLOBAL f32x4*>(G(a.env_last_actions) + n * D);
-#pragma unroll
-                for (int c = 0; c < DV; ++c) { ra[c] = f32x4{0.f, 0.f, 0.f, 0.f}; rl[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            }
-            if (reset_env & 2) G(a.episode_length)[n] = 0;
-            if (a.max_episode_length && a.max_random_scaling > 0.0f) {
-                const float u = draw_unit4(seed, a.stream_reset, genv, 0u).x;
-                const float rnd = uniform_range(u, -1.0f, 1.0f) * a.max_random_scaling;
-                G(a.max_episode_length)[n] = (int32_t)rintf((float)a.base_max_episode_length + rnd);
-            }
-            if (scene_reset) {
-                GF_GLOBAL float* wp = G(a.pos) + 3 * n;
-                wp[0] = a.reset_pos[0]; wp[1] = a.reset_pos[1]; wp[2] = a.reset_pos[2];
-                if (a.set_quat) {
-                    if (a.quat_stash) reinterpret_cast<GF_GLOBAL f32x4*>(G(a.quat_stash))[n] = f32x4{q.x, q.y, q.z, q.w};
-                    reinterpret_cast<GF_GLOBAL f32x4*>(G(a.quat))[n] = f32x4{a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]};
-                }
-                if (zero_velocity) {
-                    GF_GLOBAL float* wl = G(a.lin_vel) + 3 * n;
-                    GF_GLOBAL float* wa = G(a.ang_vel) + 3 * n;
-                    wl[0] = 0.f; wl[1] = 0.f; wl[2] = 0.f;
-                    wa[0] = 0.f; wa[1] = 0.f; wa[2] = 0.f;
-                }
-            }
-        }
-    } else if (wave == 1) {
-        // ---- reward: the term fold (reward_manager.py:166-195) + the manager's reset folded into the sum update -----------------
-        if (has_reward) {
-            RewardRegs rr;
-            rr.pos = pos;
-            rr.blin = V3{xch[(X_BLIN + 0) * kEnvBlock + lane], xch[(X_BLIN + 1) * kEnvBlock + lane], xch[(X_BLIN + 2) * kEnvBlock + lane]};
-            rr.bang = V3{xch[(X_BANG + 0) * kEnvBlock + lane], xch[(X_BANG + 1) * kEnvBlock + lane], xch[(X_BANG + 2) * kEnvBlock + lane]};
-            rr.grav = V3{xch[(X_GRAV + 0) * kEnvBlock + lane], xch[(X_GRAV + 1) * kEnvBlock + lane], xch[(X_GRAV + 2) * kEnvBlock + lane]};
-            rr.dof_dev = dof_dev; rr.act_rate = act_rate; rr.terminated = xch[X_TERM * kEnvBlock + lane] != 0.f ? 1 : 0;
-            rr.cmd0[0] = cmd0[0]; rr.cmd0[1] = cmd0[1]; rr.cmd0[2] = cmd0[2];
-            rr.n = n; rr.live = live;
-            const float dt = uni(a.dt);
-            const uint32_t log_mask = uni(a.reward_log_mask);
-            const float secs_new = secs_in + dt;
-            float buf = 0.f;
-            const bool log_reset = logging && done_mask != 0;
-            for (int k = 0; k < n_rew; ++k) {
-                const GfTerm t = a.rterms[k];
-                float v = eval_reward_term(t, a, rr);
-                v = v * t.w;
-                buf += v;
-                if (logging) {
-                    float s = lds_sums[k * kEnvBlock + lane] + v;
-                    if (log_reset) {
-                        const float per_sec = done ? s / secs_new : 0.f;
-                        if (shard && (log_mask & (1u << t.row))) {
-                            if (popc64(done_mask) > 4) {
-                                const double w = wave_sum((double)per_sec);
-                                if (lane == 0) unsafeAtomicAdd(&shard->reward_episode_sum[t.row], w);
-                            } else if (done) {
-                                unsafeAtomicAdd(&shard->reward_episode_sum[t.row], (double)per_sec);
-                            }
-                        }
-                        if (done) s = 0.f;
-                    }
-                    if (live) G(k_sums)[(int64_t)t.row * N + n_raw] = s;
-                }
-            }
-            if (live) {
-                G(k_reward)[n_raw] = buf;
-                G(uni(a.episode_seconds))[n_raw] = done ? 1e-10f : secs_new;
-            }
-            if (done && logging)
-                for (int row = 0; row < a.reward_rows; ++row)
-                    if (a.uncovered_rows & (1u << row)) G(k_sums)[(int64_t)row * N + n_raw] = 0.f;
-        }
-    } else if (wave == 2) {
-        // ---- DOF reset of done envs: memory and the registers the observation reads (position_action_manager.py:455-464) --------
-        if (done) {
-            float* const k_dvel = uni(a.dof_vel);
-            if (uni(a.reset_dofs)) {
-                const float dof_noise = a.dof_noise_scale;
-                if (dof_noise != 0.0f) {
-#pragma nounroll
-                    for (int c = 0; c < DV; ++c) {
-                        const float4 r4 = draw_unit4(seed, a.stream_reset, genv, (uint32_t)(1 + c));
-                        float* sc = lds_aux + (4 * c) * kEnvBlock + lane;
-                        sc[0 * kEnvBlock] = uniform_range(r4.x, -1.0f, 1.0f) * dof_noise;
-                        sc[1 * kEnvBlock] = uniform_range(r4.y, -1.0f, 1.0f) * dof_noise;
-                        sc[2 * kEnvBlock] = uniform_range(r4.z, -1.0f, 1.0f) * dof_noise;
-                        sc[3 * kEnvBlock] = uniform_range(r4.w, -1.0f, 1.0f) * dof_noise;
-                    }
-                }
-                GF_GLOBAL f32x4* dp = reinterpret_cast<GF_GLOBAL f32x4*>(G(a.dof_pos) + n * D);
-                GF_GLOBAL f32x4* dv = reinterpret_cast<GF_GLOBAL f32x4*>(G(k_dvel) + n * D);
-#pragma unroll
-                for (int c = 0; c < DV; ++c) {
-                    float4 p = r_c[c];
-                    if (dof_noise != 0.0f) {
-                        const float* sc = lds_aux + (4 * c) * kEnvBlock + lane;
-                        p.x = p.x + sc[0 * kEnvBlock];
-                        p.y = p.y + sc[1 * kEnvBlock];
-                        p.z = p.z + sc[2 * kEnvBlock];
-                        p.w = p.w + sc[3 * kEnvBlock];
-                    }
-                    r_a[c] = p;
-                    dp[c] = f32x4{p.x, p.y, p.z, p.w};
-                    if (k_dvel) { dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; r_b[c] = z4; }
-                }
-            }
-            if (scene_reset && zero_velocity && k_dvel) {
-                GF_GLOBAL f32x4* dv = reinterpret_cast<GF_GLOBAL f32x4*>(G(k_dvel) + n * D);
-#pragma unroll
-                for (int c = 0; c < DV; ++c) { dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; r_b[c] = z4; }
-            }
-        }
-    } else {
-        if (done && (reset_env & 1) && a.env_actions) {
-#pragma unroll
-            for (int c = 0; c < DV; ++c) r_b[c] = z4;  // raw actions of a reset env read as zero
-        }
-    }
-    if (wave == state_writer) {
-        const int dirty = (int)xch[X_DIRTY * kEnvBlock + lane];
-#pragma unroll
-        for (int c = 0; c < GF_POST_MAX_CMD; ++c) {
-            if (c < n_cmd && (dirty & (1 << c)) && live) {
-                const PostCmd cm = a.cmds[c];
-                GF_GLOBAL float* crow = G(cm.command) + n * cm.width;
-#pragma unroll
-                for (int j = 0; j < kPostMaxRanges; ++j)
-                    if (j < cm.width) crow[j] = xch[(X_CMD + c * kPostMaxRanges + j) * kEnvBlock + lane];
-            }
-        }
-        if (done) {
-            for (int m = 0; m < a.n_air; ++m) {
-                const int L = a.air_links[m];
-                for (int s = 0; s < 4; ++s) {
-                    GF_GLOBAL float* p = G(a.air_state[m][s]);
-                    if (p)
-                        for (int l = 0; l < L; ++l) p[n * L + l] = 0.0f;
-                }
-            }
-        }
-    }
-
-    // ---- observations: waves 2 and 3 assemble the tile, all four stream it out ---------------------------------------------------
-    for (int m = 0; m < n_obs; ++m) {
-        const PostObs& ob = a.obs[m];
-        const int O = uni(ob.width), S = O + 1, H = uni(ob.history), n_items = uni(ob.num_items);
-        float* const ob_out = uni(ob.obs);
-        const float* const ob_prev = uni(ob.prev);
-        const uint64_t ob_stream = uni(ob.stream);
-        if (wave >= 2) {
-            float* row = tile + lane * S;
-            const bool zeroed = done && scene_reset && zero_velocity;
-            int col = 0;
-            for (int i = 0; i < n_items; ++i) {
-                const GfObsItem it = ob.items[i];
-                const int op = uni(it.op), it_w = uni(it.width);
-                const float it_scale = uni(it.scale), it_noise = uni(it.noise);
-                const ObsFin f{it_scale, it_scale != 1.0f};
-                const bool row_item = op == GF_O_DOF_POS || op == GF_O_DOF_VEL;
-                if (row_item == (wave == 2)) {
-                    switch (op) {
-                        case GF_O_DOF_POS: put_row<DV>(f, r_a, row, col); break;
-                        case GF_O_DOF_VEL: put_row<DV>(f, r_b, row, col); break;
-                        case GF_O_ACTIONS: put_row<DV>(f, r_a, row, col); break;
-                        case GF_O_RAW_ACTIONS: put_row<DV>(f, r_b, row, col); break;
-                        case GF_O_COMMAND: {
-                            const int owner = a.cmd_of_view[it.i0];
-                            if (owner >= 0) {
-#pragma unroll
-                                for (int j = 0; j < kPostMaxRanges; ++j)
-                                    if (j < it_w) row[col + j] = obs_finish(f, xch[(X_CMD + owner * kPostMaxRanges + j) * kEnvBlock + lane], col + j);
-                            } else {
-                                const GfCommandView cv = a.command[it.i0];
-                                for (int j = 0; j < it_w; ++j) row[col + j] = obs_finish(f, G(cv.command)[n * cv.width + j], col + j);
-                            }
-                        } break;
-                        case GF_O_ANG_VEL_BODY:
-                        case GF_O_LIN_VEL_BODY:
-                        case GF_O_PROJ_GRAVITY: {
-                            const int base = op == GF_O_ANG_VEL_BODY ? X_BANG : (op == GF_O_LIN_VEL_BODY ? X_BLIN : X_GRAV);
-                            const bool z = zeroed && op != GF_O_PROJ_GRAVITY;  // rot_inv(q, 0) is exactly +0
-                            row[col + 0] = obs_finish(f, z ? 0.f : xch[(base + 0) * kEnvBlock + lane], col + 0);
-                            row[col + 1] = obs_finish(f, z ? 0.f : xch[(base + 1) * kEnvBlock + lane], col + 1);
-                            row[col + 2] = obs_finish(f, z ? 0.f : xch[(base + 2) * kEnvBlock + lane], col + 2);
-                        } break;
-                        case GF_O_DOF_FORCE: {
-                            const GF_GLOBAL float* r = G(a.dof_force) + n * D;
-                            for (int j = 0; j < it_w; ++j) row[col + j] = obs_finish(f, r[j], col + j);
-                        } break;
-                        case GF_O_CONTACT_FORCE_NORM: {
-                            const GfContactView cv = a.contact[it.i0];
-                            const GF_GLOBAL float* r = G(cv.contacts) + n * cv.num_links * 3;
-                            for (int l = 0; l < it_w; ++l) row[col + l] = obs_finish(f, norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]), col + l);
-                        } break;
-                        default: break;
-                    }
-                    if (it_noise != 0.0f) {
-#pragma nounroll
-                        for (int j = 0; j < it_w; ++j) {
-                            const uint32_t cj = (uint32_t)(col + j);
-                            const float4 u4 = draw_unit4(seed, ob_stream, genv, cj >> 2);
-                            const uint32_t sel = cj & 3u;
-                            const float u = sel == 0 ? u4.x : (sel == 1 ? u4.y : (sel == 2 ? u4.z : u4.w));
-                            row[col + j] = row[col + j] + uniform_range(u, -1.0f, 1.0f) * it_noise;
-                        }
-                    }
-                }
-                col += it_w;
-            }
-        }
-        __syncthreads();
-        {
-            const int rows = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
-            const int64_t OH = (int64_t)O * H;
-            GF_GLOBAL float* out = G(ob_out) + n0 * OH;
-            const int t = threadIdx.x;
-            if ((O & 3) == 0) {
-                const int o4 = O >> 2;
-                const int qstep = kWsBlock / o4, rstep = kWsBlock - qstep * o4;
-                int rw = t / o4, c4 = t - rw * o4;
-                for (int i = t; i < rows * o4; i += kWsBlock) {
-                    const float* r = tile + rw * S + c4 * 4;
-                    reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OH)[c4] = f32x4{r[0], r[1], r[2], r[3]};
-                    rw += qstep; c4 += rstep;
-                    if (c4 >= o4) { c4 -= o4; ++rw; }
-                }
-                if (H > 1) {
-                    const int h4 = (O * (H - 1)) >> 2;
-                    const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
-                    for (int i = t; i < rows * h4; i += kWsBlock) {
-                        const int rw2 = i / h4, j = i - rw2 * h4;
-                        reinterpret_cast<GF_GLOBAL f32x4*>(out + rw2 * OH + O)[j] = reinterpret_cast<const GF_GLOBAL f32x4*>(prev + rw2 * OH)[j];
-                    }
-                }
-            } else {
-                for (int i = t; i < rows * O; i += kWsBlock) {
-                    const int rw = i / O, cc = i - rw * O;
-                    out[rw * OH + cc] = tile[rw * S + cc];
-                }
-                if (H > 1) {
-                    const int hw = O * (H - 1);
-                    const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
-                    for (int i = t; i < rows * hw; i += kWsBlock) {
-                        const int rw = i / hw, j = i - rw * hw;
-                        out[rw * OH + O + j] = prev[rw * OH + j];
-                    }
-                }
-            }
-        }
-        if (m + 1 < n_obs) __syncthreads();  // the tile is reused by the next observation manager
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // Host side: validate that the per-phase descriptors describe one fusable step and pack them.
 // ------------------------------------------------------------------------------------------------------------
 static int cmd_slot_of_reward_op(int op) {
@@ -1405,6 +795,38 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_check(cons
     return gf::pack(r, pk);
 }
 
+static size_t lds_ws_floats(int omax) {
+    return (size_t)(gf::X_FIELDS + gf::kPostMaxReward + gf::kPostAuxRows) * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock;
+}
+
+// Static programs in registration order; program id = 1 + index (0 = table interpreter).
+#define GF_POST_PROGRAMS(X) X(1, gf::ProgGo2CommandDirection)
+
+static int select_program(const gf::GfPostArgs& a) {
+    if (gf::g_options[GF_OPT_POST_VARIANT] < 2) return 0;
+#define GF_MATCH(id, P) \
+    if (gf::program_matches<P>(a)) return id;
+    GF_POST_PROGRAMS(GF_MATCH)
+#undef GF_MATCH
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int gf_post_physics_describe(const GfPostRefs* r, char* buf, int cap) {
+    gf::Packer pk;
+    const int rc = gf::pack(r, pk);
+    if (rc) return rc;
+    if (!buf || cap <= 0) return GF_E_NULL;
+    const int id = select_program(pk.a);
+    const char* name = "interpreter";
+#define GF_NAME(pid, P) \
+    if (id == pid) name = P::name;
+    GF_POST_PROGRAMS(GF_NAME)
+#undef GF_NAME
+    int n = snprintf(buf, (size_t)cap, "program %d (%s): ", id, name);
+    if (n < cap) gf::describe_program(pk.a, buf + n, cap - n);
+    return GF_OK;
+}
+
 extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const GfPostRefs* r, void* stream) {
     gf::Packer pk;
     const int rc = gf::pack(r, pk);
@@ -1423,10 +845,16 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     if (gf::g_options[GF_OPT_POST_VARIANT] == 0) {
         if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid, gf::kEnvBlock, lds, s, a);
         else GF_LAUNCH(scope, gf::post_kernel<3>, grid, gf::kEnvBlock, lds, s, a);
+    } else if (const int prog = select_program(a)) {
+        const size_t lds_st = lds_ws_floats(omax) * sizeof(float);
+#define GF_RUN(id, P) \
+        if (prog == id) GF_LAUNCH(scope, gf::post_ws_kernel<P>, grid, gf::kWsBlock, lds_st, s, a);
+        GF_POST_PROGRAMS(GF_RUN)
+#undef GF_RUN
     } else {
-        const size_t lds_ws = lds + (size_t)gf::X_FIELDS * gf::kEnvBlock * sizeof(float);
-        if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_ws_kernel<7>, grid, gf::kWsBlock, lds_ws, s, a);
-        else GF_LAUNCH(scope, gf::post_ws_kernel<3>, grid, gf::kWsBlock, lds_ws, s, a);
+        const size_t lds_ws = sizeof(gf::GfPostArgs) + lds_ws_floats(omax) * sizeof(float);
+        if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<7>>, grid, gf::kWsBlock, lds_ws, s, a);
+        else GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<3>>, grid, gf::kWsBlock, lds_ws, s, a);
     }
     return gf::launch_status();
 }

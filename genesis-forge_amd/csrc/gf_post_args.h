@@ -1,0 +1,159 @@
+// gf_post_args.h — packed descriptor of the fused post-physics launch and the small device helpers its kernels share
+// (gf_post.hip: single-wave interpreter; gf_post_ws.h: wave-specialised interpreter and the static programs).
+#pragma once
+
+#include "gf_launch.h"
+#include "gf_terms.h"
+
+// Diagnostic build only (tools/stamp_post.hip, -DGF_STAMPS): lane 0 of one workgroup records the 100 MHz wall
+// clock at the phase boundaries into a buffer of its own; no product build contains a stamp.
+#ifdef GF_STAMPS
+extern "C" unsigned long long* gf_debug_stamps;  // host variable set by the tool
+#define GF_STAMP(i)                                                                                          \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (a.stamps && blockIdx.x == a.stamp_block && threadIdx.x == 0) {                                   \
+            a.stamps[i] = __builtin_amdgcn_s_memrealtime();                                                  \
+            a.stamps[16 + i] = __builtin_amdgcn_s_memtime();                                                 \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+// per-wave stamps of the wave-specialised kernel: stamps[64 + 16*wave + i]
+#define GF_WSTAMP(i)                                                                                         \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (a.stamps && blockIdx.x == a.stamp_block && (threadIdx.x & 63) == 0)                              \
+            a.stamps[64 + 16 * (threadIdx.x >> 6) + i] = __builtin_amdgcn_s_memrealtime();                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+#else
+#define GF_STAMP(i)
+#define GF_WSTAMP(i)
+#endif
+
+namespace gf {
+
+constexpr int kPostMaxTerm = 8;
+constexpr int kPostMaxReward = 16;
+constexpr int kPostAuxRows = 32;  // per-lane scratch rows: 4 per float4 chunk of a DOF row, up to D = 28
+constexpr int kPostMaxItems = 12;
+constexpr int kPostMaxRanges = 4;
+
+struct PostCmd {
+    float* command;
+    int32_t width;
+    int32_t resample_steps;
+    uint64_t stream_step;
+    uint64_t stream_reset;
+    float lo[kPostMaxRanges];
+    float hi[kPostMaxRanges];
+};
+
+struct PostObs {
+    float* obs;
+    const float* prev;
+    uint64_t stream;
+    int32_t num_items;
+    int32_t width;
+    int32_t history;
+    int32_t _pad;
+    GfObsItem items[kPostMaxItems];
+};
+
+struct alignas(16) GfPostArgs {
+    int32_t num_envs, num_dofs, num_term, num_rew;
+    uint32_t needs;
+    int32_t n_cmd, n_obs, logging;
+    float dt;
+    int32_t reward_rows;
+    uint32_t reward_log_mask;
+    uint32_t uncovered_rows;   // rows of episode_sums no active term owns (zero weight): still zeroed on reset
+    uint64_t seed;
+    uint32_t env_offset;
+    int32_t has_maxlen;
+    // state
+    float *pos, *quat, *lin_vel, *ang_vel;       // entity views (writable: scene-side reset)
+    float *dof_pos, *dof_vel;
+    const float *dof_force, *targets, *default_dof_pos;
+    float *env_actions, *env_last_actions;
+    int32_t *episode_length, *max_episode_length;
+    uint8_t *terminated, *truncated;
+    float *reward, *episode_sums, *episode_seconds;
+    GfStepStats* stats;
+    float* quat_stash;
+    // views shared by every phase (slot indices in the copied terms/items are remapped onto these)
+    GfContactView contact[GF_MAX_CONTACT_VIEWS];
+    GfCommandView command[GF_MAX_COMMAND_VIEWS];
+    int32_t cmd_of_view[GF_MAX_COMMAND_VIEWS];   // index into cmds[] of the manager that owns the view's buffer, or -1
+    const float* ext[1];
+    float* state[4];
+    // reset
+    int32_t scene_reset, set_quat, zero_velocity, reset_env /* bit0: actions rows, bit1: episode_length */, reset_dofs;
+    int32_t base_max_episode_length;
+    float max_random_scaling, dof_noise_scale;
+    float reset_pos[3], reset_quat[4];
+    uint64_t stream_reset;
+    float* air_state[GF_MAX_CONTACT_VIEWS][4];
+    int32_t air_links[GF_MAX_CONTACT_VIEWS];
+    int32_t n_air;
+    int32_t _pad0;
+    GfTerm tterms[kPostMaxTerm];
+    GfTerm rterms[kPostMaxReward];
+    PostCmd cmds[GF_POST_MAX_CMD];
+    PostObs obs[GF_POST_MAX_OBS];
+#ifdef GF_STAMPS
+    unsigned long long* stamps;
+    uint32_t stamp_block;
+#endif
+};
+static_assert(sizeof(GfPostArgs) <= 4096, "GfPostArgs must fit the 4 KB kernarg segment");
+
+enum : uint32_t {
+    PN_POS = 1, PN_QUAT = 2, PN_LIN = 4, PN_ANG = 8, PN_DOFPOS = 16, PN_DOFVEL = 32, PN_TARGETS = 64, PN_ACTIONS = 128, PN_LAST = 256,
+    PN_EPLEN = 512, PN_MAXLEN = 1024, PN_DOFDEV = 2048, PN_ACTRATE = 4096, PN_DOFFORCE = 8192,
+};
+
+// scale / noise of one observation element (observation_manager.py:242-250); everything it needs arrives by value
+struct ObsFin {
+    float scale;
+    bool scaled;
+};
+__device__ __forceinline__ float obs_finish(const ObsFin& f, float v, int) { return f.scaled ? v * f.scale : v; }
+
+// All ≤ 4 range draws of one command resample come out of ONE Philox block (columns 0..3 share counter col>>2 == 0),
+// exactly the values philox_uniform(seed, stream, env, j) returns for j = 0..3.
+// (register-only signature: a real call, no stack, so the rarely-taken resample paths cost one Philox body in the binary)
+__device__ __noinline__ float4 draw_unit4(uint64_t seed, uint64_t stream, uint32_t genv, uint32_t block) {
+    const U4 r = philox4x32_10(genv, block, (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+    return make_float4(u24_to_unit(r.x), u24_to_unit(r.y), u24_to_unit(r.z), u24_to_unit(r.w));
+}
+
+// one [D] row of registers → the lane's observation tile row (separate call per source keeps every index static)
+template <int DV>
+__device__ __forceinline__ void put_row(const ObsFin& f, const float4 (&r)[DV], float* row, int col) {
+#pragma unroll
+    for (int c = 0; c < DV; ++c) {
+        row[col + 4 * c + 0] = obs_finish(f, r[c].x, col + 4 * c + 0);
+        row[col + 4 * c + 1] = obs_finish(f, r[c].y, col + 4 * c + 1);
+        row[col + 4 * c + 2] = obs_finish(f, r[c].z, col + 4 * c + 2);
+        row[col + 4 * c + 3] = obs_finish(f, r[c].w, col + 4 * c + 3);
+    }
+}
+
+// wave-uniform value that lives in a VGPR (read from the LDS-staged descriptor) → SGPR
+template <typename T>
+__device__ __forceinline__ T uni(T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "uni: 4- or 8-byte types");
+    if constexpr (sizeof(T) == 4) {
+        uint32_t u = __builtin_bit_cast(uint32_t, v);
+        u = __builtin_amdgcn_readfirstlane(u);
+        return __builtin_bit_cast(T, u);
+    } else {
+        uint64_t u = __builtin_bit_cast(uint64_t, v);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        u = ((uint64_t)hi << 32) | lo;
+        return __builtin_bit_cast(T, u);
+    }
+}
+
+}  // namespace gf

@@ -1,0 +1,95 @@
+// gf_post_programs.h — static programs of the fused post-physics kernel (see gf_post_ws.h, point 2).
+//
+// A program pins the STRUCTURE of one task configuration: the opcode sequence of the termination and reward tables with the
+// flags / view slots that select code paths, the command widths and the observation layout.  Numbers (weights, thresholds,
+// ranges, scales, rows, pointers, sizes, seeds) stay run-time kernel arguments.  program_matches<P>() compares a packed
+// descriptor against the signature field by field; only an exact match launches post_ws_kernel<P>, anything else runs the
+// table interpreter.  gf_post_physics_describe() prints a packed descriptor in exactly this notation, so registering a new
+// task is: run it once, paste the printed struct here, add it to GF_POST_PROGRAMS.
+#pragma once
+
+#include "gf_post_ws.h"
+
+namespace gf {
+
+// examples/command_direction (Go2, 12 DOF): genesis-forge's headline locomotion task and BASELINE.json's benchmark config
+struct ProgGo2CommandDirection {
+    static constexpr bool kStatic = true;
+    static constexpr const char* name = "go2_command_direction";
+    static constexpr int DV = 3;
+    static constexpr int n_term = 2;
+    static constexpr TermSig term[n_term] = {{GF_T_TIMEOUT, GF_TERM_FLAG_TIME_OUT}, {GF_T_BAD_ORIENTATION, 0}};
+    static constexpr int n_rew = 6;
+    static constexpr RewSig rew[n_rew] = {{GF_R_BASE_HEIGHT, 0, 0, 0},       {GF_R_CMD_TRACK_LIN_VEL, 0, 0, 0}, {GF_R_CMD_TRACK_ANG_VEL, 0, 0, 2},
+                                          {GF_R_LIN_VEL_Z_L2, 0, 0, 0},      {GF_R_ACTION_RATE_L2, 0, 0, 0},    {GF_R_DOF_SIMILAR_TO_DEFAULT, 0, 0, 0}};
+    static constexpr int n_cmd = 1;
+    static constexpr int cmd_width[GF_POST_MAX_CMD] = {3, 0};
+    static constexpr int n_obs = 1;
+    static constexpr int obs_width[GF_POST_MAX_OBS] = {48, 0};
+    static constexpr int obs_history[GF_POST_MAX_OBS] = {1, 0};
+    static constexpr int obs_items[GF_POST_MAX_OBS] = {7, 0};
+    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {{{GF_O_COMMAND, 3, 0, false, false},
+                                                                      {GF_O_ANG_VEL_BODY, 3, 0, false, false},
+                                                                      {GF_O_LIN_VEL_BODY, 3, 0, false, false},
+                                                                      {GF_O_PROJ_GRAVITY, 3, 0, false, false},
+                                                                      {GF_O_DOF_POS, 12, 0, false, false},
+                                                                      {GF_O_DOF_VEL, 12, 0, true, false},
+                                                                      {GF_O_ACTIONS, 12, 0, false, false}},
+                                                                     {}};
+    static constexpr int n_air = 0;
+};
+
+// ---- matching -------------------------------------------------------------------------------------------------------------------
+template <class P>
+bool program_matches(const GfPostArgs& a) {
+    if (a.num_dofs != 4 * P::DV || a.num_term != P::n_term || a.num_rew != P::n_rew || a.n_cmd != P::n_cmd || a.n_obs != P::n_obs || a.n_air != P::n_air)
+        return false;
+    for (int k = 0; k < P::n_term; ++k)
+        if (a.tterms[k].op != P::term[k].op || a.tterms[k].flags != P::term[k].flags) return false;
+    for (int k = 0; k < P::n_rew; ++k) {
+        const GfTerm& t = a.rterms[k];
+        if (t.op != P::rew[k].op || t.flags != P::rew[k].flags || t.i[0] != P::rew[k].i0 || t.i[1] != P::rew[k].i1) return false;
+    }
+    for (int c = 0; c < P::n_cmd; ++c)
+        if (a.cmds[c].width != P::cmd_width[c]) return false;
+    for (int m = 0; m < P::n_obs; ++m) {
+        const PostObs& ob = a.obs[m];
+        if (ob.width != P::obs_width[m] || ob.history != P::obs_history[m] || ob.num_items != P::obs_items[m]) return false;
+        for (int i = 0; i < P::obs_items[m]; ++i) {
+            const GfObsItem& it = ob.items[i];
+            const ItemSig& sg = P::item[m][i];
+            if (it.op != sg.op || it.width != sg.width || it.i0 != sg.i0 || (it.scale != 1.0f) != sg.scaled || (it.noise != 0.0f) != sg.noisy) return false;
+        }
+    }
+    return true;
+}
+
+// prints the signature of a packed descriptor as a program struct (the notation above)
+inline int describe_program(const GfPostArgs& a, char* buf, int cap) {
+    int n = 0;
+    auto put = [&](const char* fmt, auto... v) {
+        if (n < cap) {
+            const int w = snprintf(buf + n, (size_t)(cap - n), fmt, v...);
+            n += w > 0 ? w : 0;
+        }
+    };
+    put("DV = %d; n_term = %d; term = {", a.num_dofs / 4, a.num_term);
+    for (int k = 0; k < a.num_term; ++k) put("{%d, %d}%s", a.tterms[k].op, a.tterms[k].flags, k + 1 < a.num_term ? ", " : "");
+    put("}; n_rew = %d; rew = {", a.num_rew);
+    for (int k = 0; k < a.num_rew; ++k) put("{%d, %d, %d, %d}%s", a.rterms[k].op, a.rterms[k].flags, a.rterms[k].i[0], a.rterms[k].i[1], k + 1 < a.num_rew ? ", " : "");
+    put("}; n_cmd = %d; cmd_width = {", a.n_cmd);
+    for (int c = 0; c < a.n_cmd; ++c) put("%d%s", a.cmds[c].width, c + 1 < a.n_cmd ? ", " : "");
+    put("}; n_obs = %d;", a.n_obs);
+    for (int m = 0; m < a.n_obs; ++m) {
+        put(" obs[%d]: width %d history %d items {", m, a.obs[m].width, a.obs[m].history);
+        for (int i = 0; i < a.obs[m].num_items; ++i) {
+            const GfObsItem& it = a.obs[m].items[i];
+            put("{%d, %d, %d, %s, %s}%s", it.op, it.width, it.i0, it.scale != 1.0f ? "true" : "false", it.noise != 0.0f ? "true" : "false", i + 1 < a.obs[m].num_items ? ", " : "");
+        }
+        put("%s", "};");
+    }
+    put(" n_air = %d", a.n_air);
+    return n;
+}
+
+}  // namespace gf

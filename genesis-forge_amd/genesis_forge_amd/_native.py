@@ -79,7 +79,7 @@ GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
 (GF_PHASE_ACTION, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
  GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_COUNT) = range(11)
 
-GF_OPT_POST_VARIANT = 0  # gf_set_option: 0 = one wave per tile, 1 = four specialised waves per tile (default)
+GF_OPT_POST_VARIANT = 0  # gf_set_option: 0 = interpreter, one wave per tile; 1 = interpreter, four waves; 2 = + static programs (default)
 
 GF_ERRORS = {-1: "GF_E_NULL", -2: "GF_E_RANGE", -3: "GF_E_OPCODE", -4: "GF_E_SLOT", -5: "GF_E_UNSUPPORTED"}
 
@@ -342,6 +342,8 @@ class HipBackend(Backend):
         self.lib.gf_stats_pack.argtypes = [C.POINTER(GfStatsPackArgs), C.c_void_p]
         self.lib.gf_post_physics_check.restype = C.c_int
         self.lib.gf_post_physics_check.argtypes = [C.POINTER(GfPostRefs)]
+        self.lib.gf_post_physics_describe.restype = C.c_int
+        self.lib.gf_post_physics_describe.argtypes = [C.POINTER(GfPostRefs), C.c_char_p, C.c_int]
         self.lib.gf_event_create.restype = C.c_void_p
         self.lib.gf_event_synchronize.restype = C.c_int
         self.lib.gf_event_synchronize.argtypes = [C.c_void_p]
@@ -380,6 +382,13 @@ class HipBackend(Backend):
 
     def post_check(self, refs) -> bool:
         return self.lib.gf_post_physics_check(C.byref(refs)) == 0
+
+    def post_describe(self, refs) -> str:
+        buf = C.create_string_buffer(4096)
+        rc = self.lib.gf_post_physics_describe(C.byref(refs), buf, len(buf))
+        if rc != 0:
+            self._raise("post_physics_describe", rc)
+        return buf.value.decode()
 
     def stats_pack(self, src_ptr: int, dst_ptr: int) -> None:
         a = GfStatsPackArgs()

@@ -447,8 +447,10 @@ typedef struct GfSynthSceneArgs {
  * Entry points.  `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream).
  * ---------------------------------------------------------------------------------------- */
 int gf_abi_version(void);
-/* library-wide tuning switches (process global).  GF_OPT_POST_VARIANT: 0 = one wave per 64-env tile, 1 = four
- * specialised waves per tile (default).  Both variants produce bit-identical results. */
+/* library-wide tuning switches (process global).  GF_OPT_POST_VARIANT selects the fused post-physics kernel:
+ * 0 = table interpreter, one wave per 64-env tile; 1 = table interpreter, four specialised waves per tile;
+ * 2 = (default) as 1, plus the static programs: a config whose structure matches a registered program runs
+ * straight-line code compiled for it.  All variants produce bit-identical results. */
 enum { GF_OPT_POST_VARIANT = 0, GF_OPT_COUNT = 4 };
 int gf_set_option(int option, int value);
 int gf_sizeof(int which);   /* sizeof of the ABI structs, in header order (0 = GfStepStats … 11 = GfObsItem): binding self-check */
@@ -495,6 +497,10 @@ typedef struct GfPostRefs {
 
 int gf_post_physics_check(const GfPostRefs* r);               /* GF_OK if gf_post_physics_step can fuse this combination */
 int gf_post_physics_step(const GfPostRefs* r, void* stream);  /* replaces managed_env.py:303-326 in one launch */
+/* Writes "program <id> (<name>): <structure signature>" for this combination into buf: which kernel
+ * gf_post_physics_step would launch (id 0 = table interpreter, >0 = a static program compiled for exactly this
+ * structure) and the signature in the notation of csrc/gf_post_programs.h.  Host-only, no GPU needed. */
+int gf_post_physics_describe(const GfPostRefs* r, char* buf, int cap);
 
 /* ------------------------------------------------------------------------------------------
  * Recorded step: the fixed launch sequence of one ManagedEnvironment.step() replayed with a single

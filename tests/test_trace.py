@@ -84,22 +84,24 @@ def test_traced_step_equals_ordinary_hip(hip_backend):
 
 @pytest.fixture
 def post_variant(hip_backend, request):
-    """Selects the fused kernel's variant (0 = one wave per tile, 1 = four specialised waves) for one test."""
+    """Selects the fused kernel's variant (0 = interpreter, one wave per tile; 1 = interpreter, four specialised waves;
+    2 = static programs where the config matches one) for one test."""
     from genesis_forge_amd import _native as nat
 
     hip_backend.set_option(nat.GF_OPT_POST_VARIANT, request.param)
     yield request.param
-    hip_backend.set_option(nat.GF_OPT_POST_VARIANT, 1)
+    hip_backend.set_option(nat.GF_OPT_POST_VARIANT, 2)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("post_variant", [0, 1], indirect=True)
+@pytest.mark.parametrize("post_variant,obs_noise", [(0, True), (1, True), (2, True), (2, False)], indirect=["post_variant"])
 @pytest.mark.parametrize("n", [1, 65, 4096])
-def test_fused_post_physics_equals_phase_by_phase_hip(hip_backend, post_variant, n):
-    """gf_post_physics_step (one launch) against the same recorded step replayed phase by phase."""
+def test_fused_post_physics_equals_phase_by_phase_hip(hip_backend, post_variant, obs_noise, n):
+    """gf_post_physics_step (one launch) against the same recorded step replayed phase by phase.  Without observation noise
+    this is the structure of examples/command_direction, which variant 2 runs as a static program."""
     outs = []
     for fuse in (False, True):
-        env = Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, obs_noise=True, scene_kwargs=dict(ang_noise=0.3, seed=11))
+        env = Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, obs_noise=obs_noise, scene_kwargs=dict(ang_noise=0.3, seed=11))
         env.fuse_post_physics = fuse
         env.build()
         env.seed(77)
@@ -112,6 +114,9 @@ def test_fused_post_physics_equals_phase_by_phase_hip(hip_backend, post_variant,
                         env.velocity_command._command.cpu().clone(), env.episode_length.cpu().clone(), env.max_episode_length.cpu().clone(),
                         env.reward_manager._episode_sums.cpu().clone(), env.robot.dof_pos.cpu().clone(), env.robot.quat.cpu().clone()))
         assert env._trace is not None and (env._trace.post_refs is not None) == fuse
+        if fuse:
+            static = post_variant == 2 and not obs_noise
+            assert hip_backend.post_describe(env._trace.post_refs).startswith("program 1 (go2_command_direction)" if static else "program 0 (interpreter)")
         outs.append(seq)
     for t, (x, y) in enumerate(zip(*outs)):
         for k in (0, 1, 2, 3, 5, 6, 7, 8, 9, 10):
@@ -160,7 +165,7 @@ def test_humanoid_config_traced_equals_ordinary_cpu(oracle_backend, dofs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("post_variant", [0, 1], indirect=True)
+@pytest.mark.parametrize("post_variant", [0, 1, 2], indirect=True)
 @pytest.mark.parametrize("dofs,n", [(12, 200), (28, 200), (28, 1), (12, 4097)])
 def test_humanoid_config_fused_hip(hip_backend, post_variant, dofs, n):
     """Two command managers, two observation managers, three contact managers, 13 reward terms, D=28 variant."""
@@ -171,3 +176,22 @@ def test_humanoid_config_fused_hip(hip_backend, post_variant, dofs, n):
     assert env_c._trace is not None and env_c._trace.post_refs is not None, "this config must take the fused kernel"
     _same_h(a, b)
     _same_h(a, c)
+
+
+def test_static_program_selection_is_host_side(oracle_backend):
+    """gf_post_physics_describe needs no GPU: the command_direction structure selects the static program, any structural change
+    (here: observation noise, a history ring) falls back to the table interpreter."""
+    from genesis_forge_amd import _native as nat
+
+    hip = nat.HipBackend()  # loads libgf_step.so; describe() is host-only
+    for kwargs, want in ((dict(), "program 1 (go2_command_direction)"), (dict(obs_noise=True), "program 0 (interpreter)"),
+                         (dict(history=2), "program 0 (interpreter)")):
+        env = Go2CommandDirectionEnv(num_envs=8, **kwargs)
+        env.build()
+        env.reset()
+        for _ in range(3):
+            env.step(torch.zeros(8, 12))
+        assert env._trace is not None and env._trace.post_refs is not None
+        text = hip.post_describe(env._trace.post_refs)
+        assert text.startswith(want), text
+        assert "n_rew = 6" in text

@@ -180,6 +180,11 @@ int main(int argc, char** argv) {
             time_loop("gf_post_physics_step (1 wave)", iters, 566.0 * Nd, [&] { chk(gf_post_physics_step(&pr, 0), "post"); });
             gf_set_option(GF_OPT_POST_VARIANT, 1);
             time_loop("gf_post_physics_step (4 waves)", iters, 566.0 * Nd, [&] { chk(gf_post_physics_step(&pr, 0), "post"); });
+            gf_set_option(GF_OPT_POST_VARIANT, 2);
+            char what[2048];
+            gf_post_physics_describe(&pr, what, sizeof(what));
+            printf("%s\n", what);
+            time_loop("gf_post_physics_step (static)", iters, 566.0 * Nd, [&] { chk(gf_post_physics_step(&pr, 0), "post"); });
         }
     }
     int failed = -1;

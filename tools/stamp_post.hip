@@ -177,10 +177,11 @@ int main(int argc, char** argv) {
     {
         const int rc = gf_post_physics_check(&pr);
         printf("gf_post_physics_check: %d (%s)\n", rc, gf_error_string(rc));
+        gf_set_option(GF_OPT_POST_VARIANT, 0);
         if (rc == 0) time_loop("gf_post_physics_step", iters, 566.0 * Nd, [&] { chk(gf_post_physics_step(&pr, 0), "post"); });
     }
     {
-        unsigned long long* st = dalloc<unsigned long long>(32);
+        unsigned long long* st = dalloc<unsigned long long>(128);
         gf_debug_stamps = st;
         for (int rep = 0; rep < 3; ++rep) {
             for (int i = 0; i < 50; ++i) chk(gf_post_physics_step(&pr, 0), "post");
@@ -191,6 +192,22 @@ int main(int argc, char** argv) {
             printf("stamps (us, middle workgroup):");
             for (int i = 1; i < 10; ++i) printf("  %s %.2f", names[i - 1], (double)(h[i] - h[i - 1]) / 100.0);
             printf("  | total %.2f us, %.0f shader cycles -> %.0f MHz\n", (double)(h[9] - h[0]) / 100.0, (double)(h[25] - h[16]), (double)(h[25] - h[16]) / ((double)(h[9] - h[0]) / 100.0));
+        }
+        gf_set_option(GF_OPT_POST_VARIANT, 1);
+        time_loop("gf_post_physics_step (4 waves, stamped)", iters, 566.0 * Nd, [&] { chk(gf_post_physics_step(&pr, 0), "post"); });
+        for (int rep = 0; rep < 3; ++rep) {
+            for (int i = 0; i < 50; ++i) chk(gf_post_physics_step(&pr, 0), "post");
+            CK(hipDeviceSynchronize());
+            unsigned long long h[128];
+            CK(hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull;
+            for (int w = 0; w < 4; ++w) t0 = h[64 + 16 * w + 1] < t0 ? h[64 + 16 * w + 1] : t0;
+            printf("ws stamps (us since first wave had its args; staged | pre-barrier done | past barrier A | role stores | state writer | tile built | past barrier B | end)\n");
+            for (int w = 0; w < 4; ++w) {
+                printf("  wave %d:", w);
+                for (int i = 1; i <= 8; ++i) printf(" %6.2f", (double)(long long)(h[64 + 16 * w + i] - t0) / 100.0);
+                printf("\n");
+            }
         }
         gf_debug_stamps = nullptr;
     }
