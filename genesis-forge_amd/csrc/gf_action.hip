@@ -35,8 +35,13 @@ __global__ __launch_bounds__(256) void action_kernel(const GfActionArgs a, const
         constexpr int kWords = (int)(sizeof(GfStepStats) * GF_STATS_SHARDS / 4);
         for (int64_t w = i; w < kWords; w += (int64_t)gridDim.x * blockDim.x) reinterpret_cast<uint32_t*>(a.stats_zero)[w] = 0u;
     }
-    // fold the previous step's statistics slot (complete by stream order) into its row of the vector ring
-    if (a.stats_fold_src && a.stats_fold_dst && blockIdx.x == 0) fold_stats_block256(a.stats_fold_src, a.stats_fold_dst, a.stats_last_reset);
+    // fold the previous step's statistics slot (complete by stream order) into its row of the vector ring: one entry per
+    // wave, spread over the first waves of the grid so no single workgroup becomes the kernel's tail
+    if (a.stats_fold_src && a.stats_fold_dst) {
+        const int waves = (int)(gridDim.x * (blockDim.x / GF_WAVE));
+        for (int v = (int)(blockIdx.x * (blockDim.x / GF_WAVE) + threadIdx.x / GF_WAVE); v < GF_STATS_VECTOR_LEN; v += waves)
+            fold_stats_entry(a.stats_fold_src, a.stats_fold_dst, a.stats_last_reset, v);
+    }
     const int D = a.num_dofs;
     const int mode = a.mode;
     int flags = 0;

@@ -138,8 +138,7 @@ __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m)
 __device__ __forceinline__ GfStepStats* stats_shard(GfStepStats* s) { return s + (blockIdx.x % GF_STATS_SHARDS); }
 
 // Fold the GF_STATS_SHARDS shards of one statistics slot into the GF_STATS_VECTOR_LEN-entry f64 vector (layout of
-// gf_stats_pack): shards add, flag entries fold with max.  Run by ONE 256-thread workgroup: lane = shard, each of the 4
-// waves owns 12 entries; all of a lane's loads are issued together and each entry is reduced across the wave with
+// gf_stats_pack): shards add, flag entries fold with max.  lane = shard, each entry is reduced across a wave with
 // shuffles (a lane-per-entry loop over the shards would be 64 dependent memory round trips).
 __device__ __forceinline__ double stats_entry(const GfStepStats& b, int v) {
     if (v < GF_MAX_TERM_TERMS) return (double)b.term_fired[v];
@@ -152,34 +151,32 @@ __device__ __forceinline__ double stats_entry(const GfStepStats& b, int v) {
     return 0.0;
 }
 
-__device__ __forceinline__ void fold_stats_block256(const GfStepStats* src, double* dst, double* last_reset) {
+// One entry, one wave: lane = shard, shuffle tree.  (The tree order is part of the result for the f64 reward sums; every
+// caller folds with this function so a statistic reads the same whichever kernel folded it.)
+__device__ __forceinline__ void fold_stats_entry(const GfStepStats* src, double* dst, double* last_reset, int v) {
     static_assert(GF_STATS_SHARDS == GF_WAVE, "one lane per shard");
-    constexpr int kPerWave = (GF_STATS_VECTOR_LEN + 3) / 4;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (GF_WAVE - 1);
+    const int lane = threadIdx.x & (GF_WAVE - 1);
     const GfStepStats& b = src[lane];
-    double x[kPerWave];
+    double r = stats_entry(b, v);
+    const double resets = last_reset ? wave_sum((double)b.reset_count) : 0.0;  // valid in lane 0
+    const bool is_flag = v > GF_MAX_TERM_TERMS && v < GF_MAX_TERM_TERMS + 4;
+    if (is_flag) {
 #pragma unroll
-    for (int j = 0; j < kPerWave; ++j) x[j] = stats_entry(b, wave * kPerWave + j);
-    const double resets = wave_sum((double)b.reset_count);  // valid in lane 0
-#pragma unroll
-    for (int j = 0; j < kPerWave; ++j) {
-        const int v = wave * kPerWave + j;
-        const bool is_flag = v > GF_MAX_TERM_TERMS && v < GF_MAX_TERM_TERMS + 4;
-        double r = x[j];
-        if (is_flag) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double o = __shfl_down(r, off, GF_WAVE);
-                r = o > r ? o : r;
-            }
-        } else {
-            r = wave_sum(r);
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_down(r, off, GF_WAVE);
+            r = o > r ? o : r;
         }
-        if (lane == 0 && v < GF_STATS_VECTOR_LEN) {
-            dst[v] = r;
-            if (last_reset && resets > 0.0) last_reset[v] = r;
-        }
+    } else {
+        r = wave_sum(r);
     }
+    if (lane == 0 && v < GF_STATS_VECTOR_LEN) {
+        dst[v] = r;
+        if (last_reset && resets > 0.0) last_reset[v] = r;
+    }
+}
+
+__device__ __forceinline__ void fold_stats_block256(const GfStepStats* src, double* dst, double* last_reset) {
+    for (int v = (int)(threadIdx.x / GF_WAVE); v < GF_STATS_VECTOR_LEN; v += 4) fold_stats_entry(src, dst, last_reset, v);
 }
 
 // contact predicates shared by termination / reward terms

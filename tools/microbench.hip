@@ -159,6 +159,14 @@ int main(int argc, char** argv) {
     float4* cp_dst = dalloc<float4>(copy4);
     time_loop("copy 272B/env (float4)", iters, 272.0 * Nd, [&] { copy_kernel<<<(unsigned)((copy4 + 255) / 256), 256>>>(cp_src, cp_dst, copy4); });
     time_loop("gf_action_step", iters, 248.0 * Nd, [&] { chk(gf_action_step(&aa, 0), "action"); });
+    {   // as the recorded step runs it: zero the next statistics slot, fold the previous one into the vector ring
+        GfStepStats* ring = dalloc<GfStepStats>(3 * GF_STATS_SHARDS);
+        double* vec = dalloc<double>(64);
+        double* last = dalloc<double>(64);
+        GfActionArgs ar = aa;
+        ar.stats = ring; ar.stats_zero = ring + GF_STATS_SHARDS; ar.stats_fold_src = ring + 2 * GF_STATS_SHARDS; ar.stats_fold_dst = vec; ar.stats_last_reset = last;
+        time_loop("gf_action_step (+ring)", iters, 248.0 * Nd, [&] { chk(gf_action_step(&ar, 0), "action"); });
+    }
     time_loop("gf_synth_scene_step", iters, 0, [&] { sa.tick++; chk(gf_synth_scene_step(&sa, 0), "scene"); });
     time_loop("gf_termination_step", iters, 26.0 * Nd, [&] { chk(gf_termination_step(&ta, 0), "termination"); });
     time_loop("gf_reward_step", iters, 268.0 * Nd, [&] { chk(gf_reward_step(&ra, 0), "reward"); });

@@ -193,7 +193,9 @@ int main(int argc, char** argv) {
             for (int i = 1; i < 10; ++i) printf("  %s %.2f", names[i - 1], (double)(h[i] - h[i - 1]) / 100.0);
             printf("  | total %.2f us, %.0f shader cycles -> %.0f MHz\n", (double)(h[9] - h[0]) / 100.0, (double)(h[25] - h[16]), (double)(h[25] - h[16]) / ((double)(h[9] - h[0]) / 100.0));
         }
-        gf_set_option(GF_OPT_POST_VARIANT, 1);
+      for (int variant = 1; variant <= 2; ++variant) {
+        gf_set_option(GF_OPT_POST_VARIANT, variant);
+        printf("---- variant %d\n", variant);
         time_loop("gf_post_physics_step (4 waves, stamped)", iters, 566.0 * Nd, [&] { chk(gf_post_physics_step(&pr, 0), "post"); });
         for (int rep = 0; rep < 3; ++rep) {
             for (int i = 0; i < 50; ++i) chk(gf_post_physics_step(&pr, 0), "post");
@@ -209,6 +211,7 @@ int main(int argc, char** argv) {
                 printf("\n");
             }
         }
+      }
         gf_debug_stamps = nullptr;
     }
     int failed = -1;
