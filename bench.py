@@ -94,7 +94,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--num-envs", type=int, default=65536, help="envs per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event bracketing of the reward kernel")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stamping of the dominant kernel")
+    ap.add_argument("--profile-stride", type=int, default=4,
+                    help="stamp every k-th launch of the dominant kernel in the timed region (a stamped launch costs the host "
+                         "several microseconds more than a plain one; 1 = every launch)")
     args = ap.parse_args()
 
     import torch
@@ -130,6 +133,7 @@ def main():
     fused = env._trace is not None and env._trace.post_refs is not None
     prof_phase = nat.GF_PHASE_POST if fused else nat.GF_PHASE_REWARD
     if not args.no_profile:
+        backend.set_option(nat.GF_OPT_PROFILE_STRIDE, max(1, args.profile_stride))
         backend.profile_begin(prof_phase, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -153,7 +157,11 @@ def main():
         T = sum(1 for c in rm.cfg.values() if c.weight != 0)
         per_env = post_bytes_per_env(12, T, 3, 48, 1) if fused else reward_bytes_per_env(12, T, 3)
         bytes_per_launch = per_env * N
-        kernel = "gf::post_kernel<3> (termination+reward+command+reset+observe fused)" if fused else "gf::reward_kernel<3>"
+        kernel = "gf::reward_kernel<3>"
+        if fused:
+            # which kernel gf_post_physics_step launches for this config: "program <id> (<name>): <signature>"
+            what = backend.post_describe(env._trace.post_refs).split(":")[0]
+            kernel = f"gf::post_ws_kernel, {what} (termination+reward+command+reset+observe fused)"
         roof = None
         traffic, traffic_src = None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -161,13 +169,13 @@ def main():
             # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected in
             # separate rocprofv3 --pmc passes over this same command and committed under profiles/ (r01_pmc_traffic.md)
             rec = json.load(open(pmc_file)).get(str(N))
-            if rec:
+            if rec and ("Prog" in rec["kernel"]) == ("program 0" not in what):  # counters were taken on this same kernel
                 traffic, traffic_src = rec["traffic_bytes"], "profiles/r01_pmc_traffic.md"
         if prof_n > 0:
             avg_s = prof_ms / prof_n / 1e3
             achieved = bytes_per_launch / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "algorithmic_bytes_per_env": per_env, "avg_launch_us": avg_s * 1e6, "launches": prof_n,
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "algorithmic_bytes_per_env": per_env, "avg_launch_us": avg_s * 1e6, "launches": prof_n, "launch_sampling": f"every {max(1, args.profile_stride)}th launch of the timed region",
                     "algorithmic_bytes_per_launch": bytes_per_launch}
         out = {
             "metric": "env-steps/sec", "value": world * N * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world,

@@ -124,6 +124,7 @@ GF_EXPORT int gf_profile_begin(int phase, int max_samples) {
     p.events.resize((size_t)max_samples * 2);
     for (auto& e : p.events) GF_HIP_CHECK(hipEventCreate(&e));
     p.count = 0;
+    p.calls = 0;
     p.max_samples = max_samples;
     p.phase = phase;
     return GF_OK;

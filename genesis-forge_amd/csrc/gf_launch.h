@@ -23,6 +23,7 @@ struct Profiler {
     int phase = -1;
     int max_samples = 0;
     int count = 0;
+    int calls = 0;  // launches of the profiled phase seen since gf_profile_begin (every g_options[GF_OPT_PROFILE_STRIDE]-th is stamped)
     std::vector<hipEvent_t> events;
 };
 extern Profiler g_prof;
@@ -38,7 +39,10 @@ struct PhaseScope {
     hipStream_t stream;
     PhaseScope(int phase, hipStream_t s) : stream(s) {
         Profiler& p = g_prof;
-        if (p.phase == phase && p.count < p.max_samples) idx = p.count;
+        if (p.phase == phase) {
+            const int stride = g_options[GF_OPT_PROFILE_STRIDE] > 1 ? g_options[GF_OPT_PROFILE_STRIDE] : 1;
+            if ((p.calls++ % stride) == 0 && p.count < p.max_samples) idx = p.count;
+        }
     }
     bool active() const { return idx >= 0; }
     void use_dispatch_events() { dispatch = true; }

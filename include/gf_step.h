@@ -451,7 +451,9 @@ int gf_abi_version(void);
  * 0 = table interpreter, one wave per 64-env tile; 1 = table interpreter, four specialised waves per tile;
  * 2 = (default) as 1, plus the static programs: a config whose structure matches a registered program runs
  * straight-line code compiled for it.  All variants produce bit-identical results. */
-enum { GF_OPT_POST_VARIANT = 0, GF_OPT_COUNT = 4 };
+/* GF_OPT_PROFILE_STRIDE: gf_profile_begin stamps every k-th launch of the profiled phase (default 1 = every launch); a
+ * stamped launch costs the host several microseconds more than a plain one, so a timed region samples instead. */
+enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_COUNT = 4 };
 int gf_set_option(int option, int value);
 int gf_sizeof(int which);   /* sizeof of the ABI structs, in header order (0 = GfStepStats … 11 = GfObsItem): binding self-check */
 const char* gf_build_info(void);
