@@ -124,6 +124,103 @@ __device__ __forceinline__ float clamp_max(float x, float hi) { return x > hi ? 
 __device__ __forceinline__ float clamp_min(float x, float lo) { return x < lo ? lo : x; }
 
 // ---------------------------------------------------------------------------------------------
+// TerrainManager.get_terrain_height for one point (terrain_manager.py:100-166): the in-place normalisation chain, then
+// F.grid_sample(bilinear, border, align_corners=True) on the [H,W] field.  One rounding per op, taps summed left to right
+// (nw, ne, sw, se); the oracle restates exactly this sequence.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float terrain_height(const GfTerrainView& tv, float x, float y) {
+    if (!tv.height_field) return tv.origin_z;
+    float nx = x - tv.x_min;
+    nx = nx / tv.x_span;
+    nx = nx * 2.0f;
+    nx = nx - 1.0f;
+    float ny = y - tv.y_min;
+    ny = ny / tv.y_span;
+    ny = ny * 2.0f;
+    ny = ny - 1.0f;
+    const int W = tv.cols, H = tv.rows;
+    float ix = ((nx + 1.0f) / 2.0f) * (float)(W - 1);
+    float iy = ((ny + 1.0f) / 2.0f) * (float)(H - 1);
+    ix = clamp_max(clamp_min(ix, 0.0f), (float)(W - 1));
+    iy = clamp_max(clamp_min(iy, 0.0f), (float)(H - 1));
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
+    const float nw = (fx1 - ix) * (fy1 - iy);
+    const float ne = (ix - fx0) * (fy1 - iy);
+    const float sw = (fx1 - ix) * (iy - fy0);
+    const float se = (ix - fx0) * (iy - fy0);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const bool x1_in = x0 + 1 < W, y1_in = y0 + 1 < H;
+    const int x1 = x1_in ? x0 + 1 : x0, y1 = y1_in ? y0 + 1 : y0;
+    const GF_GLOBAL float* f = G(tv.height_field);
+    const float v_nw = f[y0 * W + x0];
+    const float v_ne = x1_in ? f[y0 * W + x1] : 0.0f;
+    const float v_sw = y1_in ? f[y1 * W + x0] : 0.0f;
+    const float v_se = (x1_in && y1_in) ? f[y1 * W + x1] : 0.0f;
+    return ((v_nw * nw + v_ne * ne) + v_sw * sw) + v_se * se;
+}
+
+// sin and cos with a fixed sequence of f32 operations (3-part Cody-Waite reduction by pi/2, Cephes minimax polynomials on
+// [-pi/4, pi/4]), so the quaternion a reset writes is bit-identical on the GPU and in the oracle; within 2 ulp of libm.
+__device__ __forceinline__ void sincos_det(float x, float* s, float* c) {
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    const float z = r * r;
+    const float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    const float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    const int q = (int)k & 3;
+    const float sv = (q & 1) ? pc : ps, cv = (q & 1) ? ps : pc;
+    *s = (q & 2) ? -sv : sv;
+    *c = ((q + 1) & 2) ? -cv : cv;
+}
+
+// genesis.utils.geom.xyz_to_quat restated (mdp/reset.py:63,194): extrinsic x-y-z Euler angles (radians) -> (w,x,y,z)
+__device__ __forceinline__ float4 xyz_to_quat_det(float ax, float ay, float az) {
+    float sx, cx, sy, cy, sz, cz;
+    sincos_det(ax * 0.5f, &sx, &cx);
+    sincos_det(ay * 0.5f, &sy, &cy);
+    sincos_det(az * 0.5f, &sz, &cz);
+    float4 q;
+    q.x = (cx * cy) * cz + (sx * sy) * sz;
+    q.y = (sx * cy) * cz - (cx * sy) * sz;
+    q.z = (cx * sy) * cz + (sx * cy) * sz;
+    q.w = (cx * cy) * sz - (sx * sy) * cz;
+    return q;
+}
+
+// mdp.reset.randomize_terrain_position for one env (mdp/reset.py:199-226 -> terrain_manager.py:170-279); `A` exposes the
+// spawn_* fields and the terrain view of GfResetArgs.  `u` holds the five unit draws (x, y, rot x, rot y, rot z).
+template <class A>
+__device__ __forceinline__ void spawn_pose(const A& a, const float (&u)[5], float (&pos)[3], float4* quat) {
+    pos[0] = u[0] * a.spawn_x_span + a.spawn_x_min;
+    pos[1] = u[1] * a.spawn_y_span + a.spawn_y_min;
+    pos[2] = terrain_height(a.terrain, pos[0], pos[1]) + a.spawn_height_offset;
+    const int m = a.spawn_rot_mask;
+    const float rx = (m & 1) ? uniform_range(u[2], a.spawn_rot_lo[0], a.spawn_rot_hi[0]) : 0.0f;
+    const float ry = (m & 2) ? uniform_range(u[3], a.spawn_rot_lo[1], a.spawn_rot_hi[1]) : 0.0f;
+    const float rz = (m & 4) ? uniform_range(u[4], a.spawn_rot_lo[2], a.spawn_rot_hi[2]) : 0.0f;
+    *quat = xyz_to_quat_det(rx, ry, rz);
+}
+
+// the five spawn draws of env `genv`: dense parity draws, or Philox blocks GF_SPAWN_BLOCK (x, y, rot z) and +1 (rot x, rot y)
+__device__ __forceinline__ void spawn_draws(const float* draws, int64_t n, uint64_t seed, uint64_t stream, uint32_t genv, int rot_mask, float (&u)[5]) {
+    if (draws) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) u[j] = draws[n * 5 + j];
+        return;
+    }
+    const U4 r0 = philox4x32_10(genv, GF_SPAWN_BLOCK, (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+    u[0] = u24_to_unit(r0.x); u[1] = u24_to_unit(r0.y); u[4] = u24_to_unit(r0.z);
+    u[2] = 0.0f; u[3] = 0.0f;
+    if (rot_mask & 3) {
+        const U4 r1 = philox4x32_10(genv, GF_SPAWN_BLOCK + 1u, (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+        u[2] = u24_to_unit(r1.x); u[3] = u24_to_unit(r1.y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wave-level reductions (64 lanes) used only for the logging statistics.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {

@@ -19,6 +19,10 @@
 // exactly that); tests compare the two paths bit for bit.
 // Algorithmic traffic, Go2 command config: R 13·4 + 5 rows·48 + cmd 12 + ep/max 8 + secs 4 + sums 24 = 340,
 // W masks 2 + reward 4 + sums 24 + secs 4 + obs 192 = 226  →  566 B/env.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
 #include "gf_post_args.h"
 #include "gf_post_ws.h"
 #include "gf_post_programs.h"
@@ -302,10 +306,19 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
         }
         if (a.scene_reset) {
             GF_GLOBAL float* wp = G(const_cast<float*>(k_pos)) + 3 * n;
-            wp[0] = a.reset_pos[0]; wp[1] = a.reset_pos[1]; wp[2] = a.reset_pos[2];
-            if (a.set_quat) {
+            float np[3] = {a.reset_pos[0], a.reset_pos[1], a.reset_pos[2]};
+            float4 nq = make_float4(a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]);
+            bool set_quat = a.set_quat != 0;
+            if (a.spawn_mode) {  // mdp.reset.randomize_terrain_position
+                float u[5];
+                spawn_draws(nullptr, n, seed, a.stream_reset, genv, a.spawn_rot_mask, u);
+                spawn_pose(a, u, np, &nq);
+                set_quat = a.spawn_set_quat != 0;
+            }
+            wp[0] = np[0]; wp[1] = np[1]; wp[2] = np[2];
+            if (set_quat) {
                 if (a.quat_stash) reinterpret_cast<GF_GLOBAL f32x4*>(G(a.quat_stash))[n] = f32x4{q.x, q.y, q.z, q.w};
-                reinterpret_cast<GF_GLOBAL f32x4*>(G(const_cast<float*>(k_quat)))[n] = f32x4{a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]};
+                reinterpret_cast<GF_GLOBAL f32x4*>(G(const_cast<float*>(k_quat)))[n] = f32x4{nq.x, nq.y, nq.z, nq.w};
             }
             if (a.zero_velocity) {
                 GF_GLOBAL float* wl = G(const_cast<float*>(k_lin)) + 3 * n;
@@ -514,9 +527,17 @@ static void merge_entity(GfPostArgs& a, const GfEntityView& v) {
     if (v.ang_vel) a.ang_vel = const_cast<float*>(v.ang_vel);
 }
 
-#define UNSUP(cond)                          \
-    do {                                     \
-        if (cond) return GF_E_UNSUPPORTED;   \
+// GF_POST_WHY=1 in the environment names the rule that kept a step from fusing (development aid; checked once)
+static bool why_enabled() {
+    static const bool on = getenv("GF_POST_WHY") != nullptr;
+    return on;
+}
+#define UNSUP(cond)                                                                                  \
+    do {                                                                                             \
+        if (cond) {                                                                                  \
+            if (why_enabled()) fprintf(stderr, "gf_post_physics: not fusable (%s:%d): %s\n", __FILE__, __LINE__, #cond); \
+            return GF_E_UNSUPPORTED;                                                                 \
+        }                                                                                            \
     } while (0)
 
 static int pack(const GfPostRefs* r, Packer& pk) {
@@ -530,6 +551,7 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     UNSUP(r->num_command < 0 || r->num_command > GF_POST_MAX_CMD || r->num_observe < 0 || r->num_observe > GF_POST_MAX_OBS);
     UNSUP(RS.num_envs != N || RS.mask != T.terminated || RS.mask2 != T.truncated);
     UNSUP(RS.len_draws || RS.dof_draws);
+    bool have_terrain = false;  // one terrain map per fused step: the reward's and the spawn's must be the same
     a.num_envs = N;
     a.terminated = T.terminated; a.truncated = T.truncated; a.stats = T.stats ? T.stats : RS.stats;
     UNSUP(RS.stats && T.stats && RS.stats != T.stats);
@@ -605,7 +627,15 @@ static int pack(const GfPostRefs* r, Packer& pk) {
             switch (t.op) {
                 case GF_R_IS_ALIVE:
                 case GF_R_TERMINATED: UNSUP(RW->terminated != T.terminated); break;
-                case GF_R_BASE_HEIGHT: needs |= PN_POS; UNSUP(t.flags & GF_RW_FLAG_TERRAIN); break;
+                case GF_R_BASE_HEIGHT:
+                    needs |= PN_POS;
+                    if (t.flags & GF_RW_FLAG_TERRAIN) {
+                        UNSUP(RW->terrain.height_field && (RW->terrain.rows < 1 || RW->terrain.cols < 1));
+                        UNSUP(have_terrain && memcmp(&a.terrain, &RW->terrain, sizeof(GfTerrainView)) != 0);
+                        a.terrain = RW->terrain;
+                        have_terrain = true;
+                    }
+                    break;
                 case GF_R_DOF_SIMILAR_TO_DEFAULT:
                 case GF_R_STAND_STILL: needs |= PN_DOFPOS | PN_DOFDEV; break;
                 case GF_R_LIN_VEL_Z_L2: needs |= PN_QUAT | PN_LIN; break;
@@ -696,11 +726,23 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     }
     a.scene_reset = RS.scene_pos != nullptr;
     if (RS.scene_pos) {
-        GfEntityView ev{RS.scene_pos, RS.set_quat ? RS.scene_quat : nullptr, RS.zero_velocity ? RS.scene_lin_vel : nullptr,
+        const bool writes_quat = RS.spawn_mode ? RS.spawn_set_quat != 0 : RS.set_quat != 0;
+        GfEntityView ev{RS.scene_pos, writes_quat ? RS.scene_quat : nullptr, RS.zero_velocity ? RS.scene_lin_vel : nullptr,
                         RS.zero_velocity ? RS.scene_ang_vel : nullptr};
         GfEntityView cur{a.pos, a.quat, a.lin_vel, a.ang_vel};
         UNSUP(!same_entity(cur, ev));
-        UNSUP(RS.set_quat && !RS.scene_quat);
+        UNSUP(writes_quat && !RS.scene_quat);
+        if (RS.spawn_mode) {
+            UNSUP(RS.spawn_draws);  // dense parity draws run phase by phase
+            UNSUP(RS.terrain.height_field && (RS.terrain.rows < 1 || RS.terrain.cols < 1));
+            UNSUP(have_terrain && memcmp(&a.terrain, &RS.terrain, sizeof(GfTerrainView)) != 0);
+            a.terrain = RS.terrain;
+            have_terrain = true;
+            a.spawn_mode = 1; a.spawn_set_quat = RS.spawn_set_quat; a.spawn_rot_mask = RS.spawn_rot_mask;
+            a.spawn_x_min = RS.spawn_x_min; a.spawn_x_span = RS.spawn_x_span; a.spawn_y_min = RS.spawn_y_min; a.spawn_y_span = RS.spawn_y_span;
+            a.spawn_height_offset = RS.spawn_height_offset;
+            for (int j = 0; j < 3; ++j) { a.spawn_rot_lo[j] = RS.spawn_rot_lo[j]; a.spawn_rot_hi[j] = RS.spawn_rot_hi[j]; }
+        }
         UNSUP(RS.zero_velocity && (!RS.scene_lin_vel || !RS.scene_ang_vel));
         merge_entity(a, ev);
         a.set_quat = RS.set_quat; a.zero_velocity = RS.zero_velocity; a.quat_stash = RS.quat_stash;
@@ -760,7 +802,7 @@ static int pack(const GfPostRefs* r, Packer& pk) {
             UNSUP(!same_entity(cur, ob->entity));
             merge_entity(a, ob->entity);
             // stale quaternion source must be this step's reset (or absent when the reset does not touch quat)
-            if (a.scene_reset && a.set_quat) UNSUP(ob->stale_quat != a.quat_stash || ob->stale_mask != T.terminated || ob->stale_mask2 != T.truncated);
+            if (a.scene_reset && (a.spawn_mode ? a.spawn_set_quat : a.set_quat)) UNSUP(ob->stale_quat != a.quat_stash || ob->stale_mask != T.terminated || ob->stale_mask2 != T.truncated);
             else UNSUP(ob->stale_quat != nullptr);
         }
     }

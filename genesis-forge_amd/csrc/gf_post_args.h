@@ -93,6 +93,12 @@ struct alignas(16) GfPostArgs {
     float max_random_scaling, dof_noise_scale;
     float reset_pos[3], reset_quat[4];
     uint64_t stream_reset;
+    // mdp.reset.randomize_terrain_position (field names as in GfResetArgs so spawn_pose() serves both) + the terrain map the
+    // spawn and base_height(terrain_manager=…) sample
+    int32_t spawn_mode, spawn_set_quat, spawn_rot_mask;
+    float spawn_x_min, spawn_x_span, spawn_y_min, spawn_y_span, spawn_height_offset;
+    float spawn_rot_lo[3], spawn_rot_hi[3];
+    GfTerrainView terrain;
     float* air_state[GF_MAX_CONTACT_VIEWS][4];
     int32_t air_links[GF_MAX_CONTACT_VIEWS];
     int32_t n_air;

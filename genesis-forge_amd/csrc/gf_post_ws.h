@@ -313,10 +313,19 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             }
             if (scene_reset) {
                 GF_GLOBAL float* wp = G(a.pos) + 3 * n;
-                wp[0] = a.reset_pos[0]; wp[1] = a.reset_pos[1]; wp[2] = a.reset_pos[2];
-                if (a.set_quat) {
+                float np[3] = {a.reset_pos[0], a.reset_pos[1], a.reset_pos[2]};
+                float4 nq = make_float4(a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]);
+                bool set_quat = a.set_quat != 0;
+                if (UNI(a.spawn_mode)) {  // mdp.reset.randomize_terrain_position
+                    float u[5];
+                    spawn_draws(nullptr, n, seed, a.stream_reset, genv, a.spawn_rot_mask, u);
+                    spawn_pose(a, u, np, &nq);
+                    set_quat = a.spawn_set_quat != 0;
+                }
+                wp[0] = np[0]; wp[1] = np[1]; wp[2] = np[2];
+                if (set_quat) {
                     if (a.quat_stash) reinterpret_cast<GF_GLOBAL f32x4*>(G(a.quat_stash))[n] = f32x4{q.x, q.y, q.z, q.w};
-                    reinterpret_cast<GF_GLOBAL f32x4*>(G(a.quat))[n] = f32x4{a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]};
+                    reinterpret_cast<GF_GLOBAL f32x4*>(G(a.quat))[n] = f32x4{nq.x, nq.y, nq.z, nq.w};
                 }
                 if (zero_velocity) {
                     GF_GLOBAL float* wl = G(a.lin_vel) + 3 * n;

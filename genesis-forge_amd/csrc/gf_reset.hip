@@ -83,11 +83,20 @@ __global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
         }
     }
     if (a.scene_pos) {
-        for (int j = 0; j < 3; ++j) a.scene_pos[3 * n + j] = a.reset_pos[j];
-        if (a.set_quat && a.scene_quat) {
+        float p[3] = {a.reset_pos[0], a.reset_pos[1], a.reset_pos[2]};
+        float4 q = make_float4(a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]);
+        bool set_quat = a.set_quat != 0;
+        if (a.spawn_mode) {  // mdp.reset.randomize_terrain_position
+            float u[5];
+            spawn_draws(a.spawn_draws, n, a.seed, a.stream, (uint32_t)n + a.env_offset, a.spawn_rot_mask, u);
+            spawn_pose(a, u, p, &q);
+            set_quat = a.spawn_set_quat != 0;
+        }
+        for (int j = 0; j < 3; ++j) a.scene_pos[3 * n + j] = p[j];
+        if (set_quat && a.scene_quat) {
             float4* qp = reinterpret_cast<float4*>(a.scene_quat) + n;
             if (a.quat_stash) reinterpret_cast<float4*>(a.quat_stash)[n] = *qp;  // pre-reset quat for this tick's observation
-            *qp = make_float4(a.reset_quat[0], a.reset_quat[1], a.reset_quat[2], a.reset_quat[3]);
+            *qp = q;
         }
         if (a.zero_velocity) {
             if (a.scene_lin_vel) for (int j = 0; j < 3; ++j) a.scene_lin_vel[3 * n + j] = 0.0f;
@@ -106,6 +115,7 @@ extern "C" __attribute__((visibility("default"))) int gf_masked_reset(const GfRe
     if (a->num_contact < 0 || a->num_contact > GF_MAX_CONTACT_VIEWS) return GF_E_RANGE;
     if (a->env_actions && !a->env_last_actions) return GF_E_NULL;
     if (a->scene_dof_pos && !a->default_dof_pos) return GF_E_NULL;
+    if (a->spawn_mode && a->terrain.height_field && (a->terrain.rows < 1 || a->terrain.cols < 1)) return GF_E_RANGE;
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_RESET, s);

@@ -190,7 +190,7 @@ extern "C" __attribute__((visibility("default"))) int gf_reward_step(const GfRew
             case GF_R_BASE_HEIGHT:
                 needs |= gf::RN_POS;
                 if (t.flags & GF_RW_FLAG_CMD) rc = need_cmd(t.i[0], 1);
-                if ((t.flags & GF_RW_FLAG_TERRAIN) && (t.i[1] < 0 || t.i[1] >= GF_MAX_EXT || !a->ext[t.i[1]])) rc = GF_E_SLOT;
+                if ((t.flags & GF_RW_FLAG_TERRAIN) && a->terrain.height_field && (a->terrain.rows < 1 || a->terrain.cols < 1)) rc = GF_E_RANGE;
                 break;
             case GF_R_DOF_SIMILAR_TO_DEFAULT: needs |= gf::RN_DOF_DEV; break;
             case GF_R_LIN_VEL_Z_L2: needs |= gf::RN_QUAT | gf::RN_LIN; break;

@@ -80,7 +80,7 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
         case GF_R_TERMINATED: v = terminated ? 1.f : 0.f; break;
         case GF_R_BASE_HEIGHT: {
             float h = pos.z;
-            if (t.flags & GF_RW_FLAG_TERRAIN) h = h - G(a.ext[t.i[1]])[n];
+            if (t.flags & GF_RW_FLAG_TERRAIN) h = h - terrain_height(a.terrain, pos.x, pos.y);
             const float target = (t.flags & GF_RW_FLAG_CMD) ? G(a.command[t.i[0]].command)[n * a.command[t.i[0]].width] : t.p[0];
             const float e = h - target;
             v = e * e;

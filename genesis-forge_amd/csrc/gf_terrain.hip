@@ -1,0 +1,39 @@
+// gf_terrain.hip — TerrainManager.get_terrain_height as a standalone call (managers/terrain_manager.py:100-166).
+//
+// The reference normalises x and y with ten in-place elementwise launches, fills a [n,1,1,2] grid, expands the height
+// field to n batch entries and calls F.grid_sample (≈ 16 launches); here one lane samples one point with the shared
+// terrain_height() of gf_device.h — the same function base_height(terrain_manager=…) and the terrain spawn of the masked
+// reset inline, so a height reads the same wherever it is computed.  The field is a read-only table shared by every env
+// (Go2 rough_terrain: 24 m / 0.25 m → ~97² floats = 38 KB) and lives in L2; traffic is the two strided coordinates in
+// and one float out, 12 B per query.
+#include "gf_launch.h"
+
+namespace gf {
+
+__global__ __launch_bounds__(256) void terrain_height_kernel(const GfTerrainHeightArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.num) return;
+    float h = a.terrain.origin_z;  // no height field: constant (terrain_manager.py:112-114), x / y are never read
+    if (a.terrain.height_field) {
+        const float x = G(a.x)[i * a.x_stride], y = G(a.y)[i * a.y_stride];
+        h = terrain_height(a.terrain, x, y);
+    }
+    G(a.out)[i] = h;
+}
+
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_terrain_height(const GfTerrainHeightArgs* a, void* stream) {
+    if (!a || !a->out) return GF_E_NULL;
+    if (a->num < 0) return GF_E_RANGE;
+    if (a->terrain.height_field) {
+        if (!a->x || !a->y) return GF_E_NULL;
+        if (a->terrain.rows < 1 || a->terrain.cols < 1 || a->x_stride < 0 || a->y_stride < 0) return GF_E_RANGE;
+    }
+    if (a->num == 0) return GF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    gf::PhaseScope scope(GF_PHASE_TERRAIN, s);
+    scope.begin_bracket();
+    gf::terrain_height_kernel<<<gf::env_grid(a->num, 256), 256, 0, s>>>(*a);
+    return gf::launch_status();
+}

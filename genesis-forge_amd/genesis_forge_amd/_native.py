@@ -77,7 +77,7 @@ GF_O_BASE_QUAT = 13
 GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
 
 (GF_PHASE_ACTION, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
- GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_COUNT) = range(11)
+ GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_COUNT) = range(12)
 
 GF_OPT_PROFILE_STRIDE = 1  # gf_set_option: stamp every k-th launch of the profiled phase
 GF_OPT_POST_VARIANT = 0  # gf_set_option: 0 = interpreter, one wave per tile; 1 = interpreter, four waves; 2 = + static programs (default)
@@ -98,6 +98,16 @@ class GfContactView(C.Structure):
 
 class GfCommandView(C.Structure):
     _fields_ = [("command", P), ("width", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GfTerrainView(C.Structure):
+    _fields_ = [("height_field", P), ("rows", C.c_int32), ("cols", C.c_int32), ("x_min", C.c_float), ("x_span", C.c_float),
+                ("y_min", C.c_float), ("y_span", C.c_float), ("origin_z", C.c_float), ("_pad", C.c_int32)]
+
+
+class GfTerrainHeightArgs(C.Structure):
+    _fields_ = [("num", C.c_int64), ("x", P), ("y", P), ("x_stride", C.c_int64), ("y_stride", C.c_int64),
+                ("terrain", GfTerrainView), ("out", P)]
 
 
 class GfTerm(C.Structure):
@@ -144,7 +154,7 @@ class GfRewardArgs(C.Structure):
                 ("dof_pos", P), ("default_dof_pos", P), ("actions", P), ("last_actions", P), ("terminated", P),
                 ("contact", GfContactView * GF_MAX_CONTACT_VIEWS), ("command", GfCommandView * GF_MAX_COMMAND_VIEWS),
                 ("ext", P * GF_MAX_EXT), ("state", P * 4),
-                ("reward", P), ("episode_sums", P), ("episode_seconds", P), ("term_out", P),
+                ("reward", P), ("episode_sums", P), ("episode_seconds", P), ("term_out", P), ("terrain", GfTerrainView),
                 ("terms", GfTerm * GF_MAX_TERMS)]
 
 
@@ -166,7 +176,11 @@ class GfResetArgs(C.Structure):
                 ("scene_dof_pos", P), ("scene_dof_vel", P), ("default_dof_pos", P), ("dof_noise_scale", C.c_float),
                 ("dof_draws", P), ("scene_pos", P), ("scene_quat", P), ("quat_stash", P), ("scene_lin_vel", P), ("scene_ang_vel", P),
                 ("reset_pos", C.c_float * 3), ("reset_quat", C.c_float * 4), ("set_quat", C.c_int32), ("zero_velocity", C.c_int32),
-                ("seed", C.c_uint64), ("stream", C.c_uint64), ("env_offset", C.c_uint32), ("_pad2", C.c_uint32), ("stats", P)]
+                ("seed", C.c_uint64), ("stream", C.c_uint64), ("env_offset", C.c_uint32),
+                ("spawn_mode", C.c_int32), ("spawn_set_quat", C.c_int32), ("spawn_rot_mask", C.c_int32),
+                ("spawn_x_min", C.c_float), ("spawn_x_span", C.c_float), ("spawn_y_min", C.c_float), ("spawn_y_span", C.c_float),
+                ("spawn_height_offset", C.c_float), ("spawn_rot_lo", C.c_float * 3), ("spawn_rot_hi", C.c_float * 3),
+                ("spawn_draws", P), ("terrain", GfTerrainView), ("stats", P)]
 
 
 class GfObsItem(C.Structure):
@@ -219,7 +233,7 @@ class GfPostRefs(C.Structure):
                 ("command_step", P * GF_POST_MAX_CMD), ("command_reset", P * GF_POST_MAX_CMD), ("observe", P * GF_POST_MAX_OBS)]
 
 ABI_STRUCTS = [GfStepStats, GfActionArgs, GfContactArgs, GfTerminationArgs, GfRewardArgs, GfCommandArgs,
-               GfResetArgs, GfObservationArgs, GfRotateArgs, GfSynthSceneArgs, GfTerm, GfObsItem]
+               GfResetArgs, GfObservationArgs, GfRotateArgs, GfSynthSceneArgs, GfTerm, GfObsItem, GfTerrainView, GfTerrainHeightArgs]
 
 PHASE_FUNCS = {
     "action_step": GfActionArgs,
@@ -231,6 +245,7 @@ PHASE_FUNCS = {
     "observe": GfObservationArgs,
     "entity_rotate": GfRotateArgs,
     "synth_scene_step": GfSynthSceneArgs,
+    "terrain_height": GfTerrainHeightArgs,
 }
 
 
@@ -238,6 +253,7 @@ PHASE_OF_FN = {
     "action_step": GF_PHASE_ACTION, "contact_step": GF_PHASE_CONTACT, "termination_step": GF_PHASE_TERMINATION,
     "reward_step": GF_PHASE_REWARD, "command_step": GF_PHASE_COMMAND, "masked_reset": GF_PHASE_RESET,
     "observe": GF_PHASE_OBSERVE, "entity_rotate": GF_PHASE_ROTATE, "synth_scene_step": GF_PHASE_SCENE,
+    "terrain_height": GF_PHASE_TERRAIN,
 }
 
 

@@ -28,7 +28,7 @@ class TermSpec:
 
     def __init__(self, op: int, p=(), i=(), flags: int = 0, entity=None, action_manager=None, needs_actions: bool = False,
                  needs_terminated: bool = False, cmd: Optional[dict] = None, contact: Optional[dict] = None, ext: Optional[dict] = None,
-                 state: Optional[dict] = None, link_vel: bool = False, after: Optional[Callable[[], None]] = None):
+                 state: Optional[dict] = None, link_vel: bool = False, after: Optional[Callable[[], None]] = None, terrain=None):
         self.op = op
         self.p = list(p) + [0.0] * (4 - len(p))
         self.i = list(i) + [0] * (4 - len(i))
@@ -43,6 +43,7 @@ class TermSpec:
         self.state = state or {}      # {index into i[]: Tensor [N,6]}
         self.link_vel = link_vel
         self.after = after
+        self.terrain = terrain        # TerrainManager whose map the term samples in-kernel (GfRewardArgs.terrain)
 
 
 def _col(t: torch.Tensor, n: int, dtype) -> torch.Tensor:
@@ -66,6 +67,7 @@ class _Slots:
         self.contacts: list = []   # [manager, need_link_vel]
         self.exts: list = []
         self.states: list = []
+        self.terrain = None        # the one TerrainManager a phase may sample
         #: True when a launch bound a per-step temporary (Python-evaluated column, link velocities fetched through a
         #: Genesis getter, an external command controller): such a descriptor must never be frozen into a recorded step
         self.volatile = False
@@ -113,6 +115,10 @@ class _Slots:
             term.i[j] = self.ext(prov)
         for j, t in spec.state.items():
             term.i[j] = self.state(t)
+        if spec.terrain is not None:
+            if self.terrain is not None and self.terrain is not spec.terrain:
+                raise RuntimeError("a fused phase can sample one TerrainManager")
+            self.terrain = spec.terrain
         term.op = spec.op
         term.flags = spec.flags
 
@@ -143,6 +149,8 @@ class _Slots:
         if hasattr(args, "state"):
             for k, t in enumerate(self.states):
                 args.state[k] = t.data_ptr()
+        if self.terrain is not None and hasattr(args, "terrain"):
+            self.terrain.gf_view(args.terrain)
 
 
 def spec_of(fn, env, params) -> Optional[TermSpec]:

@@ -33,7 +33,7 @@ class EntityManager(BaseManager):
         self._entity_attr = entity_attr
         self.on_reset: dict[str, ConfigItem] = {}
         for name, cfg in (on_reset or {}).items():
-            self.on_reset[name] = ConfigItem(cfg, env)
+            self.on_reset[name] = ConfigItem(cfg, env, on_dirty=getattr(env, "invalidate_trace", None))  # params feed the fused reset
         N = env.num_envs
         self._global_gravity = torch.tensor([0.0, 0.0, -1.0], device=gs.device, dtype=gs.tc_float).expand(N, 3)
         self._base_pos = torch.zeros(N, 3, device=gs.device, dtype=gs.tc_float)
@@ -125,12 +125,21 @@ class EntityManager(BaseManager):
 
     # -- fused reset --------------------------------------------------------------------------------
     def _can_fuse_reset(self) -> bool:
-        """True when every on_reset entry is a fixed-pose ``mdp.reset.position`` and the scene has masked setters."""
+        """True when the scene has masked setters and the on_reset entry is a fixed-pose ``mdp.reset.position`` or a
+        ``mdp.reset.randomize_terrain_position`` whose arguments are static (see its ``gf_spawn``)."""
         if not hasattr(self.entity, "gf_masked_base"):
             return False
         from ..mdp import reset as reset_mdp
         items = list(self.on_reset.values())
-        return len(items) <= 1 and all(isinstance(c.fn, reset_mdp.position) for c in items)
+        if len(items) > 1:
+            return False
+        for c in items:
+            if isinstance(c.fn, reset_mdp.randomize_terrain_position):
+                if c.fn.gf_spawn(**c.params) is None:
+                    return False
+            elif not isinstance(c.fn, reset_mdp.position):
+                return False
+        return True
 
     def _after_fused_reset(self, mask, mask2) -> None:
         if getattr(self, "_stash_armed", False) or getattr(self, "_stash_always", False):
@@ -142,11 +151,33 @@ class EntityManager(BaseManager):
             self._stash_armed = False
 
     def _fill_reset(self, a: nat.GfResetArgs) -> None:
+        from ..mdp import reset as reset_mdp
         for cfg in self.on_reset.values():
             fn = cfg.fn
             pos, quat, lin, ang = self.entity.gf_masked_base()
             a.scene_pos, a.scene_quat = pos.data_ptr(), quat.data_ptr()
             a.scene_lin_vel, a.scene_ang_vel = lin.data_ptr(), ang.data_ptr()
+            if isinstance(fn, reset_mdp.randomize_terrain_position):
+                # re-read every reset: params (height_offset, rotation ranges) may be mutated like any other cfg entry
+                (x_min, x_max, y_min, y_max), offset, rot, zero_velocity = fn.gf_spawn(**cfg.params)
+                a.spawn_mode = 1
+                a.spawn_x_min, a.spawn_x_span = x_min, x_max - x_min   # rand * (x_max - x_min) + x_min, terrain_manager.py:236-241
+                a.spawn_y_min, a.spawn_y_span = y_min, y_max - y_min
+                a.spawn_height_offset = offset
+                a.spawn_set_quat, a.spawn_rot_mask = (0 if rot is None else 1), 0
+                for k in range(3):
+                    if rot is not None and rot[k] is not None:
+                        a.spawn_rot_mask |= 1 << k
+                        a.spawn_rot_lo[k], a.spawn_rot_hi[k] = float(rot[k][0]), float(rot[k][1])
+                cfg.params["terrain_manager"].gf_view(a.terrain)
+                d = self.env.take_draws("spawn")
+                self._keep_spawn = d
+                a.spawn_draws = None if d is None else d.data_ptr()
+                a.zero_velocity = 1 if zero_velocity else 0
+                if rot is not None:
+                    a.quat_stash = self._stash.data_ptr()
+                    self._stash_armed = True
+                continue
             host = getattr(fn, "_gf_host_pose", None)
             if host is None:  # read the fixed pose back once; never per step (a device->host copy is a sync)
                 host = (fn.reset_pos.tolist(), None if fn.reset_quat is None else fn.reset_quat.tolist())

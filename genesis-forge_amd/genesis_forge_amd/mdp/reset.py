@@ -63,20 +63,50 @@ class position(ResetMdpFnClass):
 
 
 class randomize_terrain_position(ResetMdpFnClass):
-    """Random position on the terrain (reset.py:127-226), via TerrainManager.generate_random_env_pos."""
+    """Random position on the terrain and (by default) a random yaw (reset.py:127-226).
+
+    On an entity with masked setters the EntityManager folds this whole function into the masked reset (``GfResetArgs.spawn_*``:
+    the draws, the terrain-height lookup, ``xyz_to_quat`` and the pose write happen per lane, no ``nonzero`` / gather / scatter);
+    ``gf_spawn`` describes it.  Called directly it runs the reference's sequence through the public setters."""
 
     def __init__(self, env, entity, terrain_manager, height_offset: float = 0.1e-3, subterrain=None,
                  rotation: dict | None = {"z": (0, 2 * math.pi)}, zero_velocity: bool = True):
         self.env = env
-        self.zero_velocity = zero_velocity
+        self.rotation = rotation
+        self._rotation_buffer = None
+        self._quat_buffer = None
+
+    def build(self):
+        self._rotation_buffer = torch.zeros((self.env.num_envs, 3), device=gs.device, dtype=gs.tc_float)
+        self._quat_buffer = torch.zeros((self.env.num_envs, 4), device=gs.device, dtype=gs.tc_float)
+
+    def define_quat(self, envs_idx, rotation: dict):
+        """Only axes given as ``(lo, hi)`` tuples are written; scalars leave the axis at 0 (reset.py:172-196)."""
+        for k, axis in enumerate("xyz"):
+            v = rotation.get(axis, 0)
+            if isinstance(v, tuple):
+                self._rotation_buffer[envs_idx, k] = torch.empty(len(envs_idx), device=gs.device).uniform_(*v)
+        self._quat_buffer[envs_idx] = xyz_to_quat(self._rotation_buffer[envs_idx])
+
+    def gf_spawn(self, terrain_manager, height_offset: float = 0.1e-3, subterrain=None, rotation: dict | None = {"z": (0, 2 * math.pi)},
+                 zero_velocity: bool = True):
+        """(usable area, height offset, rotation ranges, zero_velocity) for the fused reset, or None when it cannot be described
+        statically (``subterrain`` given as a callable is re-evaluated by the reference on every reset)."""
+        if callable(subterrain) or not hasattr(terrain_manager, "gf_view"):
+            return None
+        rot = None
+        if rotation is not None:
+            rot = [rotation.get(axis) if isinstance(rotation.get(axis), tuple) else None for axis in "xyz"]
+        return terrain_manager.usable_area(0.5, subterrain), float(height_offset), rot, bool(zero_velocity)
 
     def __call__(self, env, entity, envs_idx, terrain_manager, height_offset: float = 0.1e-3, subterrain=None,
                  rotation: dict | None = {"z": (0, 2 * math.pi)}, zero_velocity: bool = True):
         sub = subterrain() if callable(subterrain) else subterrain
         pos = terrain_manager.generate_random_env_pos(envs_idx=envs_idx, subterrain=sub, height_offset=height_offset)
-        entity.set_pos(pos, envs_idx=envs_idx, zero_velocity=self.zero_velocity)
+        entity.set_pos(pos, envs_idx=envs_idx, zero_velocity=zero_velocity)
         if rotation is not None:
-            set_rotation(env, entity, envs_idx, **rotation)
+            self.define_quat(envs_idx, rotation)
+            entity.set_quat(self._quat_buffer[envs_idx], envs_idx=envs_idx, zero_velocity=zero_velocity)
 
 
 def randomize_link_mass_shift(env, entity, envs_idx, link_name: str, add_mass_range: tuple[float, float]):

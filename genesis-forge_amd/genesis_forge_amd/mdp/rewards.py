@@ -30,7 +30,10 @@ def _term(spec_fn):
 
     def deco(fn):
         def public(env, *args, **kwargs):
-            return eval_reward_spec(env, spec_fn(env, *args, **kwargs))
+            spec = spec_fn(env, *args, **kwargs)
+            if spec is None:  # no opcode for this combination of arguments: the function body is the torch restatement
+                return fn(env, *args, **kwargs)
+            return eval_reward_spec(env, spec)
 
         public.__name__ = fn.__name__
         public.__qualname__ = fn.__qualname__
@@ -56,7 +59,7 @@ def terminated(env):
 def _spec_base_height(env, target_height: Union[float, torch.Tensor] = None, height_command=None, terrain_manager=None,
                       entity_attr: str = "robot", entity_manager=None):
     ent = _entity(env, entity_attr, entity_manager)
-    flags, cmd, ext, p0 = 0, {}, {}, 0.0
+    flags, cmd, ext, p0, terrain = 0, {}, {}, 0.0, None
     if height_command is not None:
         flags |= nat.GF_RW_FLAG_CMD
         cmd[0] = height_command
@@ -66,19 +69,22 @@ def _spec_base_height(env, target_height: Union[float, torch.Tensor] = None, hei
     else:
         p0 = float(target_height)
     if terrain_manager is not None:
-        flags |= nat.GF_RW_FLAG_TERRAIN
-
-        def terrain_h(ent=ent, tm=terrain_manager):
-            pos = ent.get_pos()
-            return tm.get_terrain_height(pos[:, 0], pos[:, 1])
-
-        ext[1] = terrain_h
-    return TermSpec(nat.GF_R_BASE_HEIGHT, p=[p0], flags=flags, entity=ent, cmd=cmd, ext=ext)
+        if not hasattr(terrain_manager, "gf_view"):
+            return None  # a foreign terrain object: the whole term is evaluated by Python (EXTERNAL column)
+        flags |= nat.GF_RW_FLAG_TERRAIN  # the kernel samples the manager's height field under the base
+        terrain = terrain_manager
+    return TermSpec(nat.GF_R_BASE_HEIGHT, p=[p0], flags=flags, entity=ent, cmd=cmd, ext=ext, terrain=terrain)
 
 
 @_term(_spec_base_height)
 def base_height(env, target_height=None, height_command=None, terrain_manager=None, entity_attr="robot", entity_manager=None):
     """``(base_z - terrain_height - target)^2`` (rewards.py:54-90)."""
+    # only reached with a terrain object that is not this package's TerrainManager
+    pos = _entity(env, entity_attr, entity_manager).get_pos()
+    offset = terrain_manager.get_terrain_height(pos[:, 0], pos[:, 1]) if terrain_manager is not None else 0.0
+    if height_command is not None:
+        target_height = height_command.command.squeeze(-1)
+    return torch.square(pos[:, 2] - offset - target_height)
 
 
 def _spec_dof_similar(env, action_manager):

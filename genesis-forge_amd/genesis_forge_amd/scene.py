@@ -105,6 +105,76 @@ class SyntheticPlane:
         self.n_links = 1
 
 
+class _TerrainMorph:
+    """The attributes of ``gs.morphs.Terrain`` that TerrainManager reads (terrain_manager.py:281-359)."""
+
+    def __init__(self, pos=(0.0, 0.0, 0.0), n_subterrains=(1, 1), subterrain_size=(12.0, 12.0), horizontal_scale=0.25,
+                 vertical_scale=0.005, subterrain_types="flat_terrain", subterrain_parameters=None, height_field=None, **_ignored):
+        self.pos = tuple(float(v) for v in pos)
+        self.n_subterrains = tuple(int(v) for v in n_subterrains)
+        self.subterrain_size = tuple(float(v) for v in subterrain_size)
+        self.horizontal_scale = float(horizontal_scale)
+        self.vertical_scale = float(vertical_scale)
+        if isinstance(subterrain_types, str):
+            subterrain_types = [[subterrain_types] * self.n_subterrains[1] for _ in range(self.n_subterrains[0])]
+        self.subterrain_types = subterrain_types
+        self.subterrain_parameters = subterrain_parameters or {}
+        self.height_field = height_field
+
+
+class _TerrainGeom:
+    def __init__(self, metadata, lo, hi, pos):
+        self.metadata = metadata
+        self._aabb = torch.tensor([lo, hi], dtype=torch.float32)
+        self._pos = torch.tensor(pos, dtype=torch.float32)
+
+    def get_AABB(self):
+        return self._aabb
+
+    def get_pos(self):
+        return self._pos
+
+
+class SyntheticTerrain(SyntheticPlane):
+    """``scene.add_entity(morph=gs.morphs.Terrain(…))``: a static height-field entity.
+
+    The height field has Genesis' layout — integer height steps, shape ``(n_sub_x * rows, n_sub_y * cols)`` with
+    ``rows = subterrain_size[0] / horizontal_scale``, metres = value * vertical_scale — and is filled per subterrain type:
+    ``flat_terrain`` zeros; anything else a deterministic blocky random field between the type's ``min_height`` and
+    ``max_height`` (a stand-in for Genesis' generators: TerrainManager only ever samples the field, it never generates it)."""
+
+    def __init__(self, scene, link_start: int, morph: "Morph"):
+        super().__init__(scene, link_start)
+        import numpy as np
+
+        m = _TerrainMorph(**morph.kw)
+        self.morph = m
+        rows = int(m.subterrain_size[0] / m.horizontal_scale + 1e-9)
+        cols = int(m.subterrain_size[1] / m.horizontal_scale + 1e-9)
+        if m.height_field is not None:
+            hf = np.asarray(m.height_field, dtype=np.int16)
+        else:
+            hf = np.zeros((m.n_subterrains[0] * rows, m.n_subterrains[1] * cols), dtype=np.int16)
+            rng = np.random.RandomState(scene.seed & 0x7FFFFFFF)
+            for i in range(m.n_subterrains[0]):
+                for j in range(m.n_subterrains[1]):
+                    kind = m.subterrain_types[i][j]
+                    if kind == "flat_terrain":
+                        continue
+                    par = m.subterrain_parameters.get(kind, {})
+                    lo = int(round(par.get("min_height", 0.0) / m.vertical_scale))
+                    hi = max(lo, int(round(par.get("max_height", 0.1) / m.vertical_scale)))
+                    blk = 4
+                    coarse = rng.randint(lo, hi + 1, size=((rows + blk - 1) // blk, (cols + blk - 1) // blk))
+                    hf[i * rows:(i + 1) * rows, j * cols:(j + 1) * cols] = np.kron(coarse, np.ones((blk, blk), dtype=np.int64))[:rows, :cols]
+        x0, y0, z0 = m.pos
+        lo = (x0, y0, z0 + float(hf.min()) * m.vertical_scale)
+        hi = (x0 + m.n_subterrains[0] * m.subterrain_size[0], y0 + m.n_subterrains[1] * m.subterrain_size[1], z0 + float(hf.max()) * m.vertical_scale)
+        self.geoms = [_TerrainGeom({"height_field": hf}, lo, hi, m.pos)]
+        self.bounds = (lo[0], hi[0], lo[1], hi[1])
+        self.links = [Link("terrain", link_start, 0)]
+
+
 class SyntheticEntity:
     """Articulated robot with a free base; state lives in ``[N, …]`` device tensors."""
 
@@ -328,7 +398,9 @@ class SyntheticScene:
     def add_entity(self, morph=None, model: Optional[RobotModel] = None, **kw):
         if isinstance(morph, RobotModel):
             model, morph = morph, None
-        if model is None and morph is not None and morph.kind in ("plane", "terrain"):
+        if model is None and morph is not None and morph.kind == "terrain":
+            ent = SyntheticTerrain(self, self._n_links, morph)
+        elif model is None and morph is not None and morph.kind == "plane":
             ent = SyntheticPlane(self, self._n_links)
         else:
             if model is None:

@@ -79,6 +79,21 @@ typedef struct GfCommandView {
     int32_t _pad;
 } GfCommandView;
 
+/* TerrainManager's map of the terrain (managers/terrain_manager.py:281-359): the height field after `* vertical_scale` and
+ * the transpose of :354-359, i.e. rows index y and cols index x, plus the bounds get_terrain_height normalises with
+ * (:117-136).  A NULL height_field is the "no height field" case of :112-114: every query returns origin_z. */
+typedef struct GfTerrainView {
+    const float* height_field;  /* [rows, cols] f32 metres, or NULL */
+    int32_t rows;               /* H (y direction) */
+    int32_t cols;               /* W (x direction) */
+    float x_min;                /* (float)bounds[0] */
+    float x_span;               /* (float)(bounds[1] - bounds[0]), the double difference rounded once (`div_(x_max - x_min)`) */
+    float y_min;
+    float y_span;
+    float origin_z;
+    int32_t _pad;
+} GfTerrainView;
+
 /* One row of a term table.  Meaning of p[]/i[] is per opcode (see enums below). */
 typedef struct GfTerm {
     int32_t op;
@@ -184,6 +199,7 @@ enum {
     GF_T_CONTACT_FORCE_GRACE = 7,  /* i0 = view, p0 = thr, i1 = grace steps         (terminations.py:175-205)*/
     GF_T_EXTERNAL = 8              /* i0 = ext slot (bool column evaluated by the host) */
 };
+#define GF_SPAWN_BLOCK 0x100000u  /* Philox counter block of the spawn draws: (x, y, rot z, -) and, in the next block, (rot x, rot y, -, -) */
 #define GF_TERM_FLAG_TIME_OUT 1    /* TerminationConfigItem.time_out → OR into truncated */
 
 typedef struct GfTerminationArgs {
@@ -207,7 +223,7 @@ typedef struct GfTerminationArgs {
 enum {
     GF_R_IS_ALIVE = 1,           /* rewards.py:31-37  */
     GF_R_TERMINATED = 2,         /* rewards.py:40-46  */
-    GF_R_BASE_HEIGHT = 3,        /* p0 = target | i0 = command view (flag CMD), i1 = ext slot of terrain height (flag TERRAIN)  rewards.py:54-90 */
+    GF_R_BASE_HEIGHT = 3,        /* p0 = target | i0 = command view (flag CMD); flag TERRAIN: minus the terrain height under the base  rewards.py:54-90 */
     GF_R_DOF_SIMILAR_TO_DEFAULT = 4, /* rewards.py:93-109  */
     GF_R_LIN_VEL_Z_L2 = 5,       /* rewards.py:112-135 */
     GF_R_ANG_VEL_XY_L2 = 6,      /* rewards.py:138-161 */
@@ -224,7 +240,7 @@ enum {
     GF_R_EXTERNAL = 17           /* i0 = ext slot ([N] f32 column evaluated by the host) */
 };
 #define GF_RW_FLAG_CMD 1         /* base_height: target from command view i0 column 0 */
-#define GF_RW_FLAG_TERRAIN 2     /* base_height: subtract ext[i1] terrain height */
+#define GF_RW_FLAG_TERRAIN 2     /* base_height: subtract get_terrain_height(pos.x, pos.y) sampled from GfRewardArgs.terrain */
 #define GF_RW_FLAG_MAX 4         /* feet_air_time: clamp max */
 #define GF_RW_FLAG_FIRST_CALL 8  /* body_acceleration_exp: no prev state yet */
 
@@ -251,6 +267,7 @@ typedef struct GfRewardArgs {
     float* episode_sums;       /* [T,N] in/out (STEP, logging) */
     float* episode_seconds;    /* [N]   in/out (STEP) */
     float* term_out;           /* [T,N] out (EVAL): unweighted term values */
+    GfTerrainView terrain;     /* base_height(terrain_manager=…): sampled in the kernel (rewards.py:84-88) */
     GfTerm terms[GF_MAX_TERMS];
 } GfRewardArgs;
 
@@ -328,7 +345,20 @@ typedef struct GfResetArgs {
     uint64_t seed;
     uint64_t stream;
     uint32_t env_offset;        /* global index of local env 0 */
-    uint32_t _pad2;
+    /* mdp.reset.randomize_terrain_position (mdp/reset.py:127-226 → terrain_manager.py:170-279): with spawn_mode = 1 the base of a
+     * reset env goes to x = u0*spawn_x_span + spawn_x_min, y = u1*spawn_y_span + spawn_y_min (the usable centre area),
+     * z = terrain height there + spawn_height_offset, instead of reset_pos; with spawn_set_quat = 1 its orientation becomes
+     * xyz_to_quat(rx, ry, rz) where axis k is U(spawn_rot_lo[k], spawn_rot_hi[k]) if bit k of spawn_rot_mask is set and 0
+     * otherwise (define_quat only writes the axes given as (lo, hi) tuples, reset.py:172-196; default {"z": (0, 2π)}). */
+    int32_t spawn_mode;
+    int32_t spawn_set_quat;
+    int32_t spawn_rot_mask;
+    float spawn_x_min, spawn_x_span;
+    float spawn_y_min, spawn_y_span;
+    float spawn_height_offset;
+    float spawn_rot_lo[3], spawn_rot_hi[3];
+    const float* spawn_draws;   /* [N,5] U[0,1) (x, y, rot x, rot y, rot z) or NULL → Philox blocks GF_SPAWN_BLOCK, +1 of `stream` */
+    GfTerrainView terrain;
     GfStepStats* stats;         /* may be NULL */
 } GfResetArgs;
 
@@ -407,6 +437,26 @@ typedef struct GfRotateArgs {
 } GfRotateArgs;
 
 /* ------------------------------------------------------------------------------------------
+ * TerrainManager.get_terrain_height (managers/terrain_manager.py:100-166): bilinear sample of the shared
+ * height field at world (x, y), `F.grid_sample(mode="bilinear", padding_mode="border", align_corners=True)`:
+ *   nx = ((x - x_min) / x_span) * 2 - 1            (the in-place chain of :123-136, one rounding per op)
+ *   ix = clamp(((nx + 1) / 2) * (W - 1), 0, W - 1) (unnormalise + border clip), same for iy with H
+ *   out = nw*v[y0,x0] + ne*v[y0,x1] + sw*v[y1,x0] + se*v[y1,x1], weights (x1-ix)(y1-iy) …, taps outside the field
+ *   contribute nothing (only x1 = W / y1 = H, where the weight is 0 anyway).
+ * x and y are strided so `pos[:, 0]`, `pos[:, 1]` of an [N,3] tensor (rewards.py:85-87) or columns of the spawn
+ * buffer (terrain_manager.py:236-239) are read in place.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct GfTerrainHeightArgs {
+    int64_t num;           /* number of queries */
+    const float* x;        /* element i at x[i * x_stride] */
+    const float* y;
+    int64_t x_stride;      /* in floats */
+    int64_t y_stride;
+    GfTerrainView terrain;
+    float* out;            /* [num] */
+} GfTerrainHeightArgs;
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic scene tick — stands in for Genesis' scene.step() in benchmarks and parity tests
  * (SURVEY.md §7 step 5).  Deterministic, integer-Philox driven, f32 ops in a fixed order so the
  * HIP kernel, the C oracle and the numpy model used to drive the reference agree bit for bit.
@@ -469,6 +519,7 @@ int gf_command_step(const GfCommandArgs* a, void* stream);        /* replaces co
 int gf_masked_reset(const GfResetArgs* a, void* stream);          /* replaces managed_env.py:336-366 fan-out */
 int gf_observe(const GfObservationArgs* a, void* stream);         /* replaces observation_manager.py:218-256 */
 int gf_entity_rotate(const GfRotateArgs* a, void* stream);        /* replaces entity_manager.py:130-146 */
+int gf_terrain_height(const GfTerrainHeightArgs* a, void* stream);/* replaces terrain_manager.py:100-166 */
 int gf_synth_scene_step(const GfSynthSceneArgs* a, void* stream); /* stands in for scene.step() (managed_env.py:292) */
 
 /* ------------------------------------------------------------------------------------------
@@ -543,7 +594,7 @@ int gf_event_synchronize(void* event);   /* blocks the host until the event has 
 /* Optional per-phase HIP-event timing used by bench.py (events recorded on `stream`
  * immediately around the kernel launch of the selected phase). */
 enum { GF_PHASE_ACTION = 0, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
-       GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_COUNT };
+       GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_COUNT };
 int gf_profile_begin(int phase, int max_samples);     /* start recording event pairs for `phase` */
 int gf_profile_end(double* total_ms, int* samples);    /* sync events, return Σ elapsed + count, free them */
 

@@ -85,6 +85,86 @@ static inline void proj_gravity(const GfEntityView* e, int64_t n, float* o) {
     rot_inv(e->quat + 4 * n, g, o);
 }
 
+/* ---------------------------------------------------------------- terrain ---------------- */
+/* TerrainManager.get_terrain_height for one point (managers/terrain_manager.py:100-166).
+ *   :117-136  norm = 2*(v - v_min)/(v_max - v_min) - 1 as the in-place chain sub_, div_, mul_(2), sub_(1)
+ *   :153-159  F.grid_sample(field[1,H,W], grid(x->W, y->H), bilinear, border, align_corners=True):
+ *             unnormalise ((c+1)/2)*(size-1), clip to [0,size-1], floor, the four corner weights, taps outside the field
+ *             contribute 0 (ATen GridSampler: grid_sampler_compute_source_index / bilinear taps nw,ne,sw,se)
+ *   :112-114  no height field: the terrain origin's z. */
+static float terrain_height(const GfTerrainView* tv, float x, float y) {
+    if (!tv->height_field) return tv->origin_z;
+    float nx = x - tv->x_min;
+    nx = nx / tv->x_span;
+    nx = nx * 2.0f;
+    nx = nx - 1.0f;
+    float ny = y - tv->y_min;
+    ny = ny / tv->y_span;
+    ny = ny * 2.0f;
+    ny = ny - 1.0f;
+    const int W = tv->cols, H = tv->rows;
+    float ix = ((nx + 1.0f) / 2.0f) * (float)(W - 1);
+    float iy = ((ny + 1.0f) / 2.0f) * (float)(H - 1);
+    if (ix < 0.0f) ix = 0.0f;
+    if (ix > (float)(W - 1)) ix = (float)(W - 1);
+    if (iy < 0.0f) iy = 0.0f;
+    if (iy > (float)(H - 1)) iy = (float)(H - 1);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
+    const float nw = (fx1 - ix) * (fy1 - iy);
+    const float ne = (ix - fx0) * (fy1 - iy);
+    const float sw = (fx1 - ix) * (iy - fy0);
+    const float se = (ix - fx0) * (iy - fy0);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float* f = tv->height_field;
+    const float v_nw = f[y0 * W + x0];
+    const float v_ne = x1 < W ? f[y0 * W + x1] : 0.0f;
+    const float v_sw = y1 < H ? f[y1 * W + x0] : 0.0f;
+    const float v_se = (x1 < W && y1 < H) ? f[y1 * W + x1] : 0.0f;
+    return ((v_nw * nw + v_ne * ne) + v_sw * sw) + v_se * se;
+}
+
+GFO_EXPORT int gfo_terrain_height(const GfTerrainHeightArgs* a) {
+    if (!a || !a->out) return GF_E_NULL;
+    if (a->num < 0) return GF_E_RANGE;
+    if (a->terrain.height_field) {
+        if (!a->x || !a->y) return GF_E_NULL;
+        if (a->terrain.rows < 1 || a->terrain.cols < 1 || a->x_stride < 0 || a->y_stride < 0) return GF_E_RANGE;
+    }
+    for (int64_t i = 0; i < a->num; ++i)
+        a->out[i] = a->terrain.height_field ? terrain_height(&a->terrain, a->x[i * a->x_stride], a->y[i * a->y_stride]) : a->terrain.origin_z;
+    return GF_OK;
+}
+
+/* sin / cos as a fixed f32 operation sequence (the library's arithmetic contract for the spawn quaternion: the same
+ * sequence runs on the GPU, so both sides produce the same bits; within 2 ulp of libm, i.e. of the reference's torch.sin/cos):
+ * k = rint(x*2/pi), three-part Cody-Waite reduction r = x - k*pi/2, Cephes minimax polynomials on [-pi/4, pi/4]. */
+static void sincos_det(float x, float* s, float* c) {
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    const float z = r * r;
+    const float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    const float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    const int q = (int)k & 3;
+    const float sv = (q & 1) ? pc : ps, cv = (q & 1) ? ps : pc;
+    *s = (q & 2) ? -sv : sv;
+    *c = ((q + 1) & 2) ? -cv : cv;
+}
+
+/* genesis.utils.geom.xyz_to_quat (third-party, absent; call sites mdp/reset.py:63,194): extrinsic x-y-z Euler -> (w,x,y,z) */
+static void xyz_to_quat(float ax, float ay, float az, float* q) {
+    float sx, cx, sy, cy, sz, cz;
+    sincos_det(ax * 0.5f, &sx, &cx);
+    sincos_det(ay * 0.5f, &sy, &cy);
+    sincos_det(az * 0.5f, &sz, &cz);
+    q[0] = (cx * cy) * cz + (sx * sy) * sz;
+    q[1] = (sx * cy) * cz - (cx * sy) * sz;
+    q[2] = (cx * sy) * cz + (sx * cy) * sz;
+    q[3] = (cx * cy) * sz - (sx * sy) * cz;
+}
+
 /* ---------------------------------------------------------------- stats ------------------ */
 GFO_EXPORT int gfo_stats_clear(GfStepStats* s) {
     if (!s) return GF_E_NULL;
@@ -298,7 +378,8 @@ static float eval_reward(const GfRewardArgs* a, const GfTerm* t, int64_t n) {
         case GF_R_TERMINATED: return a->terminated[n] ? 1.0f : 0.0f; /* rewards.py:45-46 */
         case GF_R_BASE_HEIGHT: { /* rewards.py:77-90 */
             float h = a->entity.pos[3 * n + 2];
-            if (t->flags & GF_RW_FLAG_TERRAIN) h = h - a->ext[t->i[1]][n];
+            if (t->flags & GF_RW_FLAG_TERRAIN) /* rewards.py:84-88 */
+                h = h - terrain_height(&a->terrain, a->entity.pos[3 * n], a->entity.pos[3 * n + 1]);
             const float target = (t->flags & GF_RW_FLAG_CMD)
                                      ? a->command[t->i[0]].command[(int64_t)n * a->command[t->i[0]].width]
                                      : t->p[0];
@@ -524,11 +605,43 @@ GFO_EXPORT int gfo_masked_reset(const GfResetArgs* a) {
         }
         /* mdp.reset.position  reset.py:102-124 */
         if (a->scene_pos) {
-            for (int j = 0; j < 3; ++j) a->scene_pos[3 * n + j] = a->reset_pos[j];
-            if (a->set_quat && a->scene_quat) {
+            float p[3] = {a->reset_pos[0], a->reset_pos[1], a->reset_pos[2]};
+            float q[4] = {a->reset_quat[0], a->reset_quat[1], a->reset_quat[2], a->reset_quat[3]};
+            int set_quat = a->set_quat;
+            if (a->spawn_mode) {
+                /* mdp.reset.randomize_terrain_position (reset.py:199-226):
+                 *   terrain_manager.py:236-247  x = rand*(x_max-x_min)+x_min, y likewise (usable centre area), z = height + offset
+                 *   reset.py:172-196            every axis given as a (lo, hi) tuple is uniform_, the others stay 0; xyz_to_quat */
+                float u[5] = {0, 0, 0, 0, 0};
+                const uint32_t genv = (uint32_t)n + a->env_offset;
+                if (a->spawn_draws) {
+                    for (int j = 0; j < 5; ++j) u[j] = a->spawn_draws[n * 5 + j];
+                } else {
+                    uint32_t r[4];
+                    philox4x32_10(genv, GF_SPAWN_BLOCK, (uint32_t)a->stream, (uint32_t)(a->stream >> 32), (uint32_t)a->seed, (uint32_t)(a->seed >> 32), r);
+                    u[0] = (float)(r[0] >> 8) * 5.9604644775390625e-8f;
+                    u[1] = (float)(r[1] >> 8) * 5.9604644775390625e-8f;
+                    u[4] = (float)(r[2] >> 8) * 5.9604644775390625e-8f;
+                    if (a->spawn_rot_mask & 3) {
+                        philox4x32_10(genv, GF_SPAWN_BLOCK + 1u, (uint32_t)a->stream, (uint32_t)(a->stream >> 32), (uint32_t)a->seed, (uint32_t)(a->seed >> 32), r);
+                        u[2] = (float)(r[0] >> 8) * 5.9604644775390625e-8f;
+                        u[3] = (float)(r[1] >> 8) * 5.9604644775390625e-8f;
+                    }
+                }
+                p[0] = u[0] * a->spawn_x_span + a->spawn_x_min;
+                p[1] = u[1] * a->spawn_y_span + a->spawn_y_min;
+                p[2] = terrain_height(&a->terrain, p[0], p[1]) + a->spawn_height_offset;
+                const float rx = (a->spawn_rot_mask & 1) ? uniform_range(u[2], a->spawn_rot_lo[0], a->spawn_rot_hi[0]) : 0.0f;
+                const float ry = (a->spawn_rot_mask & 2) ? uniform_range(u[3], a->spawn_rot_lo[1], a->spawn_rot_hi[1]) : 0.0f;
+                const float rz = (a->spawn_rot_mask & 4) ? uniform_range(u[4], a->spawn_rot_lo[2], a->spawn_rot_hi[2]) : 0.0f;
+                xyz_to_quat(rx, ry, rz, q);
+                set_quat = a->spawn_set_quat;
+            }
+            for (int j = 0; j < 3; ++j) a->scene_pos[3 * n + j] = p[j];
+            if (set_quat && a->scene_quat) {
                 if (a->quat_stash)
                     for (int j = 0; j < 4; ++j) a->quat_stash[4 * n + j] = a->scene_quat[4 * n + j];
-                for (int j = 0; j < 4; ++j) a->scene_quat[4 * n + j] = a->reset_quat[j];
+                for (int j = 0; j < 4; ++j) a->scene_quat[4 * n + j] = q[j];
             }
             if (a->zero_velocity) {
                 if (a->scene_lin_vel) for (int j = 0; j < 3; ++j) a->scene_lin_vel[3 * n + j] = 0.0f;
@@ -735,6 +848,7 @@ GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
             case GF_PHASE_OBSERVE: rc = gfo_observe((const GfObservationArgs*)a); break;
             case GF_PHASE_ROTATE: rc = gfo_entity_rotate((const GfRotateArgs*)a); break;
             case GF_PHASE_SCENE: rc = gfo_synth_scene_step((const GfSynthSceneArgs*)a); break;
+            case GF_PHASE_TERRAIN: rc = gfo_terrain_height((const GfTerrainHeightArgs*)a); break;
             case GF_OP_STATS_CLEAR: rc = gfo_stats_clear((GfStepStats*)a); break;
             case GF_OP_POST_PHYSICS: rc = gfo_post_physics_step((const GfPostRefs*)a); break;
             case GF_OP_STATS_PACK: rc = gfo_stats_pack((const GfStatsPackArgs*)a); break;
@@ -768,6 +882,8 @@ GFO_EXPORT int gfo_sizeof(int which) {
         case 9: return (int)sizeof(GfSynthSceneArgs);
         case 10: return (int)sizeof(GfTerm);
         case 11: return (int)sizeof(GfObsItem);
+        case 12: return (int)sizeof(GfTerrainView);
+        case 13: return (int)sizeof(GfTerrainHeightArgs);
         default: return -1;
     }
 }

@@ -144,3 +144,74 @@ class HumanoidGaitLikeEnv(ManagedEnvironment):
             "force": {"fn": observations.entity_dofs_force, "params": {"action_manager": self.action_manager}},
             "raw": {"fn": observations.current_actions},
         })
+
+
+class Go2RoughTerrainEnv(ManagedEnvironment):
+    """BASELINE config 3 (cf. examples/rough_terrain/environment.py:87-287): Go2 on a height-field terrain, TerrainManager,
+    random terrain spawn with random yaw on reset, out_of_bounds termination, two contact managers, 9 reward terms — plus
+    (``height_reward=True``) ``base_height(terrain_manager=…)`` so the in-kernel height lookup is on the path."""
+
+    def __init__(self, num_envs=1, dt=1 / 50, max_episode_length_s=20, scene_kwargs=None, height_reward=True, rotation="default",
+                 terrain_kwargs=None, cmd_resample_s=5.0):
+        super().__init__(num_envs=num_envs, dt=dt, max_episode_length_sec=max_episode_length_s, max_episode_random_scaling=0.1)
+        kw = dict(scene_kwargs or {})
+        kw.setdefault("max_collision_pairs", 12)
+        self._height_reward, self._rotation, self._cmd_resample_s = height_reward, rotation, cmd_resample_s
+        self.scene = SyntheticScene(dt=self.dt, substeps=2, **kw)
+        tk = dict(pos=(-12, -12, 0), n_subterrains=(1, 1), subterrain_size=(24, 24), vertical_scale=0.001,
+                  subterrain_types=[["random_uniform_terrain"]],
+                  subterrain_parameters={"random_uniform_terrain": {"min_height": 0.0, "max_height": 0.1, "step": 0.05, "downsampled_scale": 0.25}})
+        tk.update(terrain_kwargs or {})
+        self.terrain = self.scene.add_entity(morph=morphs.Terrain(**tk))
+        self.robot = self.scene.add_entity(morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=INITIAL_BODY_POSITION, quat=INITIAL_QUAT))
+
+    def config(self):
+        from genesis_forge_amd.managers import TerrainManager
+
+        self.terrain_manager = TerrainManager(self)
+        params = {"height_offset": 0.4, "terrain_manager": self.terrain_manager}
+        if self._rotation != "default":
+            params["rotation"] = self._rotation
+        self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={"position": {"fn": reset.randomize_terrain_position, "params": params}})
+        self.action_manager = PositionActionManager(
+            self, joint_names=["FL_.*_joint", "FR_.*_joint", "RL_.*_joint", "RR_.*_joint"],
+            default_pos={".*_hip_joint": 0.0, "FL_thigh_joint": 0.8, "FR_thigh_joint": 0.8, "RL_thigh_joint": 1.0, "RR_thigh_joint": 1.0,
+                         ".*_calf_joint": -1.5},
+            scale=0.25, use_default_offset=True, pd_kp=20, pd_kv=0.5, max_force=23.5)
+        self.velocity_command = VelocityCommandManager(
+            self, range={"lin_vel_x": [-1.0, 1.0], "lin_vel_y": [-1.0, 1.0], "ang_vel_z": [-0.5, 0.5]}, standing_probability=0.05,
+            resample_time_sec=self._cmd_resample_s)
+        self.foot_contact_manager = ContactManager(self, link_names=[".*_calf"], track_air_time=True, air_time_contact_threshold=5.0)
+        self.undesired_contacts = ContactManager(self, link_names=[".*_thigh", "base"])
+        rcfg = {
+            "tracking_lin_vel": {"weight": 1.5, "fn": rewards.command_tracking_lin_vel,
+                                 "params": {"vel_cmd_manager": self.velocity_command, "entity_manager": self.robot_manager}},
+            "tracking_ang_vel": {"weight": 0.75, "fn": rewards.command_tracking_ang_vel,
+                                 "params": {"vel_cmd_manager": self.velocity_command, "entity_manager": self.robot_manager}},
+            "lin_vel_z": {"weight": -2.0, "fn": rewards.lin_vel_z_l2, "params": {"entity_manager": self.robot_manager}},
+            "ang_vel_xy": {"weight": -0.05, "fn": rewards.ang_vel_xy_l2, "params": {"entity_manager": self.robot_manager}},
+            "undesired_contacts": {"weight": -1.0, "fn": rewards.has_contact, "params": {"contact_manager": self.undesired_contacts, "threshold": 5.0}},
+            "action_rate": {"weight": -0.01, "fn": rewards.action_rate_l2},
+            "similar_to_default": {"weight": -0.1, "fn": rewards.dof_similar_to_default, "params": {"action_manager": self.action_manager}},
+            "flat_orientation": {"weight": -1.5, "fn": rewards.flat_orientation_l2},
+            "terminated": {"weight": -100.0, "fn": rewards.terminated},
+        }
+        if self._height_reward:
+            rcfg["base_height"] = {"weight": -30.0, "fn": rewards.base_height,
+                                   "params": {"target_height": 0.35, "terrain_manager": self.terrain_manager, "entity_manager": self.robot_manager}}
+        self.reward_manager = RewardManager(self, logging_enabled=True, cfg=rcfg)
+        self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg={
+            "timeout": {"fn": terminations.timeout, "time_out": True},
+            "out_of_bounds": {"fn": terminations.out_of_bounds, "params": {"terrain_manager": self.terrain_manager}},
+            "bad_orientation": {"fn": terminations.bad_orientation,
+                                "params": {"limit_angle": 30.0, "entity_manager": self.robot_manager, "grace_steps": 20}},
+        })
+        self.observation_manager = ObservationManager(self, cfg={
+            "velocity_cmd": {"fn": self.velocity_command.observation},
+            "angle_velocity": {"fn": lambda env: self.robot_manager.get_angular_velocity()},
+            "linear_velocity": {"fn": lambda env: self.robot_manager.get_linear_velocity()},
+            "projected_gravity": {"fn": lambda env: self.robot_manager.get_projected_gravity()},
+            "dof_position": {"fn": lambda env: self.action_manager.get_dofs_position()},
+            "dof_velocity": {"fn": lambda env: self.action_manager.get_dofs_velocity(), "scale": 0.05},
+            "actions": {"fn": lambda env: self.action_manager.get_actions()},
+        })

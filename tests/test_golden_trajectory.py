@@ -7,7 +7,7 @@ import pytest
 import helpers
 
 
-@pytest.mark.parametrize("name", ["traj_go2_cmd", "traj_go2_contacts_hist"])
+@pytest.mark.parametrize("name", ["traj_go2_cmd", "traj_go2_contacts_hist", "traj_go2_rough"])
 def test_trajectory_matches_reference_cpu_oracle(oracle_backend, name):
     fix = helpers.load(name)
     res = helpers.replay_trajectory(fix, "cpu")
@@ -15,7 +15,7 @@ def test_trajectory_matches_reference_cpu_oracle(oracle_backend, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["traj_go2_cmd", "traj_go2_contacts_hist"])
+@pytest.mark.parametrize("name", ["traj_go2_cmd", "traj_go2_contacts_hist", "traj_go2_rough"])
 def test_trajectory_matches_reference_hip(hip_backend, name):
     fix = helpers.load(name)
     res = helpers.replay_trajectory(fix, "cuda")

@@ -12,11 +12,15 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(dev, n, steps, contacts, history, seed=7):
-    from envs import Go2CommandDirectionEnv
+def _run(dev, n, steps, contacts, history, seed=7, rough=False):
+    from envs import Go2CommandDirectionEnv, Go2RoughTerrainEnv
 
-    env = Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, contacts=contacts, history=history,
-                                 obs_noise=True, scene_kwargs=dict(ang_noise=0.25, seed=seed))
+    if rough:  # terrain spawn (Philox x / y / yaw, in-kernel height lookup, deterministic sincos) + base_height over the terrain
+        env = Go2RoughTerrainEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, scene_kwargs=dict(ang_noise=0.4, seed=seed),
+                                 rotation={"x": (-0.2, 0.2), "z": (0, 6.283185307179586)} if history else "default")
+    else:
+        env = Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, contacts=contacts, history=history,
+                                     obs_noise=True, scene_kwargs=dict(ang_noise=0.25, seed=seed))
     env.build()
     env.seed(seed)
     obs, _ = env.reset()
@@ -28,26 +32,27 @@ def _run(dev, n, steps, contacts, history, seed=7):
             act[0, 0] = float("nan")
         obs, rew, term, trunc, extras = env.step(act.to(dev))
         state = [obs, rew, term, trunc, env.velocity_command._command, env.episode_length, env.max_episode_length,
-                 env.reward_manager._episode_sums, env.reward_manager._episode_seconds]
+                 env.reward_manager._episode_sums, env.reward_manager._episode_seconds, env.robot.get_pos(), env.robot.get_quat()]
         out.append(([x.cpu().clone() for x in state], {k: float(v) for k, v in extras["episode"].items()}))
     return out
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,contacts,history", [(1, False, None), (63, True, 3), (64, False, None), (65, True, None), (1000, True, 2),
-                                                  (4096, False, None)])
-def test_pipeline_hip_equals_oracle(hip_backend, oracle_lib_path, n, contacts, history):
+@pytest.mark.parametrize("n,contacts,history,rough", [(1, False, None, False), (63, True, 3, False), (64, False, None, False), (65, True, None, False),
+                                                        (1000, True, 2, False), (4096, False, None, False), (130, False, None, True),
+                                                        (1000, False, 1, True)])
+def test_pipeline_hip_equals_oracle(hip_backend, oracle_lib_path, n, contacts, history, rough):
     from genesis_forge_amd import _native as nat
     from genesis_forge_amd import gs
     from oracle_backend import OracleBackend
 
     steps = 60
-    hip = _run("cuda", n, steps, contacts, history)
+    hip = _run("cuda", n, steps, contacts, history, rough=rough)
     torch.cuda.synchronize()
     gs.set_device("cpu")
     nat.set_backend(OracleBackend(oracle_lib_path))
     try:
-        ref = _run("cpu", n, steps, contacts, history)
+        ref = _run("cpu", n, steps, contacts, history, rough=rough)
     finally:
         nat.set_backend(None)
         gs.set_device("cuda:0")
@@ -55,6 +60,8 @@ def test_pipeline_hip_equals_oracle(hip_backend, oracle_lib_path, n, contacts, h
     for t, ((a, la), (b, lb)) in enumerate(zip(hip, ref)):
         for k in (2, 3, 5, 6):  # masks, episode_length, max_episode_length: bit exact
             assert torch.equal(a[k], b[k]), f"integer/mask state {k} differs at step {t}"
+        for k in (9, 10):  # base pose incl. the terrain spawn: same operation sequence on both sides
+            assert torch.equal(a[k], b[k]), f"base pose {k} differs at step {t}: {(a[k] - b[k]).abs().max()}"
         for k in (0, 1, 4, 7, 8):
             assert torch.allclose(a[k], b[k], atol=1e-5, rtol=0, equal_nan=True), f"float state {k} differs at step {t}: {(a[k] - b[k]).abs().max()}"
         assert set(la) == set(lb), f"log keys differ at step {t}"

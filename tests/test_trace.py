@@ -126,6 +126,45 @@ def test_fused_post_physics_equals_phase_by_phase_hip(hip_backend, post_variant,
             assert abs(x[4][key] - y[4][key]) <= 1e-6 + 1e-6 * abs(y[4][key]), (t, key)
 
 
+def _run_rough(dev, mode, n, steps=60):
+    from envs import Go2RoughTerrainEnv
+
+    env = Go2RoughTerrainEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, scene_kwargs=dict(ang_noise=0.4, seed=9))
+    env.trace_enabled = mode != "ordinary"
+    env.fuse_post_physics = mode == "fused"
+    env.build()
+    env.seed(13)
+    env.reset()
+    g = torch.Generator().manual_seed(2)
+    seq = []
+    for t in range(steps):
+        o, r, te, tr, ex = env.step(torch.randn(n, 12, generator=g).to(dev))
+        seq.append((o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone(), {k: float(v) for k, v in ex["episode"].items()},
+                    env.robot.get_pos().cpu().clone(), env.robot.get_quat().cpu().clone(), env.velocity_command._command.cpu().clone(),
+                    env.max_episode_length.cpu().clone(), env.foot_contact_manager.current_air_time.cpu().clone(),
+                    env.reward_manager._episode_sums.cpu().clone()))
+    return seq, env
+
+
+def test_rough_terrain_traced_equals_ordinary_cpu(oracle_backend):
+    a, _ = _run_rough("cpu", "ordinary", 70)
+    b, env = _run_rough("cpu", "fused", 70)
+    assert env._trace is not None and env._trace.post_refs is not None
+    _same_h(a, b)
+    assert sum(int(x[2].sum() + x[3].sum()) for x in a) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("post_variant", [0, 1, 2], indirect=True)
+@pytest.mark.parametrize("n", [70, 4097])
+def test_rough_terrain_fused_hip(hip_backend, post_variant, n):
+    """Terrain spawn + base_height over the height field inside the fused launch (both kernel layouts) against the phase list."""
+    a, _ = _run_rough("cuda", "ordinary", n)
+    c, env_c = _run_rough("cuda", "fused", n)
+    assert env_c._trace is not None and env_c._trace.post_refs is not None, "this config must take the fused kernel"
+    _same_h(a, c)
+
+
 def _run_humanoid(dev, mode, n, dofs, steps=50):
     from envs import HumanoidGaitLikeEnv
 

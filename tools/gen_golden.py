@@ -61,6 +61,8 @@ def _patched_uniform(self, lo=0.0, hi=1.0):
     elif mode == "obs":     # observation_manager.py:249 — next noisy item's columns
         c0, w = CTX["cols"].pop(0)
         u = CTX["u"][:, c0:c0 + w]
+    elif mode == "spawn":   # mdp/reset.py:182-193 — one call per axis given as a (lo, hi) tuple, in x, y, z order
+        u = CTX["u"][CTX["ids"], 2 + CTX["axes"].pop(0)]
     else:
         raise RuntimeError(mode)
     val = (u.astype(np.float32) * np.float32(hi32 - lo32) + lo32).astype(np.float32)
@@ -69,6 +71,18 @@ def _patched_uniform(self, lo=0.0, hi=1.0):
 
 
 torch.Tensor.uniform_ = _patched_uniform
+
+
+def _patched_rand_like(t, *a, **k):
+    """terrain_manager.py:236-241: the x then the y coordinates of the spawn points."""
+    if CTX["mode"] != "spawn":
+        raise RuntimeError("rand_like outside a known context")
+    u = CTX["u"][CTX["ids"], CTX["i"]]
+    CTX["i"] += 1
+    return torch.from_numpy(np.ascontiguousarray(u.astype(np.float32))).reshape(t.shape)
+
+
+torch.rand_like = _patched_rand_like
 
 
 class Draws:
@@ -159,6 +173,22 @@ def install_contexts(env, draws_obj: Draws):
 
     om.ObservationManager._perform_observation = perform_wrap
 
+    from genesis_forge.mdp import reset as rmod
+
+    orig_spawn = rmod.randomize_terrain_position.__call__
+
+    def spawn_wrap(self, env, entity, envs_idx, terrain_manager, height_offset=0.1e-3, subterrain=None,
+                   rotation={"z": (0, 2 * math.pi)}, zero_velocity=True):
+        axes = [k for k, ax in enumerate("xyz") if rotation is not None and isinstance(rotation.get(ax, 0), tuple)]
+        CTX.update(mode="spawn", ids=_ids_np(envs_idx, env.num_envs), i=0, axes=axes, u=draws.get(4, 5))
+        try:
+            return orig_spawn(self, env, entity, envs_idx, terrain_manager, height_offset=height_offset, subterrain=subterrain,
+                              rotation=rotation, zero_velocity=zero_velocity)
+        finally:
+            CTX["mode"] = None
+
+    rmod.randomize_terrain_position.__call__ = spawn_wrap
+
 
 OBS_WIDTHS = {}
 
@@ -240,14 +270,87 @@ class RefGo2Env(ref.ManagedEnvironment):
 
 CMD_RESAMPLE_S = 1.0
 
+ROUGH_TERRAIN = dict(pos=(-12, -12, 0), n_subterrains=(1, 1), subterrain_size=(24, 24), vertical_scale=0.001,
+                     subterrain_types=[["random_uniform_terrain"]],
+                     subterrain_parameters={"random_uniform_terrain": {"min_height": 0.0, "max_height": 0.1, "step": 0.05,
+                                                                      "downsampled_scale": 0.25}})
+
+
+class RefGo2RoughEnv(ref.ManagedEnvironment):
+    """Reference managers in the arrangement of examples/rough_terrain/environment.py:87-287 (plus base_height over the terrain),
+    on the synthetic scene with a height-field terrain entity.  Mirrors tests/envs.py Go2RoughTerrainEnv."""
+
+    def __init__(self, num_envs, episode_s=20, scene_kwargs=None, terrain_kwargs=None, rotation="default"):
+        super().__init__(num_envs=num_envs, dt=1 / 50, max_episode_length_sec=episode_s, max_episode_random_scaling=0.1)
+        kw = dict(scene_kwargs or {})
+        kw.setdefault("max_collision_pairs", 12)
+        self.scene = my_scene.SyntheticScene(dt=self.dt, substeps=2, **kw)
+        tk = dict(ROUGH_TERRAIN)
+        tk.update(terrain_kwargs or {})
+        self.terrain = self.scene.add_entity(morph=my_scene.morphs.Terrain(**tk))
+        self.robot = self.scene.add_entity(my_scene.morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=INITIAL_BODY_POSITION, quat=INITIAL_QUAT))
+        self._rotation = rotation
+
+    def config(self):
+        from genesis_forge.managers import TerrainManager
+
+        self.terrain_manager = TerrainManager(self)
+        params = {"height_offset": 0.4, "terrain_manager": self.terrain_manager}
+        if self._rotation != "default":
+            params["rotation"] = self._rotation
+        self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={"position": {"fn": reset.randomize_terrain_position, "params": params}})
+        self.action_manager = PositionActionManager(self, joint_names=GO2_JOINTS, default_pos=GO2_DEFAULT, scale=0.25, use_default_offset=True,
+                                                    pd_kp=20, pd_kv=0.5, max_force=23.5)
+        self.velocity_command = VelocityCommandManager(
+            self, range={"lin_vel_x": [-1.0, 1.0], "lin_vel_y": [-1.0, 1.0], "ang_vel_z": [-0.5, 0.5]}, standing_probability=0.05,
+            resample_time_sec=CMD_RESAMPLE_S)
+        self.foot_contact_manager = ContactManager(self, link_names=[".*_calf"], track_air_time=True, air_time_contact_threshold=5.0)
+        self.undesired_contacts = ContactManager(self, link_names=[".*_thigh", "base"])
+        RewardManager(self, logging_enabled=True, cfg={
+            "tracking_lin_vel": {"weight": 1.5, "fn": rewards.command_tracking_lin_vel,
+                                 "params": {"vel_cmd_manager": self.velocity_command, "entity_manager": self.robot_manager}},
+            "tracking_ang_vel": {"weight": 0.75, "fn": rewards.command_tracking_ang_vel,
+                                 "params": {"vel_cmd_manager": self.velocity_command, "entity_manager": self.robot_manager}},
+            "lin_vel_z": {"weight": -2.0, "fn": rewards.lin_vel_z_l2, "params": {"entity_manager": self.robot_manager}},
+            "ang_vel_xy": {"weight": -0.05, "fn": rewards.ang_vel_xy_l2, "params": {"entity_manager": self.robot_manager}},
+            "undesired_contacts": {"weight": -1.0, "fn": rewards.has_contact, "params": {"contact_manager": self.undesired_contacts, "threshold": 5.0}},
+            "action_rate": {"weight": -0.01, "fn": rewards.action_rate_l2},
+            "similar_to_default": {"weight": -0.1, "fn": rewards.dof_similar_to_default, "params": {"action_manager": self.action_manager}},
+            "flat_orientation": {"weight": -1.5, "fn": rewards.flat_orientation_l2},
+            "terminated": {"weight": -100.0, "fn": rewards.terminated},
+            "base_height": {"weight": -30.0, "fn": rewards.base_height,
+                            "params": {"target_height": 0.35, "terrain_manager": self.terrain_manager, "entity_manager": self.robot_manager}},
+        })
+        self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg={
+            "timeout": {"fn": terminations.timeout, "time_out": True},
+            "out_of_bounds": {"fn": terminations.out_of_bounds, "params": {"terrain_manager": self.terrain_manager}},
+            "bad_orientation": {"fn": terminations.bad_orientation,
+                                "params": {"limit_angle": 30.0, "entity_manager": self.robot_manager, "grace_steps": 20}},
+        })
+        ocfg = {
+            "velocity_cmd": {"fn": self.velocity_command.observation},
+            "angle_velocity": {"fn": lambda env: self.robot_manager.get_angular_velocity()},
+            "linear_velocity": {"fn": lambda env: self.robot_manager.get_linear_velocity()},
+            "projected_gravity": {"fn": lambda env: self.robot_manager.get_projected_gravity()},
+            "dof_position": {"fn": lambda env: self.action_manager.get_dofs_position()},
+            "dof_velocity": {"fn": lambda env: self.action_manager.get_dofs_velocity(), "scale": 0.05},
+            "actions": {"fn": lambda env: self.action_manager.get_actions()},
+        }
+        for (k, w) in zip(ocfg.keys(), [3, 3, 3, 3, 12, 12, 12]):
+            OBS_WIDTHS[("policy", k)] = w
+        ObservationManager(self, cfg=ocfg)
+
 
 def episode_scalars(extras):
     return {k: float(v) for k, v in extras["episode"].items()}
 
 
-def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2):
+def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2, variant="cmd", rotation="default"):
     torch.manual_seed(0)
-    env = RefGo2Env(n, episode_s=episode_s, scene_kwargs=scene_kwargs, contacts=contacts, history=history)
+    if variant == "rough":
+        env = RefGo2RoughEnv(n, episode_s=episode_s, scene_kwargs=scene_kwargs, rotation=rotation)
+    else:
+        env = RefGo2Env(n, episode_s=episode_s, scene_kwargs=scene_kwargs, contacts=contacts, history=history)
     obs_w = 48 + (4 if contacts else 0)
     draws = Draws(n, 3, obs_w)
     install_contexts(env, draws)
@@ -255,7 +358,7 @@ def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2)
     env.build()
     obs0, _ = env.reset()
     rng = np.random.RandomState(7)
-    rec = {k: [] for k in ("actions", "obs", "reward", "terminated", "truncated", "command", "episode_length", "max_episode_length")}
+    rec = {k: [] for k in ("actions", "obs", "reward", "terminated", "truncated", "command", "episode_length", "max_episode_length", "pos", "quat")}
     logs = []
     for t in range(steps):
         draws.step = t + 1
@@ -271,6 +374,8 @@ def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2)
         rec["command"].append(env.velocity_command._command.numpy().copy())
         rec["episode_length"].append(env.episode_length.numpy().copy())
         rec["max_episode_length"].append(env.max_episode_length.numpy().copy())
+        rec["pos"].append(env.robot.get_pos().numpy().copy())
+        rec["quat"].append(env.robot.get_quat().numpy().copy())
         logs.append(episode_scalars(extras))
     keys = sorted({k for d in logs for k in d})
     log_arr = np.full((steps, len(keys)), np.nan, dtype=np.float64)
@@ -281,7 +386,8 @@ def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2)
     out = {k: np.stack(v) for k, v in rec.items()}
     out.update(obs0=obs0.numpy().copy(), log_keys=np.array(keys), log_values=log_arr, seed=np.int64(SEED), n=np.int64(n),
                steps=np.int64(steps), contacts=np.int64(contacts), history=np.int64(history or 1), episode_s=np.float64(episode_s),
-               cmd_resample_s=np.float64(CMD_RESAMPLE_S), scene_kwargs=np.array(repr(scene_kwargs)))
+               cmd_resample_s=np.float64(CMD_RESAMPLE_S), scene_kwargs=np.array(repr(scene_kwargs)), variant=np.array(variant),
+               rotation=np.array(repr(rotation)))
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     print(name, "steps", steps, "terminated", int(out["terminated"].sum()), "truncated", int(out["truncated"].sum()),
           "log keys", len(keys))
@@ -496,8 +602,49 @@ def gen_air_time():
     print("air_time: ok")
 
 
+def gen_terrain():
+    """TerrainManager on a 2x2 height-field terrain: get_terrain_height at in-range, edge and out-of-range points
+    (terrain_manager.py:100-166), bounds / subterrain bounds (:281-343) and generate_random_positions with given draws (:168-248)."""
+    n = 64
+    tk = dict(pos=(-3.0, 1.5, 0.25), n_subterrains=(2, 2), subterrain_size=(6.0, 5.0), horizontal_scale=0.25, vertical_scale=0.005,
+              subterrain_types=[["flat_terrain", "random_uniform_terrain"], ["pyramid_stairs_terrain", "discrete_obstacles_terrain"]],
+              subterrain_parameters={"random_uniform_terrain": {"min_height": -0.05, "max_height": 0.2},
+                                     "pyramid_stairs_terrain": {"min_height": 0.0, "max_height": 0.4},
+                                     "discrete_obstacles_terrain": {"min_height": -0.1, "max_height": 0.1}})
+    env = RefGo2RoughEnv(n, scene_kwargs=dict(seed=77), terrain_kwargs=tk)
+    install_contexts(env, Draws(n, 3, 48))
+    env.build()
+    tm = env.terrain_manager
+    rng = np.random.RandomState(11)
+    xs = np.concatenate([rng.uniform(-3.0, 9.0, 40), [-3.0, 9.0, -3.0, 9.0, -4.0, 10.5, 2.999, 3.0, 3.001, 0.0, 8.99999, -2.99999],
+                         rng.uniform(-6.0, 12.0, 12)]).astype(np.float32)
+    ys = np.concatenate([rng.uniform(1.5, 11.5, 40), [1.5, 11.5, 11.5, 1.5, 0.0, 13.0, 6.499, 6.5, 6.501, 5.0, 11.49999, 1.50001],
+                         rng.uniform(-1.0, 14.0, 12)]).astype(np.float32)
+    assert len(xs) == n
+    heights = tm.get_terrain_height(torch.from_numpy(xs), torch.from_numpy(ys)).numpy().copy()
+    out = dict(height_field=env.terrain.geoms[0].metadata["height_field"], terrain_kwargs=np.array(repr(tk)), x=xs, y=ys, heights=heights,
+               bounds=np.array(tm.get_bounds(), dtype=np.float64), n=np.int64(n), seed=np.int64(SEED))
+    names = [name for row in tk["subterrain_types"] for name in row]
+    out["sub_names"] = np.array(names)
+    out["sub_bounds"] = np.array([tm.get_bounds(s) for s in names], dtype=np.float64)
+    cases = [(0.5, None, 0.1e-3), (0.25, "random_uniform_terrain", 0.3), (0.9, "discrete_obstacles_terrain", 0.0), (1.0, "pyramid_stairs_terrain", 0.05)]
+    for k, (ratio, sub, off) in enumerate(cases):
+        u = philox.draws(SEED, 100 + k, 4, n, 5)
+        CTX.update(mode="spawn", ids=np.arange(n), i=0, axes=[], u=u)
+        pos = tm.generate_random_positions(num=n, usable_ratio=ratio, subterrain=sub, height_offset=off).numpy().copy()
+        CTX["mode"] = None
+        out[f"spawn{k}_pos"] = pos
+        out[f"spawn{k}_cfg"] = np.array(repr((ratio, sub, off)))
+    # the flat case: no height field -> the origin's z
+    np.savez_compressed(os.path.join(GOLD, "terrain.npz"), **out)
+    print("terrain: ok, heights", float(heights.min()), float(heights.max()))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    gen_terrain()
+    run_trajectory("traj_go2_rough", n=16, steps=170, contacts=False, history=None, episode_s=1.5, variant="rough",
+                   scene_kwargs=dict(ang_noise=0.4, lin_noise=0.05, seed=41, contact_prob=0.3, contact_force=30.0))
     gen_terms()
     gen_orientation_sweep()
     gen_action()
