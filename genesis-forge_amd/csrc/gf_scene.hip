@@ -26,6 +26,15 @@ __global__ __launch_bounds__(kEnvBlock) void rotate_kernel(const GfRotateArgs a)
     r[0] = o.x; r[1] = o.y; r[2] = o.z;
 }
 
+// Where the synthetic scene puts link l relative to the base: scene link 0 is the ground entity, 1 the robot's base,
+// then chains of four (hip, thigh, calf, foot) hanging 8.5 cm apart below the four corners of the body.
+struct LinkOffset { float x, y, z; };
+__device__ __forceinline__ LinkOffset synth_link_offset(int l) {
+    if (l <= 1) return {0.0f, 0.0f, 0.0f};
+    const int leg = (l - 2) / 4, depth = (l - 2) % 4 + 1;
+    return {leg < 2 ? 0.19f : -0.19f, (leg & 1) ? -0.11f : 0.11f, -0.085f * (float)depth};
+}
+
 template <int DV>
 __global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSceneArgs a) {
     const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
@@ -102,6 +111,14 @@ __global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSce
     if (a.links_vel_out)
         for (int l = 0; l < NL; ++l)
             for (int j = 0; j < 3; ++j) a.links_vel_out[(n * NL + l) * 3 + j] = v[j] + (float)(l % 3 == j ? 1 : 0) * 0.05f * w[j];
+    if (a.links_pos_out)
+        for (int l = 0; l < NL; ++l) {
+            const LinkOffset o = synth_link_offset(l);
+            float* lp = a.links_pos_out + (n * NL + l) * 3;
+            lp[0] = p[0] + o.x;
+            lp[1] = p[1] + o.y;
+            lp[2] = (p[2] + o.z) + 0.03f * w[l % 3];
+        }
     if (C > 0 && a.contact_force_out) {
         for (int c = 0; c < C; ++c) {
             const uint32_t col = (uint32_t)(8 + 8 * c);

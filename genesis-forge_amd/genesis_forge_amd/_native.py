@@ -207,7 +207,7 @@ class GfSynthSceneArgs(C.Structure):
                 ("height_target", C.c_float), ("contact_prob", C.c_float), ("contact_force", C.c_float), ("_padf", C.c_float),
                 ("targets", P), ("pos", P), ("quat", P), ("lin_vel", P), ("ang_vel", P), ("dof_pos", P), ("dof_vel", P),
                 ("contact_force_out", P), ("contact_pos_out", P), ("link_a_out", P), ("link_b_out", P),
-                ("links_quat_out", P), ("links_vel_out", P), ("seed", C.c_uint64), ("tick", C.c_uint64),
+                ("links_quat_out", P), ("links_vel_out", P), ("links_pos_out", P), ("seed", C.c_uint64), ("tick", C.c_uint64),
                 ("env_offset", C.c_uint32), ("_pad2", C.c_uint32)]
 
 

@@ -13,13 +13,40 @@ def install(pkg, with_genesis_shim: bool = True) -> None:
     for n in names:
         mod = importlib.import_module(pkg.__name__ + n)
         sys.modules["genesis_forge" + n] = mod
+    # module paths the reference has and user code imports from (examples/gait_trainer/gait_command_manager.py:10-14)
+    from .managers import command as _command
+
+    for alias in ("genesis_forge.managers.command", "genesis_forge.managers.command.command_manager",
+                  "genesis_forge.managers.command.velocity_command"):
+        sys.modules[alias] = _command
+    sys.modules["genesis_forge.gamepads"] = _gamepads_module()
     if with_genesis_shim and "genesis" not in sys.modules:
         try:
             importlib.import_module("genesis")
             return
         except Exception:
             pass
-        sys.modules["genesis"] = make_genesis_shim()
+        shim = make_genesis_shim()
+        sys.modules["genesis"] = shim
+        sys.modules.update(shim._submodules)
+
+
+#: extra ``SyntheticScene`` options applied to every ``gs.Scene(...)`` the shim constructs: reference task configs build
+#: their scene themselves, so tests and benchmarks steer the stand-in physics (noise levels, contact density, seed) here
+SCENE_OVERRIDES: dict = {}
+
+
+def _gamepads_module() -> types.ModuleType:
+    """``genesis_forge.gamepads``: the HID reader is out of scope; the name ``Gamepad`` exists so
+    type annotations in user managers resolve, and constructing one says why it cannot work here."""
+    m = types.ModuleType("genesis_forge.gamepads")
+
+    class Gamepad:
+        def __init__(self, *a, **k):
+            raise NotImplementedError("gamepad HID input is outside the manager-step pipeline (SURVEY.md §2 row 19)")
+
+    m.Gamepad = Gamepad
+    return m
 
 
 def make_genesis_shim() -> types.ModuleType:
@@ -45,11 +72,29 @@ def make_genesis_shim() -> types.ModuleType:
         dt = getattr(sim_options, "dt", None) or getattr(rigid_options, "dt", None) or 0.02
         substeps = getattr(sim_options, "substeps", 1)
         pairs = getattr(rigid_options, "max_collision_pairs", 0) or 0
-        return _scene.SyntheticScene(dt=dt, substeps=substeps, max_collision_pairs=pairs)
+        opts = dict(dt=dt, substeps=substeps, max_collision_pairs=pairs)
+        opts.update(SCENE_OVERRIDES)
+        return _scene.SyntheticScene(**opts)
 
     def _init(backend=None, **kw):
         return None
 
+    class _Surfaces:
+        Default = Rough = Smooth = Plastic = _Opt
+
+    class _Textures:
+        ImageTexture = ColorTexture = _Opt
+
+    m.surfaces = _Surfaces
+    m.textures = _Textures
+    m.__path__ = []  # a package, so ``from genesis.engine.entities import RigidEntity`` resolves
+    eng = types.ModuleType("genesis.engine")
+    eng.__path__ = []
+    ents = types.ModuleType("genesis.engine.entities")
+    ents.RigidEntity = _scene.SyntheticEntity
+    eng.entities = ents
+    m.engine = eng
+    m._submodules = {"genesis.engine": eng, "genesis.engine.entities": ents}
     m.options = _Options
     m.constraint_solver = _Solver
     m.Scene = _scene_factory

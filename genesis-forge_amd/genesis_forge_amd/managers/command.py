@@ -109,9 +109,24 @@ class CommandManager(BaseManager):
         a.stats = env.stats.ptr if mode == nat.GF_CMD_STEP else None
         env.backend.call("command_step", a, owner=self)
 
+    def _user_resamples(self) -> bool:
+        """A user subclass supplies its own ``resample_command`` (e.g. examples/gait_trainer/gait_command_manager.py:185-211):
+        it must be called with env ids exactly as the reference's base class calls it (command_manager.py:152-170)."""
+        for klass in type(self).__mro__:
+            if "resample_command" in klass.__dict__:
+                return not klass.__module__.startswith(__package__.rsplit(".", 1)[0] + ".")
+        return False
+
+    def _can_fuse_reset(self) -> bool:
+        return not self._user_resamples()
+
     def step(self):
         """Resample where ``episode_length % resample_steps == 0`` (command_manager.py:152-162)."""
         if not self.enabled or self._external_controller is not None:
+            return
+        if self._user_resamples():
+            ids = (self.env.episode_length % self._resample_steps == 0).nonzero(as_tuple=False).reshape(-1)
+            self.resample_command(ids)
             return
         self._launch(nat.GF_CMD_STEP, draws_key=f"command:{self._index}")
 

@@ -34,6 +34,15 @@ class Link:
     name: str
     idx: int
     idx_local: int
+    entity: object = field(default=None, repr=False, compare=False)
+
+    def get_vel(self, envs_idx=None):
+        """World-frame velocity of this link, ``[N,3]`` (Genesis ``RigidLink.get_vel``; call site
+        examples/gait_trainer/gait_command_manager.py:329)."""
+        return self.entity.get_links_vel(links_idx_local=[self.idx_local])[:, 0]
+
+    def get_pos(self, envs_idx=None):
+        return self.entity.get_links_pos(links_idx_local=[self.idx_local])[:, 0]
 
 
 @dataclass
@@ -186,7 +195,7 @@ class SyntheticEntity:
         self.joints = [Joint("root_joint", int(gs.JOINT_TYPE.FREE), 0)]
         for k, (name, lo, hi) in enumerate(model.joints):
             self.joints.append(Joint(name, int(gs.JOINT_TYPE.REVOLUTE), 6 + k))
-        self.links = [Link(n, link_start + k, k) for k, n in enumerate(model.links)]
+        self.links = [Link(n, link_start + k, k, self) for k, n in enumerate(model.links)]
         self.n_links = len(self.links)
         self.n_act = len(model.joints)
         self.n_dofs = 6 + self.n_act
@@ -209,6 +218,7 @@ class SyntheticEntity:
         self._own_targets = torch.zeros(n, self.n_act, device=dev)
         self._targets = self._own_targets
         self.links_vel = torch.zeros(n, self.n_links, 3, device=dev)
+        self.links_pos = None  # view of the scene's per-link positions once the scene tick produces them
         self._lower = self._lower.to(dev)
         self._upper = self._upper.to(dev)
         self._views = EntityViews(self.pos, self.quat, self.lin_vel, self.ang_vel)
@@ -277,8 +287,13 @@ class SyntheticEntity:
         return self.links_vel[:, idx]
 
     def get_links_pos(self, links_idx_local=None, envs_idx=None):
-        n = self.n_links if links_idx_local is None else len(links_idx_local)
-        return self.pos.unsqueeze(1).expand(-1, n, -1).clone()
+        if self.links_pos is None:
+            n = self.n_links if links_idx_local is None else len(links_idx_local)
+            return self.pos.unsqueeze(1).expand(-1, n, -1).clone()
+        if links_idx_local is None:
+            return self.links_pos.clone()
+        idx = links_idx_local.tolist() if isinstance(links_idx_local, torch.Tensor) else list(links_idx_local)
+        return self.links_pos[:, idx]
 
     def get_link(self, name: str):
         for l in self.links:
@@ -435,6 +450,9 @@ class SyntheticScene:
         self.links_quat = torch.zeros(n_envs, max(self._n_links, 1), 4, device=dev)
         self.links_quat[..., 0] = 1.0
         self.links_vel_all = torch.zeros(n_envs, max(self._n_links, 1), 3, device=dev)
+        self.links_pos_all = torch.zeros(n_envs, max(self._n_links, 1), 3, device=dev)
+        import numpy as _np
+        self.envs_offset = _np.zeros((n_envs, 3), dtype=_np.float32)  # gs.Scene.envs_offset (viewer placement; velocity_command.py:244)
         self.is_built = True
 
     # -- solver surface -------------------------------------------------------------------------------
@@ -443,7 +461,7 @@ class SyntheticScene:
 
     def gf_contacts(self) -> dict:
         return {"force": self.contact_force, "position": self.contact_pos, "link_a": self.link_a, "link_b": self.link_b,
-                "links_quat": self.links_quat, "links_vel": self.links_vel_all}
+                "links_quat": self.links_quat, "links_vel": self.links_vel_all, "links_pos": self.links_pos_all}
 
     def step(self):
         """One synthetic tick (stands in for managed_env.py:292)."""
@@ -462,11 +480,13 @@ class SyntheticScene:
             a.link_a_out, a.link_b_out = self.link_a.data_ptr(), self.link_b.data_ptr()
             a.links_quat_out = self.links_quat.data_ptr()
             a.links_vel_out = self.links_vel_all.data_ptr()
+            a.links_pos_out = self.links_pos_all.data_ptr()
         a.seed, a.tick, a.env_offset = self.seed, self.tick, self.env_offset
         nat.get_backend().call("synth_scene_step", a, owner=self)
         if self.n_contacts > 0:
             s = r.links[0].idx
             r.links_vel = self.links_vel_all[:, s:s + r.n_links]
+            r.links_pos = self.links_pos_all[:, s:s + r.n_links]
         self.tick += 1
 
     # viewer / debug API accepted and ignored

@@ -487,6 +487,7 @@ typedef struct GfSynthSceneArgs {
     int32_t* link_b_out;      /* [N,C] */
     float* links_quat_out;    /* [N,num_scene_links,4] */
     float* links_vel_out;     /* [N,num_scene_links,3] or NULL */
+    float* links_pos_out;     /* [N,num_scene_links,3] or NULL: world position of every link (RigidEntity.get_links_pos) */
     uint64_t seed;
     uint64_t tick;
     uint32_t env_offset;      /* global index of local env 0 */

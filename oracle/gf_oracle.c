@@ -766,6 +766,21 @@ GFO_EXPORT int gfo_synth_scene_step(const GfSynthSceneArgs* a) {
             for (int64_t l = 0; l < NL; ++l)
                 for (int j = 0; j < 3; ++j)
                     a->links_vel_out[(n * NL + l) * 3 + j] = v[j] + (float)(l % 3 == (int64_t)j ? 1 : 0) * 0.05f * w[j];
+        if (a->links_pos_out)
+            for (int64_t l = 0; l < NL; ++l) {
+                /* scene link 0 = ground, 1 = robot base, then (hip, thigh, calf, foot) chains under the body corners */
+                float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+                if (l > 1) {
+                    const int64_t leg = (l - 2) / 4, depth = (l - 2) % 4 + 1;
+                    ox = leg < 2 ? 0.19f : -0.19f;
+                    oy = (leg & 1) ? -0.11f : 0.11f;
+                    oz = -0.085f * (float)depth;
+                }
+                float* lp = a->links_pos_out + (n * NL + l) * 3;
+                lp[0] = p[0] + ox;
+                lp[1] = p[1] + oy;
+                lp[2] = (p[2] + oz) + 0.03f * w[l % 3];
+            }
         if (C > 0 && a->contact_force_out) {
             for (int64_t c = 0; c < C; ++c) {
                 const uint32_t col = (uint32_t)(8 + 8 * c);

@@ -12,6 +12,164 @@ INITIAL_BODY_POSITION = [0.0, 0.0, 0.4]
 INITIAL_QUAT = [1.0, 0.0, 0.0, 0.0]
 
 
+GO2_JOINTS = ["FL_.*_joint", "FR_.*_joint", "RL_.*_joint", "RR_.*_joint"]
+GO2_DEFAULT_POS = {".*_hip_joint": 0.0, "FL_thigh_joint": 0.8, "FR_thigh_joint": 0.8, "RL_thigh_joint": 1.0, "RR_thigh_joint": 1.0,
+                   ".*_calf_joint": -1.5}
+
+
+def _std_obs(self, velocity_cmd=True, scales=None):
+    """The observation layout every shipped Go2 / humanoid example uses (e.g. examples/command_direction/environment.py:223-247)."""
+    sc = scales or {}
+    cfg = {}
+    if velocity_cmd:
+        cfg["velocity_cmd"] = {"fn": self.velocity_command.observation}
+    cfg.update({
+        "angle_velocity": {"fn": lambda env: self.robot_manager.get_angular_velocity(), "scale": sc.get("ang", 1.0)},
+        "linear_velocity": {"fn": lambda env: self.robot_manager.get_linear_velocity(), "scale": sc.get("lin", 1.0)},
+        "projected_gravity": {"fn": lambda env: self.robot_manager.get_projected_gravity()},
+        "dof_position": {"fn": lambda env: self.action_manager.get_dofs_position()},
+        "dof_velocity": {"fn": lambda env: self.action_manager.get_dofs_velocity(), "scale": 0.05},
+        "actions": {"fn": lambda env: self.action_manager.get_actions()},
+    })
+    return cfg
+
+
+class Go2SimpleEnv(ManagedEnvironment):
+    """BASELINE config 1 (cf. examples/simple/environment.py:95-243): static target command, action clip ±100, no command
+    manager, observation scales 0.25 / 2.0 / 0.05 (O = 45)."""
+
+    def __init__(self, num_envs=1, dt=1 / 50, max_episode_length_s=20, scene_kwargs=None):
+        super().__init__(num_envs=num_envs, dt=dt, max_episode_length_sec=max_episode_length_s, max_episode_random_scaling=0.1)
+        from genesis_forge_amd import gs
+        self.target_command = torch.zeros((self.num_envs, 3), device=gs.device, dtype=gs.tc_float)
+        self.target_command[:, 0] = 0.5
+        self.scene = SyntheticScene(dt=self.dt, substeps=2, **dict(dict(max_collision_pairs=30), **(scene_kwargs or {})))
+        self.terrain = self.scene.add_entity(morphs.Plane())
+        self.robot = self.scene.add_entity(morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=INITIAL_BODY_POSITION, quat=INITIAL_QUAT))
+
+    def config(self):
+        self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={
+            "position": {"fn": reset.position, "params": {"position": INITIAL_BODY_POSITION, "quat": INITIAL_QUAT, "zero_velocity": True}}})
+        self.action_manager = PositionActionManager(self, joint_names=GO2_JOINTS, default_pos=GO2_DEFAULT_POS, scale=0.25,
+                                                    clip=(-100.0, 100.0), use_default_offset=True, pd_kp=20, pd_kv=0.5)
+        RewardManager(self, logging_enabled=True, cfg={
+            "base_height_target": {"weight": -50.0, "fn": rewards.base_height, "params": {"target_height": 0.3, "entity_attr": "robot"}},
+            "tracking_lin_vel": {"weight": 1.0, "fn": rewards.command_tracking_lin_vel,
+                                 "params": {"command": self.target_command[:, :2], "entity_manager": self.robot_manager}},
+            "tracking_ang_vel": {"weight": 0.2, "fn": rewards.command_tracking_ang_vel,
+                                 "params": {"commanded_ang_vel": self.target_command[:, 2], "entity_manager": self.robot_manager}},
+            "lin_vel_z": {"weight": -1.0, "fn": rewards.lin_vel_z_l2, "params": {"entity_manager": self.robot_manager}},
+            "action_rate": {"weight": -0.005, "fn": rewards.action_rate_l2},
+            "similar_to_default": {"weight": -0.1, "fn": rewards.dof_similar_to_default, "params": {"action_manager": self.action_manager}},
+        })
+        self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg={
+            "timeout": {"fn": terminations.timeout, "time_out": True},
+            "fall_over": {"fn": terminations.bad_orientation, "params": {"limit_angle": 10.0, "entity_manager": self.robot_manager}},
+        })
+        ObservationManager(self, cfg=_std_obs(self, velocity_cmd=False, scales={"ang": 0.25, "lin": 2.0}))
+
+
+class Go2ContactsEnv(ManagedEnvironment):
+    """cf. examples/contacts/environment.py:95-290: feet_air_time on the calves (threshold 0.5 s), flat_orientation, 20° limit."""
+
+    def __init__(self, num_envs=1, dt=1 / 50, max_episode_length_s=20, scene_kwargs=None):
+        super().__init__(num_envs=num_envs, dt=dt, max_episode_length_sec=max_episode_length_s, max_episode_random_scaling=0.1)
+        self.scene = SyntheticScene(dt=self.dt, substeps=2, **dict(dict(max_collision_pairs=30), **(scene_kwargs or {})))
+        self.terrain = self.scene.add_entity(morphs.Plane())
+        self.robot = self.scene.add_entity(morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=[0.0, 0.0, 0.35], quat=INITIAL_QUAT))
+
+    def config(self):
+        self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={
+            "position": {"fn": reset.position, "params": {"position": [0.0, 0.0, 0.35], "quat": INITIAL_QUAT}}})
+        self.action_manager = PositionActionManager(self, joint_names=GO2_JOINTS, default_pos=GO2_DEFAULT_POS, scale=0.5,
+                                                    use_default_offset=True, pd_kp=20, pd_kv=0.5)
+        self.velocity_command = VelocityCommandManager(
+            self, range={"lin_vel_x": [-1.0, 1.0], "lin_vel_y": [0, 0], "ang_vel_z": [-0.5, 0.5]}, standing_probability=0.0,
+            resample_time_sec=5.0, debug_visualizer=True, debug_visualizer_cfg={"envs_idx": [0]})
+        self.foot_contact_manager = ContactManager(self, link_names=[".*_calf"], track_air_time=True, air_time_contact_threshold=5.0)
+        em, vc = self.robot_manager, self.velocity_command
+        RewardManager(self, logging_enabled=True, cfg={
+            "foot_air_time": {"weight": 2.5, "fn": rewards.feet_air_time,
+                              "params": {"contact_manager": self.foot_contact_manager, "vel_cmd_manager": vc, "time_threshold": 0.5}},
+            "tracking_lin_vel": {"weight": 1.0, "fn": rewards.command_tracking_lin_vel, "params": {"vel_cmd_manager": vc, "entity_manager": em}},
+            "tracking_ang_vel": {"weight": 0.5, "fn": rewards.command_tracking_ang_vel, "params": {"vel_cmd_manager": vc, "entity_manager": em}},
+            "lin_vel_z": {"weight": -1.0, "fn": rewards.lin_vel_z_l2, "params": {"entity_manager": em}},
+            "ang_vel_xy": {"weight": -0.05, "fn": rewards.ang_vel_xy_l2, "params": {"entity_manager": em}},
+            "action_rate": {"weight": -0.005, "fn": rewards.action_rate_l2},
+            "similar_to_default": {"weight": -0.1, "fn": rewards.dof_similar_to_default, "params": {"action_manager": self.action_manager}},
+            "flat_orientation": {"weight": -2.5, "fn": rewards.flat_orientation_l2},
+        })
+        self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg={
+            "timeout": {"fn": terminations.timeout, "time_out": True},
+            "fall_over": {"fn": terminations.bad_orientation, "params": {"limit_angle": 20.0, "entity_manager": em}},
+        })
+        ObservationManager(self, cfg=_std_obs(self))
+
+
+class BerkeleyHumanoidEnv(ManagedEnvironment):
+    """BASELINE config 4 (cf. examples/berkeley_humanoid/environment.py:82-274): the reference's MJCF has 12 actuated joints;
+    torso contact termination (default threshold 1.0), feet_air_time clamped to 0.2 … 0.5 s."""
+
+    POS = [0.0, 0.0, 0.515]
+
+    def __init__(self, num_envs=1, dt=1 / 50, max_episode_length_s=20, scene_kwargs=None):
+        super().__init__(num_envs=num_envs, dt=dt, max_episode_length_sec=max_episode_length_s, max_episode_random_scaling=0.1)
+        self.scene = SyntheticScene(dt=self.dt, substeps=2, **(scene_kwargs or {}))
+        self.terrain = self.scene.add_entity(morphs.Plane())
+        self.robot = self.scene.add_entity(morphs.MJCF(file="./model/berkeley_humanoid.xml", pos=self.POS, quat=INITIAL_QUAT))
+
+    def config(self):
+        self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={
+            "position": {"fn": reset.position, "params": {"position": self.POS, "quat": INITIAL_QUAT, "zero_velocity": True}}})
+        self.action_manager = PositionActionManager(
+            self, joint_names=[".*"],
+            default_pos={"LL_HR": -0.071, "LR_HR": 0.071, "LL_HAA": 0.103, "LR_HAA": -0.103, "LL_HFE": -0.463, "LR_HFE": -0.463,
+                         "LL_KFE": 0.983, "LR_KFE": 0.983, "LL_FFE": -0.350, "LR_FFE": -0.350, "LL_FAA": 0.126, "LR_FAA": -0.126},
+            scale=0.5, use_default_offset=True, pd_kp=15.0, pd_kv=1.0,
+            max_force={".*_HR": 20.0, ".*_HAA": 20.0, ".*_HFE": 30.0, ".*_KFE": 30.0, ".*_FFE": 20.0, ".*_FAA": 5.0})
+        self.velocity_command = VelocityCommandManager(
+            self, range={"lin_vel_x": [0.0, 1.0], "lin_vel_y": [0.0, 0.0], "ang_vel_z": [-0.5, 0.5]}, standing_probability=0.02,
+            resample_time_sec=5.0, debug_visualizer=True, debug_visualizer_cfg={"envs_idx": [0], "arrow_offset": 0.12})
+        self.torso_contact_manager = ContactManager(self, link_names=["torso"])
+        self.feet_contact_manager = ContactManager(self, link_names=[".*_faa"], track_air_time=True)
+        em, vc = self.robot_manager, self.velocity_command
+        RewardManager(self, logging_enabled=True, cfg={
+            "tracking_lin_vel": {"weight": 1.0, "fn": rewards.command_tracking_lin_vel, "params": {"vel_cmd_manager": vc, "entity_manager": em}},
+            "tracking_ang_vel": {"weight": 0.5, "fn": rewards.command_tracking_ang_vel, "params": {"vel_cmd_manager": vc, "entity_manager": em}},
+            "lin_vel_z": {"weight": -2.0, "fn": rewards.lin_vel_z_l2, "params": {"entity_manager": em}},
+            "ang_vel_xy_l2": {"weight": -0.05, "fn": rewards.ang_vel_xy_l2, "params": {"entity_manager": em}},
+            "action_rate": {"weight": -0.005, "fn": rewards.action_rate_l2},
+            "similar_to_default": {"weight": -0.05, "fn": rewards.dof_similar_to_default, "params": {"action_manager": self.action_manager}},
+            "feet_air_time": {"weight": 2.0, "fn": rewards.feet_air_time,
+                              "params": {"time_threshold": 0.2, "time_threshold_max": 0.5, "contact_manager": self.feet_contact_manager,
+                                         "vel_cmd_manager": vc}},
+        })
+        self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg={
+            "timeout": {"fn": terminations.timeout, "time_out": True},
+            "torso_contact": {"fn": terminations.contact_force, "params": {"contact_manager": self.torso_contact_manager}},
+        })
+        ObservationManager(self, cfg=_std_obs(self))
+
+
+def make_example(name: str, case: dict):
+    """This package's restatement of the reference example ``name`` with the case's scene options (tests/example_cases.py)."""
+    kw = dict(num_envs=case["n"], max_episode_length_s=case["episode_s"], scene_kwargs=dict(case["scene"]))
+    if name == "simple":
+        return Go2SimpleEnv(**kw)
+    if name == "command_direction":
+        kw["scene_kwargs"].setdefault("max_collision_pairs", 30)
+        return Go2CommandDirectionEnv(**kw)
+    if name == "contacts":
+        return Go2ContactsEnv(**kw)
+    if name == "rough_terrain":
+        return Go2RoughTerrainEnv(height_reward=False, **kw)
+    if name == "berkeley_humanoid":
+        return BerkeleyHumanoidEnv(**kw)
+    if name == "gait_trainer":
+        return Go2GaitTrainingEnv(**kw)
+    raise KeyError(name)
+
+
 class Go2CommandDirectionEnv(ManagedEnvironment):
     """BASELINE config 2: Go2 12-DOF, 6 rewards, 2 terminations, velocity command, 7 observation items (O=48)."""
 

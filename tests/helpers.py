@@ -88,3 +88,96 @@ def compare_trajectory(fix, res, T=None, tol=FLOAT_TOL):
         assert set(got) == set(want), f"log keys differ at step {t}: {sorted(got)} vs {sorted(want)}"
         for k in want:
             assert abs(got[k] - want[k]) <= 1e-5 + 1e-5 * abs(want[k]), f"log {k} at step {t}: {got[k]} vs {want[k]}"
+
+
+# ----------------------------------------------------------------------------------------------------
+# The reference's shipped task configs (tests/example_cases.py, fixtures traj_ex_<name>.npz)
+# ----------------------------------------------------------------------------------------------------
+GAIT_FIELDS = ("foot_offset", "foot_height", "gait_period", "gait_time", "gait_phase", "clock_input", "gait_selected")
+
+
+def _command_managers(env):
+    return list(env.managers["command"])
+
+
+def set_example_draws(env, seed, step, dev):
+    """Same draw convention as tools/gen_golden.py: kind 0/1 command step/reset, 2 episode length, 3 observation noise,
+    4 terrain spawn, 5/6 gait step/reset ([N,3]: gait select, foot clearance, gait period)."""
+    n = env.num_envs
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d = {"episode_length": t(philox.draws(seed, step, 2, n, 1)[:, 0].copy()), "spawn": t(philox.draws(seed, step, 4, n, 5))}
+    for i, m in enumerate(_command_managers(env)):
+        r = m._command.shape[1] if hasattr(m, "_command") else 0
+        if getattr(m, "_gf_native_gait", False):
+            d[f"gait:{i}"] = t(philox.draws(seed, step, 5, n, 3))
+            d[f"gait_reset:{i}"] = t(philox.draws(seed, step, 6, n, 3))
+        elif r > 0:
+            d[f"command:{i}"] = t(philox.draws(seed, step, 0, n, r))
+            d[f"command_reset:{i}"] = t(philox.draws(seed, step, 1, n, r))
+    env.set_draws(**d)
+
+
+def replay_example(fix, case, env, dev="cpu", user_gait_cls=None):
+    """Drive ``env`` (a task config of tests/example_cases.py, built here) with the fixture's actions and draws."""
+    import example_cases
+
+    seed, n = int(fix["seed"]), case["n"]
+    cur = {"step": 0}
+    if user_gait_cls is not None:
+        import gait_rng
+        gait_rng.install(user_gait_cls, lambda mgr, phase: philox.draws(seed, cur["step"], 5 if phase == "step" else 6, n, 3))
+    env.build()
+    for attr, sec in case["resample"].items():
+        getattr(env, attr).resample_time_sec = sec
+    set_example_draws(env, seed, 0, dev)
+    obs0, _ = env.reset()
+    f = lambda t: t.detach().cpu().numpy().copy()
+    out = {"obs0": f(obs0)}
+    rec = {}
+    logs = []
+    for t in range(case["steps"]):
+        if t in case["events"]:
+            example_cases.apply_event(env, case["events"][t])
+        cur["step"] = t + 1
+        set_example_draws(env, seed, t + 1, dev)
+        obs, rew, term, trunc, extras = env.step(torch.from_numpy(fix["actions"][t]).to(dev))
+        vals = dict(obs=obs, reward=rew, terminated=term, truncated=trunc, episode_length=env.episode_length,
+                    max_episode_length=env.max_episode_length, pos=env.robot.get_pos(), quat=env.robot.get_quat())
+        for k, m in enumerate(_command_managers(env)):
+            vals[f"command{k}"] = m.command
+        for name, o in extras["observations"].items():
+            if name != "policy":
+                vals["obs_" + name] = o
+        g = getattr(env, "gait_command_manager", None)
+        if g is not None:
+            for fld in GAIT_FIELDS:
+                vals["gait_" + fld] = getattr(g, fld if fld != "gait_selected" else "_gait_selected")
+        for k, v in vals.items():
+            rec.setdefault(k, []).append(f(v))
+        logs.append({k: float(v) for k, v in extras["episode"].items()})
+    out.update({k: np.stack(v) for k, v in rec.items()})
+    out["logs"] = logs
+    return out
+
+
+def compare_example(fix, res, tol=FLOAT_TOL):
+    T = len(res["reward"])
+    np.testing.assert_allclose(res["obs0"], fix["obs0"], atol=tol, rtol=0)
+    exact = ("terminated", "truncated", "episode_length", "max_episode_length", "gait_gait_selected")
+    skip = ("actions", "obs0", "log_keys", "log_values", "seed", "example")
+    keys = [k for k in fix.files if k not in skip]
+    for k in keys:
+        assert k in res, f"fixture field {k} not produced"
+    for t in range(T):
+        for k in keys:
+            if k in exact:
+                assert np.array_equal(res[k][t], fix[k][t]), f"{k} differs at step {t}"
+            else:
+                np.testing.assert_allclose(res[k][t].reshape(fix[k][t].shape), fix[k][t], atol=tol, rtol=0, err_msg=f"{k} step {t}")
+    lkeys = [str(k) for k in fix["log_keys"]]
+    for t in range(T):
+        want = {k: fix["log_values"][t, j] for j, k in enumerate(lkeys) if not np.isnan(fix["log_values"][t, j])}
+        got = res["logs"][t]
+        assert set(got) == set(want), f"log keys differ at step {t}: {sorted(got)} vs {sorted(want)}"
+        for k in want:
+            assert abs(got[k] - want[k]) <= 1e-5 + 1e-5 * abs(want[k]), f"log {k} at step {t}: {got[k]} vs {want[k]}"
