@@ -40,6 +40,9 @@ GF_EXPORT int gf_sizeof(int which) {
         case 11: return (int)sizeof(GfObsItem);
         case 12: return (int)sizeof(GfTerrainView);
         case 13: return (int)sizeof(GfTerrainHeightArgs);
+        case 14: return (int)sizeof(GfGaitArgs);
+        case 15: return (int)sizeof(GfContactView);
+        case 16: return (int)sizeof(GfCommandView);
         default: return -1;
     }
 }
@@ -89,6 +92,7 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
             case GF_PHASE_ROTATE: rc = gf_entity_rotate((const GfRotateArgs*)a, stream); break;
             case GF_PHASE_SCENE: rc = gf_synth_scene_step((const GfSynthSceneArgs*)a, stream); break;
             case GF_PHASE_TERRAIN: rc = gf_terrain_height((const GfTerrainHeightArgs*)a, stream); break;
+            case GF_PHASE_GAIT: rc = gf_gait_step((const GfGaitArgs*)a, stream); break;
             case GF_OP_STATS_CLEAR: rc = gf_stats_clear((GfStepStats*)const_cast<void*>(a), stream); break;
             case GF_OP_POST_PHYSICS: rc = gf_post_physics_step((const GfPostRefs*)a, stream); break;
             case GF_OP_STATS_PACK: rc = gf_stats_pack((const GfStatsPackArgs*)a, stream); break;

@@ -74,6 +74,12 @@ __global__ __launch_bounds__(kEnvBlock) void contact_kernel(const GfContactArgs 
             a.link_vel_out[3 * k + 1] = sv[1];
             a.link_vel_out[3 * k + 2] = sv[2];
         }
+        if (a.links_pos && a.link_pos_out) {  // … and of their positions (the gait manager's foot_height_reward)
+            const float* sp = a.links_pos + (n * a.num_scene_links + target) * 3;
+            a.link_pos_out[3 * k + 0] = sp[0];
+            a.link_pos_out[3 * k + 1] = sp[1];
+            a.link_pos_out[3 * k + 2] = sp[2];
+        }
         if (a.track_air_time) {  // contact_manager.py:441-477
             const float dt = a.dt;
             const bool is_contact = norm3(f0, f1, f2) > a.air_time_threshold;

@@ -119,6 +119,23 @@ __device__ __forceinline__ float4 load_quat(const float* __restrict__ p, int64_t
     return reinterpret_cast<const float4*>(p)[n];
 }
 
+// row stride of a command view in floats (0 = dense)
+__device__ __forceinline__ int cmd_stride(const GfCommandView& c) { return c.stride ? c.stride : c.width; }
+
+// torch's `%` on float tensors (aten remainder): fmod, then moved to the divisor's sign
+__device__ __forceinline__ float torch_remainder(float a, float b) {
+    float m = fmodf(a, b);
+    if ((m != 0.0f) && ((b < 0.0f) != (m < 0.0f))) m += b;
+    return m;
+}
+
+// swing / stance of one foot in the gait cycle (examples/gait_trainer/gait_command_manager.py:331-338): bit 0 = swing
+// (0 <= phi < π), bit 1 = stance (π <= phi < 2π), phi = fmod(phase + offset, 1)·(float)2π; NaN is neither
+__device__ __forceinline__ int gait_foot_flags(float phase, float offset, float two_pi, float pi) {
+    const float phi = torch_remainder(phase + offset, 1.0f) * two_pi;
+    return (((phi >= 0.0f) && (phi < pi)) ? 1 : 0) | (((phi >= pi) && (phi < two_pi)) ? 2 : 0);
+}
+
 // NaN-propagating clamps with torch semantics (Appendix B of SURVEY.md)
 __device__ __forceinline__ float clamp_max(float x, float hi) { return x > hi ? hi : x; }
 __device__ __forceinline__ float clamp_min(float x, float lo) { return x < lo ? lo : x; }
@@ -244,7 +261,8 @@ __device__ __forceinline__ double stats_entry(const GfStepStats& b, int v) {
     if (v == GF_MAX_TERM_TERMS + 2) return (double)((b.action_flags >> 1) & 1);
     if (v == GF_MAX_TERM_TERMS + 3) return (double)(b.contact_flags & 1);
     if (v == GF_MAX_TERM_TERMS + 4) return (double)b.resample_count;
-    if (v < GF_STATS_VECTOR_LEN) return b.reward_episode_sum[v - (GF_MAX_TERM_TERMS + 5)];
+    if (v < GF_MAX_TERM_TERMS + 5 + GF_MAX_TERMS) return b.reward_episode_sum[v - (GF_MAX_TERM_TERMS + 5)];
+    if (v < GF_STATS_VECTOR_LEN) return (double)b.gait_count[v - (GF_MAX_TERM_TERMS + 5 + GF_MAX_TERMS)];
     return 0.0;
 }
 

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kEnvBlock) void observe_kernel(const GfObservationA
         const GfObsItem& it = a.items[i];
         const int w = it.width;
         switch (it.op) {
-            case GF_O_COMMAND: copy_rows<V>(c, it, a.command[it.i0].command, a.command[it.i0].width, w, col); break;
+            case GF_O_COMMAND: copy_rows<V>(c, it, a.command[it.i0].command, cmd_stride(a.command[it.i0]), w, col); break;
             case GF_O_DOF_POS: copy_rows<V>(c, it, a.dof_pos, D, w, col); break;
             case GF_O_DOF_VEL: copy_rows<V>(c, it, a.dof_vel, D, w, col); break;
             case GF_O_DOF_FORCE: copy_rows<V>(c, it, a.dof_force, D, w, col); break;
@@ -195,7 +195,7 @@ extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObserva
             case GF_O_COMMAND:
                 if (it.i0 < 0 || it.i0 >= GF_MAX_COMMAND_VIEWS || !a->command[it.i0].command) return GF_E_SLOT;
                 if (it.width != a->command[it.i0].width) return GF_E_RANGE;
-                src = a->command[it.i0].command; stride = it.width;
+                src = a->command[it.i0].command; stride = a->command[it.i0].stride ? a->command[it.i0].stride : it.width;
                 break;
             case GF_O_DOF_POS: src = a->dof_pos; stride = D; break;
             case GF_O_DOF_VEL: src = a->dof_vel; stride = D; break;

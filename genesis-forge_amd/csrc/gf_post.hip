@@ -505,6 +505,7 @@ struct Packer {
         return n_contact++;
     }
     int view_slot(const GfCommandView& v) {
+        if (v.stride && v.stride != v.width) return -1;  // strided rows (the gait manager's state) stay on the phase-by-phase path
         for (int k = 0; k < n_view; ++k)
             if (a.command[k].command == v.command) return k;
         if (n_view >= GF_MAX_COMMAND_VIEWS) return -1;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kEnvBlock) void reward_kernel(const GfRewardArgs a,
     const float *k_dof = a.dof_pos, *k_def = a.default_dof_pos, *k_act = a.actions, *k_last = a.last_actions;
     const float *k_secs = a.episode_seconds, *k_cmd = a.command[0].command;
     const uint8_t* k_term = a.terminated;
-    int k_cw = a.command[0].width;
+    int k_cw = a.command[0].stride ? a.command[0].stride : a.command[0].width;
     asm volatile("" : "+s"(k_quat), "+s"(k_pos), "+s"(k_lin), "+s"(k_ang), "+s"(k_dof), "+s"(k_def));
     asm volatile("" : "+s"(k_act), "+s"(k_last), "+s"(k_secs), "+s"(k_cmd), "+s"(k_term), "+s"(k_cw));
 
@@ -218,6 +218,15 @@ extern "C" __attribute__((visibility("default"))) int gf_reward_step(const GfRew
             case GF_R_EXTERNAL:
                 if (t.i[0] < 0 || t.i[0] >= GF_MAX_EXT || !a->ext[t.i[0]]) rc = GF_E_SLOT;
                 break;
+            case GF_R_GAIT_PHASE:
+            case GF_R_FOOT_HEIGHT: {
+                rc = need_contact(t.i[0]);
+                if (!rc) rc = need_cmd(t.i[1], GF_GAIT_OBS_WIDTH);
+                if (!rc && (a->command[t.i[1]].stride < GF_GAIT_ROW || !a->contact[t.i[0]].link_vel)) rc = GF_E_SLOT;
+                if (!rc && t.op == GF_R_FOOT_HEIGHT && !a->contact[t.i[0]].link_pos) rc = GF_E_SLOT;
+                for (int f = 0; !rc && f < 4; ++f)
+                    if (((t.i[2] >> (8 * f)) & 0xff) >= a->contact[t.i[0]].num_links) rc = GF_E_RANGE;
+            } break;
             default: return GF_E_OPCODE;
         }
         if (rc) return rc;

@@ -66,6 +66,58 @@ struct RewardRegs {
     bool live;
 };
 
+// the gait opcodes exist only behind descriptors that can carry them (the fused post-physics kernel never sees one)
+template <class Args> struct HasGaitTerms { static constexpr bool value = false; };
+template <> struct HasGaitTerms<GfRewardArgs> { static constexpr bool value = true; };
+
+template <class Args>
+__device__ __forceinline__ float gait_phase_term(const GfTerm& t, const Args& a, int64_t n) {
+    // gait_phase_reward (examples/gait_trainer/gait_command_manager.py:295-345): per foot, force is penalised in the
+    // swing half of its cycle and speed in the stance half; the four foot terms add left to right (FL, FR, RL, RR)
+    const GfContactView& cv = a.contact[t.i[0]];
+    const GfCommandView& gv = a.command[t.i[1]];
+    const GF_GLOBAL float* g = G(gv.command) + n * cmd_stride(gv);
+    const GF_GLOBAL float* fr = G(cv.contacts) + n * cv.num_links * 3;
+    const GF_GLOBAL float* lv = G(cv.link_vel) + n * cv.num_links * 3;
+    const float phase = g[GF_GAIT_PHASE];
+    const bool env0 = n == 0 && a.gait_counts != nullptr;  // the reference's index-list quirk (see gf_step.h)
+    float quad = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int l = (t.i[2] >> (8 * f)) & 0xff;
+        const float force = norm3(fr[3 * l], fr[3 * l + 1], fr[3 * l + 2]);
+        const float vel = norm3(lv[3 * l], lv[3 * l + 1], lv[3 * l + 2]);
+        int fl = gait_foot_flags(phase, g[GF_GAIT_OFFSET + f], t.p[1], t.p[2]);  // p1 = (float)(2π), p2 = (float)π
+        if (env0) {
+            if (G(a.gait_counts)[2 * f + 1] > 0) fl = 2;
+            else if (G(a.gait_counts)[2 * f] > 0) fl = 1;
+        }
+        const float fw = (fl & 1) ? -1.0f : 0.0f, vw = (fl & 2) ? -1.0f : 0.0f;
+        const float foot = vw * vel + fw * force;
+        quad = f == 0 ? foot : quad + foot;
+    }
+    return expf(quad);
+}
+
+template <class Args>
+__device__ __forceinline__ float foot_height_term(const GfTerm& t, const Args& a, int64_t n) {
+    // foot_height_reward (:278-293): exp(-Σ_feet |v_xy| (z - foot_height)^2 / sensitivity)
+    const GfContactView& cv = a.contact[t.i[0]];
+    const GfCommandView& gv = a.command[t.i[1]];
+    const float target = G(gv.command)[n * cmd_stride(gv) + GF_GAIT_HEIGHT];
+    const GF_GLOBAL float* lv = G(cv.link_vel) + n * cv.num_links * 3;
+    const GF_GLOBAL float* lp = G(cv.link_pos) + n * cv.num_links * 3;
+    float err = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int l = (t.i[2] >> (8 * f)) & 0xff;
+        const float d = lp[3 * l + 2] - target;
+        const float e = norm2(lv[3 * l], lv[3 * l + 1]) * (d * d);
+        err = f == 0 ? e : err + e;
+    }
+    return expf((-err) / t.p[0]);
+}
+
 template <class Args>
 __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a, const RewardRegs& r) {
     const V3 &pos = r.pos, &blin = r.blin, &bang = r.bang, &grav = r.grav;
@@ -81,7 +133,7 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
         case GF_R_BASE_HEIGHT: {
             float h = pos.z;
             if (t.flags & GF_RW_FLAG_TERRAIN) h = h - terrain_height(a.terrain, pos.x, pos.y);
-            const float target = (t.flags & GF_RW_FLAG_CMD) ? G(a.command[t.i[0]].command)[n * a.command[t.i[0]].width] : t.p[0];
+            const float target = (t.flags & GF_RW_FLAG_CMD) ? G(a.command[t.i[0]].command)[n * cmd_stride(a.command[t.i[0]])] : t.p[0];
             const float e = h - target;
             v = e * e;
         } break;
@@ -108,8 +160,8 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
             float c0 = cmd0[0], c1 = cmd0[1];
             if (t.i[0] != 0) {
                 const GfCommandView& c = a.command[t.i[0]];
-                c0 = G(c.command)[n * c.width];
-                c1 = G(c.command)[n * c.width + 1];
+                c0 = G(c.command)[n * cmd_stride(c)];
+                c1 = G(c.command)[n * cmd_stride(c) + 1];
             }
             const float e0 = c0 - blin.x;
             const float e1 = c1 - blin.y;
@@ -122,7 +174,7 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
                 cz = t.i[1] == 0 ? cmd0[0] : (t.i[1] == 1 ? cmd0[1] : cmd0[2]);
             } else {
                 const GfCommandView& c = a.command[t.i[0]];
-                cz = G(c.command)[n * c.width + t.i[1]];
+                cz = G(c.command)[n * cmd_stride(c) + t.i[1]];
             }
             const float e = cz - bang.z;
             v = expf((-(e * e)) / t.p[0]);
@@ -131,8 +183,8 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
             float c0 = cmd0[0], c1 = cmd0[1];
             if (t.i[0] != 0) {
                 const GfCommandView& c = a.command[t.i[0]];
-                c0 = G(c.command)[n * c.width];
-                c1 = G(c.command)[n * c.width + 1];
+                c0 = G(c.command)[n * cmd_stride(c)];
+                c1 = G(c.command)[n * cmd_stride(c) + 1];
             }
             const float m = norm2(c0, c1);
             v = dof_dev * ((m < t.p[0]) ? 1.f : 0.f);
@@ -159,8 +211,8 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
                 float c0 = cmd0[0], c1 = cmd0[1];
                 if (t.i[1] != 0) {
                     const GfCommandView& c = a.command[t.i[1]];
-                    c0 = G(c.command)[n * c.width];
-                    c1 = G(c.command)[n * c.width + 1];
+                    c0 = G(c.command)[n * cmd_stride(c)];
+                    c1 = G(c.command)[n * cmd_stride(c) + 1];
                 }
                 s = s * ((norm2(c0, c1) > 0.1f) ? 1.f : 0.f);
             }
@@ -178,6 +230,12 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
             v = s;
         } break;
         case GF_R_EXTERNAL: v = G(a.ext[t.i[0]])[n]; break;
+        case GF_R_GAIT_PHASE:
+            if constexpr (HasGaitTerms<Args>::value) v = gait_phase_term(t, a, n);
+            break;
+        case GF_R_FOOT_HEIGHT:
+            if constexpr (HasGaitTerms<Args>::value) v = foot_height_term(t, a, n);
+            break;
         default: break;
     }
     return v;

@@ -13,7 +13,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-GF_ABI_VERSION = 1
+GF_ABI_VERSION = 2
 GF_MAX_TERMS = 24
 GF_MAX_TERM_TERMS = 16
 GF_MAX_OBS_ITEMS = 24
@@ -23,6 +23,7 @@ GF_MAX_EXT = 16
 GF_MAX_LINK_IDS = 32
 GF_MAX_RANGES = 8
 GF_MAX_OBS_WIDTH = 256
+GF_MAX_GAITS = 4
 GF_STATS_SHARDS = 64
 
 # opcodes ------------------------------------------------------------------------------------
@@ -55,10 +56,14 @@ GF_R_CONTACT_FORCE = 14
 GF_R_FEET_AIR_TIME = 15
 GF_R_FEET_SLIDE = 16
 GF_R_EXTERNAL = 17
+GF_R_GAIT_PHASE = 18
+GF_R_FOOT_HEIGHT = 19
 GF_RW_FLAG_CMD, GF_RW_FLAG_TERRAIN, GF_RW_FLAG_MAX, GF_RW_FLAG_FIRST_CALL = 1, 2, 4, 8
 GF_REWARD_MODE_STEP, GF_REWARD_MODE_EVAL = 0, 1
 
 GF_CMD_STEP, GF_CMD_MASKED, GF_CMD_ALL = 0, 1, 2
+(GF_GAIT_OFFSET, GF_GAIT_HEIGHT, GF_GAIT_PERIOD, GF_GAIT_CLOCK, GF_GAIT_TIME, GF_GAIT_PHASE, GF_GAIT_ROW,
+ GF_GAIT_OBS_WIDTH) = 0, 4, 5, 6, 14, 15, 16, 14
 
 GF_O_COMMAND = 1
 GF_O_ANG_VEL_BODY = 2
@@ -77,7 +82,7 @@ GF_O_BASE_QUAT = 13
 GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
 
 (GF_PHASE_ACTION, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
- GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_COUNT) = range(12)
+ GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_COUNT) = range(13)
 
 GF_OPT_PROFILE_STRIDE = 1  # gf_set_option: stamp every k-th launch of the profiled phase
 GF_OPT_POST_VARIANT = 0  # gf_set_option: 0 = interpreter, one wave per tile; 1 = interpreter, four waves; 2 = + static programs (default)
@@ -92,12 +97,12 @@ class GfEntityView(C.Structure):
 
 
 class GfContactView(C.Structure):
-    _fields_ = [("contacts", P), ("last_air_time", P), ("current_contact_time", P), ("link_vel", P),
+    _fields_ = [("contacts", P), ("last_air_time", P), ("current_contact_time", P), ("link_vel", P), ("link_pos", P),
                 ("num_links", C.c_int32), ("_pad", C.c_int32)]
 
 
 class GfCommandView(C.Structure):
-    _fields_ = [("command", P), ("width", C.c_int32), ("_pad", C.c_int32)]
+    _fields_ = [("command", P), ("width", C.c_int32), ("stride", C.c_int32)]
 
 
 class GfTerrainView(C.Structure):
@@ -118,7 +123,7 @@ class GfTerm(C.Structure):
 class GfStepStats(C.Structure):
     _fields_ = [("term_fired", C.c_int32 * GF_MAX_TERM_TERMS), ("reset_count", C.c_int32),
                 ("action_flags", C.c_int32), ("contact_flags", C.c_int32), ("resample_count", C.c_int32),
-                ("_pad", C.c_int32 * 4), ("reward_episode_sum", C.c_double * GF_MAX_TERMS)]
+                ("gait_count", C.c_int32 * GF_MAX_GAITS), ("reward_episode_sum", C.c_double * GF_MAX_TERMS)]
 
 
 class GfActionArgs(C.Structure):
@@ -132,7 +137,7 @@ class GfContactArgs(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_contacts", C.c_int32), ("num_scene_links", C.c_int32),
                 ("num_targets", C.c_int32), ("num_with", C.c_int32), ("has_with_filter", C.c_int32),
                 ("track_air_time", C.c_int32), ("_pad", C.c_int32),
-                ("force", P), ("position", P), ("link_a", P), ("link_b", P), ("links_quat", P), ("links_vel", P), ("link_vel_out", P),
+                ("force", P), ("position", P), ("link_a", P), ("link_b", P), ("links_quat", P), ("links_vel", P), ("link_vel_out", P), ("links_pos", P), ("link_pos_out", P),
                 ("target_link_ids", C.c_int32 * GF_MAX_LINK_IDS), ("with_link_ids", C.c_int32 * GF_MAX_LINK_IDS),
                 ("air_time_threshold", C.c_float), ("dt", C.c_float),
                 ("contacts", P), ("contact_positions", P), ("position_counts", P),
@@ -155,7 +160,7 @@ class GfRewardArgs(C.Structure):
                 ("contact", GfContactView * GF_MAX_CONTACT_VIEWS), ("command", GfCommandView * GF_MAX_COMMAND_VIEWS),
                 ("ext", P * GF_MAX_EXT), ("state", P * 4),
                 ("reward", P), ("episode_sums", P), ("episode_seconds", P), ("term_out", P), ("terrain", GfTerrainView),
-                ("terms", GfTerm * GF_MAX_TERMS)]
+                ("gait_counts", P), ("terms", GfTerm * GF_MAX_TERMS)]
 
 
 class GfCommandArgs(C.Structure):
@@ -215,6 +220,15 @@ class GfOp(C.Structure):
     _fields_ = [("phase", C.c_int32), ("_pad", C.c_int32), ("args", P)]
 
 
+class GfGaitArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("mode", C.c_int32), ("resample_steps", C.c_int32), ("num_gaits", C.c_int32),
+                ("episode_length", P), ("mask", P), ("mask2", P), ("draws", P), ("seed", C.c_uint64), ("stream", C.c_uint64),
+                ("env_offset", C.c_uint32), ("fixed_clearance_mask", C.c_int32), ("cum_weight", C.c_float * GF_MAX_GAITS),
+                ("gait_offsets", (C.c_float * 4) * GF_MAX_GAITS), ("clearance_lo", C.c_float), ("clearance_hi", C.c_float),
+                ("period_lo", C.c_float), ("period_hi", C.c_float), ("dt", C.c_float), ("two_pi", C.c_float),
+                ("state", P), ("selected", P), ("phase_counts", P), ("stats", P)]
+
+
 class GfStatsCopyArgs(C.Structure):
     _fields_ = [("src", P), ("dst", P), ("event", P)]
 
@@ -233,7 +247,7 @@ class GfPostRefs(C.Structure):
                 ("command_step", P * GF_POST_MAX_CMD), ("command_reset", P * GF_POST_MAX_CMD), ("observe", P * GF_POST_MAX_OBS)]
 
 ABI_STRUCTS = [GfStepStats, GfActionArgs, GfContactArgs, GfTerminationArgs, GfRewardArgs, GfCommandArgs,
-               GfResetArgs, GfObservationArgs, GfRotateArgs, GfSynthSceneArgs, GfTerm, GfObsItem, GfTerrainView, GfTerrainHeightArgs]
+               GfResetArgs, GfObservationArgs, GfRotateArgs, GfSynthSceneArgs, GfTerm, GfObsItem, GfTerrainView, GfTerrainHeightArgs, GfGaitArgs, GfContactView, GfCommandView]
 
 PHASE_FUNCS = {
     "action_step": GfActionArgs,
@@ -246,6 +260,7 @@ PHASE_FUNCS = {
     "entity_rotate": GfRotateArgs,
     "synth_scene_step": GfSynthSceneArgs,
     "terrain_height": GfTerrainHeightArgs,
+    "gait_step": GfGaitArgs,
 }
 
 
@@ -253,7 +268,7 @@ PHASE_OF_FN = {
     "action_step": GF_PHASE_ACTION, "contact_step": GF_PHASE_CONTACT, "termination_step": GF_PHASE_TERMINATION,
     "reward_step": GF_PHASE_REWARD, "command_step": GF_PHASE_COMMAND, "masked_reset": GF_PHASE_RESET,
     "observe": GF_PHASE_OBSERVE, "entity_rotate": GF_PHASE_ROTATE, "synth_scene_step": GF_PHASE_SCENE,
-    "terrain_height": GF_PHASE_TERRAIN,
+    "terrain_height": GF_PHASE_TERRAIN, "gait_step": GF_PHASE_GAIT,
 }
 
 

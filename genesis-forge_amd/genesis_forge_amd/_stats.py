@@ -29,18 +29,19 @@ _INTS = BLOCK_BYTES // 4
 class HostStats:
     """One step's folded statistics on the host (same field names as GfStepStats)."""
 
-    __slots__ = ("term_fired", "reset_count", "action_flags", "contact_flags", "resample_count", "reward_episode_sum")
+    __slots__ = ("term_fired", "reset_count", "action_flags", "contact_flags", "resample_count", "reward_episode_sum", "gait_count")
 
-    def __init__(self, term_fired, reset_count, action_flags, contact_flags, resample_count, reward_episode_sum):
+    def __init__(self, term_fired, reset_count, action_flags, contact_flags, resample_count, reward_episode_sum, gait_count=None):
         self.term_fired, self.reset_count, self.action_flags = term_fired, reset_count, action_flags
         self.contact_flags, self.resample_count, self.reward_episode_sum = contact_flags, resample_count, reward_episode_sum
+        self.gait_count = gait_count if gait_count is not None else np.zeros(nat.GF_MAX_GAITS, dtype=np.int64)
 
 
 def fold_shards(raw: np.ndarray):
     """Fold the shards of a batch of statistics blocks, ``raw`` = uint8 [B, GF_STATS_SHARDS * BLOCK_BYTES]: counts and
     sums add, flag words OR.  Returns (int64 [B, 24], float64 [B, GF_MAX_TERMS]) — vectorised over the batch."""
     blocks = raw.reshape(raw.shape[0], nat.GF_STATS_SHARDS, BLOCK_BYTES)
-    ints = np.ascontiguousarray(blocks[:, :, :96]).view(np.int32)  # term_fired[16], reset, action_flags, contact_flags, resample, pad[4]
+    ints = np.ascontiguousarray(blocks[:, :, :96]).view(np.int32)  # term_fired[16], reset, action_flags, contact_flags, resample, gait_count[4]
     f64 = np.ascontiguousarray(blocks[:, :, 96:96 + 8 * nat.GF_MAX_TERMS]).view(np.float64)
     tot = ints.sum(axis=1, dtype=np.int64)
     o = nat.GF_MAX_TERM_TERMS
@@ -51,7 +52,8 @@ def fold_shards(raw: np.ndarray):
 
 def host_stats(tot_row: np.ndarray, sums_row: np.ndarray) -> HostStats:
     o = nat.GF_MAX_TERM_TERMS
-    return HostStats(tot_row[:o], int(tot_row[o]), int(tot_row[o + 1]), int(tot_row[o + 2]), int(tot_row[o + 3]), sums_row)
+    return HostStats(tot_row[:o], int(tot_row[o]), int(tot_row[o + 1]), int(tot_row[o + 2]), int(tot_row[o + 3]), sums_row,
+                     tot_row[o + 4:o + 4 + nat.GF_MAX_GAITS])
 
 
 def sum_shards(buf: bytes) -> HostStats:
@@ -292,7 +294,7 @@ class StepStats:
         tot = ints.sum(dim=0)
         flags = ints[:, _NT + 1]
         head = torch.stack([tot[_NT], (flags & 1).max(), ((flags >> 1) & 1).max(), (ints[:, _NT + 2] & 1).max(), tot[_NT + 3]]).to(torch.float64)
-        return torch.cat([tot[:_NT].to(torch.float64), head, f64])
+        return torch.cat([tot[:_NT].to(torch.float64), head, f64, tot[_NT + 4:_NT + 4 + nat.GF_MAX_GAITS].to(torch.float64)])
 
     def _snapshot_reduced(self, i: int) -> StatsSnapshot:
         """Sum the block over the ranks of ``self.group`` — the single collective of the path (RCCL over xGMI on
@@ -384,7 +386,8 @@ class LazyEpisodeLog(dict):
 
 
 _NT = nat.GF_MAX_TERM_TERMS
-STATS_VECTOR_LEN = _NT + 5 + nat.GF_MAX_TERMS
+_NG = _NT + 5 + nat.GF_MAX_TERMS  # first gait_count entry
+STATS_VECTOR_LEN = _NG + nat.GF_MAX_GAITS
 
 
 def stats_to_vector(st) -> np.ndarray:
@@ -396,10 +399,12 @@ def stats_to_vector(st) -> np.ndarray:
     v[_NT + 2] = (st.action_flags >> 1) & 1
     v[_NT + 3] = st.contact_flags & 1
     v[_NT + 4] = st.resample_count
-    v[_NT + 5:] = list(st.reward_episode_sum)
+    v[_NT + 5:_NG] = list(st.reward_episode_sum)
+    v[_NG:] = list(st.gait_count)
     return v
 
 
 def vector_to_stats(v: np.ndarray) -> HostStats:
     return HostStats(np.rint(v[:_NT]).astype(np.int64), int(round(v[_NT])), (1 if v[_NT + 1] > 0 else 0) | (2 if v[_NT + 2] > 0 else 0),
-                     1 if v[_NT + 3] > 0 else 0, int(round(v[_NT + 4])), np.array(v[_NT + 5:], dtype=np.float64))
+                     1 if v[_NT + 3] > 0 else 0, int(round(v[_NT + 4])), np.array(v[_NT + 5:_NG], dtype=np.float64),
+                     np.rint(v[_NG:]).astype(np.int64))

@@ -151,7 +151,7 @@ class StepTrace:
             self.afters.append(owner.manager._publish)
         elif fn == "reward_step":
             pass
-        elif fn == "command_step":
+        elif fn in ("command_step", "gait_step"):
             self.patches.append(owner._trace_patch(args))
         elif fn == "masked_reset":
             def patch(_actions, a=args, env=env):

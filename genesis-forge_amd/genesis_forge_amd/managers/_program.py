@@ -28,7 +28,7 @@ class TermSpec:
 
     def __init__(self, op: int, p=(), i=(), flags: int = 0, entity=None, action_manager=None, needs_actions: bool = False,
                  needs_terminated: bool = False, cmd: Optional[dict] = None, contact: Optional[dict] = None, ext: Optional[dict] = None,
-                 state: Optional[dict] = None, link_vel: bool = False, after: Optional[Callable[[], None]] = None, terrain=None):
+                 state: Optional[dict] = None, link_vel: bool = False, link_pos: bool = False, after: Optional[Callable[[], None]] = None, terrain=None):
         self.op = op
         self.p = list(p) + [0.0] * (4 - len(p))
         self.i = list(i) + [0] * (4 - len(i))
@@ -42,6 +42,7 @@ class TermSpec:
         self.ext = ext or {}          # {index into i[]: () -> Tensor}
         self.state = state or {}      # {index into i[]: Tensor [N,6]}
         self.link_vel = link_vel
+        self.link_pos = link_pos      # the term reads the tracked links' world positions (GfContactView.link_pos)
         self.after = after
         self.terrain = terrain        # TerrainManager whose map the term samples in-kernel (GfRewardArgs.terrain)
 
@@ -81,14 +82,15 @@ class _Slots:
         self.cmds.append(src)
         return len(self.cmds) - 1
 
-    def contact(self, mgr, link_vel: bool) -> int:
+    def contact(self, mgr, link_vel: bool, link_pos: bool = False) -> int:
         for k, s in enumerate(self.contacts):
             if s[0] is mgr:
                 s[1] = s[1] or link_vel
+                s[2] = s[2] or link_pos
                 return k
         if len(self.contacts) >= nat.GF_MAX_CONTACT_VIEWS:
             raise RuntimeError(f"a fused phase can read at most {nat.GF_MAX_CONTACT_VIEWS} ContactManagers")
-        self.contacts.append([mgr, link_vel])
+        self.contacts.append([mgr, link_vel, link_pos])
         return len(self.contacts) - 1
 
     def ext(self, provider) -> int:
@@ -110,7 +112,7 @@ class _Slots:
         for j, src in spec.cmd.items():
             term.i[j] = -1 if src is None else self.cmd(src)
         for j, mgr in spec.contact.items():
-            term.i[j] = self.contact(mgr, spec.link_vel)
+            term.i[j] = self.contact(mgr, spec.link_vel, spec.link_pos)
         for j, prov in spec.ext.items():
             term.i[j] = self.ext(prov)
         for j, t in spec.state.items():
@@ -129,6 +131,9 @@ class _Slots:
         for k, src in enumerate(self.cmds):
             if getattr(src, "_external_controller", None) is not None:
                 self.volatile = True
+            if hasattr(src, "_gf_command_view"):  # a manager that owns strided state rows (GaitCommandManager)
+                src._gf_command_view(args.command[k], args)
+                continue
             t = src.command if hasattr(src, "command") else src
             if t.dim() == 1:
                 t = t.unsqueeze(-1)
@@ -136,9 +141,10 @@ class _Slots:
             keep.append(t)
             args.command[k].command = t.data_ptr()
             args.command[k].width = t.shape[1]
+            args.command[k].stride = 0
         if hasattr(args, "contact"):
-            for k, (mgr, lv) in enumerate(self.contacts):
-                tmp = mgr.view(args.contact[k], need_link_vel=lv)
+            for k, (mgr, lv, lp) in enumerate(self.contacts):
+                tmp = mgr.view(args.contact[k], need_link_vel=lv, need_link_pos=lp)
                 if tmp:
                     self.volatile = True  # link velocities are a fresh tensor every step
                 keep.extend(tmp)

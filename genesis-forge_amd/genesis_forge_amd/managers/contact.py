@@ -87,7 +87,9 @@ class ContactManager(BaseManager):
         self.contact_positions = torch.zeros((N, L, 3), device=gs.device)
         self._contact_position_counts = torch.zeros((N, L), device=gs.device)
         self.link_vel = torch.zeros((N, L, 3), device=gs.device)  # velocity of each tracked link, refreshed by step()
+        self.link_pos = torch.zeros((N, L, 3), device=gs.device)  # world position of each tracked link, refreshed by step()
         self._has_link_vel = False
+        self._has_link_pos = False
         if self._track_air_time:
             self.last_air_time = torch.zeros((N, L), device=gs.device)
             self.current_air_time = torch.zeros_like(self.last_air_time)
@@ -158,6 +160,17 @@ class ContactManager(BaseManager):
         else:
             a.links_vel = a.link_vel_out = None
             self._has_link_vel = False
+        lp = c.get("links_pos") if isinstance(c, dict) else None
+        if lp is None and hasattr(solver, "get_links_pos"):
+            lp = solver.get_links_pos()
+        if lp is not None:
+            lp = lp.to(torch.float32).contiguous()
+            self._keep = self._keep + (lp,)
+            a.links_pos, a.link_pos_out = lp.data_ptr(), self.link_pos.data_ptr()
+            self._has_link_pos = True
+        else:
+            a.links_pos = a.link_pos_out = None
+            self._has_link_pos = False
         a.dt = float(env.scene.dt)
         a.contacts = self.contacts.data_ptr()
         a.contact_positions = self.contact_positions.data_ptr()
@@ -168,7 +181,7 @@ class ContactManager(BaseManager):
         a.stats = env.stats.ptr
         env.backend.call("contact_step", a, owner=self)
 
-    def view(self, v: nat.GfContactView, need_link_vel: bool = False) -> tuple:
+    def view(self, v: nat.GfContactView, need_link_vel: bool = False, need_link_pos: bool = False) -> tuple:
         """Fill a GfContactView for term kernels; returns tensors to keep alive."""
         v.contacts = self.contacts.data_ptr()
         v.num_links = self.contacts.shape[1]
@@ -184,6 +197,15 @@ class ContactManager(BaseManager):
             keep = (lv,)
         else:
             v.link_vel = None
+        if need_link_pos and self._has_link_pos:
+            v.link_pos = self.link_pos.data_ptr()   # persistent, filled by gf_contact_step
+        elif need_link_pos:
+            robot = getattr(self.env, self._entity_attr)
+            lp = robot.get_links_pos(links_idx_local=self._local_link_ids).to(torch.float32).contiguous()
+            v.link_pos = lp.data_ptr()
+            keep = keep + (lp,)
+        else:
+            v.link_pos = None
         return keep
 
     # -- implementation -----------------------------------------------------------------------------

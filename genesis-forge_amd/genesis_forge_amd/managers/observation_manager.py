@@ -196,11 +196,14 @@ class ObservationManager(BaseManager):
         # ext columns are [N, w]
         n = env.num_envs
         for k, src in enumerate(self._slots.cmds):
+            if hasattr(src, "_gf_command_view"):
+                src._gf_command_view(a.command[k])
+                continue
             t = src.command
             t = _col(t.unsqueeze(-1) if t.dim() == 1 else t, n, torch.float32)
             keep.append(t)
-            a.command[k].command, a.command[k].width = t.data_ptr(), t.shape[1]
-        for k, (mgr, lv) in enumerate(self._slots.contacts):
+            a.command[k].command, a.command[k].width, a.command[k].stride = t.data_ptr(), t.shape[1], 0
+        for k, (mgr, lv, _lp) in enumerate(self._slots.contacts):
             keep.extend(mgr.view(a.contact[k], need_link_vel=False))
         for k, prov in enumerate(self._slots.exts):
             t = prov()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 1
+#define GF_ABI_VERSION 2
 
 #define GF_MAX_TERMS 24          /* reward terms per manager          */
 #define GF_MAX_TERM_TERMS 16     /* termination terms per manager     */
@@ -40,6 +40,7 @@ extern "C" {
 #define GF_MAX_LINK_IDS 32       /* target / with link ids            */
 #define GF_MAX_RANGES 8          /* command ranges per CommandManager */
 #define GF_MAX_OBS_WIDTH 256     /* single-frame observation width    */
+#define GF_MAX_GAITS 4           /* gaits a GaitCommandManager samples from */
 
 /* error codes */
 #define GF_OK 0
@@ -67,16 +68,17 @@ typedef struct GfContactView {
     const float* contacts;              /* [N,L,3] link-local net force  */
     const float* last_air_time;         /* [N,L] or NULL                 */
     const float* current_contact_time;  /* [N,L] or NULL                 */
-    const float* link_vel;              /* [N,L,3] world link velocity (feet_slide) or NULL */
+    const float* link_vel;              /* [N,L,3] world link velocity (feet_slide, gait rewards) or NULL */
+    const float* link_pos;              /* [N,L,3] world link position (foot_height_reward) or NULL */
     int32_t num_links;                  /* L */
     int32_t _pad;
 } GfContactView;
 
 /* CommandManager._command (managers/command/command_manager.py:77-81). */
 typedef struct GfCommandView {
-    const float* command;  /* [N,width] */
+    const float* command;  /* [N,width], row n at command + n*stride */
     int32_t width;
-    int32_t _pad;
+    int32_t stride;        /* floats between rows; 0 = width (dense).  The gait manager's 14 observed columns live in 16-float rows */
 } GfCommandView;
 
 /* TerrainManager's map of the terrain (managers/terrain_manager.py:281-359): the height field after `* vertical_scale` and
@@ -117,7 +119,7 @@ typedef struct GfStepStats {
     int32_t action_flags;                  /* bit0: NaN action seen, bit1: Inf action seen (position_action_manager.py:402-406) */
     int32_t contact_flags;                 /* bit0: non-finite contact force sanitised (contact_manager.py:399-403) */
     int32_t resample_count;                /* #envs whose command was resampled by command.step() */
-    int32_t _pad[4];
+    int32_t gait_count[GF_MAX_GAITS];      /* #envs currently on gait g, counted every step by gf_gait_step ("Metrics / gait_<name>_envs") */
     double reward_episode_sum[GF_MAX_TERMS]; /* Σ over reset envs of episode_sum[t]/episode_seconds (reward_manager.py:207-216) */
 } GfStepStats;
 
@@ -171,6 +173,8 @@ typedef struct GfContactArgs {
     const float* links_quat;  /* [N,num_scene_links,4] */
     const float* links_vel;   /* [N,num_scene_links,3] world link velocities, or NULL */
     float* link_vel_out;      /* [N,L,3] out: velocity of each tracked link (what rewards.feet_slide reads, rewards.py:496-504), or NULL */
+    const float* links_pos;   /* [N,num_scene_links,3] world link positions, or NULL */
+    float* link_pos_out;      /* [N,L,3] out: position of each tracked link (gait foot_height_reward), or NULL */
     int32_t target_link_ids[GF_MAX_LINK_IDS];
     int32_t with_link_ids[GF_MAX_LINK_IDS];
     float air_time_threshold; /* (float)air_time_contact_threshold */
@@ -237,7 +241,16 @@ enum {
     GF_R_CONTACT_FORCE = 14,     /* i0 = contact view, p0 = thr   rewards.py:413-428 */
     GF_R_FEET_AIR_TIME = 15,     /* i0 = contact view, i1 = command view or -1, p0 = time_threshold, p1 = max-thr (flag MAX), p2 = (float)(dt+1e-8)  rewards.py:431-469 */
     GF_R_FEET_SLIDE = 16,        /* i0 = contact view  rewards.py:472-504 */
-    GF_R_EXTERNAL = 17           /* i0 = ext slot ([N] f32 column evaluated by the host) */
+    GF_R_EXTERNAL = 17,          /* i0 = ext slot ([N] f32 column evaluated by the host) */
+    /* GaitCommandManager rewards (examples/gait_trainer/gait_command_manager.py:278-345): i0 = contact view of the feet
+     * (contacts, link_vel, link_pos), i1 = command view of the gait state rows (GF_GAIT_* columns), i2 = the row of each foot
+     * (FL, FR, RL, RR) inside that contact view, one byte each */
+    GF_R_GAIT_PHASE = 18,        /* exp(Σ_feet swing ? -|F| : stance ? -|v| : 0)                 :295-345
+                                  * Reference quirk reproduced when GfRewardArgs.gait_counts is set: the reference builds its index
+                                  * lists with `mask.nonzero().flatten()` on an [N,1] mask (:335-338), which interleaves the COLUMN
+                                  * indices (all 0) with the row indices — so env 0 gets the stance weights of a foot whenever ANY
+                                  * env is in stance for it, else the swing weights whenever any env is in swing. */
+    GF_R_FOOT_HEIGHT = 19        /* exp(-Σ_feet |v_xy| (z - foot_height)^2 / p0), p0 = sensitivity  :278-293 */
 };
 #define GF_RW_FLAG_CMD 1         /* base_height: target from command view i0 column 0 */
 #define GF_RW_FLAG_TERRAIN 2     /* base_height: subtract get_terrain_height(pos.x, pos.y) sampled from GfRewardArgs.terrain */
@@ -268,6 +281,7 @@ typedef struct GfRewardArgs {
     float* episode_seconds;    /* [N]   in/out (STEP) */
     float* term_out;           /* [T,N] out (EVAL): unweighted term values */
     GfTerrainView terrain;     /* base_height(terrain_manager=…): sampled in the kernel (rewards.py:84-88) */
+    const int32_t* gait_counts; /* GfGaitArgs.phase_counts of the gait manager GF_R_GAIT_PHASE reads (env-0 quirk), or NULL */
     GfTerm terms[GF_MAX_TERMS];
 } GfRewardArgs;
 
@@ -295,6 +309,53 @@ typedef struct GfCommandArgs {
     float* command;           /* [N,R] in/out */
     GfStepStats* stats;       /* may be NULL (STEP mode counts resamples) */
 } GfCommandArgs;
+
+/* ------------------------------------------------------------------------------------------
+ * Phase B5' — GaitCommandManager.step / reset / resample_command
+ *   examples/gait_trainer/gait_command_manager.py:185-255,347-399 (a user-level CommandManager in the reference's
+ *   gait_trainer example).  State of one env = one 64-byte row:
+ *     [0..3] foot_offset (FL,FR,RL,RR)  [4] foot_height  [5] gait_period  [6..13] clock_input (4 sin, 4 cos)
+ *     [14] gait_time  [15] gait_phase
+ *   so columns 0..13 are exactly `observation()` (:257-268) and 0..5 are `command` (:127-141).
+ *   STEP  : resample where episode_length % resample_steps == 0 (command_manager.py:152-162), count envs per gait
+ *           (_log_metrics, :430-441), then advance the clock for EVERY env (:231-239):
+ *             gait_time = fmod(gait_time + dt, period); gait_phase = gait_time / period;
+ *             clock[i] = sin(2π·fmod(phase + offset_i, 1)), clock[4+i] = cos(…)
+ *   MASKED / ALL : resample the masked envs, zero their clock_input / gait_time / gait_phase (:241-255).
+ *   Resampling (:185-211,347-399): gait g from the categorical distribution `cum_weight` (inverse CDF of draw 0; with one
+ *   gait no draw is consumed), foot offsets from the gait table, foot_height = clearance_lo for the fixed-clearance gaits
+ *   else U(clearance) from draw 1, gait_period = U(period) from draw 2.
+ * ---------------------------------------------------------------------------------------- */
+enum { GF_GAIT_OFFSET = 0, GF_GAIT_HEIGHT = 4, GF_GAIT_PERIOD = 5, GF_GAIT_CLOCK = 6, GF_GAIT_TIME = 14, GF_GAIT_PHASE = 15,
+       GF_GAIT_ROW = 16, GF_GAIT_OBS_WIDTH = 14 };
+
+typedef struct GfGaitArgs {
+    int32_t num_envs;
+    int32_t mode;               /* GF_CMD_STEP / GF_CMD_MASKED / GF_CMD_ALL */
+    int32_t resample_steps;
+    int32_t num_gaits;          /* gaits currently sampled from (curriculum), 1..GF_MAX_GAITS */
+    const int32_t* episode_length; /* STEP */
+    const uint8_t* mask;        /* MASKED */
+    const uint8_t* mask2;       /* MASKED, optional */
+    const float* draws;         /* [N,3] U[0,1) (gait select, foot clearance, gait period) or NULL → Philox */
+    uint64_t seed;
+    uint64_t stream;
+    uint32_t env_offset;
+    int32_t fixed_clearance_mask; /* bit g: gait g always uses clearance_lo ("pronk", "bound"; :366-368) */
+    float cum_weight[GF_MAX_GAITS];   /* f32 cumulative sum of the normalised gait weights (:379-399) */
+    float gait_offsets[GF_MAX_GAITS][4];
+    float clearance_lo, clearance_hi; /* _foot_clearance_range */
+    float period_lo, period_hi;       /* _gait_period_range */
+    float dt;                   /* (float)env.dt */
+    float two_pi;               /* (float)(2*pi) */
+    float* state;               /* [N,GF_GAIT_ROW] in/out */
+    int64_t* selected;          /* [N] in/out: _gait_selected */
+    int32_t* phase_counts;      /* [8] in/out, optional: per foot f, #envs whose foot is in swing [2f] / stance [2f+1] for the
+                                   CURRENT state (phi = fmod(phase + offset_f, 1)·2π; swing: 0 <= phi < π, stance: π <= phi < 2π).
+                                   Kept exact incrementally: every launch subtracts an env's old flags and adds its new ones
+                                   (the host initialises it for the all-zero state: swing = N, stance = 0). */
+    GfStepStats* stats;         /* STEP: gait_count[] += envs per gait; may be NULL */
+} GfGaitArgs;
 
 /* ------------------------------------------------------------------------------------------
  * Phase R — masked reset of all manager-owned state (ManagedEnvironment.reset fan-out)
@@ -506,7 +567,7 @@ int gf_abi_version(void);
  * stamped launch costs the host several microseconds more than a plain one, so a timed region samples instead. */
 enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_COUNT = 4 };
 int gf_set_option(int option, int value);
-int gf_sizeof(int which);   /* sizeof of the ABI structs, in header order (0 = GfStepStats … 11 = GfObsItem): binding self-check */
+int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView): binding self-check */
 const char* gf_build_info(void);
 const char* gf_error_string(int code);
 
@@ -517,6 +578,7 @@ int gf_contact_step(const GfContactArgs* a, void* stream);        /* replaces co
 int gf_termination_step(const GfTerminationArgs* a, void* stream);/* replaces termination_manager.py:151-190 */
 int gf_reward_step(const GfRewardArgs* a, void* stream);          /* replaces reward_manager.py:166-195 */
 int gf_command_step(const GfCommandArgs* a, void* stream);        /* replaces command_manager.py:152-170,290-303 */
+int gf_gait_step(const GfGaitArgs* a, void* stream);              /* replaces examples/gait_trainer/gait_command_manager.py:185-255 */
 int gf_masked_reset(const GfResetArgs* a, void* stream);          /* replaces managed_env.py:336-366 fan-out */
 int gf_observe(const GfObservationArgs* a, void* stream);         /* replaces observation_manager.py:218-256 */
 int gf_entity_rotate(const GfRotateArgs* a, void* stream);        /* replaces entity_manager.py:130-146 */
@@ -573,8 +635,8 @@ enum { GF_OP_STATS_CLEAR = 100, GF_OP_STATS_COPY = 101, GF_OP_POST_PHYSICS = 102
 
 /* Fold the GF_STATS_SHARDS shards of one statistics block into the f64 vector that is all-reduced across ranks
  * (layout: term_fired[GF_MAX_TERM_TERMS], reset_count, nan_flag, inf_flag, contact_flag, resample_count,
- * reward_episode_sum[GF_MAX_TERMS]; flags fold with max, everything else adds). */
-#define GF_STATS_VECTOR_LEN (GF_MAX_TERM_TERMS + 5 + GF_MAX_TERMS)
+ * reward_episode_sum[GF_MAX_TERMS], gait_count[GF_MAX_GAITS]; flags fold with max, everything else adds). */
+#define GF_STATS_VECTOR_LEN (GF_MAX_TERM_TERMS + 5 + GF_MAX_TERMS + GF_MAX_GAITS)
 typedef struct GfStatsPackArgs {
     const GfStepStats* src;   /* device, GF_STATS_SHARDS blocks */
     double* dst;              /* device, GF_STATS_VECTOR_LEN */
@@ -595,7 +657,7 @@ int gf_event_synchronize(void* event);   /* blocks the host until the event has 
 /* Optional per-phase HIP-event timing used by bench.py (events recorded on `stream`
  * immediately around the kernel launch of the selected phase). */
 enum { GF_PHASE_ACTION = 0, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
-       GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_COUNT };
+       GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_COUNT };
 int gf_profile_begin(int phase, int max_samples);     /* start recording event pairs for `phase` */
 int gf_profile_end(double* total_ms, int* samples);    /* sync events, return Σ elapsed + count, free them */
 

@@ -55,6 +55,22 @@ static inline float philox_uniform(uint64_t seed, uint64_t stream, uint32_t env,
     return (float)(x[col & 3] >> 8) * 5.9604644775390625e-8f; /* 2^-24 */
 }
 
+/* row stride of a command view in floats (0 = dense) */
+static inline int64_t cmd_stride(const GfCommandView* c) { return c->stride ? c->stride : c->width; }
+
+/* torch's `%` on float tensors (aten remainder kernel): fmod, then moved to the divisor's sign */
+static inline float torch_remainder(float a, float b) {
+    float m = fmodf(a, b);
+    if ((m != 0.0f) && ((b < 0.0f) != (m < 0.0f))) m += b;
+    return m;
+}
+
+/* swing (bit 0) / stance (bit 1) of one foot, examples/gait_trainer/gait_command_manager.py:331-338 */
+static inline int gait_foot_flags(float phase, float offset, float two_pi, float pi) {
+    const float phi = torch_remainder(phase + offset, 1.0f) * two_pi;
+    return (((phi >= 0.0f) && (phi < pi)) ? 1 : 0) | (((phi >= pi) && (phi < two_pi)) ? 2 : 0);
+}
+
 static inline float draw_u(const float* draws, int64_t idx, uint64_t seed, uint64_t stream, uint32_t env, uint32_t col) {
     return draws ? draws[idx] : philox_uniform(seed, stream, env, col);
 }
@@ -279,6 +295,8 @@ GFO_EXPORT int gfo_contact_step(const GfContactArgs* a) {
             if (out_c) out_c[t] = cnt;
             if (a->links_vel && a->link_vel_out)
                 for (int j = 0; j < 3; ++j) a->link_vel_out[(n * L + t) * 3 + j] = a->links_vel[((int64_t)n * a->num_scene_links + target) * 3 + j];
+            if (a->links_pos && a->link_pos_out)
+                for (int j = 0; j < 3; ++j) a->link_pos_out[(n * L + t) * 3 + j] = a->links_pos[((int64_t)n * a->num_scene_links + target) * 3 + j];
             if (a->track_air_time) {
                 const int64_t k = n * L + t;
                 const float dt = a->dt;
@@ -343,7 +361,7 @@ static int eval_termination(const GfTerminationArgs* a, const GfTerm* t, int64_t
 static int check_term_table(const GfTerm* terms, int n, int is_reward) {
     for (int k = 0; k < n; ++k) {
         const int op = terms[k].op;
-        if (is_reward ? (op < GF_R_IS_ALIVE || op > GF_R_EXTERNAL) : (op < GF_T_TIMEOUT || op > GF_T_EXTERNAL))
+        if (is_reward ? (op < GF_R_IS_ALIVE || op > GF_R_FOOT_HEIGHT) : (op < GF_T_TIMEOUT || op > GF_T_EXTERNAL))
             return GF_E_OPCODE;
     }
     return GF_OK;
@@ -381,7 +399,7 @@ static float eval_reward(const GfRewardArgs* a, const GfTerm* t, int64_t n) {
             if (t->flags & GF_RW_FLAG_TERRAIN) /* rewards.py:84-88 */
                 h = h - terrain_height(&a->terrain, a->entity.pos[3 * n], a->entity.pos[3 * n + 1]);
             const float target = (t->flags & GF_RW_FLAG_CMD)
-                                     ? a->command[t->i[0]].command[(int64_t)n * a->command[t->i[0]].width]
+                                     ? a->command[t->i[0]].command[(int64_t)n * cmd_stride(&a->command[t->i[0]])]
                                      : t->p[0];
             const float e = h - target;
             return e * e;
@@ -436,8 +454,8 @@ static float eval_reward(const GfRewardArgs* a, const GfTerm* t, int64_t n) {
             float v[3];
             body_lin_vel(&a->entity, n, v);
             const GfCommandView* c = &a->command[t->i[0]];
-            const float e0 = c->command[(int64_t)n * c->width] - v[0];
-            const float e1 = c->command[(int64_t)n * c->width + 1] - v[1];
+            const float e0 = c->command[(int64_t)n * cmd_stride(c)] - v[0];
+            const float e1 = c->command[(int64_t)n * cmd_stride(c) + 1] - v[1];
             const float err = e0 * e0 + e1 * e1;
             return expf((-err) / t->p[0]);
         }
@@ -445,14 +463,14 @@ static float eval_reward(const GfRewardArgs* a, const GfTerm* t, int64_t n) {
             float v[3];
             body_ang_vel(&a->entity, n, v);
             const GfCommandView* c = &a->command[t->i[0]];
-            const float e = c->command[(int64_t)n * c->width + t->i[1]] - v[2];
+            const float e = c->command[(int64_t)n * cmd_stride(c) + t->i[1]] - v[2];
             return expf((-(e * e)) / t->p[0]);
         }
         case GF_R_STAND_STILL: { /* rewards.py:379-385 */
             float s = 0.0f;
             for (int64_t d = 0; d < D; ++d) s += fabsf(a->dof_pos[n * D + d] - a->default_dof_pos[d]);
             const GfCommandView* c = &a->command[t->i[0]];
-            const float m = norm2(c->command[(int64_t)n * c->width], c->command[(int64_t)n * c->width + 1]);
+            const float m = norm2(c->command[(int64_t)n * cmd_stride(c)], c->command[(int64_t)n * cmd_stride(c) + 1]);
             return s * ((m < t->p[0]) ? 1.0f : 0.0f);
         }
         case GF_R_HAS_CONTACT: /* rewards.py:408-410 */
@@ -479,7 +497,7 @@ static float eval_reward(const GfRewardArgs* a, const GfTerm* t, int64_t n) {
             }
             if (t->i[1] >= 0) {
                 const GfCommandView* c = &a->command[t->i[1]];
-                const float m = norm2(c->command[(int64_t)n * c->width], c->command[(int64_t)n * c->width + 1]);
+                const float m = norm2(c->command[(int64_t)n * cmd_stride(c)], c->command[(int64_t)n * cmd_stride(c) + 1]);
                 s = s * ((m > 0.1f) ? 1.0f : 0.0f);
             }
             return s;
@@ -494,6 +512,43 @@ static float eval_reward(const GfRewardArgs* a, const GfTerm* t, int64_t n) {
             return s;
         }
         case GF_R_EXTERNAL: return a->ext[t->i[0]][n];
+        case GF_R_GAIT_PHASE: { /* examples/gait_trainer/gait_command_manager.py:295-345 */
+            const GfContactView* v = &a->contact[t->i[0]];
+            const GfCommandView* gv = &a->command[t->i[1]];
+            const float* g = gv->command + (int64_t)n * cmd_stride(gv);
+            float quad = 0.0f;
+            for (int f = 0; f < 4; ++f) {          /* fl + fr + rl + rr  :300-304 */
+                const int l = (t->i[2] >> (8 * f)) & 0xff;
+                const float force = norm3(v->contacts + (n * v->num_links + l) * 3);  /* :326-328 */
+                const float vel = norm3(v->link_vel + (n * v->num_links + l) * 3);    /* :329 */
+                int fl = gait_foot_flags(g[GF_GAIT_PHASE], g[GF_GAIT_OFFSET + f], t->p[1], t->p[2]); /* :332-338 */
+                /* `mask.nonzero().flatten()` on the [N,1] masks (:336,338) yields (row, col) pairs, so index 0 (the column)
+                 * is in the swing list whenever any env is in swing and in the stance list whenever any env is in stance;
+                 * the four assignments :340-343 then leave env 0 with the stance weights, else the swing weights */
+                if (n == 0 && a->gait_counts) {
+                    if (a->gait_counts[2 * f + 1] > 0) fl = 2;
+                    else if (a->gait_counts[2 * f] > 0) fl = 1;
+                }
+                const float fw = (fl & 1) ? -1.0f : 0.0f, vw = (fl & 2) ? -1.0f : 0.0f;    /* :340-343 */
+                const float foot = vw * vel + fw * force;                             /* :345 */
+                quad = f == 0 ? foot : quad + foot;
+            }
+            return expf(quad);
+        }
+        case GF_R_FOOT_HEIGHT: { /* :278-293 */
+            const GfContactView* v = &a->contact[t->i[0]];
+            const GfCommandView* gv = &a->command[t->i[1]];
+            const float target = gv->command[(int64_t)n * cmd_stride(gv) + GF_GAIT_HEIGHT];
+            float err = 0.0f;
+            for (int f = 0; f < 4; ++f) {
+                const int l = (t->i[2] >> (8 * f)) & 0xff;
+                const float* lv = v->link_vel + (n * v->num_links + l) * 3;
+                const float d = v->link_pos[(n * v->num_links + l) * 3 + 2] - target;
+                const float e = norm2(lv[0], lv[1]) * (d * d);
+                err = f == 0 ? e : err + e;
+            }
+            return expf((-err) / t->p[0]);
+        }
         default: return 0.0f;
     }
 }
@@ -549,6 +604,59 @@ GFO_EXPORT int gfo_command_step(const GfCommandArgs* a) {
         }
     }
     if (a->stats && a->mode == GF_CMD_STEP) a->stats->resample_count += count;
+    return GF_OK;
+}
+
+/* ---------------------------------------------------------------- Phase B5' -------------- */
+/* GaitCommandManager (examples/gait_trainer/gait_command_manager.py): step :222-239 (base step command_manager.py:152-162,
+ * _log_metrics :430-441), reset :241-255, resample_command/_set_gait :185-211,347-377, gait selection :379-399. */
+GFO_EXPORT int gfo_gait_step(const GfGaitArgs* a) {
+    if (!a || !a->state || !a->selected) return GF_E_NULL;
+    if (a->num_gaits < 1 || a->num_gaits > GF_MAX_GAITS) return GF_E_RANGE;
+    if (a->mode == GF_CMD_STEP && (a->resample_steps <= 0 || !a->episode_length)) return a->episode_length ? GF_E_RANGE : GF_E_NULL;
+    if (a->mode == GF_CMD_MASKED && !a->mask) return GF_E_NULL;
+    const int64_t N = a->num_envs;
+    for (int64_t n = 0; n < N; ++n) {
+        float* r = a->state + n * GF_GAIT_ROW;
+        const float pi = 0.5f * a->two_pi;
+        int old_flags[4];
+        for (int f = 0; f < 4; ++f) old_flags[f] = gait_foot_flags(r[GF_GAIT_PHASE], r[GF_GAIT_OFFSET + f], a->two_pi, pi);
+        int go;
+        if (a->mode == GF_CMD_STEP) go = (a->episode_length[n] % a->resample_steps) == 0;
+        else if (a->mode == GF_CMD_MASKED) go = a->mask[n] || (a->mask2 && a->mask2[n]);
+        else go = 1;
+        if (go) {
+            const uint32_t genv = (uint32_t)n + a->env_offset;
+            const float u0 = draw_u(a->draws, n * 3 + 0, a->seed, a->stream, genv, 0);
+            const float u1 = draw_u(a->draws, n * 3 + 1, a->seed, a->stream, genv, 1);
+            const float u2 = draw_u(a->draws, n * 3 + 2, a->seed, a->stream, genv, 2);
+            int g = 0;
+            for (int k = 0; k + 1 < a->num_gaits; ++k) g += (u0 >= a->cum_weight[k]) ? 1 : 0;
+            a->selected[n] = g;
+            for (int f = 0; f < 4; ++f) r[GF_GAIT_OFFSET + f] = a->gait_offsets[g][f];
+            r[GF_GAIT_HEIGHT] = ((a->fixed_clearance_mask >> g) & 1) ? a->clearance_lo : uniform_range(u1, a->clearance_lo, a->clearance_hi);
+            r[GF_GAIT_PERIOD] = uniform_range(u2, a->period_lo, a->period_hi);
+            if (a->mode != GF_CMD_STEP) {
+                for (int j = 0; j < 8; ++j) r[GF_GAIT_CLOCK + j] = 0.0f;
+                r[GF_GAIT_TIME] = 0.0f;
+                r[GF_GAIT_PHASE] = 0.0f;
+            }
+        }
+        if (a->mode == GF_CMD_STEP) {
+            if (a->stats && a->selected[n] >= 0 && a->selected[n] < GF_MAX_GAITS) a->stats->gait_count[a->selected[n]] += 1;
+            r[GF_GAIT_TIME] = torch_remainder(r[GF_GAIT_TIME] + a->dt, r[GF_GAIT_PERIOD]);  /* :231 */
+            r[GF_GAIT_PHASE] = r[GF_GAIT_TIME] / r[GF_GAIT_PERIOD];                        /* :232 */
+            for (int f = 0; f < 4; ++f) {                                                  /* :233-239 */
+                const float fp = torch_remainder(r[GF_GAIT_PHASE] + r[GF_GAIT_OFFSET + f], 1.0f);
+                sincos_det(a->two_pi * fp, &r[GF_GAIT_CLOCK + f], &r[GF_GAIT_CLOCK + 4 + f]);
+            }
+        }
+        if (a->phase_counts)
+            for (int f = 0; f < 4; ++f) {
+                const int nf = gait_foot_flags(r[GF_GAIT_PHASE], r[GF_GAIT_OFFSET + f], a->two_pi, pi);
+                for (int b = 0; b < 2; ++b) a->phase_counts[2 * f + b] += ((nf >> b) & 1) - ((old_flags[f] >> b) & 1);
+            }
+    }
     return GF_OK;
 }
 
@@ -677,7 +785,7 @@ GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
             switch (it->op) {
                 case GF_O_COMMAND: {
                     const GfCommandView* c = &a->command[it->i0];
-                    for (int j = 0; j < it->width; ++j) tmp[j] = c->command[(int64_t)n * c->width + j];
+                    for (int j = 0; j < it->width; ++j) tmp[j] = c->command[(int64_t)n * cmd_stride(c) + j];
                 } break;
                 case GF_O_ANG_VEL_BODY: body_ang_vel(&ent, n, tmp); break;
                 case GF_O_LIN_VEL_BODY: body_lin_vel(&ent, n, tmp); break;
@@ -838,7 +946,8 @@ GFO_EXPORT int gfo_stats_pack(const GfStatsPackArgs* a) {
             else if (v == GF_MAX_TERM_TERMS + 2) x = (double)((b->action_flags >> 1) & 1);
             else if (v == GF_MAX_TERM_TERMS + 3) x = (double)(b->contact_flags & 1);
             else if (v == GF_MAX_TERM_TERMS + 4) x = (double)b->resample_count;
-            else x = b->reward_episode_sum[v - (GF_MAX_TERM_TERMS + 5)];
+            else if (v < GF_MAX_TERM_TERMS + 5 + GF_MAX_TERMS) x = b->reward_episode_sum[v - (GF_MAX_TERM_TERMS + 5)];
+            else x = (double)b->gait_count[v - (GF_MAX_TERM_TERMS + 5 + GF_MAX_TERMS)];
             const int is_flag = v > GF_MAX_TERM_TERMS && v < GF_MAX_TERM_TERMS + 4;
             acc = is_flag ? (x > acc ? x : acc) : acc + x;
         }
@@ -864,6 +973,7 @@ GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
             case GF_PHASE_ROTATE: rc = gfo_entity_rotate((const GfRotateArgs*)a); break;
             case GF_PHASE_SCENE: rc = gfo_synth_scene_step((const GfSynthSceneArgs*)a); break;
             case GF_PHASE_TERRAIN: rc = gfo_terrain_height((const GfTerrainHeightArgs*)a); break;
+            case GF_PHASE_GAIT: rc = gfo_gait_step((const GfGaitArgs*)a); break;
             case GF_OP_STATS_CLEAR: rc = gfo_stats_clear((GfStepStats*)a); break;
             case GF_OP_POST_PHYSICS: rc = gfo_post_physics_step((const GfPostRefs*)a); break;
             case GF_OP_STATS_PACK: rc = gfo_stats_pack((const GfStatsPackArgs*)a); break;
@@ -899,6 +1009,9 @@ GFO_EXPORT int gfo_sizeof(int which) {
         case 11: return (int)sizeof(GfObsItem);
         case 12: return (int)sizeof(GfTerrainView);
         case 13: return (int)sizeof(GfTerrainHeightArgs);
+        case 14: return (int)sizeof(GfGaitArgs);
+        case 15: return (int)sizeof(GfContactView);
+        case 16: return (int)sizeof(GfCommandView);
         default: return -1;
     }
 }

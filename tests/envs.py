@@ -151,6 +151,88 @@ class BerkeleyHumanoidEnv(ManagedEnvironment):
         ObservationManager(self, cfg=_std_obs(self))
 
 
+class Go2GaitTrainingEnv(ManagedEnvironment):
+    """BASELINE config 5 (cf. examples/gait_trainer/environment.py:26-380): velocity + gait command managers, three contact
+    managers, the gait manager's two reward methods, policy (62 x 5) and critic (16 x 5) observations, and — with
+    ``curriculum=True`` — the example's ``reset`` override that widens the gait set from ``last_episode_mean_reward``."""
+
+    CHECK_EVERY = 100
+
+    def __init__(self, num_envs=1, dt=1 / 50, max_episode_length_s=20, scene_kwargs=None, curriculum=True):
+        super().__init__(num_envs=num_envs, dt=dt, max_episode_length_sec=max_episode_length_s, max_episode_random_scaling=0.4)
+        self._curriculum = curriculum
+        self._next_curriculum_check_step = self.CHECK_EVERY
+        self.scene = SyntheticScene(dt=self.dt, substeps=2, **dict(dict(max_collision_pairs=60), **(scene_kwargs or {})))
+        self.terrain = self.scene.add_entity(morphs.Plane())
+        self.robot = self.scene.add_entity(morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=INITIAL_BODY_POSITION, quat=INITIAL_QUAT,
+                                                       links_to_keep=["FL_foot", "FR_foot", "RL_foot", "RR_foot"]))
+
+    def config(self):
+        from genesis_forge_amd.managers import GaitCommandManager
+
+        self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={
+            "position": {"fn": reset.position, "params": {"position": INITIAL_BODY_POSITION, "quat": INITIAL_QUAT, "zero_velocity": True}}})
+        self.action_manager = PositionActionManager(self, joint_names=GO2_JOINTS, default_pos=GO2_DEFAULT_POS, scale=0.25,
+                                                    use_default_offset=True, pd_kp=20, pd_kv=0.5)
+        self.foot_contact_manager = ContactManager(self, link_names=[".*_foot"], air_time_contact_threshold=1.0)
+        self.body_contact_manager = ContactManager(self, link_names=["base"], air_time_contact_threshold=1.0)
+        self.bad_contact_manager = ContactManager(self, link_names=[".*_thigh", ".*_calf"])
+        self.velocity_command = VelocityCommandManager(
+            self, range={"lin_vel_x": [-1.0, 1.0], "lin_vel_y": [0.0, 0.0], "ang_vel_z": [-1.0, 1.0]}, standing_probability=0.00,
+            resample_time_sec=3.0)
+        self.gait_command_manager = GaitCommandManager(
+            self, foot_names={"FL": "FL_foot", "FR": "FR_foot", "RL": "RL_foot", "RR": "RR_foot"}, resample_time_sec=4.0)
+        em, vc, gait = self.robot_manager, self.velocity_command, self.gait_command_manager
+        self.reward_manager = RewardManager(self, logging_enabled=True, cfg={
+            "gait_phase_reward": {"weight": 1.5, "fn": gait.gait_phase_reward, "params": {"contact_manager": self.foot_contact_manager}},
+            "foot_height_reward": {"weight": 0.9, "fn": gait.foot_height_reward},
+            "base_height_target": {"weight": -25.0, "fn": rewards.base_height, "params": {"target_height": 0.35, "entity_attr": "robot"}},
+            "tracking_lin_vel": {"weight": 1.0, "fn": rewards.command_tracking_lin_vel, "params": {"vel_cmd_manager": vc, "entity_manager": em}},
+            "tracking_ang_vel": {"weight": 0.5, "fn": rewards.command_tracking_ang_vel, "params": {"vel_cmd_manager": vc, "entity_manager": em}},
+            "body_acceleration": {"weight": -0.1, "fn": rewards.body_acceleration_exp, "params": {"entity_manager": em}},
+            "lin_vel_z": {"weight": -0.1, "fn": rewards.lin_vel_z_l2, "params": {"entity_manager": em}},
+            "action_rate": {"weight": -0.01, "fn": rewards.action_rate_l2},
+            "bad_contact": {"weight": -1.0, "fn": rewards.contact_force, "params": {"contact_manager": self.bad_contact_manager}},
+        })
+        self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg={
+            "timeout": {"fn": terminations.timeout, "time_out": True},
+            "fall_over": {"fn": terminations.bad_orientation, "params": {"limit_angle": 20.0, "entity_manager": em}},
+            "body_contact": {"fn": terminations.contact_force, "params": {"contact_manager": self.body_contact_manager, "threshold": 1.0}},
+        })
+        ocfg = {"gait_command": {"fn": gait.observation}}
+        ocfg.update(_std_obs(self))
+        ObservationManager(self, name="policy", history_len=5, cfg=ocfg)
+        ObservationManager(self, name="critic", history_len=5, cfg={
+            "foot_contact_force": {"fn": observations.contact_force, "params": {"contact_manager": self.foot_contact_manager}},
+            "dof_force": {"fn": observations.entity_dofs_force, "params": {"action_manager": self.action_manager}, "scale": 0.1},
+        })
+
+    def update_curriculum(self):
+        """cf. examples/gait_trainer/environment.py:354-380"""
+        if self.step_count < self._next_curriculum_check_step:
+            return
+        self._next_curriculum_check_step = self.step_count + self.CHECK_EVERY
+        if self.reward_manager.last_episode_mean_reward("gait_phase_reward", before_weight=True) > 0.75:
+            self.gait_command_manager.increment_num_gaits()
+            self.gait_command_manager.increment_gait_period_range()
+        if self.reward_manager.last_episode_mean_reward("foot_height_reward", before_weight=True) > 0.8:
+            self.gait_command_manager.increment_foot_clearance_range()
+
+
+def _gait_reset_with_curriculum(self, envs_idx=None):
+    out = ManagedEnvironment.reset(self, envs_idx)
+    if envs_idx is not None and self._curriculum:
+        self.update_curriculum()
+    return out
+
+
+class Go2GaitTrainingCurriculumEnv(Go2GaitTrainingEnv):
+    """The example's ``reset`` override (examples/gait_trainer/environment.py:347-352).  Kept in a subclass: an env that
+    overrides ``reset`` gets the reference's index-list reset path and is never recorded."""
+
+    reset = _gait_reset_with_curriculum
+
+
 def make_example(name: str, case: dict):
     """This package's restatement of the reference example ``name`` with the case's scene options (tests/example_cases.py)."""
     kw = dict(num_envs=case["n"], max_episode_length_s=case["episode_s"], scene_kwargs=dict(case["scene"]))
@@ -166,7 +248,7 @@ def make_example(name: str, case: dict):
     if name == "berkeley_humanoid":
         return BerkeleyHumanoidEnv(**kw)
     if name == "gait_trainer":
-        return Go2GaitTrainingEnv(**kw)
+        return Go2GaitTrainingCurriculumEnv(**kw)
     raise KeyError(name)
 
 

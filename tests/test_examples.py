@@ -21,7 +21,7 @@ import example_cases
 import helpers
 
 EXAMPLES = list(example_cases.CASES)
-RESTATED = [e for e in EXAMPLES if e != "gait_trainer"]  # + gait_trainer once the native GaitCommandManager lands
+RESTATED = EXAMPLES  # gait_trainer runs on the native GaitCommandManager
 REF_EXAMPLES = "/root/reference/examples"
 
 
