@@ -7,6 +7,8 @@
 namespace gf {
 int g_options[GF_OPT_COUNT] = {2, 0, 0, 0};
 Profiler g_prof;
+bool contact_compatible(const GfContactArgs* x, const GfContactArgs* y);          // gf_contact.hip
+int contact_launch(const GfContactArgs* const* mgrs, int num, hipStream_t s);
 }
 
 #define GF_EXPORT __attribute__((visibility("default")))
@@ -83,7 +85,19 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
         const void* a = ops[i].args;
         switch (ops[i].phase) {
             case GF_PHASE_ACTION: rc = gf_action_step((const GfActionArgs*)a, stream); break;
-            case GF_PHASE_CONTACT: rc = gf_contact_step((const GfContactArgs*)a, stream); break;
+            case GF_PHASE_CONTACT: {
+                // consecutive ContactManagers over the same scene arrays share one launch (slot ids read once for all of them)
+                const GfContactArgs* run[4] = {(const GfContactArgs*)a};
+                int cnt = 1, links = run[0] ? run[0]->num_targets : 0;
+                while (run[0] && cnt < 4 && i + cnt < num_ops && ops[i + cnt].phase == GF_PHASE_CONTACT && ops[i + cnt].args) {
+                    const GfContactArgs* nx = (const GfContactArgs*)ops[i + cnt].args;
+                    if (!gf::contact_compatible(run[0], nx) || links + nx->num_targets > 64) break;
+                    links += nx->num_targets;
+                    run[cnt++] = nx;
+                }
+                rc = gf::contact_launch(run, cnt, s);
+                if (rc == GF_OK) i += cnt - 1;
+            } break;
             case GF_PHASE_TERMINATION: rc = gf_termination_step((const GfTerminationArgs*)a, stream); break;
             case GF_PHASE_REWARD: rc = gf_reward_step((const GfRewardArgs*)a, stream); break;
             case GF_PHASE_COMMAND: rc = gf_command_step((const GfCommandArgs*)a, stream); break;

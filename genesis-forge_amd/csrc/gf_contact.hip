@@ -1,4 +1,4 @@
-// gf_contact.hip — Phase B2: ContactManager.step as one launch.
+// gf_contact.hip — Phase B2: ContactManager.step for ALL ContactManagers of a scene as one launch.
 //
 // Replaces, per ContactManager (the gait config has three):
 //   managers/contact/contact_manager.py:399-403   isnan/isinf .any() (2 host syncs) + nan_to_num
@@ -6,45 +6,91 @@
 //   managers/contact/kernel.py:35-90              the Taichi kernel (atomic += over (env, contact, target))
 //   managers/contact/contact_manager.py:434-477   norm > threshold + 4 torch.where air-time updates
 //
-// One lane per (env, target link) pair: the lane walks that env's C contact slots in slot order and
-// keeps its force / position / count accumulators in registers, so there are no atomics at all and
-// the f32 sum order is fixed (the Taichi reference's atomic order is not).  The L lanes of one env
-// read the same link_a/link_b words (broadcast) and consecutive envs are adjacent in memory.  The
-// force-norm / threshold / air-time state update that the reference runs afterwards as ~12 separate
-// launches is done by the same lane while the summed force is still in registers.
-// Algorithmic traffic per env: R C*(8+12+12) contact slots (+16 per matched slot for the link
-// quaternion), W 28L (forces, mean positions, counts), RW 32L air-time state.
+// Layout.  A workgroup owns E consecutive envs.  Their link_a / link_b rows (E·C ints each, contiguous in memory) are
+// staged into LDS with flat coalesced loads — every contact slot id is read from HBM exactly once, whatever the number of
+// managers and tracked links.  Then one lane per (env, tracked link of any manager) walks that env's C slot ids in LDS in
+// slot order and keeps its force / position / count accumulators in registers: no atomics, and the f32 sum order is
+// fixed (the Taichi reference's atomic order is not).  Force, position and link quaternion are fetched from global memory
+// only for the slots that match (contacts are sparse).  The force-norm / threshold / air-time state update that the
+// reference runs afterwards as ~12 separate launches is done by the same lane while the summed force is in registers.
+// gf_run_ops folds consecutive contact_step ops over the same scene arrays into one launch of this kernel.
+// Algorithmic traffic per env: R 8C slot ids once (+ 40 B per matched slot), W 28L (forces, mean positions, counts)
+// (+ 24L link velocity / position copies when the scene provides them), RW 32L air-time state.
 #include "gf_launch.h"
 
 namespace gf {
 
-__global__ __launch_bounds__(kEnvBlock) void contact_kernel(const GfContactArgs a) {
-    const int64_t gid = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
-    const int L = a.num_targets, C = a.num_contacts, W = a.num_with;
-    const int64_t n = gid / L;
-    const int t = (int)(gid - n * L);
-    const bool live = n < a.num_envs;
+constexpr int kContactMaxMgr = 4;
+constexpr int kContactMaxTargets = 64;   // tracked links over all managers of one launch
+constexpr int kContactBlock = 256;
+constexpr int kContactLdsBytes = 48 * 1024;
+
+struct ContactMgr {
+    int32_t num_targets, num_with, has_with_filter, track_air_time;
+    float air_time_threshold;
+    int32_t _pad;
+    float *contacts, *contact_positions, *position_counts, *link_vel_out, *link_pos_out;
+    float *last_air_time, *current_air_time, *last_contact_time, *current_contact_time;
+    GfStepStats* stats;
+    int32_t with_link_ids[GF_MAX_LINK_IDS];
+};
+
+struct ContactMultiArgs {
+    int32_t num_envs, num_contacts, num_scene_links, num_mgr;
+    int32_t total_targets, envs_per_block;
+    float dt;
+    int32_t _pad;
+    const float *force, *position, *links_quat, *links_vel, *links_pos;
+    const int32_t *link_a, *link_b;
+    int32_t target_ids[kContactMaxTargets];
+    uint8_t mgr_of[kContactMaxTargets];
+    uint8_t local_of[kContactMaxTargets];
+    ContactMgr m[kContactMaxMgr];
+};
+static_assert(sizeof(ContactMultiArgs) <= 4096, "kernarg segment");
+
+__global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMultiArgs a) {
+    extern __shared__ int32_t lds_ids[];  // [E*C] link_a, then [E*C] link_b
+    const int C = a.num_contacts, T = a.total_targets, E = a.envs_per_block;
+    const int64_t n0 = (int64_t)blockIdx.x * E;
+    const int envs_here = (int)((int64_t)a.num_envs - n0 < E ? (int64_t)a.num_envs - n0 : E);
+    const int words = envs_here * C;
+    int32_t* sa = lds_ids;
+    int32_t* sb = lds_ids + E * C;
+    {   // the E rows are contiguous: flat coalesced copy
+        const GF_GLOBAL int32_t* ga = G(a.link_a) + n0 * C;
+        const GF_GLOBAL int32_t* gb = G(a.link_b) + n0 * C;
+        for (int i = threadIdx.x; i < words; i += blockDim.x) { sa[i] = ga[i]; sb[i] = gb[i]; }
+    }
+    __syncthreads();
+    const int e = (int)threadIdx.x / T;
+    const int t = (int)threadIdx.x - e * T;
+    const bool live = e < envs_here;
     int flag = 0;
+    const int mi = a.mgr_of[t < T ? t : 0];
     if (live) {
-        const int target = a.target_link_ids[t];
+        const ContactMgr& mg = a.m[mi];
+        const int64_t n = n0 + e;
+        const int lt = a.local_of[t], L = mg.num_targets, W = mg.num_with;
+        const int target = a.target_ids[t];
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, cnt = 0.f;
-        const int32_t* la_row = a.link_a + n * C;
-        const int32_t* lb_row = a.link_b + n * C;
+        const int32_t* la_row = sa + e * C;
+        const int32_t* lb_row = sb + e * C;
         for (int c = 0; c < C; ++c) {
             const int la = la_row[c], lb = lb_row[c];
             const bool is_a = la == target, is_b = lb == target;
             if (!(is_a || is_b)) continue;
             bool include = true;
-            if (a.has_with_filter) {
+            if (mg.has_with_filter) {
                 include = false;
                 for (int w = 0; w < W; ++w) {
-                    const int wl = a.with_link_ids[w];
+                    const int wl = mg.with_link_ids[w];
                     if ((is_a && lb == wl) || (is_b && la == wl)) { include = true; break; }
                 }
             }
             if (!include) continue;
-            const float* fr = a.force + (n * C + c) * 3;
-            const float* pr = a.position + (n * C + c) * 3;
+            const GF_GLOBAL float* fr = G(a.force) + (n * C + c) * 3;
+            const GF_GLOBAL float* pr = G(a.position) + (n * C + c) * 3;
             float fx = fr[0], fy = fr[1], fz = fr[2];
             // torch.nan_to_num(force, nan=0, posinf=0, neginf=0)   contact_manager.py:401-403
             if (isnan(fx) || isinf(fx)) { fx = 0.f; flag = 1; }
@@ -54,63 +100,115 @@ __global__ __launch_bounds__(kEnvBlock) void contact_kernel(const GfContactArgs 
             cnt += 1.0f;
             // force is expressed on link_b; on link_a it is the reaction (kernel.py:74-78)
             const int ql = is_b ? lb : la;
-            const float4 q = load_quat(a.links_quat, n * a.num_scene_links + ql);
+            const float4 q = ldg4(G(a.links_quat) + (n * a.num_scene_links + ql) * 4);
             const V3 r = is_b ? rot_inv(q, V3{fx, fy, fz}) : rot_inv(q, V3{-fx, -fy, -fz});
             f0 += r.x; f1 += r.y; f2 += r.z;
         }
-        const int64_t k = n * L + t;
-        a.contacts[3 * k + 0] = f0;
-        a.contacts[3 * k + 1] = f1;
-        a.contacts[3 * k + 2] = f2;
-        if (a.contact_positions) {  // kernel.py:84-90
-            a.contact_positions[3 * k + 0] = cnt > 0.f ? p0 / cnt : p0;
-            a.contact_positions[3 * k + 1] = cnt > 0.f ? p1 / cnt : p1;
-            a.contact_positions[3 * k + 2] = cnt > 0.f ? p2 / cnt : p2;
+        const int64_t k = n * L + lt;
+        GF_GLOBAL float* co = G(mg.contacts) + 3 * k;
+        co[0] = f0; co[1] = f1; co[2] = f2;
+        if (mg.contact_positions) {  // kernel.py:84-90
+            GF_GLOBAL float* po = G(mg.contact_positions) + 3 * k;
+            po[0] = cnt > 0.f ? p0 / cnt : p0;
+            po[1] = cnt > 0.f ? p1 / cnt : p1;
+            po[2] = cnt > 0.f ? p2 / cnt : p2;
         }
-        if (a.position_counts) a.position_counts[k] = cnt;
-        if (a.links_vel && a.link_vel_out) {  // compact per-manager copy of the tracked links' velocities (feet_slide)
-            const float* sv = a.links_vel + (n * a.num_scene_links + target) * 3;
-            a.link_vel_out[3 * k + 0] = sv[0];
-            a.link_vel_out[3 * k + 1] = sv[1];
-            a.link_vel_out[3 * k + 2] = sv[2];
+        if (mg.position_counts) G(mg.position_counts)[k] = cnt;
+        if (a.links_vel && mg.link_vel_out) {  // compact per-manager copy of the tracked links' velocities (feet_slide)
+            const GF_GLOBAL float* sv = G(a.links_vel) + (n * a.num_scene_links + target) * 3;
+            GF_GLOBAL float* o = G(mg.link_vel_out) + 3 * k;
+            o[0] = sv[0]; o[1] = sv[1]; o[2] = sv[2];
         }
-        if (a.links_pos && a.link_pos_out) {  // … and of their positions (the gait manager's foot_height_reward)
-            const float* sp = a.links_pos + (n * a.num_scene_links + target) * 3;
-            a.link_pos_out[3 * k + 0] = sp[0];
-            a.link_pos_out[3 * k + 1] = sp[1];
-            a.link_pos_out[3 * k + 2] = sp[2];
+        if (a.links_pos && mg.link_pos_out) {  // … and of their positions (the gait manager's foot_height_reward)
+            const GF_GLOBAL float* sp = G(a.links_pos) + (n * a.num_scene_links + target) * 3;
+            GF_GLOBAL float* o = G(mg.link_pos_out) + 3 * k;
+            o[0] = sp[0]; o[1] = sp[1]; o[2] = sp[2];
         }
-        if (a.track_air_time) {  // contact_manager.py:441-477
+        if (mg.track_air_time) {  // contact_manager.py:441-477
             const float dt = a.dt;
-            const bool is_contact = norm3(f0, f1, f2) > a.air_time_threshold;
-            const float cur_air = a.current_air_time[k], cur_con = a.current_contact_time[k];
+            const bool is_contact = norm3(f0, f1, f2) > mg.air_time_threshold;
+            const float cur_air = G(mg.current_air_time)[k], cur_con = G(mg.current_contact_time)[k];
             const bool new_contact = (cur_air > 0.f) && is_contact;
             const bool new_detach = (cur_con > 0.f) && !is_contact;
-            if (new_contact) a.last_air_time[k] = cur_air + dt;
-            a.current_air_time[k] = !is_contact ? cur_air + dt : 0.f;
-            if (new_detach) a.last_contact_time[k] = cur_con + dt;
-            a.current_contact_time[k] = is_contact ? cur_con + dt : 0.f;
+            if (new_contact) G(mg.last_air_time)[k] = cur_air + dt;
+            G(mg.current_air_time)[k] = !is_contact ? cur_air + dt : 0.f;
+            if (new_detach) G(mg.last_contact_time)[k] = cur_con + dt;
+            G(mg.current_contact_time)[k] = is_contact ? cur_con + dt : 0.f;
         }
     }
-    if (a.stats) {
-        const unsigned long long m = __ballot(flag);
-        if (m && threadIdx.x == 0) atomicOr(&stats_shard(a.stats)->contact_flags, 1);
+    // non-finite force seen: one flag per manager (contact_manager.py:399-403 prints a warning)
+    for (int m = 0; m < a.num_mgr; ++m) {
+        if (!a.m[m].stats) continue;
+        const unsigned long long b = __ballot(flag && live && mi == m);
+        if (b && (threadIdx.x & (GF_WAVE - 1)) == 0) atomicOr(&stats_shard(a.m[m].stats)->contact_flags, 1);
     }
 }
 
-}  // namespace gf
-
-extern "C" __attribute__((visibility("default"))) int gf_contact_step(const GfContactArgs* a, void* stream) {
+static int validate_contact(const GfContactArgs* a) {
     if (!a || !a->contacts) return GF_E_NULL;
     if (a->num_targets <= 0 || a->num_targets > GF_MAX_LINK_IDS || a->num_with < 0 || a->num_with > GF_MAX_LINK_IDS) return GF_E_RANGE;
     if (a->num_contacts < 0 || a->num_envs < 0) return GF_E_RANGE;
     if (a->num_contacts > 0 && (!a->force || !a->position || !a->link_a || !a->link_b || !a->links_quat)) return GF_E_NULL;
     if (a->num_contacts > 0 && (reinterpret_cast<uintptr_t>(a->links_quat) & 15u)) return GF_E_UNSUPPORTED;
     if (a->track_air_time && (!a->last_air_time || !a->current_air_time || !a->last_contact_time || !a->current_contact_time)) return GF_E_NULL;
-    if (a->num_envs == 0) return GF_OK;
-    hipStream_t s = (hipStream_t)stream;
-    gf::PhaseScope scope(GF_PHASE_CONTACT, s);
-    scope.begin_bracket();
-    gf::contact_kernel<<<gf::env_grid((int64_t)a->num_envs * a->num_targets), gf::kEnvBlock, 0, s>>>(*a);
-    return gf::launch_status();
+    return GF_OK;
+}
+
+// Managers that can share one launch read the same scene arrays (the usual case: every ContactManager of an env).
+bool contact_compatible(const GfContactArgs* x, const GfContactArgs* y) {
+    return x->num_envs == y->num_envs && x->num_contacts == y->num_contacts && x->num_scene_links == y->num_scene_links &&
+           x->force == y->force && x->position == y->position && x->link_a == y->link_a && x->link_b == y->link_b &&
+           x->links_quat == y->links_quat && x->links_vel == y->links_vel && x->links_pos == y->links_pos && x->dt == y->dt;
+}
+
+int contact_launch(const GfContactArgs* const* mgrs, int num, hipStream_t s) {
+    if (num < 1 || num > kContactMaxMgr) return GF_E_RANGE;
+    ContactMultiArgs k{};
+    int total = 0;
+    for (int m = 0; m < num; ++m) {
+        const GfContactArgs* a = mgrs[m];
+        const int rc = validate_contact(a);
+        if (rc) return rc;
+        if (m > 0 && !contact_compatible(mgrs[0], a)) return GF_E_UNSUPPORTED;
+        if (total + a->num_targets > kContactMaxTargets) return GF_E_RANGE;
+        ContactMgr& o = k.m[m];
+        o.num_targets = a->num_targets; o.num_with = a->num_with; o.has_with_filter = a->has_with_filter; o.track_air_time = a->track_air_time;
+        o.air_time_threshold = a->air_time_threshold;
+        o.contacts = a->contacts; o.contact_positions = a->contact_positions; o.position_counts = a->position_counts;
+        o.link_vel_out = a->link_vel_out; o.link_pos_out = a->link_pos_out;
+        o.last_air_time = a->last_air_time; o.current_air_time = a->current_air_time;
+        o.last_contact_time = a->last_contact_time; o.current_contact_time = a->current_contact_time;
+        o.stats = a->stats;
+        for (int w = 0; w < a->num_with; ++w) o.with_link_ids[w] = a->with_link_ids[w];
+        for (int t = 0; t < a->num_targets; ++t) {
+            k.target_ids[total] = a->target_link_ids[t];
+            k.mgr_of[total] = (uint8_t)m;
+            k.local_of[total] = (uint8_t)t;
+            ++total;
+        }
+    }
+    const GfContactArgs* a0 = mgrs[0];
+    if (a0->num_envs == 0) return GF_OK;
+    k.num_envs = a0->num_envs; k.num_contacts = a0->num_contacts; k.num_scene_links = a0->num_scene_links; k.num_mgr = num;
+    k.total_targets = total; k.dt = a0->dt;
+    k.force = a0->force; k.position = a0->position; k.links_quat = a0->links_quat; k.links_vel = a0->links_vel; k.links_pos = a0->links_pos;
+    k.link_a = a0->link_a; k.link_b = a0->link_b;
+    const int C = a0->num_contacts;
+    int E = kContactBlock / total;
+    if (E > 64) E = 64;
+    if (C > 0 && E > kContactLdsBytes / (C * 8)) E = kContactLdsBytes / (C * 8);
+    if (E < 1) return GF_E_RANGE;  // more than 6 144 contact slots per env
+    k.envs_per_block = E;
+    const int threads = ((E * total + GF_WAVE - 1) / GF_WAVE) * GF_WAVE;
+    const unsigned grid = (unsigned)(((int64_t)a0->num_envs + E - 1) / E);
+    const size_t lds = (size_t)E * (C > 0 ? C : 1) * 8;
+    PhaseScope scope(GF_PHASE_CONTACT, s);
+    GF_LAUNCH(scope, contact_kernel, grid, threads, lds, s, k);
+    return launch_status();
+}
+
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_contact_step(const GfContactArgs* a, void* stream) {
+    return gf::contact_launch(&a, 1, (hipStream_t)stream);
 }

@@ -28,6 +28,8 @@ __global__ __launch_bounds__(kEnvBlock) void gait_kernel(const GfGaitArgs a) {
         else if (a.mode == GF_CMD_MASKED) go = a.mask[m] || (a.mask2 && a.mask2[m]);
         else go = true;
     }
+    // a masked launch touches only the 64-env blocks that contain a reset env (resets are sparse): 2 B/env for the rest
+    if (!step && __ballot(go) == 0ull) return;
     const GF_GLOBAL float* row = G(a.state) + m * GF_GAIT_ROW;
     float4 r0 = ldg4(row), r1 = ldg4(row + 4), r2 = ldg4(row + 8), r3 = ldg4(row + 12);
     int sel = (step || go) ? (int)G(a.selected)[m] : 0;
@@ -35,10 +37,6 @@ __global__ __launch_bounds__(kEnvBlock) void gait_kernel(const GfGaitArgs a) {
     float height = r1.x, period = r1.y;
     float clock[8] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y};
     float gtime = r3.z, phase = r3.w;
-    const float pi = 0.5f * a.two_pi;  // exact halving: (float)(2π)/2 == (float)π
-    int old_flags[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) old_flags[f] = gait_foot_flags(phase, off[f], a.two_pi, pi);
 
     if (go) {  // resample_command → _set_gait (:185-211, 347-377)
         float u0, u1, u2;
@@ -80,17 +78,16 @@ __global__ __launch_bounds__(kEnvBlock) void gait_kernel(const GfGaitArgs a) {
             sincos_det(a.two_pi * fp, &clock[f], &clock[4 + f]);
         }
     }
-    if (a.phase_counts) {  // keep the per-foot swing / stance env counts exact: - old flags, + new flags (wave ballots)
-        const bool changed = live && (step || go);
+    if (a.wave_flags) {  // this block's "any env in swing / stance" byte, from the rows as they are after this launch
+        const float pi = 0.5f * a.two_pi;  // exact halving: (float)(2π)/2 == (float)π
+        uint32_t byte = 0;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const int nf = changed ? gait_foot_flags(phase, off[f], a.two_pi, pi) : old_flags[f];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int add = popc64(__ballot(live && ((nf >> b) & 1))) - popc64(__ballot(live && ((old_flags[f] >> b) & 1)));
-                if (add != 0 && threadIdx.x == 0) atomicAdd(&a.phase_counts[2 * f + b], add);
-            }
+            const int fl = gait_foot_flags(phase, off[f], a.two_pi, pi);
+            if (__ballot(live && (fl & 1))) byte |= 1u << (2 * f);
+            if (__ballot(live && (fl & 2))) byte |= 2u << (2 * f);
         }
+        if (threadIdx.x == 0) a.wave_flags[blockIdx.x] = (uint8_t)byte;
     }
     if (live && (step || go)) {
         typedef float f32x4v __attribute__((ext_vector_type(4)));

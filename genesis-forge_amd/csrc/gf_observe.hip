@@ -4,7 +4,7 @@
 // += uniform_(-1,1)*noise, then torch.cat; history list pop/insert + another cat: 29 aten ops /
 // 23 launches for the 7-item Go2 config) and the mdp/observations.py getters.
 //
-// One wave owns a tile of 64 consecutive envs.  The tile's [64, O] frame is assembled in LDS
+// One 256-thread workgroup owns a tile of 64 consecutive envs.  The tile's [64, O] frame is assembled in LDS
 // (row stride O+1 words, so the row-per-lane writes of the entity items and the flat cooperative
 // copies of the [N,w] items are both conflict-free), then streamed out with full-width coalesced
 // stores — the [N,O] row-major result is written exactly once, never re-read.
@@ -24,12 +24,26 @@ namespace gf {
 
 enum : uint32_t { ON_QUAT = 1, ON_LIN = 2, ON_ANG = 4 };
 
+// Four waves share a 64-env tile: wave 0 computes the per-env (body-frame) items, all 256 lanes do the flat copies into the
+// LDS tile, the write-out and the history shift.  (One wave per tile left a 310-wide frame with 300 dependent
+// load → store round trips per lane.)
+constexpr int kObsBlock = 256;
+
+// floor(i / d) by multiply-shift with m = ceil(2^40 / d): exact for i < 2^40 / d (here i < 64·d and d < 2^17) — the flat copies
+// turn an element index into (row, column) once per element, and d (an item or frame width) is a run-time value
+struct FastDiv {
+    uint64_t m;
+    uint32_t d;
+    __device__ __forceinline__ explicit FastDiv(int div) : m(div > 1 ? ((1ull << 40) + (uint64_t)div - 1ull) / (uint64_t)div : 0ull), d((uint32_t)div) {}
+    __device__ __forceinline__ int div(int i) const { return d > 1 ? (int)(((uint64_t)(uint32_t)i * m) >> 40) : i; }
+};
+
 struct TileCtx {
     float* tile;      // LDS, [64][S]
     int S;            // row stride in words (O+1)
     int64_t n0;       // first env of the tile
     int rows;         // live rows in the tile (<= 64)
-    int lane;
+    int tid;
     const GfObservationArgs* a;
 };
 
@@ -48,14 +62,15 @@ __device__ __forceinline__ void copy_rows(const TileCtx& c, const GfObsItem& it,
     const GfObservationArgs& a = *c.a;
     const float* base = src + c.n0 * src_stride;
     const int total = c.rows * w;
+    const FastDiv dw(w);
     int done = 0;
     if (V == 4 && src_stride == w && (reinterpret_cast<uintptr_t>(base) & 15u) == 0) {
         const int total4 = total >> 2;
-        for (int i = c.lane; i < total4; i += GF_WAVE) {
+        for (int i = c.tid; i < total4; i += kObsBlock) {
             const float4 x = reinterpret_cast<const float4*>(base)[i];
             const float xs[4] = {x.x, x.y, x.z, x.w};
             const int e = i * 4;
-            int row = e / w, cc = e - row * w;
+            int row = dw.div(e), cc = e - row * w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 c.tile[row * c.S + col0 + cc] = finish(a, it, xs[j], c.n0 + row, col0 + cc);
@@ -64,36 +79,64 @@ __device__ __forceinline__ void copy_rows(const TileCtx& c, const GfObsItem& it,
         }
         done = total4 << 2;  // ragged tail (partial tile, w % 4 != 0) falls through to the scalar loop
     }
-    for (int i = done + c.lane; i < total; i += GF_WAVE) {
-        const int row = i / w, cc = i - row * w;
+    for (int i = done + c.tid; i < total; i += kObsBlock) {
+        const int row = dw.div(i), cc = i - row * w;
         c.tile[row * c.S + col0 + cc] = finish(a, it, base[row * src_stride + cc], c.n0 + row, col0 + cc);
     }
 }
 
+// History shift: frame slots 1..H-1 of the new rows are slots 0..H-2 of the previous output.  `hw` units per row, rows
+// OHu units apart, `T` = float4 / float2 / float.  Four independent loads are in flight per lane before the first store.
+template <typename T>
+__device__ __forceinline__ void shift_history(T* __restrict__ dst, const T* __restrict__ src, int rows, int hw, int64_t OHu, int tid) {
+    const FastDiv dh(hw);
+    const int total = rows * hw;
+    int i = tid;
+    for (; i + 3 * kObsBlock < total; i += 4 * kObsBlock) {
+        T v[4];
+        int64_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = i + k * kObsBlock, row = dh.div(e);
+            o[k] = (int64_t)row * OHu + (e - row * hw);
+            v[k] = src[o[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[o[k]] = v[k];
+    }
+    for (; i < total; i += kObsBlock) {
+        const int row = dh.div(i);
+        const int64_t o = (int64_t)row * OHu + (i - row * hw);
+        dst[o] = src[o];
+    }
+}
+
+// V = floats per memory operation of the write-out and the history shift: 4 when O % 4 == 0, 2 when O is even, else 1
 template <int V>
-__global__ __launch_bounds__(kEnvBlock) void observe_kernel(const GfObservationArgs a, const uint32_t needs) {
+__global__ __launch_bounds__(kObsBlock) void observe_kernel(const GfObservationArgs a, const uint32_t needs) {
     prefetch_args<GfObservationArgs>();
     extern __shared__ __attribute__((aligned(16))) float tile[];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const int64_t n0 = (int64_t)blockIdx.x * kEnvBlock;
     const int64_t N = a.num_envs;
     const int rows = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
     const int O = a.obs_width, H = a.history_len, S = O + 1, D = a.num_dofs;
-    const bool live = lane < rows;
-    const int64_t n = live ? n0 + lane : n0;
+    const bool owner = tid < kEnvBlock;      // wave 0: lane = env
+    const bool live = owner && tid < rows;
+    const int64_t n = live ? n0 + tid : n0;
 
-    TileCtx c{tile, S, n0, rows, lane, &a};
+    TileCtx c{tile, S, n0, rows, tid, &a};
 
-    // per-env entity state, requested before anything else
+    // per-env entity state, requested before anything else (wave 0 only; the other waves read the zero pad)
     const uint32_t e = (uint32_t)n;
     // quirk: envs reset in this tick are rotated by their pre-reset quaternion (entity_manager.py:189-195)
     const bool use_stale = a.stale_quat != nullptr;
-    const int s1 = *gsel(use_stale && a.stale_mask, a.stale_mask, e);
-    const int s2 = *gsel(use_stale && a.stale_mask2, a.stale_mask2, e);
+    const int s1 = *gsel(owner && use_stale && a.stale_mask, a.stale_mask, e);
+    const int s2 = *gsel(owner && use_stale && a.stale_mask2, a.stale_mask2, e);
     const float* qsrc = (use_stale && (s1 | s2)) ? a.stale_quat : a.entity.quat;
-    const float4 q = ldg4(gsel((needs & ON_QUAT) != 0, qsrc, 4u * e));
-    const GF_GLOBAL float* lp = gsel((needs & ON_LIN) != 0, a.entity.lin_vel, 3u * e);
-    const GF_GLOBAL float* ap = gsel((needs & ON_ANG) != 0, a.entity.ang_vel, 3u * e);
+    const float4 q = ldg4(gsel(owner && (needs & ON_QUAT) != 0, qsrc, 4u * e));
+    const GF_GLOBAL float* lp = gsel(owner && (needs & ON_LIN) != 0, a.entity.lin_vel, 3u * e);
+    const GF_GLOBAL float* ap = gsel(owner && (needs & ON_ANG) != 0, a.entity.ang_vel, 3u * e);
     const V3 lin{lp[0], lp[1], lp[2]}, ang{ap[0], ap[1], ap[2]};
 
     int col = 0;
@@ -113,9 +156,9 @@ __global__ __launch_bounds__(kEnvBlock) void observe_kernel(const GfObservationA
             case GF_O_ANG_VEL_BODY:
             case GF_O_LIN_VEL_BODY:
             case GF_O_PROJ_GRAVITY: {
-                const V3 v = it.op == GF_O_ANG_VEL_BODY ? rot_inv(q, ang) : (it.op == GF_O_LIN_VEL_BODY ? rot_inv(q, lin) : rot_inv(q, V3{0.f, 0.f, -1.f}));
                 if (live) {
-                    float* r = tile + lane * S + col;
+                    const V3 v = it.op == GF_O_ANG_VEL_BODY ? rot_inv(q, ang) : (it.op == GF_O_LIN_VEL_BODY ? rot_inv(q, lin) : rot_inv(q, V3{0.f, 0.f, -1.f}));
+                    float* r = tile + tid * S + col;
                     r[0] = finish(a, it, v.x, n, col);
                     r[1] = finish(a, it, v.y, n, col + 1);
                     r[2] = finish(a, it, v.z, n, col + 2);
@@ -125,7 +168,7 @@ __global__ __launch_bounds__(kEnvBlock) void observe_kernel(const GfObservationA
                 const GfContactView& cv = a.contact[it.i0];
                 if (live) {
                     const float* r = cv.contacts + n * cv.num_links * 3;
-                    for (int l = 0; l < w; ++l) tile[lane * S + col + l] = finish(a, it, norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]), n, col + l);
+                    for (int l = 0; l < w; ++l) tile[tid * S + col + l] = finish(a, it, norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]), n, col + l);
                 }
             } break;
             default: break;
@@ -133,42 +176,39 @@ __global__ __launch_bounds__(kEnvBlock) void observe_kernel(const GfObservationA
         col += w;
     }
 
-    // LDS writes of other lanes must be visible before the transposed read-out (single wave: no
-    // s_barrier needed, only the LDS counter).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
     const int64_t OH = (int64_t)O * H;
     float* out = a.obs + n0 * OH;
+    // the history shift does not depend on the tile: issue it before the barrier so its loads overlap the assembly
+    if (H > 1) {
+        const float* prev = a.prev_obs + n0 * OH;
+        const int hw = O * (H - 1);
+        if (V == 4) shift_history(reinterpret_cast<float4*>(out + O), reinterpret_cast<const float4*>(prev), rows, hw >> 2, OH >> 2, tid);
+        else if (V == 2) shift_history(reinterpret_cast<float2*>(out + O), reinterpret_cast<const float2*>(prev), rows, hw >> 1, OH >> 1, tid);
+        else shift_history(out + O, prev, rows, hw, OH, tid);
+    }
+    __syncthreads();
+
     if (V == 4) {
         const int o4 = O >> 2;
-        for (int i = lane; i < rows * o4; i += GF_WAVE) {
-            const int row = i / o4, c4 = i - row * o4;
+        const FastDiv d4(o4);
+        for (int i = tid; i < rows * o4; i += kObsBlock) {
+            const int row = d4.div(i), c4 = i - row * o4;
             const float* r = tile + row * S + c4 * 4;
             reinterpret_cast<float4*>(out + row * OH)[c4] = make_float4(r[0], r[1], r[2], r[3]);
         }
-        if (H > 1) {
-            const int h4 = (O * (H - 1)) >> 2;
-            const float* prev = a.prev_obs + n0 * OH;
-            for (int i = lane; i < rows * h4; i += GF_WAVE) {
-                const int row = i / h4, j = i - row * h4;
-                reinterpret_cast<float4*>(out + row * OH + O)[j] = reinterpret_cast<const float4*>(prev + row * OH)[j];
-            }
+    } else if (V == 2) {
+        const int o2 = O >> 1;
+        const FastDiv d2(o2);
+        for (int i = tid; i < rows * o2; i += kObsBlock) {
+            const int row = d2.div(i), c2 = i - row * o2;
+            const float* r = tile + row * S + c2 * 2;
+            reinterpret_cast<float2*>(out + row * OH)[c2] = make_float2(r[0], r[1]);
         }
     } else {
-        for (int i = lane; i < rows * O; i += GF_WAVE) {
-            const int row = i / O, cc = i - row * O;
+        const FastDiv d1(O);
+        for (int i = tid; i < rows * O; i += kObsBlock) {
+            const int row = d1.div(i), cc = i - row * O;
             out[row * OH + cc] = tile[row * S + cc];
-        }
-        if (H > 1) {
-            const int hw = O * (H - 1);
-            const float* prev = a.prev_obs + n0 * OH;
-            for (int i = lane; i < rows * hw; i += GF_WAVE) {
-                const int row = i / hw, j = i - row * hw;
-                out[row * OH + O + j] = prev[row * OH + j];
-            }
         }
     }
 }
@@ -185,7 +225,9 @@ extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObserva
     int wsum = 0;
     uint32_t needs = 0;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    bool vec = (O % 4 == 0) && al16(a->obs) && (a->history_len == 1 || al16(a->prev_obs));
+    auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+    const bool vec4 = (O % 4 == 0) && al16(a->obs) && (a->history_len == 1 || al16(a->prev_obs));
+    const bool vec2 = (O % 2 == 0) && al8(a->obs) && (a->history_len == 1 || al8(a->prev_obs));
     for (int i = 0; i < a->num_items; ++i) {
         const GfObsItem& it = a->items[i];
         if (it.width <= 0) return GF_E_RANGE;
@@ -238,7 +280,9 @@ extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObserva
     const size_t lds = (size_t)(O + 1) * gf::kEnvBlock * sizeof(float);
     gf::PhaseScope scope(GF_PHASE_OBSERVE, s);
     scope.begin_bracket();
-    if (vec) gf::observe_kernel<4><<<gf::env_grid(a->num_envs), gf::kEnvBlock, lds, s>>>(*a, needs);
-    else gf::observe_kernel<1><<<gf::env_grid(a->num_envs), gf::kEnvBlock, lds, s>>>(*a, needs);
+    const unsigned grid = gf::env_grid(a->num_envs);  // one 256-thread workgroup per 64-env tile
+    if (vec4) gf::observe_kernel<4><<<grid, gf::kObsBlock, lds, s>>>(*a, needs);
+    else if (vec2) gf::observe_kernel<2><<<grid, gf::kObsBlock, lds, s>>>(*a, needs);
+    else gf::observe_kernel<1><<<grid, gf::kObsBlock, lds, s>>>(*a, needs);
     return gf::launch_status();
 }

@@ -105,42 +105,60 @@ __global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSce
     for (int j = 0; j < 3; ++j) { wp[j] = w[j]; vp[j] = v[j]; pp[j] = p[j]; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) qp[j] = nq[j];
-    if (a.links_quat_out)
-        for (int l = 0; l < NL; ++l)
-            for (int j = 0; j < 4; ++j) a.links_quat_out[(n * NL + l) * 4 + j] = nq[j];
-    if (a.links_vel_out)
-        for (int l = 0; l < NL; ++l)
-            for (int j = 0; j < 3; ++j) a.links_vel_out[(n * NL + l) * 3 + j] = v[j] + (float)(l % 3 == j ? 1 : 0) * 0.05f * w[j];
-    if (a.links_pos_out)
-        for (int l = 0; l < NL; ++l) {
-            const LinkOffset o = synth_link_offset(l);
-            float* lp = a.links_pos_out + (n * NL + l) * 3;
-            lp[0] = p[0] + o.x;
-            lp[1] = p[1] + o.y;
-            lp[2] = (p[2] + o.z) + 0.03f * w[l % 3];
-        }
-    if (C > 0 && a.contact_force_out) {
-        for (int c = 0; c < C; ++c) {
-            const uint32_t col = (uint32_t)(8 + 8 * c);
-            // columns col..col+3 share one Philox block, col+4 starts the next
-            const U4 r0 = philox4x32_10(genv, col >> 2, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-            const U4 r1 = philox4x32_10(genv, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-            const float u_act = u24_to_unit(r0.x), u_link = u24_to_unit(r0.y);
-            const float fx = u24_to_unit(r0.z) * 2.0f - 1.0f, fy = u24_to_unit(r0.w) * 2.0f - 1.0f, fz = u24_to_unit(r1.x);
-            const bool active = u_act < a.contact_prob;
-            const int64_t k = n * C + c;
-            int lb = 1 + (int)(u_link * (float)(NL - 1));
-            if (lb > NL - 1) lb = NL - 1;
-            a.link_a_out[k] = active ? 0 : -1;
-            a.link_b_out[k] = active ? lb : -1;
-            a.contact_force_out[k * 3 + 0] = active ? fx * a.contact_force * 0.25f : 0.0f;
-            a.contact_force_out[k * 3 + 1] = active ? fy * a.contact_force * 0.25f : 0.0f;
-            a.contact_force_out[k * 3 + 2] = active ? fz * a.contact_force : 0.0f;
-            a.contact_pos_out[k * 3 + 0] = active ? p[0] + fx * 0.2f : 0.0f;
-            a.contact_pos_out[k * 3 + 1] = active ? p[1] + fy * 0.2f : 0.0f;
-            a.contact_pos_out[k * 3 + 2] = 0.0f;
-        }
+}
+
+// Per-link outputs (orientation, velocity, position of every scene link), one lane per (env, link): the base state the main
+// kernel just wrote is read back (stream order), so consecutive lanes write consecutive floats instead of one lane walking NL rows.
+__global__ __launch_bounds__(256) void synth_links_kernel(const GfSynthSceneArgs a) {
+    const int NL = a.num_scene_links;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)a.num_envs * NL) return;
+    const int64_t n = gid / NL;
+    const int l = (int)(gid - n * NL);
+    const V3 w = load3(a.ang_vel, n), v = load3(a.lin_vel, n), p = load3(a.pos, n);
+    if (a.links_quat_out) reinterpret_cast<float4*>(a.links_quat_out)[gid] = load_quat(a.quat, n);
+    if (a.links_vel_out) {
+        float* o = a.links_vel_out + gid * 3;
+        o[0] = v.x + (float)(l % 3 == 0 ? 1 : 0) * 0.05f * w.x;
+        o[1] = v.y + (float)(l % 3 == 1 ? 1 : 0) * 0.05f * w.y;
+        o[2] = v.z + (float)(l % 3 == 2 ? 1 : 0) * 0.05f * w.z;
     }
+    if (a.links_pos_out) {
+        const LinkOffset o = synth_link_offset(l);
+        const float wl = l % 3 == 0 ? w.x : (l % 3 == 1 ? w.y : w.z);
+        float* lp = a.links_pos_out + gid * 3;
+        lp[0] = p.x + o.x;
+        lp[1] = p.y + o.y;
+        lp[2] = (p.z + o.z) + 0.03f * wl;
+    }
+}
+
+// Sampled contacts, one lane per (env, contact slot): two Philox blocks per slot, 32 B of output per lane, coalesced.
+__global__ __launch_bounds__(256) void synth_contacts_kernel(const GfSynthSceneArgs a) {
+    const int C = a.num_contacts, NL = a.num_scene_links;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= (int64_t)a.num_envs * C) return;
+    const int64_t n = k / C;
+    const int c = (int)(k - n * C);
+    const uint32_t genv = (uint32_t)n + a.env_offset;
+    const float p0 = a.pos[3 * n], p1 = a.pos[3 * n + 1];
+    const uint32_t col = (uint32_t)(8 + 8 * c);
+    // columns col..col+3 share one Philox block, col+4 starts the next
+    const U4 r0 = philox4x32_10(genv, col >> 2, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    const U4 r1 = philox4x32_10(genv, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    const float u_act = u24_to_unit(r0.x), u_link = u24_to_unit(r0.y);
+    const float fx = u24_to_unit(r0.z) * 2.0f - 1.0f, fy = u24_to_unit(r0.w) * 2.0f - 1.0f, fz = u24_to_unit(r1.x);
+    const bool active = u_act < a.contact_prob;
+    int lb = 1 + (int)(u_link * (float)(NL - 1));
+    if (lb > NL - 1) lb = NL - 1;
+    a.link_a_out[k] = active ? 0 : -1;
+    a.link_b_out[k] = active ? lb : -1;
+    a.contact_force_out[k * 3 + 0] = active ? fx * a.contact_force * 0.25f : 0.0f;
+    a.contact_force_out[k * 3 + 1] = active ? fy * a.contact_force * 0.25f : 0.0f;
+    a.contact_force_out[k * 3 + 2] = active ? fz * a.contact_force : 0.0f;
+    a.contact_pos_out[k * 3 + 0] = active ? p0 + fx * 0.2f : 0.0f;
+    a.contact_pos_out[k * 3 + 1] = active ? p1 + fy * 0.2f : 0.0f;
+    a.contact_pos_out[k * 3 + 2] = 0.0f;
 }
 
 }  // namespace gf
@@ -164,6 +182,7 @@ extern "C" __attribute__((visibility("default"))) int gf_synth_scene_step(const 
     if (a->num_envs < 0 || a->num_dofs <= 0 || a->num_contacts < 0) return GF_E_RANGE;
     if (a->num_contacts > 0 && a->contact_force_out && (!a->contact_pos_out || !a->link_a_out || !a->link_b_out || a->num_scene_links < 2)) return GF_E_NULL;
     if (reinterpret_cast<uintptr_t>(a->quat) & 15u) return GF_E_UNSUPPORTED;
+    if (a->links_quat_out && (reinterpret_cast<uintptr_t>(a->links_quat_out) & 15u)) return GF_E_UNSUPPORTED;
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_SCENE, s);
@@ -174,5 +193,9 @@ extern "C" __attribute__((visibility("default"))) int gf_synth_scene_step(const 
     if (rows16 && a->num_dofs == 12) gf::synth_scene_kernel<3><<<grid, gf::kEnvBlock, 0, s>>>(*a);
     else if (rows16 && a->num_dofs == 28) gf::synth_scene_kernel<7><<<grid, gf::kEnvBlock, 0, s>>>(*a);
     else gf::synth_scene_kernel<0><<<grid, gf::kEnvBlock, 0, s>>>(*a);
+    if ((a->links_quat_out || a->links_vel_out || a->links_pos_out) && a->num_scene_links > 0)
+        gf::synth_links_kernel<<<gf::env_grid((int64_t)a->num_envs * a->num_scene_links, 256), 256, 0, s>>>(*a);
+    if (a->num_contacts > 0 && a->contact_force_out)
+        gf::synth_contacts_kernel<<<gf::env_grid((int64_t)a->num_envs * a->num_contacts, 256), 256, 0, s>>>(*a);
     return gf::launch_status();
 }

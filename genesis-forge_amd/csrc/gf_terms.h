@@ -80,7 +80,19 @@ __device__ __forceinline__ float gait_phase_term(const GfTerm& t, const Args& a,
     const GF_GLOBAL float* fr = G(cv.contacts) + n * cv.num_links * 3;
     const GF_GLOBAL float* lv = G(cv.link_vel) + n * cv.num_links * 3;
     const float phase = g[GF_GAIT_PHASE];
-    const bool env0 = n == 0 && a.gait_counts != nullptr;  // the reference's index-list quirk (see gf_step.h)
+    // the reference's index-list quirk (see gf_step.h): env 0 needs "does ANY env have foot f in swing / stance".  The gait
+    // kernel keeps one such byte per 64-env block; the wave that owns env 0 ORs them (4 bytes per lane per pass + a butterfly).
+    uint32_t any = 0;
+    const bool quirk = a.gait_wave_flags != nullptr && blockIdx.x == 0;  // wave-uniform
+    if (quirk) {
+        const int words = (int)(((int64_t)a.num_envs + 255) / 256);
+        const GF_GLOBAL uint32_t* w = reinterpret_cast<const GF_GLOBAL uint32_t*>(G(a.gait_wave_flags));
+        for (int i = (int)(threadIdx.x & (GF_WAVE - 1)); i < words; i += GF_WAVE) any |= w[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) any |= (uint32_t)__shfl_xor((int)any, o, GF_WAVE);
+        any = (any | (any >> 8) | (any >> 16) | (any >> 24)) & 0xffu;
+    }
+    const bool env0 = quirk && n == 0;
     float quad = 0.f;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -89,8 +101,8 @@ __device__ __forceinline__ float gait_phase_term(const GfTerm& t, const Args& a,
         const float vel = norm3(lv[3 * l], lv[3 * l + 1], lv[3 * l + 2]);
         int fl = gait_foot_flags(phase, g[GF_GAIT_OFFSET + f], t.p[1], t.p[2]);  // p1 = (float)(2π), p2 = (float)π
         if (env0) {
-            if (G(a.gait_counts)[2 * f + 1] > 0) fl = 2;
-            else if (G(a.gait_counts)[2 * f] > 0) fl = 1;
+            if ((any >> (2 * f + 1)) & 1u) fl = 2;
+            else if ((any >> (2 * f)) & 1u) fl = 1;
         }
         const float fw = (fl & 1) ? -1.0f : 0.0f, vw = (fl & 2) ? -1.0f : 0.0f;
         const float foot = vw * vel + fw * force;

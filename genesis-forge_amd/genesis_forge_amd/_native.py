@@ -160,7 +160,7 @@ class GfRewardArgs(C.Structure):
                 ("contact", GfContactView * GF_MAX_CONTACT_VIEWS), ("command", GfCommandView * GF_MAX_COMMAND_VIEWS),
                 ("ext", P * GF_MAX_EXT), ("state", P * 4),
                 ("reward", P), ("episode_sums", P), ("episode_seconds", P), ("term_out", P), ("terrain", GfTerrainView),
-                ("gait_counts", P), ("terms", GfTerm * GF_MAX_TERMS)]
+                ("gait_wave_flags", P), ("terms", GfTerm * GF_MAX_TERMS)]
 
 
 class GfCommandArgs(C.Structure):
@@ -226,7 +226,7 @@ class GfGaitArgs(C.Structure):
                 ("env_offset", C.c_uint32), ("fixed_clearance_mask", C.c_int32), ("cum_weight", C.c_float * GF_MAX_GAITS),
                 ("gait_offsets", (C.c_float * 4) * GF_MAX_GAITS), ("clearance_lo", C.c_float), ("clearance_hi", C.c_float),
                 ("period_lo", C.c_float), ("period_hi", C.c_float), ("dt", C.c_float), ("two_pi", C.c_float),
-                ("state", P), ("selected", P), ("phase_counts", P), ("stats", P)]
+                ("state", P), ("selected", P), ("wave_flags", P), ("stats", P)]
 
 
 class GfStatsCopyArgs(C.Structure):

@@ -99,8 +99,11 @@ class GaitCommandManager(CommandManager):
         n = env.num_envs
         self._state = torch.zeros((n, nat.GF_GAIT_ROW), device=gs.device, dtype=torch.float32)
         self._gait_selected = torch.zeros(n, dtype=torch.long, device=gs.device)
-        # per foot: #envs in swing / in stance for the current state; the all-zero initial state is "swing" for every foot
-        self._phase_counts = torch.tensor([n, 0] * 4, dtype=torch.int32, device=gs.device)
+        # per block of 64 envs: bit 2f / 2f+1 = some env has foot f in swing / stance (GfGaitArgs.wave_flags); the all-zero
+        # initial state is "swing" for every foot.  Padded with zeros to whole 32-bit words.
+        blocks = (n + 63) // 64
+        self._wave_flags = torch.zeros((blocks + 3) // 4 * 4, dtype=torch.uint8, device=gs.device)
+        self._wave_flags[:blocks] = 0x55
         #: reproduce the reference's env-0 index-list quirk in gait_phase_reward (see GF_R_GAIT_PHASE in gf_step.h)
         self.reference_env0_quirk = True
         self._gait_args = {m: nat.GfGaitArgs() for m in (nat.GF_CMD_STEP, nat.GF_CMD_MASKED, nat.GF_CMD_ALL)}
@@ -144,8 +147,8 @@ class GaitCommandManager(CommandManager):
 
     def _gf_command_view(self, v: nat.GfCommandView, args=None) -> None:
         v.command, v.width, v.stride = self._state.data_ptr(), nat.GF_GAIT_OBS_WIDTH, nat.GF_GAIT_ROW
-        if args is not None and hasattr(args, "gait_counts"):
-            args.gait_counts = self._phase_counts.data_ptr() if self.reference_env0_quirk else None
+        if args is not None and hasattr(args, "gait_wave_flags"):
+            args.gait_wave_flags = self._wave_flags.data_ptr() if self.reference_env0_quirk else None
 
     # -- curriculum (:146-180) ------------------------------------------------------------------------------------------
     def increment_num_gaits(self):
@@ -172,9 +175,19 @@ class GaitCommandManager(CommandManager):
         robot = getattr(self.env, self._robot_entity_attr)
         self.foot_links = [robot.get_link(self._foot_names[key]) for key in ("FL", "FR", "RL", "RR")]
 
+    def _cfg_key(self) -> tuple:
+        """What the curriculum (or the user) can change between launches (:146-180, resample_time_sec)."""
+        return (self._num_gaits, self._all_gaits_learned, self._gait_period_range[0], self._gait_period_range[1],
+                self._foot_clearance_range[0], self._foot_clearance_range[1], self._resample_steps)
+
     def _fill(self, a: nat.GfGaitArgs, mode: int) -> None:
-        """Everything the curriculum can change is re-read on every launch (:195-211, 347-399)."""
+        """Everything the curriculum can change is re-read on every launch (:195-211, 347-399); the descriptor is only
+        rewritten when one of those values actually changed."""
         env = self.env
+        key = self._cfg_key()
+        if getattr(a, "_gf_key", None) == key:
+            return
+        a._gf_key = key
         a.num_envs, a.mode, a.resample_steps = env.num_envs, mode, self._resample_steps
         g = self._num_gaits
         a.num_gaits = g
@@ -198,7 +211,7 @@ class GaitCommandManager(CommandManager):
         a.dt, a.two_pi = float(env.dt), 2 * math.pi
         a.seed, a.env_offset = env._rng_seed, env.env_offset
         a.state, a.selected = self._state.data_ptr(), self._gait_selected.data_ptr()
-        a.phase_counts = self._phase_counts.data_ptr()
+        a.wave_flags = self._wave_flags.data_ptr()
         a.episode_length = env.episode_length.data_ptr()
 
     def _launch_gait(self, mode: int, mask=None, mask2=None, draws_key: Optional[str] = None) -> None:

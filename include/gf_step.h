@@ -246,7 +246,7 @@ enum {
      * (contacts, link_vel, link_pos), i1 = command view of the gait state rows (GF_GAIT_* columns), i2 = the row of each foot
      * (FL, FR, RL, RR) inside that contact view, one byte each */
     GF_R_GAIT_PHASE = 18,        /* exp(Σ_feet swing ? -|F| : stance ? -|v| : 0)                 :295-345
-                                  * Reference quirk reproduced when GfRewardArgs.gait_counts is set: the reference builds its index
+                                  * Reference quirk reproduced when GfRewardArgs.gait_wave_flags is set: the reference builds its index
                                   * lists with `mask.nonzero().flatten()` on an [N,1] mask (:335-338), which interleaves the COLUMN
                                   * indices (all 0) with the row indices — so env 0 gets the stance weights of a foot whenever ANY
                                   * env is in stance for it, else the swing weights whenever any env is in swing. */
@@ -281,7 +281,7 @@ typedef struct GfRewardArgs {
     float* episode_seconds;    /* [N]   in/out (STEP) */
     float* term_out;           /* [T,N] out (EVAL): unweighted term values */
     GfTerrainView terrain;     /* base_height(terrain_manager=…): sampled in the kernel (rewards.py:84-88) */
-    const int32_t* gait_counts; /* GfGaitArgs.phase_counts of the gait manager GF_R_GAIT_PHASE reads (env-0 quirk), or NULL */
+    const uint8_t* gait_wave_flags; /* GfGaitArgs.wave_flags of the gait manager GF_R_GAIT_PHASE reads (env-0 quirk), or NULL */
     GfTerm terms[GF_MAX_TERMS];
 } GfRewardArgs;
 
@@ -350,10 +350,11 @@ typedef struct GfGaitArgs {
     float two_pi;               /* (float)(2*pi) */
     float* state;               /* [N,GF_GAIT_ROW] in/out */
     int64_t* selected;          /* [N] in/out: _gait_selected */
-    int32_t* phase_counts;      /* [8] in/out, optional: per foot f, #envs whose foot is in swing [2f] / stance [2f+1] for the
-                                   CURRENT state (phi = fmod(phase + offset_f, 1)·2π; swing: 0 <= phi < π, stance: π <= phi < 2π).
-                                   Kept exact incrementally: every launch subtracts an env's old flags and adds its new ones
-                                   (the host initialises it for the all-zero state: swing = N, stance = 0). */
+    uint8_t* wave_flags;        /* [ceil(N/64) rounded up to 4] out, optional: for each block of 64 envs, bit 2f = some env of the
+                                   block has foot f in swing, bit 2f+1 = in stance, for the CURRENT state (phi = fmod(phase +
+                                   offset_f, 1)·2π; swing: 0 <= phi < π, stance: π <= phi < 2π).  Every launch that changes an env
+                                   rewrites its block's byte from the 64 rows it holds: no atomics, nothing incremental.  The
+                                   host initialises it for the all-zero state (every foot in swing: 0x55). */
     GfStepStats* stats;         /* STEP: gait_count[] += envs per gait; may be NULL */
 } GfGaitArgs;
 

@@ -525,9 +525,11 @@ static float eval_reward(const GfRewardArgs* a, const GfTerm* t, int64_t n) {
                 /* `mask.nonzero().flatten()` on the [N,1] masks (:336,338) yields (row, col) pairs, so index 0 (the column)
                  * is in the swing list whenever any env is in swing and in the stance list whenever any env is in stance;
                  * the four assignments :340-343 then leave env 0 with the stance weights, else the swing weights */
-                if (n == 0 && a->gait_counts) {
-                    if (a->gait_counts[2 * f + 1] > 0) fl = 2;
-                    else if (a->gait_counts[2 * f] > 0) fl = 1;
+                if (n == 0 && a->gait_wave_flags) {
+                    unsigned any = 0;
+                    for (int64_t b = 0; b < ((int64_t)a->num_envs + 63) / 64; ++b) any |= a->gait_wave_flags[b];
+                    if ((any >> (2 * f + 1)) & 1u) fl = 2;
+                    else if ((any >> (2 * f)) & 1u) fl = 1;
                 }
                 const float fw = (fl & 1) ? -1.0f : 0.0f, vw = (fl & 2) ? -1.0f : 0.0f;    /* :340-343 */
                 const float foot = vw * vel + fw * force;                             /* :345 */
@@ -618,9 +620,6 @@ GFO_EXPORT int gfo_gait_step(const GfGaitArgs* a) {
     const int64_t N = a->num_envs;
     for (int64_t n = 0; n < N; ++n) {
         float* r = a->state + n * GF_GAIT_ROW;
-        const float pi = 0.5f * a->two_pi;
-        int old_flags[4];
-        for (int f = 0; f < 4; ++f) old_flags[f] = gait_foot_flags(r[GF_GAIT_PHASE], r[GF_GAIT_OFFSET + f], a->two_pi, pi);
         int go;
         if (a->mode == GF_CMD_STEP) go = (a->episode_length[n] % a->resample_steps) == 0;
         else if (a->mode == GF_CMD_MASKED) go = a->mask[n] || (a->mask2 && a->mask2[n]);
@@ -651,11 +650,16 @@ GFO_EXPORT int gfo_gait_step(const GfGaitArgs* a) {
                 sincos_det(a->two_pi * fp, &r[GF_GAIT_CLOCK + f], &r[GF_GAIT_CLOCK + 4 + f]);
             }
         }
-        if (a->phase_counts)
-            for (int f = 0; f < 4; ++f) {
-                const int nf = gait_foot_flags(r[GF_GAIT_PHASE], r[GF_GAIT_OFFSET + f], a->two_pi, pi);
-                for (int b = 0; b < 2; ++b) a->phase_counts[2 * f + b] += ((nf >> b) & 1) - ((old_flags[f] >> b) & 1);
-            }
+    }
+    if (a->wave_flags) { /* per block of 64 envs: any env with foot f in swing (bit 2f) / stance (bit 2f+1), current state */
+        const float pi = 0.5f * a->two_pi;
+        for (int64_t b = 0; b < (N + 63) / 64; ++b) {
+            unsigned byte = 0;
+            for (int64_t n = b * 64; n < N && n < (b + 1) * 64; ++n)
+                for (int f = 0; f < 4; ++f)
+                    byte |= (unsigned)gait_foot_flags(a->state[n * GF_GAIT_ROW + GF_GAIT_PHASE], a->state[n * GF_GAIT_ROW + GF_GAIT_OFFSET + f], a->two_pi, pi) << (2 * f);
+            a->wave_flags[b] = (uint8_t)byte;
+        }
     }
     return GF_OK;
 }

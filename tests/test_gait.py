@@ -28,7 +28,7 @@ def _run(dev, n, steps, trace, events=None):
         if events and t in events:
             events[t](gait)
         obs, rew, term, trunc, extras = env.step(torch.randn(n, 12, generator=g).to(dev))
-        state = [obs, rew, term, trunc, extras["observations"]["critic"], gait._state, gait._gait_selected, gait._phase_counts,
+        state = [obs, rew, term, trunc, extras["observations"]["critic"], gait._state, gait._gait_selected, gait._wave_flags,
                  env.velocity_command._command, env.episode_length]
         out.append(([x.cpu().clone() for x in state], {k: float(v) for k, v in extras["episode"].items()}))
     return out, env
@@ -79,13 +79,14 @@ def test_gait_state_properties(oracle_backend):
     assert int((~ran).sum()) > 0 and torch.all(clock[~ran] == 0) and torch.all(phase[~ran] == 0)
     assert torch.allclose(clock[ran, :4], torch.sin(2 * math.pi * fp[ran]), atol=2e-6)
     assert torch.allclose(clock[ran, 4:], torch.cos(2 * math.pi * fp[ran]), atol=2e-6)
-    # the incrementally maintained swing / stance counts equal a recount from the state
+    # the per-block "any env in swing / stance" bytes equal a recount from the state
     phi = fp * np.float32(2 * math.pi)
-    pi32 = np.float32(math.pi)
-    swing = ((phi >= 0) & (phi < float(pi32))).sum(0)
-    stance = ((phi >= float(pi32)) & (phi < float(np.float32(2 * math.pi)))).sum(0)
-    want = torch.stack([swing, stance], dim=1).reshape(-1).to(torch.int32)
-    assert torch.equal(gait._phase_counts, want)
+    pi32 = float(np.float32(math.pi))
+    swing, stance = (phi >= 0) & (phi < pi32), (phi >= pi32) & (phi < float(np.float32(2 * math.pi)))
+    for b in range((n + 63) // 64):
+        rows = slice(64 * b, min(n, 64 * b + 64))
+        want = sum((int(swing[rows, f].any()) << (2 * f)) | (int(stance[rows, f].any()) << (2 * f + 1)) for f in range(4))
+        assert int(gait._wave_flags[b]) == want, f"block {b}"
     # the log carries the per-gait env counts (gait_command_manager.py:430-441)
     logs = out[-1][1]
     counts = [logs[f"Metrics / gait_{g}_envs"] for g in ("trot", "pace", "bound", "pronk")]
