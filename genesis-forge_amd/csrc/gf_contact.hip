@@ -6,13 +6,16 @@
 //   managers/contact/kernel.py:35-90              the Taichi kernel (atomic += over (env, contact, target))
 //   managers/contact/contact_manager.py:434-477   norm > threshold + 4 torch.where air-time updates
 //
-// Layout.  A workgroup owns E consecutive envs.  Their link_a / link_b rows (E·C ints each, contiguous in memory) are
+// Layout.  A workgroup owns E consecutive envs.  (1) Their link_a / link_b rows (E·C ints each, contiguous in memory) are
 // staged into LDS with flat coalesced loads — every contact slot id is read from HBM exactly once, whatever the number of
-// managers and tracked links.  Then one lane per (env, tracked link of any manager) walks that env's C slot ids in LDS in
-// slot order and keeps its force / position / count accumulators in registers: no atomics, and the f32 sum order is
-// fixed (the Taichi reference's atomic order is not).  Force, position and link quaternion are fetched from global memory
-// only for the slots that match (contacts are sparse).  The force-norm / threshold / air-time state update that the
-// reference runs afterwards as ~12 separate launches is done by the same lane while the summed force is in registers.
+// managers and tracked links — and every slot that holds a contact (ids >= 0; contacts are sparse) sets its bit in the
+// env's occupancy mask (an LDS OR: order independent).  (2) One lane per (env, tracked link of any manager) walks ONLY the
+// occupied slots of its env, in slot order (ctz over the mask), with its force / position / count accumulators in
+// registers: no float atomics, a fixed f32 sum order (the Taichi reference's atomic order is not).  Force and position are
+// fetched for matching slots only; the only quaternion a lane can need is its own target link's (a matching slot always
+// involves the target), loaded up front together with the air-time state.
+// The force-norm / threshold / air-time update that the reference runs afterwards as ~12 separate launches is done by
+// the same lane while the summed force is in registers.
 // gf_run_ops folds consecutive contact_step ops over the same scene arrays into one launch of this kernel.
 // Algorithmic traffic per env: R 8C slot ids once (+ 40 B per matched slot), W 28L (forces, mean positions, counts)
 // (+ 24L link velocity / position copies when the scene provides them), RW 32L air-time state.
@@ -23,7 +26,7 @@ namespace gf {
 constexpr int kContactMaxMgr = 4;
 constexpr int kContactMaxTargets = 64;   // tracked links over all managers of one launch
 constexpr int kContactBlock = 256;
-constexpr int kContactLdsBytes = 48 * 1024;
+constexpr int kContactLdsBytes = 16 * 1024;
 
 struct ContactMgr {
     int32_t num_targets, num_with, has_with_filter, track_air_time;
@@ -49,62 +52,97 @@ struct ContactMultiArgs {
 };
 static_assert(sizeof(ContactMultiArgs) <= 4096, "kernarg segment");
 
+// floor(i / d) by multiply-shift, exact for i < 2^40 / d (i < 64·C here)
+struct FastDivC {
+    uint64_t m;
+    uint32_t d;
+    __device__ __forceinline__ explicit FastDivC(int div) : m(div > 1 ? ((1ull << 40) + (uint64_t)div - 1ull) / (uint64_t)div : 0ull), d((uint32_t)div) {}
+    __device__ __forceinline__ int div(int i) const { return d > 1 ? (int)(((uint64_t)(uint32_t)i * m) >> 40) : i; }
+};
+
 __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMultiArgs a) {
-    extern __shared__ int32_t lds_ids[];  // [E*C] link_a, then [E*C] link_b
+    extern __shared__ __attribute__((aligned(16))) int32_t lds_raw[];
     const int C = a.num_contacts, T = a.total_targets, E = a.envs_per_block;
+    const int MW = (C + 31) >> 5;  // 32-bit words of one env's "slot holds a contact" mask
     const int64_t n0 = (int64_t)blockIdx.x * E;
     const int envs_here = (int)((int64_t)a.num_envs - n0 < E ? (int64_t)a.num_envs - n0 : E);
-    const int words = envs_here * C;
-    int32_t* sa = lds_ids;
-    int32_t* sb = lds_ids + E * C;
-    {   // the E rows are contiguous: flat coalesced copy
+    const int slots = envs_here * C;
+    int32_t* sa = lds_raw;                                                  // [E*C] link_a
+    int32_t* sb = lds_raw + E * C;                                          // [E*C] link_b
+    uint32_t* smask = reinterpret_cast<uint32_t*>(lds_raw + 2 * E * C);     // [E][MW]
+    for (int i = threadIdx.x; i < envs_here * MW; i += blockDim.x) smask[i] = 0u;
+    __syncthreads();
+    {   // phase 1: the E rows of slot ids are contiguous — flat coalesced copy; slots that hold a contact set their bit
+        // (an OR: the mask does not depend on the order the lanes arrive in)
         const GF_GLOBAL int32_t* ga = G(a.link_a) + n0 * C;
         const GF_GLOBAL int32_t* gb = G(a.link_b) + n0 * C;
-        for (int i = threadIdx.x; i < words; i += blockDim.x) { sa[i] = ga[i]; sb[i] = gb[i]; }
+        const FastDivC dc(C);
+        for (int i = threadIdx.x; i < slots; i += blockDim.x) {
+            const int la = ga[i], lb = gb[i];
+            sa[i] = la; sb[i] = lb;
+            if (la >= 0 || lb >= 0) {
+                const int e = dc.div(i), c = i - e * C;
+                atomicOr(&smask[e * MW + (c >> 5)], 1u << (c & 31));
+            }
+        }
     }
-    __syncthreads();
-    const int e = (int)threadIdx.x / T;
-    const int t = (int)threadIdx.x - e * T;
-    const bool live = e < envs_here;
-    int flag = 0;
-    const int mi = a.mgr_of[t < T ? t : 0];
-    if (live) {
+    // phase 2: one lane per (env, tracked link) walks ONLY the occupied slots of its env, in slot order
+    const int pairs = envs_here * T;
+    int flag_mask = 0;  // bit m: this lane sanitised a non-finite force for manager m
+    for (int pr0 = 0; pr0 < pairs; pr0 += blockDim.x) {
+        const int pr = pr0 + (int)threadIdx.x;
+        const bool live = pr < pairs;
+        const int e = live ? pr / T : 0;
+        const int t = live ? pr - e * T : 0;
+        const int mi = a.mgr_of[t];
         const ContactMgr& mg = a.m[mi];
         const int64_t n = n0 + e;
         const int lt = a.local_of[t], L = mg.num_targets, W = mg.num_with;
         const int target = a.target_ids[t];
+        const int64_t k = n * L + lt;
+        // loop-invariant loads first: a matching slot always involves the target link itself, so its quaternion is the only
+        // one this lane can need (kernel.py:74-78); the air-time state is read before the scan as well
+        float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (live && C > 0) q = ldg4(G(a.links_quat) + (n * a.num_scene_links + target) * 4);
+        float cur_air = 0.f, cur_con = 0.f;
+        if (live && mg.track_air_time) { cur_air = G(mg.current_air_time)[k]; cur_con = G(mg.current_contact_time)[k]; }
+        if (pr0 == 0) __syncthreads();  // phase 1's LDS writes
+        if (!live) continue;
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, cnt = 0.f;
         const int32_t* la_row = sa + e * C;
         const int32_t* lb_row = sb + e * C;
-        for (int c = 0; c < C; ++c) {
-            const int la = la_row[c], lb = lb_row[c];
-            const bool is_a = la == target, is_b = lb == target;
-            if (!(is_a || is_b)) continue;
-            bool include = true;
-            if (mg.has_with_filter) {
-                include = false;
-                for (int w = 0; w < W; ++w) {
-                    const int wl = mg.with_link_ids[w];
-                    if ((is_a && lb == wl) || (is_b && la == wl)) { include = true; break; }
+        for (int wd = 0; wd < MW; ++wd) {
+            uint32_t bits = smask[e * MW + wd];
+            while (bits) {
+                const int c = (wd << 5) + __builtin_ctz(bits);
+                bits &= bits - 1u;
+                const int la = la_row[c], lb = lb_row[c];
+                const bool is_a = la == target, is_b = lb == target;
+                if (!(is_a || is_b)) continue;
+                bool include = true;
+                if (mg.has_with_filter) {
+                    include = false;
+                    for (int w = 0; w < W; ++w) {
+                        const int wl = mg.with_link_ids[w];
+                        if ((is_a && lb == wl) || (is_b && la == wl)) { include = true; break; }
+                    }
                 }
+                if (!include) continue;
+                const GF_GLOBAL float* fr = G(a.force) + (n * C + c) * 3;
+                const GF_GLOBAL float* pr_ = G(a.position) + (n * C + c) * 3;
+                float fx = fr[0], fy = fr[1], fz = fr[2];
+                const float px = pr_[0], py = pr_[1], pz = pr_[2];
+                // torch.nan_to_num(force, nan=0, posinf=0, neginf=0)   contact_manager.py:401-403
+                if (isnan(fx) || isinf(fx)) { fx = 0.f; flag_mask |= 1 << mi; }
+                if (isnan(fy) || isinf(fy)) { fy = 0.f; flag_mask |= 1 << mi; }
+                if (isnan(fz) || isinf(fz)) { fz = 0.f; flag_mask |= 1 << mi; }
+                p0 += px; p1 += py; p2 += pz;
+                cnt += 1.0f;
+                // force is expressed on link_b; on link_a it is the reaction (kernel.py:74-78)
+                const V3 r = is_b ? rot_inv(q, V3{fx, fy, fz}) : rot_inv(q, V3{-fx, -fy, -fz});
+                f0 += r.x; f1 += r.y; f2 += r.z;
             }
-            if (!include) continue;
-            const GF_GLOBAL float* fr = G(a.force) + (n * C + c) * 3;
-            const GF_GLOBAL float* pr = G(a.position) + (n * C + c) * 3;
-            float fx = fr[0], fy = fr[1], fz = fr[2];
-            // torch.nan_to_num(force, nan=0, posinf=0, neginf=0)   contact_manager.py:401-403
-            if (isnan(fx) || isinf(fx)) { fx = 0.f; flag = 1; }
-            if (isnan(fy) || isinf(fy)) { fy = 0.f; flag = 1; }
-            if (isnan(fz) || isinf(fz)) { fz = 0.f; flag = 1; }
-            p0 += pr[0]; p1 += pr[1]; p2 += pr[2];
-            cnt += 1.0f;
-            // force is expressed on link_b; on link_a it is the reaction (kernel.py:74-78)
-            const int ql = is_b ? lb : la;
-            const float4 q = ldg4(G(a.links_quat) + (n * a.num_scene_links + ql) * 4);
-            const V3 r = is_b ? rot_inv(q, V3{fx, fy, fz}) : rot_inv(q, V3{-fx, -fy, -fz});
-            f0 += r.x; f1 += r.y; f2 += r.z;
         }
-        const int64_t k = n * L + lt;
         GF_GLOBAL float* co = G(mg.contacts) + 3 * k;
         co[0] = f0; co[1] = f1; co[2] = f2;
         if (mg.contact_positions) {  // kernel.py:84-90
@@ -127,7 +165,6 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
         if (mg.track_air_time) {  // contact_manager.py:441-477
             const float dt = a.dt;
             const bool is_contact = norm3(f0, f1, f2) > mg.air_time_threshold;
-            const float cur_air = G(mg.current_air_time)[k], cur_con = G(mg.current_contact_time)[k];
             const bool new_contact = (cur_air > 0.f) && is_contact;
             const bool new_detach = (cur_con > 0.f) && !is_contact;
             if (new_contact) G(mg.last_air_time)[k] = cur_air + dt;
@@ -139,7 +176,7 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
     // non-finite force seen: one flag per manager (contact_manager.py:399-403 prints a warning)
     for (int m = 0; m < a.num_mgr; ++m) {
         if (!a.m[m].stats) continue;
-        const unsigned long long b = __ballot(flag && live && mi == m);
+        const unsigned long long b = __ballot((flag_mask >> m) & 1);
         if (b && (threadIdx.x & (GF_WAVE - 1)) == 0) atomicOr(&stats_shard(a.m[m].stats)->contact_flags, 1);
     }
 }
@@ -194,14 +231,20 @@ int contact_launch(const GfContactArgs* const* mgrs, int num, hipStream_t s) {
     k.force = a0->force; k.position = a0->position; k.links_quat = a0->links_quat; k.links_vel = a0->links_vel; k.links_pos = a0->links_pos;
     k.link_a = a0->link_a; k.link_b = a0->link_b;
     const int C = a0->num_contacts;
+    // E envs per workgroup: 8 B of LDS per contact slot (the two ids) + the occupancy mask; ≈ one (env, link) pair per thread
+    const int per_env = (C > 0 ? C : 1) * 8 + ((C + 31) / 32) * 4;
     int E = kContactBlock / total;
     if (E > 64) E = 64;
-    if (C > 0 && E > kContactLdsBytes / (C * 8)) E = kContactLdsBytes / (C * 8);
-    if (E < 1) return GF_E_RANGE;  // more than 6 144 contact slots per env
+    if (E < 1) E = 1;
+    if (E > kContactLdsBytes / per_env) E = kContactLdsBytes / per_env;
+    if (E < 1) return GF_E_RANGE;  // more than ~2 000 contact slots per env
+    // small problems: keep at least ~2 workgroups per CU busy rather than 64-env tiles on a quarter of the chip
+    while (E > 8 && ((int64_t)a0->num_envs + E - 1) / E < 512) E >>= 1;
     k.envs_per_block = E;
-    const int threads = ((E * total + GF_WAVE - 1) / GF_WAVE) * GF_WAVE;
+    int threads = ((E * total + GF_WAVE - 1) / GF_WAVE) * GF_WAVE;
+    if (threads > kContactBlock) threads = kContactBlock;
     const unsigned grid = (unsigned)(((int64_t)a0->num_envs + E - 1) / E);
-    const size_t lds = (size_t)E * (C > 0 ? C : 1) * 8;
+    const size_t lds = (size_t)E * per_env;
     PhaseScope scope(GF_PHASE_CONTACT, s);
     GF_LAUNCH(scope, contact_kernel, grid, threads, lds, s, k);
     return launch_status();
