@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--num-envs", type=int, default=65536, help="envs per GPU (weak scaling)")
+    ap.add_argument("--reduce-every", type=int, default=16, help="recorded steps per logging all-reduce (world > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stamping of the dominant kernel")
     ap.add_argument("--profile-stride", type=int, default=4,
@@ -115,7 +116,9 @@ def main():
 
     N = args.num_envs
     env = make_env(N)
-    gfd.attach(env, global_num_envs=N * world)
+    # multi-GPU: the statistics rows of 16 steps share one all-reduce (fewer, larger collectives; bench reads its log on every
+    # rank at the same step, which is what reduce_every > 1 asks for — see distributed.attach)
+    gfd.attach(env, global_num_envs=N * world, reduce_every=args.reduce_every)
     env.seed(1234 + rank)
     env.reset()
     g = torch.Generator().manual_seed(1234 + rank)
@@ -183,7 +186,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "go2_12dof_full_manager_stack", "num_envs_per_gpu": N, "global_num_envs": N * world, "dofs": 12,
                        "reward_terms": T, "termination_terms": 2, "command_managers": 1, "obs_width": 48,
-                       "scene": "synthetic (gf_synth_scene_step)", "parallelism": f"env-shard x{world}"},
+                       "scene": "synthetic (gf_synth_scene_step)", "parallelism": f"env-shard x{world}",
+                       "stats_allreduce_every_steps": (args.reduce_every if world > 1 else None)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

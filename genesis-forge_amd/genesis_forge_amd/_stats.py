@@ -243,23 +243,60 @@ class StepStats:
         i = self.ring_pos
         j = (i + 1) % _RING
         old = self._vec_snaps[i]
-        if old is not None and old._value is None:
-            self.materialize_vec_ring()
+        if old is not None and old._value is None and (old._work is not None or self.reduce_every <= 1):
+            self.materialize_vec_ring()   # an unread, already reduced row is about to be recycled: copy the ring out (local)
         self.ring_pos = j
         return i, self.ring_ptr(i), self.ring_ptr(j), self.vec_ptr(i)
+
+    #: Rows of the vector ring all-reduced per collective.  1 (default): one all-reduce per recorded step, enqueued behind the
+    #: step's kernels — reading a log entry is then purely local, any rank may read any step at any time.  K > 1 (must divide
+    #: the ring length, at most half of it): fewer, larger collectives — the rows of K consecutive steps go out as ONE
+    #: all-reduce at every K-th step (the per-step host cost of enqueueing a collective dominates a 25 µs step).  Per-step
+    #: values are unchanged, but reading a step whose batch is still open closes the batch early — a collective — so with
+    #: K > 1 every rank must read the same steps' logs (or call ``flush_reduce()`` at the same step) — see distributed.attach.
+    reduce_every = 1
 
     def vec_ring_reduce(self, slot: int) -> "VecRingSnapshot":
         import torch.distributed as dist
 
-        row = self.vec_ring[slot]
-        work = dist.all_reduce(row, op=dist.ReduceOp.SUM, group=self.group, async_op=self.device.type == "cuda")
-        snap = VecRingSnapshot(self, slot, work)
+        if self.reduce_every <= 1:
+            row = self.vec_ring[slot]
+            work = dist.all_reduce(row, op=dist.ReduceOp.SUM, group=self.group, async_op=self.device.type == "cuda")
+            snap = VecRingSnapshot(self, slot, work)
+            self._vec_snaps[slot] = snap
+            return snap
+        snap = VecRingSnapshot(self, slot, None)
         self._vec_snaps[slot] = snap
+        pend = getattr(self, "_pending", None)
+        if pend is None:
+            pend = self._pending = []
+        if pend and pend[-1]._slot + 1 != slot:   # ring wrapped (or slots skipped): close the open batch first
+            self.flush_reduce()
+            pend = self._pending
+        pend.append(snap)
+        if len(pend) >= self.reduce_every or slot == _RING - 1:
+            self.flush_reduce()
         return snap
 
+    def flush_reduce(self) -> None:
+        """All-reduce the rows of the open batch (COLLECTIVE: every rank must call it at the same step)."""
+        import torch.distributed as dist
+
+        pend = getattr(self, "_pending", None)
+        if not pend:
+            return
+        i0, i1 = pend[0]._slot, pend[-1]._slot + 1
+        rows = self.vec_ring[i0:i1]   # contiguous rows of one batch
+        work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=self.device.type == "cuda")
+        for s in pend:
+            s._work = work if work is not None else True
+        self._pending = []
+
     def materialize_vec_ring(self) -> None:
+        if getattr(self, "_pending", None) and any(s._value is None for s in self._pending):
+            self.flush_reduce()   # somebody reads a step whose batch is still open
         for snap in self._vec_snaps:
-            if snap is not None and snap._value is None and snap._work is not None:
+            if snap is not None and snap._value is None and snap._work is not None and snap._work is not True:
                 snap._work.wait()
         host = self.vec_ring.cpu().numpy()
         for snap in self._vec_snaps:

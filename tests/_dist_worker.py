@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "genesis-forge_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run_shard(rank, world, port, out_dir, n_global, steps, sizes):
+def run_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every=1, read_lag=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from genesis_forge_amd import _native as nat
     from genesis_forge_amd import distributed as gfd
@@ -28,15 +28,19 @@ def run_shard(rank, world, port, out_dir, n_global, steps, sizes):
                                  scene_kwargs=dict(ang_noise=0.3, seed=3))
     env.build()
     env.seed(5)
-    gfd.attach(env)
+    gfd.attach(env, reduce_every=reduce_every)
     assert env.env_offset == start and env.global_num_envs == n_global
     env.reset()
     g = torch.Generator().manual_seed(0)
-    outs = []
+    outs, held = [], []
     for t in range(steps):
         act = torch.randn(n_global, 12, generator=g)[start:start + count].contiguous()
         o, r, te, tr, ex = env.step(act)
-        outs.append((o.clone(), r.clone(), te.clone(), tr.clone(), {k: float(v) for k, v in ex["episode"].items()}))
+        held.append((o.clone(), r.clone(), te.clone(), tr.clone(), ex["episode"]))
+        # logs are read `read_lag` steps late (a training loop reads them at the end of an iteration), on every rank alike
+        while held and (len(held) > read_lag or t == steps - 1):
+            h = held.pop(0)
+            outs.append(h[:4] + ({k: float(v) for k, v in h[4].items()},))
     torch.save({"start": start, "count": count, "outs": outs, "traced": env._trace is not None}, os.path.join(out_dir, f"rank{rank}.pt"))
     if world > 1:
         dist.barrier()

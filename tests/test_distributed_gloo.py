@@ -22,7 +22,10 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_sharded_run_equals_unsharded(oracle_lib_path):
+@pytest.mark.parametrize("reduce_every,read_lag", [(1, 0), (8, 11)])
+def test_sharded_run_equals_unsharded(oracle_lib_path, reduce_every, read_lag):
+    """reduce_every = 8: the statistics rows of 8 steps travel in one all-reduce; logs read 11 steps late hit closed batches
+    (no extra collective) except at the end of the run, where the read closes the open batch on both ranks."""
     n_global, steps, sizes = 70, 40, [33, 37]
     with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
         ctx = mp.get_context("spawn")
@@ -30,7 +33,7 @@ def test_sharded_run_equals_unsharded(oracle_lib_path):
         p.start(); p.join(240)
         assert p.exitcode == 0
         port = _free_port()
-        procs = [ctx.Process(target=run_shard, args=(r, 2, port, d2, n_global, steps, sizes)) for r in range(2)]
+        procs = [ctx.Process(target=run_shard, args=(r, 2, port, d2, n_global, steps, sizes, reduce_every, read_lag)) for r in range(2)]
         for q in procs:
             q.start()
         for q in procs:
