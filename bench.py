@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--reduce-every", type=int, default=16, help="recorded steps per logging all-reduce (world > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stamping of the dominant kernel")
-    ap.add_argument("--profile-stride", type=int, default=4,
+    ap.add_argument("--profile-stride", type=int, default=8,
                     help="stamp every k-th launch of the dominant kernel in the timed region (a stamped launch costs the host "
                          "several microseconds more than a plain one; 1 = every launch)")
     args = ap.parse_args()

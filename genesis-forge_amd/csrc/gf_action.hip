@@ -27,7 +27,7 @@ __device__ __forceinline__ float action_target(float x, float s, float o, float 
     return t;
 }
 
-template <bool VEC4>
+template <bool VEC4, bool CONST4 = false>
 __global__ __launch_bounds__(256) void action_kernel(const GfActionArgs a, const int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // zero the next step's statistics slot (nobody else touches it during this step)
@@ -71,17 +71,40 @@ __global__ __launch_bounds__(256) void action_kernel(const GfActionArgs a, const
             }
             const float xs[4] = {x.x, x.y, x.z, x.w};
             float ts[4];
-            int d = (int)((i * 4) % D);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float lo = mode == GF_ACTION_POSITION ? a.clip_lo[d] : 0.f;
-                const float hi = mode == GF_ACTION_POSITION ? a.clip_hi[d] : 0.f;
-                ts[j] = action_target(xs[j], a.scale[d], a.offset[d], lo, hi, mode);
-                if (a.check_finite && mode == GF_ACTION_POSITION) {
-                    flags |= isnan(xs[j]) ? 1 : 0;
-                    flags |= isinf(xs[j]) ? 2 : 0;
+            const int d0 = (int)((i * 4) % D);
+            if (CONST4) {
+                // D % 4 == 0: the lane's four elements are four consecutive DOFs that never wrap — one 16-byte load per
+                // constant array (L1 / K$ resident) instead of sixteen scalar gathers
+                const float4 sc = *reinterpret_cast<const float4*>(a.scale + d0);
+                const float4 of = *reinterpret_cast<const float4*>(a.offset + d0);
+                float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), hi4 = lo4;
+                if (mode == GF_ACTION_POSITION) {
+                    lo4 = *reinterpret_cast<const float4*>(a.clip_lo + d0);
+                    hi4 = *reinterpret_cast<const float4*>(a.clip_hi + d0);
                 }
-                d = d + 1 == D ? 0 : d + 1;
+                const float ss[4] = {sc.x, sc.y, sc.z, sc.w}, os[4] = {of.x, of.y, of.z, of.w};
+                const float ls[4] = {lo4.x, lo4.y, lo4.z, lo4.w}, hs[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ts[j] = action_target(xs[j], ss[j], os[j], ls[j], hs[j], mode);
+                    if (a.check_finite && mode == GF_ACTION_POSITION) {
+                        flags |= isnan(xs[j]) ? 1 : 0;
+                        flags |= isinf(xs[j]) ? 2 : 0;
+                    }
+                }
+            } else {
+                int d = d0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = mode == GF_ACTION_POSITION ? a.clip_lo[d] : 0.f;
+                    const float hi = mode == GF_ACTION_POSITION ? a.clip_hi[d] : 0.f;
+                    ts[j] = action_target(xs[j], a.scale[d], a.offset[d], lo, hi, mode);
+                    if (a.check_finite && mode == GF_ACTION_POSITION) {
+                        flags |= isnan(xs[j]) ? 1 : 0;
+                        flags |= isinf(xs[j]) ? 2 : 0;
+                    }
+                    d = d + 1 == D ? 0 : d + 1;
+                }
             }
             reinterpret_cast<float4*>(a.targets)[i] = make_float4(ts[0], ts[1], ts[2], ts[3]);
         }
@@ -134,7 +157,10 @@ extern "C" __attribute__((visibility("default"))) int gf_action_step(const GfAct
             const int64_t need = (a->num_envs & 3) == 0 ? (a->num_envs >> 2) : a->num_envs;
             if (need > lanes) lanes = need;
         }
-        gf::action_kernel<true><<<gf::env_grid(lanes, 256), 256, 0, s>>>(*a, total);
+        const bool const4 = (a->num_dofs & 3) == 0 && al16(a->scale) && al16(a->offset) &&
+                            (a->mode != GF_ACTION_POSITION || (al16(a->clip_lo) && al16(a->clip_hi)));
+        if (const4) gf::action_kernel<true, true><<<gf::env_grid(lanes, 256), 256, 0, s>>>(*a, total);
+        else gf::action_kernel<true><<<gf::env_grid(lanes, 256), 256, 0, s>>>(*a, total);
     } else {
         int64_t lanes = total > a->num_envs ? total : a->num_envs;
         gf::action_kernel<false><<<gf::env_grid(lanes, 256), 256, 0, s>>>(*a, total);

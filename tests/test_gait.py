@@ -134,3 +134,30 @@ def test_gait_pipeline_hip_equals_oracle(hip_backend, oracle_lib_path, n, trace)
         nat.set_backend(None)
         gs.set_device("cuda:0")
     _same(hip, ref, exact_floats=False)
+
+
+@pytest.mark.gpu
+def test_gait_step_argument_validation(hip_backend):
+    """Error convention of include/gf_step.h: < 0 = argument validation, nothing is launched."""
+    import ctypes as C
+
+    from genesis_forge_amd import _native as nat
+
+    lib = hip_backend.lib
+    lib.gf_gait_step.restype = C.c_int
+    lib.gf_gait_step.argtypes = [C.POINTER(nat.GfGaitArgs), C.c_void_p]
+    a = nat.GfGaitArgs()
+    assert lib.gf_gait_step(C.byref(a), None) == -1                       # GF_E_NULL: no state
+    st = torch.zeros(8, nat.GF_GAIT_ROW, device="cuda")
+    sel = torch.zeros(8, dtype=torch.long, device="cuda")
+    a.state, a.selected, a.num_envs, a.num_gaits, a.mode = st.data_ptr(), sel.data_ptr(), 8, 0, nat.GF_CMD_ALL
+    assert lib.gf_gait_step(C.byref(a), None) == -2                       # GF_E_RANGE: num_gaits
+    a.num_gaits, a.mode = 1, nat.GF_CMD_STEP
+    assert lib.gf_gait_step(C.byref(a), None) == -1                       # STEP needs episode_length
+    ep = torch.zeros(8, dtype=torch.int32, device="cuda")
+    a.episode_length, a.resample_steps = ep.data_ptr(), 0
+    assert lib.gf_gait_step(C.byref(a), None) == -2                       # resample_steps <= 0 (the reference would divide by zero)
+    a.mode = nat.GF_CMD_MASKED
+    assert lib.gf_gait_step(C.byref(a), None) == -1                       # MASKED needs a mask
+    a.mode, a.num_envs = nat.GF_CMD_ALL, 0
+    assert lib.gf_gait_step(C.byref(a), None) == 0                        # empty batch: success, no launch

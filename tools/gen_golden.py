@@ -605,6 +605,71 @@ def gen_air_time():
     print("air_time: ok")
 
 
+CONTACT_CASES = [  # ContactManager ctor kwargs of the contact-kernel fixture (tests/test_contact_kernel.py builds the same three)
+    dict(link_names=[".*_foot"], track_air_time=True, air_time_contact_threshold=3.0),
+    dict(link_names=[".*_thigh", "base"], with_entity_attr="terrain"),
+    dict(link_names=[".*_calf"], with_links_names=[".*_foot", "base"], track_air_time=True, air_time_contact_threshold=1.0),
+]
+
+
+def gen_contact_kernel():
+    """ContactManager.step (contact_manager.py:331-336,384-477 + the Taichi kernel contact/kernel.py:5-90, executed from the
+    reference's own source under tools/ref_stubs.py's serial ndrange) on ARBITRARY contact arrays: both link_a and link_b range
+    over every link of the scene (so the reaction-force branch `target == link_a` is exercised, which the synthetic scene never
+    produces), forces contain NaN / ±Inf, and two of the three managers carry a with-filter (other entity / own links)."""
+    n, C, steps = 37, 9, 6
+
+    class E(ref.ManagedEnvironment):
+        def __init__(self):
+            super().__init__(num_envs=n, dt=1 / 50, max_episode_length_sec=20)
+            self.scene = my_scene.SyntheticScene(dt=self.dt, max_collision_pairs=C)
+            self.terrain = self.scene.add_entity(my_scene.morphs.Plane())
+            self.robot = self.scene.add_entity(my_scene.morphs.URDF(file="go2"))
+
+        def config(self):
+            self.cms = [ContactManager(self, **kw) for kw in CONTACT_CASES]
+
+    env = E()
+    env.build()
+    sc = env.scene
+    NL = sc.links_quat.shape[1]
+    rng = np.random.RandomState(23)
+    out = {k: [] for k in ("force", "position", "link_a", "link_b", "links_quat")}
+    res = {f"m{m}_{k}": [] for m in range(3) for k in ("contacts", "contact_positions")}
+    air = {f"m{m}_air": [] for m in (0, 2)}
+    for t in range(steps):
+        la = rng.randint(-1, NL, (n, C)).astype(np.int32)
+        lb = rng.randint(0, NL, (n, C)).astype(np.int32)
+        empty = rng.uniform(size=(n, C)) < 0.35
+        la[empty], lb[empty] = -1, -1
+        f = (10.0 * rng.standard_normal((n, C, 3))).astype(np.float32)
+        f[empty] = 0.0
+        if t == 2:
+            f[1, 0, 0], f[2, 1, 1], f[3, 2, 2] = np.nan, np.inf, -np.inf
+            la[1, 0], lb[1, 0] = 0, 5
+            la[2, 1], lb[2, 1] = 0, 3
+            la[3, 2], lb[3, 2] = 8, 4
+        pos = rng.standard_normal((n, C, 3)).astype(np.float32)
+        q = rng.standard_normal((n, NL, 4)).astype(np.float32)
+        q /= np.linalg.norm(q, axis=-1, keepdims=True)
+        sc.contact_force[:], sc.contact_pos[:] = torch.from_numpy(f), torch.from_numpy(pos)
+        sc.link_a[:], sc.link_b[:] = torch.from_numpy(la), torch.from_numpy(lb)
+        sc.links_quat[:] = torch.from_numpy(q.astype(np.float32))
+        for k, v in (("force", f), ("position", pos), ("link_a", la), ("link_b", lb), ("links_quat", q.astype(np.float32))):
+            out[k].append(v)
+        for m, cm_ in enumerate(env.cms):
+            cm_.step()
+            res[f"m{m}_contacts"].append(cm_.contacts.numpy().copy())
+            res[f"m{m}_contact_positions"].append(cm_.contact_positions.numpy().copy())
+            if cm_.last_air_time is not None:
+                air[f"m{m}_air"].append(np.stack([cm_.last_air_time.numpy(), cm_.current_air_time.numpy(), cm_.last_contact_time.numpy(),
+                                                  cm_.current_contact_time.numpy()]).copy())
+    data = {k: np.stack(v) for k, v in {**out, **res, **air}.items()}
+    data.update(n=np.int64(n), C=np.int64(C), steps=np.int64(steps), cases=np.array(repr(CONTACT_CASES)))
+    np.savez_compressed(os.path.join(GOLD, "contact_kernel.npz"), **data)
+    print("contact_kernel: ok, nonzero force rows per manager", [int((np.abs(data[f"m{m}_contacts"]).sum(-1) > 0).sum()) for m in range(3)])
+
+
 def gen_terrain():
     """TerrainManager on a 2x2 height-field terrain: get_terrain_height at in-range, edge and out-of-range points
     (terrain_manager.py:100-166), bounds / subterrain bounds (:281-343) and generate_random_positions with given draws (:168-248)."""
@@ -753,12 +818,16 @@ def run_example(name):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "contact_kernel":
+        gen_contact_kernel()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "examples":
         import example_cases
         for ex in (sys.argv[2:] or example_cases.CASES):
             run_example(ex)
         sys.exit(0)
     gen_terrain()
+    gen_contact_kernel()
     run_trajectory("traj_go2_rough", n=16, steps=170, contacts=False, history=None, episode_s=1.5, variant="rough",
                    scene_kwargs=dict(ang_noise=0.4, lin_noise=0.05, seed=41, contact_prob=0.3, contact_force=30.0))
     gen_terms()
