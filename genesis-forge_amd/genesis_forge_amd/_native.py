@@ -355,6 +355,7 @@ class HipBackend(Backend):
         import torch  # plumbing only: makes sure torch's HIP runtime is the one in the process
 
         self._torch = torch
+        self._gpu_checked = False
         self.lib = C.CDLL(path)
         check_abi(self.lib, "gf_")
         self._fn = {}
@@ -391,8 +392,10 @@ class HipBackend(Backend):
 
     def _stream(self) -> int:
         torch = self._torch
-        if not torch.cuda.is_available():
-            raise GfError("no ROCm device visible: genesis_forge_amd runs its manager phases as HIP kernels only")
+        if not self._gpu_checked:  # once: every later call is on the hot path of a step
+            if not torch.cuda.is_available():
+                raise GfError("no ROCm device visible: genesis_forge_amd runs its manager phases as HIP kernels only")
+            self._gpu_checked = True
         return torch.cuda.current_stream().cuda_stream
 
     def _raise(self, fn: str, rc: int):

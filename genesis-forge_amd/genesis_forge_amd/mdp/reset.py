@@ -30,13 +30,12 @@ def xyz_to_quat(xyz: torch.Tensor) -> torch.Tensor:
 
 
 def set_rotation(env, entity, envs_idx, x=0, y=0, z=0):
-    """Absolute or randomised euler rotation (reset.py:33-64)."""
+    """Randomised euler rotation (reset.py:33-64).  As in the reference's code, only axes given as ``(lo, hi)`` tuples are
+    written — a scalar angle is accepted and ignored (the angle buffer stays 0 for that axis, :52-58)."""
     angle_buffer = torch.zeros((len(envs_idx), 3), device=gs.device)
     for k, v in enumerate((x, y, z)):
         if isinstance(v, tuple):
             angle_buffer[:, k].uniform_(*v)
-        elif v:
-            angle_buffer[:, k] = v
     entity.set_quat(xyz_to_quat(angle_buffer), envs_idx=envs_idx)
 
 
@@ -109,11 +108,31 @@ class randomize_terrain_position(ResetMdpFnClass):
             entity.set_quat(self._quat_buffer[envs_idx], envs_idx=envs_idx, zero_velocity=zero_velocity)
 
 
-def randomize_link_mass_shift(env, entity, envs_idx, link_name: str, add_mass_range: tuple[float, float]):
-    """Random mass shift of matching links (reset.py:229-284)."""
-    from ..utils import links_by_name_pattern
-    links = links_by_name_pattern(entity, link_name)
-    if not links:
-        return
-    shift = torch.empty(len(envs_idx), len(links), device=gs.device).uniform_(*add_mass_range)
-    entity.set_mass_shift(shift, links_idx_local=[l.idx_local for l in links], envs_idx=envs_idx)
+class randomize_link_mass_shift(ResetMdpFnClass):
+    """Random mass shift of the links matching ``link_name`` (reset.py:229-284) — a class-style reset fn like the reference's,
+    with its persistent ``[N, n_links]`` buffer.  Reference behaviour kept as is: ``buffer[envs_idx, :].uniform_(…)`` draws into
+    the temporary that advanced indexing returns (:271), so the buffer handed to ``set_mass_shift`` stays zero, and it is
+    handed over whole together with ``envs_idx`` (:274-278)."""
+
+    def __init__(self, _env, entity, link_name: str, add_mass_range: tuple[float, float] = (-0.2, 0.2)):
+        self.env = _env
+        self.add_mass_range = add_mass_range
+        self._entity = entity
+        self._link_name = link_name
+        self._links_idx_local: list = []
+        self._mass_shift_buffer = None
+        self.build()
+
+    def build(self):
+        from ..utils import links_by_name_pattern
+
+        self._links_idx_local = []
+        if self._link_name is not None:
+            links = links_by_name_pattern(self._entity, self._link_name)
+            if len(links) > 0:
+                self._links_idx_local = [link.idx_local for link in links]
+                self._mass_shift_buffer = torch.zeros((self.env.num_envs, len(self._links_idx_local)), device=gs.device)
+
+    def __call__(self, env, entity, envs_idx, link_name: str, add_mass_range: tuple[float, float] = (-0.2, 0.2)):
+        self._mass_shift_buffer[envs_idx, :].uniform_(*self.add_mass_range)
+        self._entity.set_mass_shift(self._mass_shift_buffer, links_idx_local=self._links_idx_local, envs_idx=envs_idx)

@@ -41,3 +41,19 @@ def py_only():
     for f in tr.afters: f()
     env._finish_step_light(snap)
 print("python bookkeeping only  %.1f us" % timeit(py_only))
+# host-side enqueue cost alone: time a short burst before the queue can fill, without waiting for the GPU
+def burst(fn, n=40, reps=30):
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n): fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        best = min(best, (t1 - t0) / n * 1e6)
+    return best
+print("enqueue only: run_ops    %.1f us (host time per call, GPU not waited for)" % burst(lambda: b.run_ops(tr.ops, tr.n_ops)))
+print("enqueue only: env.step   %.1f us" % burst(lambda: env.step(act)))
+for i in range(tr.n_ops):
+    one[0].phase, one[0].args = tr.ops[i].phase, tr.ops[i].args
+    print("   enqueue only: op phase %3d  %.1f us" % (tr.ops[i].phase, burst(lambda: b.run_ops(one, 1))))
