@@ -159,11 +159,11 @@ extern "C" __attribute__((visibility("default"))) int gf_action_step(const GfAct
         }
         const bool const4 = (a->num_dofs & 3) == 0 && al16(a->scale) && al16(a->offset) &&
                             (a->mode != GF_ACTION_POSITION || (al16(a->clip_lo) && al16(a->clip_hi)));
-        if (const4) gf::action_kernel<true, true><<<gf::env_grid(lanes, 256), 256, 0, s>>>(*a, total);
-        else gf::action_kernel<true><<<gf::env_grid(lanes, 256), 256, 0, s>>>(*a, total);
+        if (const4) gf::klaunch(gf::action_kernel<true, true>, dim3(gf::env_grid(lanes, 256)), dim3(256), 0, s, *a, total);
+        else gf::klaunch(gf::action_kernel<true>, dim3(gf::env_grid(lanes, 256)), dim3(256), 0, s, *a, total);
     } else {
         int64_t lanes = total > a->num_envs ? total : a->num_envs;
-        gf::action_kernel<false><<<gf::env_grid(lanes, 256), 256, 0, s>>>(*a, total);
+        gf::klaunch(gf::action_kernel<false>, dim3(gf::env_grid(lanes, 256)), dim3(256), 0, s, *a, total);
     }
     return gf::launch_status();
 }

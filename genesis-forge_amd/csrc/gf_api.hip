@@ -7,6 +7,7 @@
 namespace gf {
 int g_options[GF_OPT_COUNT] = {2, 0, 0, 0};
 Profiler g_prof;
+thread_local LaunchSink g_sink;
 bool contact_compatible(const GfContactArgs* x, const GfContactArgs* y);          // gf_contact.hip
 int contact_launch(const GfContactArgs* const* mgrs, int num, hipStream_t s);
 }
@@ -73,8 +74,82 @@ GF_EXPORT int gf_stats_clear(GfStepStats* stats, void* stream) {
 
 GF_EXPORT int gf_stats_pack(const GfStatsPackArgs* a, void* stream) {
     if (!a || !a->src || !a->dst) return GF_E_NULL;
-    gf::stats_pack_kernel<<<1, 256, 0, (hipStream_t)stream>>>(*a);
+    gf::klaunch(gf::stats_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a);
     return gf::launch_status();
+}
+
+// Replay a recorded step as ONE hipGraphLaunch.  *cache is an opaque handle owned by the caller (NULL at first).  The ops run
+// through their ordinary entry points — validation, packing, kernel selection — but their launches land in the launch sink
+// (gf_launch.h): the first call builds and instantiates a linear graph of kernel nodes, later calls refresh each node's
+// arguments in place and launch the graph; if the launch sequence changed shape (another kernel variant, another grid) the
+// graph is rebuilt.  Steps that cannot be expressed as kernel nodes only (memset / copy ops, a profiled phase, the option
+// switched off) run through gf_run_ops unchanged.
+static bool graphable(const GfOp* ops, int num_ops) {
+    if (!gf::g_options[GF_OPT_GRAPH] || gf::g_prof.phase >= 0) return false;
+    for (int i = 0; i < num_ops; ++i)
+        if (ops[i].phase == GF_OP_STATS_CLEAR || ops[i].phase == GF_OP_STATS_COPY) return false;
+    return true;
+}
+
+static void graph_free(gf::GraphCache* g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
+GF_EXPORT int gf_graph_destroy(void** cache) {
+    if (cache && *cache) { graph_free((gf::GraphCache*)*cache); *cache = nullptr; }
+    return GF_OK;
+}
+
+GF_EXPORT int gf_run_ops_graph(void** cache, const GfOp* ops, int num_ops, void* stream, int* failed_index) {
+    if (!cache) return GF_E_NULL;
+    if (!graphable(ops, num_ops)) return gf_run_ops(ops, num_ops, stream, failed_index);
+    gf::LaunchSink& k = gf::g_sink;
+    gf::GraphCache* g = (gf::GraphCache*)*cache;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool build = g == nullptr;
+        if (build) {
+            g = new gf::GraphCache();
+            if (hipGraphCreate(&g->graph, 0) != hipSuccess) { graph_free(g); *cache = nullptr; return gf_run_ops(ops, num_ops, stream, failed_index); }
+        }
+        k = gf::LaunchSink();
+        k.mode = build ? gf::SINK_BUILD : gf::SINK_UPDATE;
+        k.g = g;
+        const int rc = gf_run_ops(ops, num_ops, stream, failed_index);
+        const bool mismatch = k.mismatch || (!build && k.cursor != g->nodes.size());
+        const hipError_t err = k.error;
+        k = gf::LaunchSink();  // back to direct launches whatever happened
+        if (rc != GF_OK || err != hipSuccess) {   // an op failed validation, or the graph API refused: drop the graph
+            graph_free(g);
+            *cache = nullptr;
+            if (rc != GF_OK) return rc;
+            return gf_run_ops(ops, num_ops, stream, failed_index);
+        }
+        if (build) {
+            if (g->nodes.empty() || hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
+                graph_free(g);
+                *cache = nullptr;
+                return gf_run_ops(ops, num_ops, stream, failed_index);
+            }
+            *cache = g;
+        } else if (mismatch) {   // the step no longer has the recorded shape: rebuild once
+            graph_free(g);
+            g = nullptr;
+            *cache = nullptr;
+            continue;
+        }
+        const hipError_t e = hipGraphLaunch(g->exec, (hipStream_t)stream);
+        if (e == hipSuccess) return GF_OK;
+        // the runtime refuses graph launches here: plain launches from now on (nothing of this step has been enqueued yet)
+        (void)hipGetLastError();
+        graph_free(g);
+        *cache = nullptr;
+        gf::g_options[GF_OPT_GRAPH] = 0;
+        return gf_run_ops(ops, num_ops, stream, failed_index);
+    }
+    return gf_run_ops(ops, num_ops, stream, failed_index);
 }
 
 GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed_index) {

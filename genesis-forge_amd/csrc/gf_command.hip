@@ -50,6 +50,6 @@ extern "C" __attribute__((visibility("default"))) int gf_command_step(const GfCo
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_COMMAND, s);
     scope.begin_bracket();
-    gf::command_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a);
+    gf::klaunch(gf::command_kernel, dim3(gf::env_grid(a->num_envs)), dim3(gf::kEnvBlock), 0, s, *a);
     return gf::launch_status();
 }

@@ -3,6 +3,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <tuple>
+#include <utility>
 #include <vector>
 
 #include "gf_device.h"
@@ -60,6 +62,78 @@ struct PhaseScope {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Launch sink: every kernel launch of the library goes through klaunch().  Normally it is a plain hipLaunchKernel; while
+// gf_run_ops_graph is BUILDING a recorded step's hipGraph it appends a kernel node instead, and while it is UPDATING an
+// instantiated graph it refreshes that node's arguments (hipGraphExecKernelNodeSetParams) — so the entry points keep
+// doing their validation / packing per step (descriptors change: action pointer, RNG streams, ring slots) and only the
+// enqueue itself is replaced: one hipGraphLaunch per step instead of one launch per kernel.
+// ---------------------------------------------------------------------------------------------
+struct NodeShape {
+    const void* func;
+    dim3 grid, block;
+    unsigned lds;
+    bool operator==(const NodeShape& o) const {
+        return func == o.func && grid.x == o.grid.x && grid.y == o.grid.y && grid.z == o.grid.z && block.x == o.block.x &&
+               block.y == o.block.y && block.z == o.block.z && lds == o.lds;
+    }
+};
+struct GraphCache {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<hipGraphNode_t> nodes;
+    std::vector<NodeShape> shapes;
+};
+enum SinkMode { SINK_DIRECT = 0, SINK_BUILD = 1, SINK_UPDATE = 2 };
+struct LaunchSink {
+    int mode = SINK_DIRECT;
+    GraphCache* g = nullptr;
+    size_t cursor = 0;
+    bool mismatch = false;   // UPDATE: this step's launch sequence differs from the recorded graph
+    hipError_t error = hipSuccess;
+};
+extern thread_local LaunchSink g_sink;
+
+inline void sink_launch(const void* func, dim3 grid, dim3 block, size_t lds, hipStream_t s, void** args) {
+    LaunchSink& k = g_sink;
+    if (k.mode == SINK_DIRECT) {
+        (void)hipLaunchKernel(func, grid, block, args, lds, s);
+        return;
+    }
+    hipKernelNodeParams np{};
+    np.func = const_cast<void*>(func);
+    np.gridDim = grid;
+    np.blockDim = block;
+    np.sharedMemBytes = (unsigned)lds;
+    np.kernelParams = args;
+    np.extra = nullptr;
+    const NodeShape shape{func, grid, block, (unsigned)lds};
+    if (k.mode == SINK_BUILD) {
+        hipGraphNode_t node = nullptr;
+        const hipGraphNode_t* dep = k.g->nodes.empty() ? nullptr : &k.g->nodes.back();  // one stream: a linear chain
+        const hipError_t e = hipGraphAddKernelNode(&node, k.g->graph, dep, dep ? 1 : 0, &np);
+        if (e != hipSuccess) { k.error = e; return; }
+        k.g->nodes.push_back(node);
+        k.g->shapes.push_back(shape);
+        return;
+    }
+    if (k.cursor >= k.g->nodes.size() || !(k.g->shapes[k.cursor] == shape)) { k.mismatch = true; ++k.cursor; return; }
+    const hipError_t e = hipGraphExecKernelNodeSetParams(k.g->exec, k.g->nodes[k.cursor], &np);
+    if (e != hipSuccess) k.error = e;
+    ++k.cursor;
+}
+
+// kernel<<<grid, block, lds, stream>>>(args...) through the sink.  The arguments are converted to the kernel's parameter
+// types first (hipLaunchKernel / graph nodes take an array of pointers to exactly those types).
+template <class... P, class... A>
+inline void klaunch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t s, A&&... a) {
+    static_assert(sizeof...(P) == sizeof...(A), "argument count");
+    std::tuple<P...> vals(std::forward<A>(a)...);
+    void* ptrs[sizeof...(P) ? sizeof...(P) : 1];
+    std::apply([&](auto&... v) { size_t i = 0; ((ptrs[i++] = (void*)&v), ...); }, vals);
+    sink_launch(reinterpret_cast<const void*>(kernel), grid, block, lds, s, ptrs);
+}
+
 // Launch `kernel` either plainly or, when `scope` is profiling this phase, with dispatch-timestamp events.
 #define GF_LAUNCH(scope, kernel, grid, block, lds, strm, ...)                                               \
     do {                                                                                                    \
@@ -67,7 +141,7 @@ struct PhaseScope {
             (scope).use_dispatch_events();                                                                  \
             hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, strm, (scope).start(), (scope).stop(), 0, __VA_ARGS__); \
         } else {                                                                                            \
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, strm, __VA_ARGS__);                    \
+            gf::klaunch(kernel, dim3(grid), dim3(block), lds, strm, __VA_ARGS__);                           \
         }                                                                                                   \
     } while (0)
 

@@ -281,8 +281,8 @@ extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObserva
     gf::PhaseScope scope(GF_PHASE_OBSERVE, s);
     scope.begin_bracket();
     const unsigned grid = gf::env_grid(a->num_envs);  // one 256-thread workgroup per 64-env tile
-    if (vec4) gf::observe_kernel<4><<<grid, gf::kObsBlock, lds, s>>>(*a, needs);
-    else if (vec2) gf::observe_kernel<2><<<grid, gf::kObsBlock, lds, s>>>(*a, needs);
-    else gf::observe_kernel<1><<<grid, gf::kObsBlock, lds, s>>>(*a, needs);
+    if (vec4) gf::klaunch(gf::observe_kernel<4>, dim3(grid), dim3(gf::kObsBlock), lds, s, *a, needs);
+    else if (vec2) gf::klaunch(gf::observe_kernel<2>, dim3(grid), dim3(gf::kObsBlock), lds, s, *a, needs);
+    else gf::klaunch(gf::observe_kernel<1>, dim3(grid), dim3(gf::kObsBlock), lds, s, *a, needs);
     return gf::launch_status();
 }

@@ -120,6 +120,6 @@ extern "C" __attribute__((visibility("default"))) int gf_masked_reset(const GfRe
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_RESET, s);
     scope.begin_bracket();
-    gf::reset_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a);
+    gf::klaunch(gf::reset_kernel, dim3(gf::env_grid(a->num_envs)), dim3(gf::kEnvBlock), 0, s, *a);
     return gf::launch_status();
 }

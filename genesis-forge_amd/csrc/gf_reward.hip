@@ -247,11 +247,11 @@ extern "C" __attribute__((visibility("default"))) int gf_reward_step(const GfRew
     const unsigned grid = gf::env_grid(a->num_envs);
     gf::PhaseScope scope(GF_PHASE_REWARD, s);
     if (rows16 && a->num_dofs == 12) GF_LAUNCH(scope, gf::reward_kernel<3>, grid, gf::kEnvBlock, 0, s, *a, needs);
-    else if (rows16 && a->num_dofs == 28) { scope.begin_bracket(); gf::reward_kernel<7><<<grid, gf::kEnvBlock, 0, s>>>(*a, needs); }
-    else if (rows16 && a->num_dofs == 8) { scope.begin_bracket(); gf::reward_kernel<2><<<grid, gf::kEnvBlock, 0, s>>>(*a, needs); }
-    else if (rows16 && a->num_dofs == 16) { scope.begin_bracket(); gf::reward_kernel<4><<<grid, gf::kEnvBlock, 0, s>>>(*a, needs); }
-    else if (rows16 && a->num_dofs == 20) { scope.begin_bracket(); gf::reward_kernel<5><<<grid, gf::kEnvBlock, 0, s>>>(*a, needs); }
-    else if (rows16 && a->num_dofs == 24) { scope.begin_bracket(); gf::reward_kernel<6><<<grid, gf::kEnvBlock, 0, s>>>(*a, needs); }
-    else { scope.begin_bracket(); gf::reward_kernel<0><<<grid, gf::kEnvBlock, 0, s>>>(*a, needs); }
+    else if (rows16 && a->num_dofs == 28) { scope.begin_bracket(); gf::klaunch(gf::reward_kernel<7>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a, needs); }
+    else if (rows16 && a->num_dofs == 8) { scope.begin_bracket(); gf::klaunch(gf::reward_kernel<2>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a, needs); }
+    else if (rows16 && a->num_dofs == 16) { scope.begin_bracket(); gf::klaunch(gf::reward_kernel<4>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a, needs); }
+    else if (rows16 && a->num_dofs == 20) { scope.begin_bracket(); gf::klaunch(gf::reward_kernel<5>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a, needs); }
+    else if (rows16 && a->num_dofs == 24) { scope.begin_bracket(); gf::klaunch(gf::reward_kernel<6>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a, needs); }
+    else { scope.begin_bracket(); gf::klaunch(gf::reward_kernel<0>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a, needs); }
     return gf::launch_status();
 }

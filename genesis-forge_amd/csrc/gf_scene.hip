@@ -173,7 +173,7 @@ extern "C" __attribute__((visibility("default"))) int gf_entity_rotate(const GfR
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_ROTATE, s);
     scope.begin_bracket();
-    gf::rotate_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a);
+    gf::klaunch(gf::rotate_kernel, dim3(gf::env_grid(a->num_envs)), dim3(gf::kEnvBlock), 0, s, *a);
     return gf::launch_status();
 }
 
@@ -190,12 +190,12 @@ extern "C" __attribute__((visibility("default"))) int gf_synth_scene_step(const 
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const bool rows16 = (a->num_dofs % 4 == 0) && al16(a->targets) && al16(a->dof_pos) && al16(a->dof_vel);
     const unsigned grid = gf::env_grid(a->num_envs);
-    if (rows16 && a->num_dofs == 12) gf::synth_scene_kernel<3><<<grid, gf::kEnvBlock, 0, s>>>(*a);
-    else if (rows16 && a->num_dofs == 28) gf::synth_scene_kernel<7><<<grid, gf::kEnvBlock, 0, s>>>(*a);
-    else gf::synth_scene_kernel<0><<<grid, gf::kEnvBlock, 0, s>>>(*a);
+    if (rows16 && a->num_dofs == 12) gf::klaunch(gf::synth_scene_kernel<3>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
+    else if (rows16 && a->num_dofs == 28) gf::klaunch(gf::synth_scene_kernel<7>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
+    else gf::klaunch(gf::synth_scene_kernel<0>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
     if ((a->links_quat_out || a->links_vel_out || a->links_pos_out) && a->num_scene_links > 0)
-        gf::synth_links_kernel<<<gf::env_grid((int64_t)a->num_envs * a->num_scene_links, 256), 256, 0, s>>>(*a);
+        gf::klaunch(gf::synth_links_kernel, dim3(gf::env_grid((int64_t)a->num_envs * a->num_scene_links, 256)), dim3(256), 0, s, *a);
     if (a->num_contacts > 0 && a->contact_force_out)
-        gf::synth_contacts_kernel<<<gf::env_grid((int64_t)a->num_envs * a->num_contacts, 256), 256, 0, s>>>(*a);
+        gf::klaunch(gf::synth_contacts_kernel, dim3(gf::env_grid((int64_t)a->num_envs * a->num_contacts, 256)), dim3(256), 0, s, *a);
     return gf::launch_status();
 }

@@ -93,6 +93,6 @@ extern "C" __attribute__((visibility("default"))) int gf_termination_step(const 
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_TERMINATION, s);
     scope.begin_bracket();
-    gf::termination_kernel<<<gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s>>>(*a, needs);
+    gf::klaunch(gf::termination_kernel, dim3(gf::env_grid(a->num_envs)), dim3(gf::kEnvBlock), 0, s, *a, needs);
     return gf::launch_status();
 }

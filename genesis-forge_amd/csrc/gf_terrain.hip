@@ -34,6 +34,6 @@ extern "C" __attribute__((visibility("default"))) int gf_terrain_height(const Gf
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_TERRAIN, s);
     scope.begin_bracket();
-    gf::terrain_height_kernel<<<gf::env_grid(a->num, 256), 256, 0, s>>>(*a);
+    gf::klaunch(gf::terrain_height_kernel, dim3(gf::env_grid(a->num, 256)), dim3(256), 0, s, *a);
     return gf::launch_status();
 }

@@ -85,6 +85,7 @@ GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
  GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_COUNT) = range(13)
 
 GF_OPT_PROFILE_STRIDE = 1  # gf_set_option: stamp every k-th launch of the profiled phase
+GF_OPT_GRAPH = 2           # gf_set_option: 1 = recorded steps replay as one hipGraphLaunch; 0 (default: measured faster) = plain launches
 GF_OPT_POST_VARIANT = 0  # gf_set_option: 0 = interpreter, one wave per tile; 1 = interpreter, four waves; 2 = + static programs (default)
 
 GF_ERRORS = {-1: "GF_E_NULL", -2: "GF_E_RANGE", -3: "GF_E_OPCODE", -4: "GF_E_SLOT", -5: "GF_E_UNSUPPORTED"}
@@ -371,6 +372,12 @@ class HipBackend(Backend):
         self.lib.gf_build_info.restype = C.c_char_p
         self.lib.gf_run_ops.restype = C.c_int
         self.lib.gf_run_ops.argtypes = [C.POINTER(GfOp), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        self.lib.gf_run_ops_graph.restype = C.c_int
+        self.lib.gf_run_ops_graph.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GfOp), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        self.lib.gf_graph_destroy.restype = C.c_int
+        self.lib.gf_graph_destroy.argtypes = [C.POINTER(C.c_void_p)]
+        if os.environ.get("GF_GRAPH", "0") == "1":   # opt-in: measured slower than plain launches (gf_step.h, GF_OPT_GRAPH)
+            self.lib.gf_set_option(GF_OPT_GRAPH, 1)
         self.lib.gf_stats_pack.restype = C.c_int
         self.lib.gf_stats_pack.argtypes = [C.POINTER(GfStatsPackArgs), C.c_void_p]
         self.lib.gf_post_physics_check.restype = C.c_int
@@ -414,6 +421,16 @@ class HipBackend(Backend):
         rc = self.lib.gf_run_ops(ops, n, self._stream(), C.byref(failed))
         if rc != 0:
             self._raise(f"run_ops[op {failed.value}]", rc)
+
+    def run_ops_graph(self, cache, ops, n: int) -> None:
+        """``cache``: a ctypes c_void_p owned by the caller (the recorded step); see gf_run_ops_graph."""
+        failed = C.c_int(-1)
+        rc = self.lib.gf_run_ops_graph(C.byref(cache), ops, n, self._stream(), C.byref(failed))
+        if rc != 0:
+            self._raise(f"run_ops_graph[op {failed.value}]", rc)
+
+    def graph_destroy(self, cache) -> None:
+        self.lib.gf_graph_destroy(C.byref(cache))
 
     def post_check(self, refs) -> bool:
         return self.lib.gf_post_physics_check(C.byref(refs)) == 0

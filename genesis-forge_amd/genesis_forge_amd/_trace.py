@@ -80,6 +80,16 @@ class StepTrace:
             self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_PACK, C.addressof(self.pack_args)
             k += 1
         self.n_ops = k
+        #: hipGraph of this step's launches (built by the library on first replay; HIP backend only)
+        self.graph = C.c_void_p() if hasattr(self.backend, "run_ops_graph") else None
+
+    def __del__(self):
+        g = getattr(self, "graph", None)
+        if g is not None and g.value:
+            try:
+                self.backend.graph_destroy(g)
+            except Exception:
+                pass
 
     # -- fused post-physics launch -----------------------------------------------------------------------
     @staticmethod
@@ -186,7 +196,10 @@ class StepTrace:
         for a in self.stat_fields:
             a.stats = cur
         self.action_args.stats_zero = nxt
-        self.backend.run_ops(self.ops, self.n_ops)
+        if self.graph is not None:
+            self.backend.run_ops_graph(self.graph, self.ops, self.n_ops)
+        else:
+            self.backend.run_ops(self.ops, self.n_ops)
         if not self.use_ring:
             snap = env.stats.vec_ring_reduce(slot)  # the single collective of the path, asynchronous
         env._tick += 1  # scene advanced

@@ -566,7 +566,11 @@ int gf_abi_version(void);
  * straight-line code compiled for it.  All variants produce bit-identical results. */
 /* GF_OPT_PROFILE_STRIDE: gf_profile_begin stamps every k-th launch of the profiled phase (default 1 = every launch); a
  * stamped launch costs the host several microseconds more than a plain one, so a timed region samples instead. */
-enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_COUNT = 4 };
+/* GF_OPT_GRAPH (default 0): 1 = gf_run_ops_graph replays a recorded step as one hipGraphLaunch.  Off by default because it
+ * MEASURED slower on MI355X / ROCm 7.2 (every node's arguments change every step, so each replay pays one
+ * hipGraphExecKernelNodeSetParams per kernel on top of the graph launch): Go2 command config 21.7 vs 18.1 µs/step at 4 096
+ * envs, 27.8 vs 24 µs at 65 536; gait config 107 vs 94 µs at 8 192 (profiles/r01_l_graph_vs_plain.jsonl). */
+enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_GRAPH = 2, GF_OPT_COUNT = 4 };
 int gf_set_option(int option, int value);
 int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView): binding self-check */
 const char* gf_build_info(void);
@@ -651,6 +655,13 @@ typedef struct GfStatsCopyArgs {
 } GfStatsCopyArgs;
 
 int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed_index);
+/* The same replay as ONE hipGraphLaunch: the first call builds a linear hipGraph of the step's kernel launches, later calls
+ * refresh every node's kernel arguments in place (the descriptors change from step to step: action pointer, RNG streams,
+ * ring slots) and launch the graph — the host pays one graph launch instead of one launch per kernel.  *cache is an opaque
+ * handle (start with NULL, release with gf_graph_destroy).  Falls back to gf_run_ops when the step contains memset / copy
+ * ops, a phase is being profiled, GF_OPT_GRAPH is 0 or the graph API refuses. */
+int gf_run_ops_graph(void** cache, const GfOp* ops, int num_ops, void* stream, int* failed_index);
+int gf_graph_destroy(void** cache);
 void* gf_event_create(void);
 int gf_event_destroy(void* event);
 int gf_event_synchronize(void* event);   /* blocks the host until the event has completed */

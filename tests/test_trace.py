@@ -234,3 +234,18 @@ def test_static_program_selection_is_host_side(oracle_backend):
         text = hip.post_describe(env._trace.post_refs)
         assert text.startswith(want), text
         assert "n_rew = 6" in text
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_equals_plain_launches(hip_backend):
+    """GF_OPT_GRAPH: the recorded step as one hipGraphLaunch (node arguments refreshed every step) gives the same bits."""
+    from genesis_forge_amd import _native as nat
+
+    a, _ = _run("cuda", True, n=1000)
+    hip_backend.set_option(nat.GF_OPT_GRAPH, 1)
+    try:
+        b, env = _run("cuda", True, n=1000)
+        assert env._trace is not None and env._trace.graph is not None and env._trace.graph.value, "no graph was built"
+    finally:
+        hip_backend.set_option(nat.GF_OPT_GRAPH, 0)
+    _same(a, b)
