@@ -5,11 +5,13 @@
 #include "gf_launch.h"
 
 namespace gf {
-int g_options[GF_OPT_COUNT] = {2, 0, 0, 0};
+int g_options[GF_OPT_COUNT] = {2, 0, 0, 1};
 Profiler g_prof;
 thread_local LaunchSink g_sink;
 bool contact_compatible(const GfContactArgs* x, const GfContactArgs* y);          // gf_contact.hip
 int contact_launch(const GfContactArgs* const* mgrs, int num, hipStream_t s);
+int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc);   // gf_chain.hip
+int chain_b_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc);
 }
 
 #define GF_EXPORT __attribute__((visibility("default")))
@@ -173,10 +175,18 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
                 rc = gf::contact_launch(run, cnt, s);
                 if (rc == GF_OK) i += cnt - 1;
             } break;
-            case GF_PHASE_TERMINATION: rc = gf_termination_step((const GfTerminationArgs*)a, stream); break;
+            case GF_PHASE_TERMINATION: {
+                const int used = gf::chain_a_try(ops, i, num_ops, s, &rc);   // termination → reward → command.step … in one launch
+                if (used > 0) { if (rc == GF_OK) i += used - 1; break; }
+                rc = gf_termination_step((const GfTerminationArgs*)a, stream);
+            } break;
             case GF_PHASE_REWARD: rc = gf_reward_step((const GfRewardArgs*)a, stream); break;
             case GF_PHASE_COMMAND: rc = gf_command_step((const GfCommandArgs*)a, stream); break;
-            case GF_PHASE_RESET: rc = gf_masked_reset((const GfResetArgs*)a, stream); break;
+            case GF_PHASE_RESET: {
+                const int used = gf::chain_b_try(ops, i, num_ops, s, &rc);   // reset → command.reset … → observe … in one launch
+                if (used > 0) { if (rc == GF_OK) i += used - 1; break; }
+                rc = gf_masked_reset((const GfResetArgs*)a, stream);
+            } break;
             case GF_PHASE_OBSERVE: rc = gf_observe((const GfObservationArgs*)a, stream); break;
             case GF_PHASE_ROTATE: rc = gf_entity_rotate((const GfRotateArgs*)a, stream); break;
             case GF_PHASE_SCENE: rc = gf_synth_scene_step((const GfSynthSceneArgs*)a, stream); break;

@@ -11,7 +11,7 @@
 
 namespace gf {
 
-__global__ __launch_bounds__(kEnvBlock) void command_kernel(const GfCommandArgs a) {
+__device__ __forceinline__ void command_body(const GfCommandArgs& a) {
     const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
     const bool live = n < a.num_envs;
     bool go = false;
@@ -33,9 +33,15 @@ __global__ __launch_bounds__(kEnvBlock) void command_kernel(const GfCommandArgs 
     }
 }
 
+#ifndef GF_BODIES_ONLY
+__global__ __launch_bounds__(kEnvBlock) void command_kernel(const GfCommandArgs a) { command_body(a); }
+#endif
+
 }  // namespace gf
 
-extern "C" __attribute__((visibility("default"))) int gf_command_step(const GfCommandArgs* a, void* stream) {
+#ifndef GF_BODIES_ONLY
+namespace gf {
+int command_prep(const GfCommandArgs* a) {
     if (!a || !a->command) return GF_E_NULL;
     if (a->num_ranges <= 0 || a->num_ranges > GF_MAX_RANGES || a->num_envs < 0) return GF_E_RANGE;
     if (a->mode == GF_CMD_STEP) {
@@ -46,6 +52,13 @@ extern "C" __attribute__((visibility("default"))) int gf_command_step(const GfCo
     } else if (a->mode != GF_CMD_ALL) {
         return GF_E_RANGE;
     }
+    return GF_OK;
+}
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_command_step(const GfCommandArgs* a, void* stream) {
+    const int rc = gf::command_prep(a);
+    if (rc) return rc;
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_COMMAND, s);
@@ -53,3 +66,4 @@ extern "C" __attribute__((visibility("default"))) int gf_command_step(const GfCo
     gf::klaunch(gf::command_kernel, dim3(gf::env_grid(a->num_envs)), dim3(gf::kEnvBlock), 0, s, *a);
     return gf::launch_status();
 }
+#endif

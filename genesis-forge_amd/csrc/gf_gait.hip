@@ -17,7 +17,7 @@
 
 namespace gf {
 
-__global__ __launch_bounds__(kEnvBlock) void gait_kernel(const GfGaitArgs a) {
+__device__ __forceinline__ void gait_body(const GfGaitArgs& a) {
     const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
     const bool live = n < a.num_envs;
     const int64_t m = live ? n : (int64_t)a.num_envs - 1;  // tail lanes shadow the last env and never store
@@ -100,9 +100,15 @@ __global__ __launch_bounds__(kEnvBlock) void gait_kernel(const GfGaitArgs a) {
     }
 }
 
+#ifndef GF_BODIES_ONLY
+__global__ __launch_bounds__(kEnvBlock) void gait_kernel(const GfGaitArgs a) { gait_body(a); }
+#endif
+
 }  // namespace gf
 
-extern "C" __attribute__((visibility("default"))) int gf_gait_step(const GfGaitArgs* a, void* stream) {
+#ifndef GF_BODIES_ONLY
+namespace gf {
+int gait_prep(const GfGaitArgs* a) {
     if (!a || !a->state || !a->selected) return GF_E_NULL;
     if (a->num_envs < 0 || a->num_gaits < 1 || a->num_gaits > GF_MAX_GAITS) return GF_E_RANGE;
     if (a->mode == GF_CMD_STEP) {
@@ -114,9 +120,17 @@ extern "C" __attribute__((visibility("default"))) int gf_gait_step(const GfGaitA
         return GF_E_RANGE;
     }
     if (reinterpret_cast<uintptr_t>(a->state) & 15u) return GF_E_UNSUPPORTED;
+    return GF_OK;
+}
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_gait_step(const GfGaitArgs* a, void* stream) {
+    const int rc = gf::gait_prep(a);
+    if (rc) return rc;
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_GAIT, s);
     GF_LAUNCH(scope, gf::gait_kernel, gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s, *a);
     return gf::launch_status();
 }
+#endif

@@ -57,8 +57,7 @@ __device__ __forceinline__ float finish(const GfObservationArgs& a, const GfObsI
 }
 
 // Flat cooperative copy of a [rows, w] source block (row stride = src_stride words) into tile columns [col0, col0+w).
-template <int V>
-__device__ __forceinline__ void copy_rows(const TileCtx& c, const GfObsItem& it, const float* __restrict__ src, int src_stride, int w, int col0) {
+__device__ __forceinline__ void copy_rows(const int V, const TileCtx& c, const GfObsItem& it, const float* __restrict__ src, int src_stride, int w, int col0) {
     const GfObservationArgs& a = *c.a;
     const float* base = src + c.n0 * src_stride;
     const int total = c.rows * w;
@@ -111,11 +110,9 @@ __device__ __forceinline__ void shift_history(T* __restrict__ dst, const T* __re
     }
 }
 
-// V = floats per memory operation of the write-out and the history shift: 4 when O % 4 == 0, 2 when O is even, else 1
-template <int V>
-__global__ __launch_bounds__(kObsBlock) void observe_kernel(const GfObservationArgs a, const uint32_t needs) {
-    prefetch_args<GfObservationArgs>();
-    extern __shared__ __attribute__((aligned(16))) float tile[];
+// V = floats per memory operation of the write-out and the history shift: 4 when O % 4 == 0, 2 when O is even, else 1.
+// A run-time value here (wave-uniform branches); the stand-alone kernels pass a constant, which folds the branches away.
+__device__ __forceinline__ void observe_body(const int V, const GfObservationArgs& a, const uint32_t needs, float* tile) {
     const int tid = threadIdx.x;
     const int64_t n0 = (int64_t)blockIdx.x * kEnvBlock;
     const int64_t N = a.num_envs;
@@ -144,15 +141,15 @@ __global__ __launch_bounds__(kObsBlock) void observe_kernel(const GfObservationA
         const GfObsItem& it = a.items[i];
         const int w = it.width;
         switch (it.op) {
-            case GF_O_COMMAND: copy_rows<V>(c, it, a.command[it.i0].command, cmd_stride(a.command[it.i0]), w, col); break;
-            case GF_O_DOF_POS: copy_rows<V>(c, it, a.dof_pos, D, w, col); break;
-            case GF_O_DOF_VEL: copy_rows<V>(c, it, a.dof_vel, D, w, col); break;
-            case GF_O_DOF_FORCE: copy_rows<V>(c, it, a.dof_force, D, w, col); break;
-            case GF_O_ACTIONS: copy_rows<V>(c, it, a.targets, D, w, col); break;
-            case GF_O_RAW_ACTIONS: copy_rows<V>(c, it, a.env_actions, D, w, col); break;
-            case GF_O_EXTERNAL: copy_rows<V>(c, it, a.ext[it.i0], w, w, col); break;
-            case GF_O_BASE_POS: copy_rows<1>(c, it, a.entity.pos, 3, 3, col); break;
-            case GF_O_BASE_QUAT: copy_rows<V>(c, it, a.entity.quat, 4, 4, col); break;
+            case GF_O_COMMAND: copy_rows(V, c, it, a.command[it.i0].command, cmd_stride(a.command[it.i0]), w, col); break;
+            case GF_O_DOF_POS: copy_rows(V, c, it, a.dof_pos, D, w, col); break;
+            case GF_O_DOF_VEL: copy_rows(V, c, it, a.dof_vel, D, w, col); break;
+            case GF_O_DOF_FORCE: copy_rows(V, c, it, a.dof_force, D, w, col); break;
+            case GF_O_ACTIONS: copy_rows(V, c, it, a.targets, D, w, col); break;
+            case GF_O_RAW_ACTIONS: copy_rows(V, c, it, a.env_actions, D, w, col); break;
+            case GF_O_EXTERNAL: copy_rows(V, c, it, a.ext[it.i0], w, w, col); break;
+            case GF_O_BASE_POS: copy_rows(1, c, it, a.entity.pos, 3, 3, col); break;
+            case GF_O_BASE_QUAT: copy_rows(V, c, it, a.entity.quat, 4, 4, col); break;
             case GF_O_ANG_VEL_BODY:
             case GF_O_LIN_VEL_BODY:
             case GF_O_PROJ_GRAVITY: {
@@ -213,9 +210,21 @@ __global__ __launch_bounds__(kObsBlock) void observe_kernel(const GfObservationA
     }
 }
 
+#ifndef GF_BODIES_ONLY
+template <int V>
+__global__ __launch_bounds__(kObsBlock) void observe_kernel(const GfObservationArgs a, const uint32_t needs) {
+    prefetch_args<GfObservationArgs>();
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    observe_body(V, a, needs, tile);
+}
+#endif
+
 }  // namespace gf
 
-extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObservationArgs* a, void* stream) {
+#ifndef GF_BODIES_ONLY
+namespace gf {
+// validation, the entity inputs the items need, and the widest memory operation the frame width / alignment allow
+int observe_prep(const GfObservationArgs* a, uint32_t* needs_out, int* vec_out) {
     if (!a || !a->obs) return GF_E_NULL;
     if (a->num_items <= 0 || a->num_items > GF_MAX_OBS_ITEMS || a->num_envs < 0) return GF_E_RANGE;
     if (a->history_len < 1) return GF_E_RANGE;
@@ -275,7 +284,20 @@ extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObserva
     if ((needs & gf::ON_QUAT) && (!a->entity.quat || !al16(a->entity.quat))) return a->entity.quat ? GF_E_UNSUPPORTED : GF_E_NULL;
     if ((needs & gf::ON_LIN) && !a->entity.lin_vel) return GF_E_NULL;
     if ((needs & gf::ON_ANG) && !a->entity.ang_vel) return GF_E_NULL;
+    *needs_out = needs;
+    *vec_out = vec4 ? 4 : (vec2 ? 2 : 1);
+    return GF_OK;
+}
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObservationArgs* a, void* stream) {
+    uint32_t needs = 0;
+    int vec = 1;
+    const int rc = gf::observe_prep(a, &needs, &vec);
+    if (rc) return rc;
     if (a->num_envs == 0) return GF_OK;
+    const bool vec4 = vec == 4, vec2 = vec == 2;
+    const int O = a->obs_width;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)(O + 1) * gf::kEnvBlock * sizeof(float);
     gf::PhaseScope scope(GF_PHASE_OBSERVE, s);
@@ -286,3 +308,4 @@ extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObserva
     else gf::klaunch(gf::observe_kernel<1>, dim3(grid), dim3(gf::kObsBlock), lds, s, *a, needs);
     return gf::launch_status();
 }
+#endif

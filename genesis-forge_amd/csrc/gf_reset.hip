@@ -15,8 +15,7 @@
 
 namespace gf {
 
-__global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
-    prefetch_args<GfResetArgs>();
+__device__ __forceinline__ void reset_body(const GfResetArgs& a) {
     const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
     const bool live = n < a.num_envs;
     const bool go = live && (a.mask[n] || (a.mask2 && a.mask2[n]));
@@ -106,9 +105,18 @@ __global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
     }
 }
 
+#ifndef GF_BODIES_ONLY
+__global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
+    prefetch_args<GfResetArgs>();
+    reset_body(a);
+}
+#endif
+
 }  // namespace gf
 
-extern "C" __attribute__((visibility("default"))) int gf_masked_reset(const GfResetArgs* a, void* stream) {
+#ifndef GF_BODIES_ONLY
+namespace gf {
+int reset_prep(const GfResetArgs* a) {
     if (!a || !a->mask) return GF_E_NULL;
     if (a->num_envs < 0 || a->num_dofs < 0) return GF_E_RANGE;
     if (a->num_reward_terms < 0 || a->num_reward_terms > GF_MAX_TERMS) return GF_E_RANGE;
@@ -116,6 +124,13 @@ extern "C" __attribute__((visibility("default"))) int gf_masked_reset(const GfRe
     if (a->env_actions && !a->env_last_actions) return GF_E_NULL;
     if (a->scene_dof_pos && !a->default_dof_pos) return GF_E_NULL;
     if (a->spawn_mode && a->terrain.height_field && (a->terrain.rows < 1 || a->terrain.cols < 1)) return GF_E_RANGE;
+    return GF_OK;
+}
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_masked_reset(const GfResetArgs* a, void* stream) {
+    const int rc = gf::reset_prep(a);
+    if (rc) return rc;
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_RESET, s);
@@ -123,3 +138,4 @@ extern "C" __attribute__((visibility("default"))) int gf_masked_reset(const GfRe
     gf::klaunch(gf::reset_kernel, dim3(gf::env_grid(a->num_envs)), dim3(gf::kEnvBlock), 0, s, *a);
     return gf::launch_status();
 }
+#endif

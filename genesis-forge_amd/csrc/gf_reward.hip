@@ -33,10 +33,9 @@ enum : uint32_t {
     RN_DOF_DEV = 32, RN_ACT_RATE = 64, RN_TERMINATED = 128, RN_CMD0 = 256,
 };
 
+// the phase for the 64 envs of workgroup blockIdx.x; lanes = threadIdx.x < 64; lds_sums: GF_MAX_TERMS * 64 floats of LDS
 template <int DV>
-__global__ __launch_bounds__(kEnvBlock) void reward_kernel(const GfRewardArgs a, const uint32_t needs) {
-    prefetch_args<GfRewardArgs>();
-    __shared__ float lds_sums[GF_MAX_TERMS * kEnvBlock];
+__device__ __forceinline__ void reward_body(const GfRewardArgs& a, const uint32_t needs, float* lds_sums) {
 
     const int64_t N = a.num_envs;
     const int64_t n_raw = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
@@ -158,9 +157,21 @@ __global__ __launch_bounds__(kEnvBlock) void reward_kernel(const GfRewardArgs a,
     }
 }
 
+#ifndef GF_BODIES_ONLY
+template <int DV>
+__global__ __launch_bounds__(kEnvBlock) void reward_kernel(const GfRewardArgs a, const uint32_t needs) {
+    prefetch_args<GfRewardArgs>();
+    __shared__ float lds_sums[GF_MAX_TERMS * kEnvBlock];
+    reward_body<DV>(a, needs, lds_sums);
+}
+#endif
+
 }  // namespace gf
 
-extern "C" __attribute__((visibility("default"))) int gf_reward_step(const GfRewardArgs* a, void* stream) {
+#ifndef GF_BODIES_ONLY
+namespace gf {
+// validation, the inputs the term table needs, and the row-vector width the [N,D] rows allow (0 = scalar path)
+int reward_prep(const GfRewardArgs* a, uint32_t* needs_out, int* dv_out) {
     if (!a) return GF_E_NULL;
     if (a->num_terms < 0 || a->num_terms > GF_MAX_TERMS || a->num_envs < 0 || a->num_dofs < 0) return GF_E_RANGE;
     if (a->mode == GF_REWARD_MODE_STEP) {
@@ -239,10 +250,21 @@ extern "C" __attribute__((visibility("default"))) int gf_reward_step(const GfRew
     if ((needs & gf::RN_DOF_DEV) && (!a->dof_pos || !a->default_dof_pos || a->num_dofs <= 0)) return GF_E_NULL;
     if ((needs & gf::RN_ACT_RATE) && (!a->actions || !a->last_actions || a->num_dofs <= 0)) return GF_E_NULL;
     if ((needs & gf::RN_QUAT) && (reinterpret_cast<uintptr_t>(a->entity.quat) & 15u)) return GF_E_UNSUPPORTED;
-    if (a->num_envs == 0) return GF_OK;
-
     auto al16 = [](const void* p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const bool rows16 = (a->num_dofs % 4 == 0) && al16(a->dof_pos) && al16(a->actions) && al16(a->last_actions) && al16(a->default_dof_pos);
+    *needs_out = needs;
+    *dv_out = (rows16 && a->num_dofs >= 8 && a->num_dofs <= 28) ? a->num_dofs / 4 : 0;
+    return GF_OK;
+}
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_reward_step(const GfRewardArgs* a, void* stream) {
+    uint32_t needs = 0;
+    int dv = 0;
+    const int rc = gf::reward_prep(a, &needs, &dv);
+    if (rc) return rc;
+    if (a->num_envs == 0) return GF_OK;
+    const bool rows16 = dv > 0;
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = gf::env_grid(a->num_envs);
     gf::PhaseScope scope(GF_PHASE_REWARD, s);
@@ -255,3 +277,4 @@ extern "C" __attribute__((visibility("default"))) int gf_reward_step(const GfRew
     else { scope.begin_bracket(); gf::klaunch(gf::reward_kernel<0>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a, needs); }
     return gf::launch_status();
 }
+#endif

@@ -16,8 +16,8 @@ namespace gf {
 
 enum : uint32_t { NEED_QUAT = 1, NEED_POS = 2, NEED_EPLEN = 4, NEED_MAXLEN = 8 };
 
-__global__ __launch_bounds__(kEnvBlock) void termination_kernel(const GfTerminationArgs a, const uint32_t needs) {
-    prefetch_args<GfTerminationArgs>();
+// the phase for the 64 envs of workgroup blockIdx.x; lanes = threadIdx.x < 64 (also called from the phase-chain kernels)
+__device__ __forceinline__ void termination_body(const GfTerminationArgs& a, const uint32_t needs) {
     const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
     const bool live = n < a.num_envs;
     const int64_t m = live ? n : 0;  // clamp so every lane can take part in ballots
@@ -59,9 +59,19 @@ __global__ __launch_bounds__(kEnvBlock) void termination_kernel(const GfTerminat
     }
 }
 
+#ifndef GF_BODIES_ONLY
+__global__ __launch_bounds__(kEnvBlock) void termination_kernel(const GfTerminationArgs a, const uint32_t needs) {
+    prefetch_args<GfTerminationArgs>();
+    termination_body(a, needs);
+}
+#endif
+
 }  // namespace gf
 
-extern "C" __attribute__((visibility("default"))) int gf_termination_step(const GfTerminationArgs* a, void* stream) {
+#ifndef GF_BODIES_ONLY
+namespace gf {
+// validation + which inputs the term table needs (shared by the entry point and the phase-chain launcher)
+int termination_prep(const GfTerminationArgs* a, uint32_t* needs_out) {
     if (!a || !a->terminated || !a->truncated) return GF_E_NULL;
     if (a->num_terms < 0 || a->num_terms > GF_MAX_TERM_TERMS || a->num_envs < 0) return GF_E_RANGE;
     uint32_t needs = 0;
@@ -89,6 +99,15 @@ extern "C" __attribute__((visibility("default"))) int gf_termination_step(const 
     if ((needs & gf::NEED_QUAT) && !a->entity.quat) return GF_E_NULL;
     if ((needs & gf::NEED_POS) && !a->entity.pos) return GF_E_NULL;
     if ((needs & gf::NEED_EPLEN) && !a->episode_length) return GF_E_NULL;
+    *needs_out = needs;
+    return GF_OK;
+}
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_termination_step(const GfTerminationArgs* a, void* stream) {
+    uint32_t needs = 0;
+    const int rc = gf::termination_prep(a, &needs);
+    if (rc) return rc;
     if (a->num_envs == 0) return GF_OK;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_TERMINATION, s);
@@ -96,3 +115,4 @@ extern "C" __attribute__((visibility("default"))) int gf_termination_step(const 
     gf::klaunch(gf::termination_kernel, dim3(gf::env_grid(a->num_envs)), dim3(gf::kEnvBlock), 0, s, *a, needs);
     return gf::launch_status();
 }
+#endif

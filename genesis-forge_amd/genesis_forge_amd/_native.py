@@ -85,6 +85,7 @@ GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
  GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_COUNT) = range(13)
 
 GF_OPT_PROFILE_STRIDE = 1  # gf_set_option: stamp every k-th launch of the profiled phase
+GF_OPT_CHAIN = 3           # gf_set_option: 1 (default) = fold runs of per-env phases of a recorded step into phase-chain launches
 GF_OPT_GRAPH = 2           # gf_set_option: 1 = recorded steps replay as one hipGraphLaunch; 0 (default: measured faster) = plain launches
 GF_OPT_POST_VARIANT = 0  # gf_set_option: 0 = interpreter, one wave per tile; 1 = interpreter, four waves; 2 = + static programs (default)
 
@@ -376,6 +377,8 @@ class HipBackend(Backend):
         self.lib.gf_run_ops_graph.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GfOp), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         self.lib.gf_graph_destroy.restype = C.c_int
         self.lib.gf_graph_destroy.argtypes = [C.POINTER(C.c_void_p)]
+        if os.environ.get("GF_NO_CHAIN", "0") == "1":
+            self.lib.gf_set_option(GF_OPT_CHAIN, 0)
         if os.environ.get("GF_GRAPH", "0") == "1":   # opt-in: measured slower than plain launches (gf_step.h, GF_OPT_GRAPH)
             self.lib.gf_set_option(GF_OPT_GRAPH, 1)
         self.lib.gf_stats_pack.restype = C.c_int

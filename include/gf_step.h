@@ -570,7 +570,9 @@ int gf_abi_version(void);
  * MEASURED slower on MI355X / ROCm 7.2 (every node's arguments change every step, so each replay pays one
  * hipGraphExecKernelNodeSetParams per kernel on top of the graph launch): Go2 command config 21.7 vs 18.1 µs/step at 4 096
  * envs, 27.8 vs 24 µs at 65 536; gait config 107 vs 94 µs at 8 192 (profiles/r01_l_graph_vs_plain.jsonl). */
-enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_GRAPH = 2, GF_OPT_COUNT = 4 };
+/* GF_OPT_CHAIN (default 1): gf_run_ops folds runs of per-env phases the fused post-physics kernel does not cover into phase
+ * chains — termination → reward → command.step…, and reset → command.reset… → observe… — one launch each (csrc/gf_chain.hip). */
+enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_GRAPH = 2, GF_OPT_CHAIN = 3, GF_OPT_COUNT = 4 };
 int gf_set_option(int option, int value);
 int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView): binding self-check */
 const char* gf_build_info(void);

@@ -20,6 +20,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def _configs():
     import envs
 
+    # stand-in physics settings: small attitude noise (≈ 0.2 % of the envs fall over per step) and, where a config terminates
+    # on body / torso contact, a contact density that resets ≈ 0.3–0.5 % of the envs per step (an episode of a few hundred
+    # steps) — a scene that reset several per cent of its envs every step would time the reset path, not the step
     sc = dict(ang_noise=0.05, seed=1234)
     con = dict(sc, contact_prob=0.15, contact_force=40.0)
     return {
@@ -28,9 +31,9 @@ def _configs():
         "go2_cmd_65536": (65536, lambda n: envs.Go2CommandDirectionEnv(num_envs=n, scene_kwargs=dict(sc))),
         "contacts": (4096, lambda n: envs.Go2ContactsEnv(num_envs=n, scene_kwargs=dict(con))),
         "rough_terrain": (16384, lambda n: envs.Go2RoughTerrainEnv(num_envs=n, height_reward=False, scene_kwargs=dict(con, max_collision_pairs=30))),
-        "humanoid": (8192, lambda n: envs.BerkeleyHumanoidEnv(num_envs=n, scene_kwargs=dict(con, contact_prob=0.02, max_collision_pairs=30))),
-        "gait": (65536, lambda n: envs.Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(con, contact_prob=0.02))),
-        "gait_8192": (8192, lambda n: envs.Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(con, contact_prob=0.02))),
+        "humanoid": (8192, lambda n: envs.BerkeleyHumanoidEnv(num_envs=n, scene_kwargs=dict(con, contact_prob=0.002, max_collision_pairs=30))),
+        "gait": (65536, lambda n: envs.Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(con, contact_prob=0.001))),
+        "gait_8192": (8192, lambda n: envs.Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(con, contact_prob=0.001))),
     }
 
 
@@ -67,11 +70,12 @@ def main():
             env.step(acts[i % 8])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        _ = dict(env.extras["episode"])
+        log = dict(env.extras["episode"])
         tr = env._trace
         print(json.dumps({"config": name, "num_envs": n, "us_per_step": dt / args.steps * 1e6, "env_steps_per_s": n * args.steps / dt,
                           "recorded": tr is not None, "fused_post": bool(tr is not None and tr.post_refs is not None),
-                          "ops_per_step": tr.n_ops if tr is not None else None}), flush=True)
+                          "ops_per_step": tr.n_ops if tr is not None else None,
+                          "resets_last_step_frac": sum(float(v) for k, v in log.items() if k.startswith("Terminations /"))}), flush=True)
         del env
 
 
