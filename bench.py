@@ -174,12 +174,26 @@ def main():
             rec = json.load(open(pmc_file)).get(str(N))
             if rec and ("Prog" in rec["kernel"]) == ("program 0" not in what):  # counters were taken on this same kernel
                 traffic, traffic_src = rec["traffic_bytes"], "profiles/r01_pmc_traffic.md"
+        # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary of this command (unperturbed by
+        # the event stamping: stamped launches start on a drained queue and run ≈ 2 µs longer)
+        rocprof_avg_us, rocprof_src = None, None
+        import csv
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_N{N}_*kernel_stats.csv")))[::-1]:
+            for row in csv.DictReader(open(path)):
+                if ("post_ws_kernel" in row["Name"] or "post_kernel" in row["Name"]) == fused and \
+                        (("post_" in row["Name"]) if fused else ("reward_kernel" in row["Name"])):
+                    rocprof_avg_us, rocprof_src = float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT)
+                    break
+            if rocprof_avg_us is not None:
+                break
         if prof_n > 0:
             avg_s = prof_ms / prof_n / 1e3
             achieved = bytes_per_launch / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "algorithmic_bytes_per_env": per_env, "avg_launch_us": avg_s * 1e6, "launches": prof_n, "launch_sampling": f"every {max(1, args.profile_stride)}th launch of the timed region",
-                    "algorithmic_bytes_per_launch": bytes_per_launch}
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "rocprof_avg_launch_us": rocprof_avg_us, "rocprof_source": rocprof_src}
         out = {
             "metric": "env-steps/sec", "value": world * N * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
