@@ -239,14 +239,18 @@ class StepStats:
         self.ensure_ring()
 
     def vec_ring_next(self):
-        """(slot index, shard-slot pointer, next shard-slot pointer, vector-row pointer) for this step."""
+        """(slot index, shard-slot pointer, next shard-slot pointer, vector-row pointer, slot this step's action kernel
+        should fold or None) for this step.  The fold slot is only used with reduce_every > 1: the previous step's shards are
+        folded into their vector row by this step's action kernel instead of a pack launch of their own."""
         i = self.ring_pos
         j = (i + 1) % _RING
         old = self._vec_snaps[i]
         if old is not None and old._value is None and (old._work is not None or self.reduce_every <= 1):
             self.materialize_vec_ring()   # an unread, already reduced row is about to be recycled: copy the ring out (local)
         self.ring_pos = j
-        return i, self.ring_ptr(i), self.ring_ptr(j), self.vec_ptr(i)
+        prev = getattr(self, "_fold_slot", None)
+        self._fold_slot = i
+        return i, self.ring_ptr(i), self.ring_ptr(j), self.vec_ptr(i), prev
 
     #: Rows of the vector ring all-reduced per collective.  1 (default): one all-reduce per recorded step, enqueued behind the
     #: step's kernels — reading a log entry is then purely local, any rank may read any step at any time.  K > 1 (must divide
@@ -265,21 +269,33 @@ class StepStats:
             snap = VecRingSnapshot(self, slot, work)
             self._vec_snaps[slot] = snap
             return snap
+        # The rows of the steps already pending were folded by the action kernels of the steps that followed them — the newest of
+        # them by the step that has just been enqueued — so a full batch (or one that would not stay contiguous across the
+        # ring's wrap) can go out now; this step's own row is folded by the next step and joins the next batch.
         snap = VecRingSnapshot(self, slot, None)
         self._vec_snaps[slot] = snap
         pend = getattr(self, "_pending", None)
         if pend is None:
             pend = self._pending = []
-        if pend and pend[-1]._slot + 1 != slot:   # ring wrapped (or slots skipped): close the open batch first
-            self.flush_reduce()
+        if pend and (len(pend) >= self.reduce_every or pend[-1]._slot + 1 != slot):
+            self._reduce_pending()
             pend = self._pending
         pend.append(snap)
-        if len(pend) >= self.reduce_every or slot == _RING - 1:
-            self.flush_reduce()
         return snap
 
     def flush_reduce(self) -> None:
-        """All-reduce the rows of the open batch (COLLECTIVE: every rank must call it at the same step)."""
+        """Close the open batch now (COLLECTIVE: every rank must call it at the same step): the newest pending step has not been
+        followed by another recorded step yet, so its shards are folded explicitly, then every pending row is all-reduced."""
+        pend = getattr(self, "_pending", None)
+        if not pend:
+            return
+        newest = pend[-1]._slot
+        if getattr(self, "_fold_slot", None) == newest:
+            nat.get_backend().stats_pack(self.ring_ptr(newest), self.vec_ptr(newest))
+            self._fold_slot = None   # folded and about to be reduced: the next step must not fold it again
+        self._reduce_pending()
+
+    def _reduce_pending(self) -> None:
         import torch.distributed as dist
 
         pend = getattr(self, "_pending", None)

@@ -72,13 +72,19 @@ class StepTrace:
         for i in range(k - 1):  # drop the leading STATS_CLEAR op: ring slots are zeroed by the previous step's action kernel
             self.ops[i].phase, self.ops[i].args = self.ops[i + 1].phase, self.ops[i + 1].args
         k -= 1
+        #: process group + batched reduction: the previous step's statistics are folded by this step's action kernel (as in the
+        #: single-process ring) instead of a pack launch per step; rows are all-reduced K at a time (StepStats.vec_ring_reduce)
+        self.fold_mode = (not self.use_ring) and stats.reduce_every > 1
         if self.use_ring:
             stats.ensure_ring()
         else:
             stats.ensure_vec_ring()
-            self.pack_args = nat.GfStatsPackArgs()
-            self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_PACK, C.addressof(self.pack_args)
-            k += 1
+            if self.fold_mode:
+                stats._fold_slot = None   # nothing recorded before this trace is waiting for a fold
+            else:
+                self.pack_args = nat.GfStatsPackArgs()
+                self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_PACK, C.addressof(self.pack_args)
+                k += 1
         self.n_ops = k
         #: hipGraph of this step's launches (built by the library on first replay; HIP backend only)
         self.graph = C.c_void_p() if hasattr(self.backend, "run_ops_graph") else None
@@ -191,8 +197,16 @@ class StepTrace:
             aa.stats_fold_src, aa.stats_fold_dst = prev, prev_vec
             aa.stats_last_reset = env.stats.last_reset.data_ptr() if prev is not None else None
         else:
-            slot, cur, nxt, vec = env.stats.vec_ring_next()
-            self.pack_args.src, self.pack_args.dst = cur, vec
+            slot, cur, nxt, vec, fold = env.stats.vec_ring_next()
+            if self.fold_mode:
+                aa = self.action_args
+                if fold is None:
+                    aa.stats_fold_src = aa.stats_fold_dst = None
+                else:
+                    aa.stats_fold_src, aa.stats_fold_dst = env.stats.ring_ptr(fold), env.stats.vec_ptr(fold)
+                aa.stats_last_reset = None
+            else:
+                self.pack_args.src, self.pack_args.dst = cur, vec
         for a in self.stat_fields:
             a.stats = cur
         self.action_args.stats_zero = nxt

@@ -165,6 +165,10 @@ class GenesisEnv:
             rm = getattr(self, "managers", {}).get("reward") if hasattr(self, "managers") else None
             if rm is not None:
                 rm._apply_reset_stats(last)
+        if self._trace is not None and self._stats is not None and self._stats.group is not None and self._stats.reduce_every > 1:
+            # batched logging reduction: close the open batch (its newest row is folded explicitly) before the recorded step goes
+            # away — a collective, like everything that invalidates a recorded step on one rank must happen on all of them
+            self._stats.flush_reduce()
         self._trace = None
         self._trace_epoch += 1
         self._last_signature = None

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "genesis-forge_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every=1, read_lag=0):
+def run_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every=1, read_lag=0, mutate_at=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from genesis_forge_amd import _native as nat
     from genesis_forge_amd import distributed as gfd
@@ -34,6 +34,9 @@ def run_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every=1
     g = torch.Generator().manual_seed(0)
     outs, held = [], []
     for t in range(steps):
+        if mutate_at is not None and t == mutate_at:   # a curriculum step: every rank takes it at the same step
+            env.reward_manager.cfg["action_rate"].weight = -0.5
+            env.velocity_command.range["lin_vel_x"][1] = 3.0
         act = torch.randn(n_global, 12, generator=g)[start:start + count].contiguous()
         o, r, te, tr, ex = env.step(act)
         held.append((o.clone(), r.clone(), te.clone(), tr.clone(), ex["episode"]))

@@ -22,18 +22,19 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("reduce_every,read_lag", [(1, 0), (8, 11)])
-def test_sharded_run_equals_unsharded(oracle_lib_path, reduce_every, read_lag):
-    """reduce_every = 8: the statistics rows of 8 steps travel in one all-reduce; logs read 11 steps late hit closed batches
-    (no extra collective) except at the end of the run, where the read closes the open batch on both ranks."""
+@pytest.mark.parametrize("reduce_every,read_lag,mutate_at", [(1, 0, None), (8, 11, None), (16, 0, 20), (4, 3, 17)])
+def test_sharded_run_equals_unsharded(oracle_lib_path, reduce_every, read_lag, mutate_at):
+    """reduce_every = K > 1: the statistics rows of K steps travel in one all-reduce (folded by the following step's action
+    kernel, no pack launch).  Logs read later than K steps hit closed batches (no extra collective); logs read at once close
+    the open batch on both ranks every step; a curriculum mutation drops and re-records the step on both ranks."""
     n_global, steps, sizes = 70, 40, [33, 37]
     with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
         ctx = mp.get_context("spawn")
-        p = ctx.Process(target=run_shard, args=(0, 1, _free_port(), d1, n_global, steps, [n_global]))
+        p = ctx.Process(target=run_shard, args=(0, 1, _free_port(), d1, n_global, steps, [n_global], 1, 0, mutate_at))
         p.start(); p.join(240)
         assert p.exitcode == 0
         port = _free_port()
-        procs = [ctx.Process(target=run_shard, args=(r, 2, port, d2, n_global, steps, sizes, reduce_every, read_lag)) for r in range(2)]
+        procs = [ctx.Process(target=run_shard, args=(r, 2, port, d2, n_global, steps, sizes, reduce_every, read_lag, mutate_at)) for r in range(2)]
         for q in procs:
             q.start()
         for q in procs:
