@@ -107,10 +107,14 @@ def main():
     from genesis_forge_amd import distributed as gfd
     from genesis_forge_amd import gs
 
-    rank, world = gfd.init_from_env("nccl" if torch.cuda.is_available() else "gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the manager phases only exist as HIP kernels")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU over RCCL ("nccl" on ROCm).  GF_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer
+    # GPUs than ranks (ranks then share devices; RCCL refuses that)
+    dist_backend = os.environ.get("GF_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    os.environ["LOCAL_RANK"] = str(local) if dist_backend != "nccl" else os.environ.get("LOCAL_RANK", "0")
+    rank, world = gfd.init_from_env(dist_backend)
     gs.set_device(f"cuda:{local}")
     backend = nat.get_backend()
 
