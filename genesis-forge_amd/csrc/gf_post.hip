@@ -178,7 +178,8 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
             const float* v0 = uni(a.command[0].command);
             const bool nv = v0 != nullptr;
             const uint32_t w = nv ? (uint32_t)uni(a.command[0].width) : 0u;
-            const GF_GLOBAL float* cp = gsel(nv, v0, e * w);
+            const uint32_t st = nv ? (uint32_t)(uni(a.command[0].stride) ? uni(a.command[0].stride) : uni(a.command[0].width)) : 0u;
+            const GF_GLOBAL float* cp = gsel(nv, v0, e * st);
             rr.cmd0[0] = cp[0]; rr.cmd0[1] = cp[w > 1 ? 1 : 0]; rr.cmd0[2] = cp[w > 2 ? 2 : 0];
         }
         const float dt = uni(a.dt);
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
                             if (j < it.width) row[col + j] = obs_finish(f, owner == 0 ? cmd[0][j] : cmd[1][j], col + j);
                     } else {
                         const GfCommandView cv = a.command[it.i0];
-                        for (int j = 0; j < it.width; ++j) row[col + j] = obs_finish(f, G(cv.command)[n * cv.width + j], col + j);
+                        for (int j = 0; j < it.width; ++j) row[col + j] = obs_finish(f, G(cv.command)[n * cmd_stride(cv) + j], col + j);
                     }
                 } break;
                 case GF_O_ANG_VEL_BODY:
@@ -505,14 +506,18 @@ struct Packer {
         return n_contact++;
     }
     int view_slot(const GfCommandView& v) {
-        if (v.stride && v.stride != v.width) return -1;  // strided rows (the gait manager's state) stay on the phase-by-phase path
         for (int k = 0; k < n_view; ++k)
-            if (a.command[k].command == v.command) return k;
+            if (a.command[k].command == v.command && a.command[k].width == v.width && a.command[k].stride == v.stride) return k;
         if (n_view >= GF_MAX_COMMAND_VIEWS) return -1;
         a.command[n_view] = v;
         a.cmd_of_view[n_view] = -1;
         for (int c = 0; c < a.n_cmd; ++c)
-            if (a.cmds[c].command == v.command) a.cmd_of_view[n_view] = c;
+            if (a.cmds[c].command == v.command) {
+                // a fused command manager's own buffer is dense and travels through registers / LDS: a strided alias of it
+                // (a column view of a resampled command) stays on the phase-by-phase path
+                if (v.stride && v.stride != v.width) return -1;
+                a.cmd_of_view[n_view] = c;
+            }
         return n_view++;
     }
 };

@@ -249,7 +249,8 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             const float* v0 = UNI(a.command[0].command);
             const bool nv = v0 != nullptr;
             const uint32_t w = nv ? (uint32_t)UNI(a.command[0].width) : 0u;
-            const GF_GLOBAL float* cp = gsel(nv, v0, e * w);
+            const uint32_t st = nv ? (uint32_t)(UNI(a.command[0].stride) ? UNI(a.command[0].stride) : UNI(a.command[0].width)) : 0u;
+            const GF_GLOBAL float* cp = gsel(nv, v0, e * st);
             cmd0[0] = cp[0]; cmd0[1] = cp[w > 1 ? 1 : 0]; cmd0[2] = cp[w > 2 ? 2 : 0];
         }
 #pragma unroll
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                                     if (j < it_w) row[col + j] = obs_finish(f, xch[(X_CMD + owner * kPostMaxRanges + j) * kEnvBlock + lane], col + j);
                             } else {
                                 const GfCommandView cv = a.command[it.i0];
-                                for (int j = 0; j < it_w; ++j) row[col + j] = obs_finish(f, G(cv.command)[n * cv.width + j], col + j);
+                                for (int j = 0; j < it_w; ++j) row[col + j] = obs_finish(f, G(cv.command)[n * cmd_stride(cv) + j], col + j);
                             }
                         } break;
                         case GF_O_ANG_VEL_BODY:

@@ -137,7 +137,17 @@ class _Slots:
             t = src.command if hasattr(src, "command") else src
             if t.dim() == 1:
                 t = t.unsqueeze(-1)
-            t = _col(t, n, torch.float32)
+            if isinstance(t, torch.Tensor) and t.dim() == 2 and t.shape[0] == n and t.dtype == torch.float32 and t.device == gs.device \
+                    and (t.shape[1] == 1 or t.stride(1) == 1) and t.stride(0) >= t.shape[1] and t.data_ptr() % 4 == 0:
+                # read in place — also a column / slice VIEW of a wider tensor (examples/simple/environment.py:160,168 pass
+                # `self.target_command[:, :2]` and `[:, 2]`): like the reference, later in-place edits of the base stay visible
+                keep.append(t)
+                args.command[k].command = t.data_ptr()
+                args.command[k].width = t.shape[1]
+                args.command[k].stride = 0 if t.stride(0) == t.shape[1] else t.stride(0)
+                continue
+            t = _col(t, n, torch.float32)   # an exotic layout or dtype: a converted copy, valid for this launch only
+            self.volatile = True
             keep.append(t)
             args.command[k].command = t.data_ptr()
             args.command[k].width = t.shape[1]

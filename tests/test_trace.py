@@ -249,3 +249,42 @@ def test_hipgraph_replay_equals_plain_launches(hip_backend):
     finally:
         hip_backend.set_option(nat.GF_OPT_GRAPH, 0)
     _same(a, b)
+
+
+def _run_simple(dev, trace, n=40, steps=14, edit_at=8):
+    """examples/simple passes VIEWS of env.target_command to its tracking terms (environment.py:160,168); the reference sees
+    later in-place edits of the base tensor, so the recorded step must read the views in place, not a frozen copy."""
+    from envs import Go2SimpleEnv
+
+    env = Go2SimpleEnv(num_envs=n, scene_kwargs=dict(seed=3, ang_noise=0.2))
+    env.trace_enabled = trace
+    env.build()
+    env.seed(1)
+    env.reset()
+    g = torch.Generator().manual_seed(0)
+    out = []
+    for t in range(steps):
+        if t == edit_at:
+            env.target_command[:, 0] = 2.0
+            env.target_command[:, 2] = -0.7
+        o, r, *_ = env.step(torch.randn(n, 12, generator=g).to(dev))
+        out.append((o.cpu().clone(), r.cpu().clone()))
+    return out, env
+
+
+def test_recorded_step_reads_command_views_in_place_cpu(oracle_backend):
+    a, _ = _run_simple("cpu", False)
+    b, env = _run_simple("cpu", True)
+    assert env._trace is not None
+    for t, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), f"step {t}"
+    assert not torch.equal(a[7][1], a[9][1])
+
+
+@pytest.mark.gpu
+def test_recorded_step_reads_command_views_in_place_hip(hip_backend):
+    a, _ = _run_simple("cuda", False, n=1000)
+    b, env = _run_simple("cuda", True, n=1000)
+    assert env._trace is not None and env._trace.post_refs is not None, "the simple config should still fuse (strided views are read in place)"
+    for t, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), f"step {t}"
