@@ -98,3 +98,55 @@ def test_restated_config_hip(hip_backend, name):
     env = envs.make_example(name, case)
     res = helpers.replay_example(fix, case, env, "cuda")
     helpers.compare_example(fix, res)
+
+
+def _philox_run(name, dev, trace, n, steps=45):
+    """The restated config in Philox mode (no parity draws, so the step can be recorded and fused)."""
+    import envs
+
+    case = dict(example_cases.CASES[name], n=n, episode_s=1.0)
+    env = envs.make_example(name, case) if name != "gait_trainer" else envs.Go2GaitTrainingEnv(
+        num_envs=n, max_episode_length_s=1.0, scene_kwargs=dict(case["scene"]))
+    env.trace_enabled = trace
+    env.build()
+    env.seed(17)
+    for attr, sec in case["resample"].items():
+        getattr(env, attr).resample_time_sec = sec
+    env.reset()
+    g = torch.Generator().manual_seed(5)
+    d = env.action_space.shape[0]
+    out = []
+    for _ in range(steps):
+        o, r, te, tr, ex = env.step(torch.randn(n, d, generator=g).to(dev))
+        others = [v.cpu().clone() for k, v in ex["observations"].items() if k != "policy"]
+        out.append(([o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone()] + others,
+                    {k: float(v) for k, v in ex["episode"].items()}))
+    return out, env
+
+
+def _same_runs(a, b):
+    for t, ((x, lx), (y, ly)) in enumerate(zip(a, b)):
+        assert len(x) == len(y)
+        for k, (u, v) in enumerate(zip(x, y)):
+            assert torch.equal(u, v), f"output {k} differs at step {t}"
+        assert lx == ly, f"log differs at step {t}: {lx} vs {ly}"
+
+
+@pytest.mark.parametrize("name", EXAMPLES)
+def test_recorded_step_equals_ordinary_cpu(oracle_backend, name):
+    a, _ = _philox_run(name, "cpu", False, 70)
+    b, env = _philox_run(name, "cpu", True, 70)
+    assert env._trace is not None, "the config's step should be recorded"
+    _same_runs(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", EXAMPLES)
+def test_recorded_step_equals_ordinary_hip(hip_backend, name):
+    """Recorded + fused (or chained) launches vs the phase-by-phase path, bit for bit, for every shipped task structure."""
+    a, _ = _philox_run(name, "cuda", False, 1000)
+    b, env = _philox_run(name, "cuda", True, 1000)
+    assert env._trace is not None, "the config's step should be recorded"
+    if name != "gait_trainer":
+        assert env._trace.post_refs is not None, "the post-physics phases of this config should run as the fused launch"
+    _same_runs(a, b)
