@@ -163,6 +163,7 @@ class CommandManager(BaseManager):
         def patch(_actions, a=args, env=env, self=self):
             for i, r in enumerate(self._ranges()):
                 a.lo[i], a.hi[i] = float(r[0]), float(r[1])
+            a.resample_steps = self._resample_steps   # `resample_time_sec` is a live property (command_manager.py:121-130)
             a.stream = env.next_stream()
 
         return patch

@@ -288,3 +288,28 @@ def test_recorded_step_reads_command_views_in_place_hip(hip_backend):
     assert env._trace is not None and env._trace.post_refs is not None, "the simple config should still fuse (strided views are read in place)"
     for t, (x, y) in enumerate(zip(a, b)):
         assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), f"step {t}"
+
+
+def test_recorded_step_follows_resample_time_changes(oracle_backend):
+    """`CommandManager.resample_time_sec` is a settable property in the reference (command_manager.py:121-130): changing it
+    in the middle of a run must reach the recorded step."""
+    def run(trace):
+        env = Go2CommandDirectionEnv(num_envs=48, max_episode_length_s=20, cmd_resample_s=5.0, scene_kwargs=dict(seed=3))
+        env.trace_enabled = trace
+        env.build()
+        env.seed(2)
+        env.reset()
+        cmds = []
+        for t in range(30):
+            if t == 10:
+                env.velocity_command.resample_time_sec = 0.1   # every 5 steps from now on
+            env.step(torch.zeros(48, 12))
+            cmds.append(env.velocity_command._command.clone())
+        return cmds, env
+
+    a, _ = run(False)
+    b, env = run(True)
+    assert env._trace is not None
+    assert any(not torch.equal(a[t], a[t + 1]) for t in range(12, 29)), "the shorter period should resample within the run"
+    for t, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), f"commands differ at step {t}"
