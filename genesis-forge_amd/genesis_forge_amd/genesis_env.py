@@ -151,6 +151,7 @@ class GenesisEnv:
         """genesis_env.py:153-165"""
         self._max_episode_length_sec = max_episode_length_sec
         self._base_max_episode_length = math.ceil(max_episode_length_sec / self.dt)
+        self.invalidate_trace()   # the reset descriptor of a recorded step carries the base length
         return self._base_max_episode_length
 
     def seed(self, seed: int) -> None:
@@ -160,6 +161,8 @@ class GenesisEnv:
 
     def invalidate_trace(self) -> None:
         """Drop the recorded step (something its frozen descriptors depend on has changed)."""
+        if not hasattr(self, "_trace_epoch"):
+            return  # still inside __init__: nothing has been recorded
         if self._trace is not None and self._stats is not None and getattr(self._stats, "ring", None) is not None and self._stats.group is None:
             last = self._stats.end_recording()
             rm = getattr(self, "managers", {}).get("reward") if hasattr(self, "managers") else None

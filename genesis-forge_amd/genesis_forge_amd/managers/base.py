@@ -6,6 +6,24 @@ from typing import Literal
 ManagerType = Literal["action", "reward", "termination", "contact", "terrain", "entity", "command", "observation"]
 
 
+class LiveAttr:
+    """A manager attribute that the reference reads afresh on every step (``self.noise``, ``self.logging_enabled`` …):
+    assigning it marks the manager's compiled tables dirty and drops the recorded step."""
+
+    def __init__(self, name: str):
+        self.slot = "_live_" + name
+
+    def __get__(self, obj, owner=None):
+        return self if obj is None else getattr(obj, self.slot)
+
+    def __set__(self, obj, value):
+        had = hasattr(obj, self.slot)
+        old = getattr(obj, self.slot, None)
+        setattr(obj, self.slot, value)
+        if had and old != value:
+            obj._live_attr_changed()
+
+
 class BaseManager:
     """The base class used to define the interface for all other managers (base.py:16-43)."""
 
@@ -39,6 +57,16 @@ class BaseManager:
     #: managers whose ``reset`` can be expressed as a section of ``gf_masked_reset`` set this to True and
     #: implement ``_fill_reset``; everything else gets ``reset(envs_idx)`` with a compacted index list.
     _fused_reset = False
+
+    def _live_attr_changed(self) -> None:
+        """A plain attribute the reference re-reads on every call was assigned: whatever was compiled from it is stale."""
+        if hasattr(self, "_mark_dirty"):
+            self._mark_dirty()
+        elif hasattr(self, "_dirty"):
+            self._dirty = True
+        env = getattr(self, "env", None)
+        if env is not None and hasattr(env, "invalidate_trace"):
+            env.invalidate_trace()
 
     def _fill_reset(self, args) -> None:
         pass

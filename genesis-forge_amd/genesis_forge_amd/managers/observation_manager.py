@@ -23,7 +23,7 @@ from .. import _native as nat
 from .. import gs
 from ..spaces import Box
 from ._program import _Slots, _col
-from .base import BaseManager
+from .base import BaseManager, LiveAttr
 from .config import ObservationConfigItem
 
 
@@ -45,6 +45,8 @@ _OBS_RING = 3  # returned tensors stay valid for two further calls (rollout stor
 
 
 class ObservationManager(BaseManager):
+    noise = LiveAttr("noise")   # manager-wide noise, read per step in the reference (observation_manager.py:246-250)
+
     """Generates an observation tensor from a dict of items (ctor as observation_manager.py:134-156)."""
 
     def __init__(self, env, cfg: dict[str, ObservationConfig], name: str = "policy", history_len: int | None = None,

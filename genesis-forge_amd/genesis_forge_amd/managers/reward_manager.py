@@ -17,7 +17,7 @@ from .. import _native as nat
 from .. import gs
 from .._stats import RingSnapshot
 from ._program import RewardProgram, spec_of
-from .base import BaseManager
+from .base import BaseManager, LiveAttr
 from .config import RewardConfigItem
 
 
@@ -28,6 +28,8 @@ class RewardConfig(TypedDict):
 
 
 class RewardManager(BaseManager):
+    logging_enabled = LiveAttr("logging_enabled")   # checked on every step / reset in the reference (reward_manager.py:191,200)
+
     """Calculates and logs the rewards (ctor as reward_manager.py:89-118)."""
 
     _fused_reset = True

@@ -15,7 +15,7 @@ import torch
 from .. import _native as nat
 from .. import gs
 from ._program import TerminationProgram, spec_of
-from .base import BaseManager
+from .base import BaseManager, LiveAttr
 from .config import TerminationConfigItem
 
 
@@ -26,6 +26,8 @@ class TerminationConfig(TypedDict):
 
 
 class TerminationManager(BaseManager):
+    logging_enabled = LiveAttr("logging_enabled")   # checked on every step in the reference (termination_manager.py:176)
+
     """Calculates termination / truncation signals (ctor as termination_manager.py:96-118)."""
 
     def __init__(self, env, term_cfg: dict[str, TerminationConfig], logging_enabled: bool = True, logging_tag: str = "Terminations"):

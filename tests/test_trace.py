@@ -313,3 +313,35 @@ def test_recorded_step_follows_resample_time_changes(oracle_backend):
     assert any(not torch.equal(a[t], a[t + 1]) for t in range(12, 29)), "the shorter period should resample within the run"
     for t, (x, y) in enumerate(zip(a, b)):
         assert torch.equal(x, y), f"commands differ at step {t}"
+
+
+def test_recorded_step_follows_live_manager_attributes(oracle_backend):
+    """Attributes the reference re-reads every step — ObservationManager.noise, RewardManager.logging_enabled,
+    env.set_max_episode_length() — must reach a recorded step when they are assigned in the middle of a run."""
+    def run(trace):
+        env = Go2CommandDirectionEnv(num_envs=40, max_episode_length_s=1, cmd_resample_s=0.3, scene_kwargs=dict(seed=4, ang_noise=0.3))
+        env.trace_enabled = trace
+        env.build()
+        env.seed(6)
+        env.reset()
+        g = torch.Generator().manual_seed(0)
+        out = []
+        for t in range(36):
+            if t == 10:
+                env.observation_manager.noise = 0.05
+            if t == 16:
+                env.reward_manager.logging_enabled = False
+            if t == 22:
+                env.set_max_episode_length(0.4)
+            o, r, te, tr, ex = env.step(torch.randn(40, 12, generator=g))
+            out.append((o.clone(), r.clone(), te.clone(), tr.clone(), env.max_episode_length.clone(), {k: float(v) for k, v in ex["episode"].items()}))
+        return out, env
+
+    a, _ = run(False)
+    b, env = run(True)
+    assert env._trace is not None
+    for t, (x, y) in enumerate(zip(a, b)):
+        for k in range(5):
+            assert torch.equal(x[k], y[k]), f"output {k} differs at step {t}"
+        assert x[5] == y[5], f"log differs at step {t}"
+    assert not any(k.startswith("Rewards /") for k in a[-1][5]) and int(a[-1][4].min()) < 30
