@@ -163,7 +163,7 @@ class StepStats:
 
     # -- device ring used by recorded steps -------------------------------------------------------------
     # A recorded step writes its statistics into slot (step % _RING) of a device-resident ring of shard blocks.  Its
-    # action kernel zeroes the next slot and folds the PREVIOUS slot into a 45-entry f64 row of ``vec_ring`` (and into
+    # action kernel zeroes the next slot and folds the PREVIOUS slot into a 49-entry f64 row of ``vec_ring`` (and into
     # ``last_reset`` when that step reset something), so a step carries neither a memset, nor a pack launch, nor a
     # device→host copy — together those cost as much stream time as all the kernels of a step.  Rows are copied out,
     # 23 KB in one batch, only when a log entry is actually read or just before an unread slot is recycled.
