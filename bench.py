@@ -87,7 +87,39 @@ def cpu_baseline(num_envs: int, budget_s: float = 12.0) -> dict:
                       f"{os.cpu_count()} host cores present"}
 
 
+def cpu_baseline_multicore(num_envs: int, workers: int, budget_s: float = 8.0) -> dict | None:
+    """The same port on `workers` host cores: the path shards by env, so each worker process steps its own shard of
+    num_envs / workers envs with the single-threaded oracle (no GPU in the workers); the figure is the sum."""
+    import subprocess
+
+    shard = max(1, num_envs // workers)
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(shard), str(budget_s)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(workers)]
+    total, ok = 0.0, 0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=budget_s * 4 + 120)
+            total += float(out.strip().splitlines()[-1])
+            ok += 1
+        except Exception:
+            p.kill()
+    if ok != workers:
+        return None
+    return {"value": total, "unit": "env-steps/s", "cores": workers,
+            "sample": f"{workers} worker processes x {shard} envs each, ~{budget_s:.0f} s, oracle single-threaded per worker"}
+
+
+def cpu_worker(shard: int, budget_s: float) -> None:
+    import torch
+
+    torch.set_num_threads(1)
+    print(cpu_baseline(shard, budget_s)["value"], flush=True)
+
+
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(int(sys.argv[2]), float(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -210,6 +242,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N)
+            workers = min(16, os.cpu_count() or 1)   # the GPU box gives one GPU's share of the host: 16 cores
+            if workers > 1:
+                multi = cpu_baseline_multicore(N, workers)
+                if multi is not None:
+                    out["cpu_baseline"]["multicore"] = multi
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
