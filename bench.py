@@ -93,7 +93,9 @@ def cpu_baseline_multicore(num_envs: int, workers: int, budget_s: float = 8.0) -
     import subprocess
 
     shard = max(1, num_envs // workers)
-    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    # GF_DEVICE=cpu: the workers never call torch.cuda.is_available() (which opens the GPU; the box allows few processes on it)
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", GF_DEVICE="cpu", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
+               CUDA_VISIBLE_DEVICES="")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(shard), str(budget_s)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(workers)]
     total, ok = 0.0, 0

@@ -29,6 +29,9 @@ class JOINT_TYPE(enum.IntEnum):
 
 
 def _default_device() -> torch.device:
+    forced = os.environ.get("GF_DEVICE")   # e.g. "cpu": host-only helper processes must not even probe (= open) the GPU
+    if forced:
+        return torch.device(forced)
     if torch.cuda.is_available():
         return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     return torch.device("cpu")
