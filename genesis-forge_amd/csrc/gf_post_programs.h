@@ -39,6 +39,115 @@ struct ProgGo2CommandDirection {
     static constexpr int n_air = 0;
 };
 
+
+// examples/simple (Go2): static target command passed as tensor views (no command manager), observation scales, O = 45
+struct ProgGo2Simple {
+    static constexpr bool kStatic = true;
+    static constexpr const char* name = "go2_simple";
+    static constexpr int DV = 3;
+    static constexpr int n_term = 2;
+    static constexpr TermSig term[n_term] = {{GF_T_TIMEOUT, GF_TERM_FLAG_TIME_OUT}, {GF_T_BAD_ORIENTATION, 0}};
+    static constexpr int n_rew = 6;
+    static constexpr RewSig rew[n_rew] = {{GF_R_BASE_HEIGHT, 0, 0, 0}, {GF_R_CMD_TRACK_LIN_VEL, 0, 0, 0}, {GF_R_CMD_TRACK_ANG_VEL, 0, 1, 0},
+                                          {GF_R_LIN_VEL_Z_L2, 0, 0, 0}, {GF_R_ACTION_RATE_L2, 0, 0, 0}, {GF_R_DOF_SIMILAR_TO_DEFAULT, 0, 0, 0}};
+    static constexpr int n_cmd = 0;
+    static constexpr int cmd_width[GF_POST_MAX_CMD] = {0, 0};
+    static constexpr int n_obs = 1;
+    static constexpr int obs_width[GF_POST_MAX_OBS] = {45, 0};
+    static constexpr int obs_history[GF_POST_MAX_OBS] = {1, 0};
+    static constexpr int obs_items[GF_POST_MAX_OBS] = {6, 0};
+    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {{{GF_O_ANG_VEL_BODY, 3, 0, true, false},
+                                                                      {GF_O_LIN_VEL_BODY, 3, 0, true, false},
+                                                                      {GF_O_PROJ_GRAVITY, 3, 0, false, false},
+                                                                      {GF_O_DOF_POS, 12, 0, false, false},
+                                                                      {GF_O_DOF_VEL, 12, 0, true, false},
+                                                                      {GF_O_ACTIONS, 12, 0, false, false}},
+                                                                     {}};
+    static constexpr int n_air = 0;
+};
+
+// examples/contacts (Go2): feet_air_time on the calves (one air-time ContactManager), flat orientation
+struct ProgGo2Contacts {
+    static constexpr bool kStatic = true;
+    static constexpr const char* name = "go2_contacts";
+    static constexpr int DV = 3;
+    static constexpr int n_term = 2;
+    static constexpr TermSig term[n_term] = {{GF_T_TIMEOUT, GF_TERM_FLAG_TIME_OUT}, {GF_T_BAD_ORIENTATION, 0}};
+    static constexpr int n_rew = 8;
+    static constexpr RewSig rew[n_rew] = {{GF_R_FEET_AIR_TIME, 0, 0, 0}, {GF_R_CMD_TRACK_LIN_VEL, 0, 0, 0}, {GF_R_CMD_TRACK_ANG_VEL, 0, 0, 2}, {GF_R_LIN_VEL_Z_L2, 0, 0, 0},
+                                          {GF_R_ANG_VEL_XY_L2, 0, 0, 0}, {GF_R_ACTION_RATE_L2, 0, 0, 0}, {GF_R_DOF_SIMILAR_TO_DEFAULT, 0, 0, 0}, {GF_R_FLAT_ORIENTATION_L2, 0, 0, 0}};
+    static constexpr int n_cmd = 1;
+    static constexpr int cmd_width[GF_POST_MAX_CMD] = {3, 0};
+    static constexpr int n_obs = 1;
+    static constexpr int obs_width[GF_POST_MAX_OBS] = {48, 0};
+    static constexpr int obs_history[GF_POST_MAX_OBS] = {1, 0};
+    static constexpr int obs_items[GF_POST_MAX_OBS] = {7, 0};
+    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {{{GF_O_COMMAND, 3, 0, false, false},
+                                                                      {GF_O_ANG_VEL_BODY, 3, 0, false, false},
+                                                                      {GF_O_LIN_VEL_BODY, 3, 0, false, false},
+                                                                      {GF_O_PROJ_GRAVITY, 3, 0, false, false},
+                                                                      {GF_O_DOF_POS, 12, 0, false, false},
+                                                                      {GF_O_DOF_VEL, 12, 0, true, false},
+                                                                      {GF_O_ACTIONS, 12, 0, false, false}},
+                                                                     {}};
+    static constexpr int n_air = 1;
+};
+
+// examples/rough_terrain (Go2, BASELINE config 3): out_of_bounds, undesired contacts, terminated penalty, terrain spawn on reset
+struct ProgGo2RoughTerrain {
+    static constexpr bool kStatic = true;
+    static constexpr const char* name = "go2_rough_terrain";
+    static constexpr int DV = 3;
+    static constexpr int n_term = 3;
+    static constexpr TermSig term[n_term] = {{GF_T_TIMEOUT, GF_TERM_FLAG_TIME_OUT}, {GF_T_OUT_OF_BOUNDS, 0}, {GF_T_BAD_ORIENTATION, 0}};
+    static constexpr int n_rew = 9;
+    static constexpr RewSig rew[n_rew] = {{GF_R_CMD_TRACK_LIN_VEL, 0, 0, 0}, {GF_R_CMD_TRACK_ANG_VEL, 0, 0, 2}, {GF_R_LIN_VEL_Z_L2, 0, 0, 0}, {GF_R_ANG_VEL_XY_L2, 0, 0, 0},
+                                          {GF_R_HAS_CONTACT, 0, 0, 1}, {GF_R_ACTION_RATE_L2, 0, 0, 0}, {GF_R_DOF_SIMILAR_TO_DEFAULT, 0, 0, 0},
+                                          {GF_R_FLAT_ORIENTATION_L2, 0, 0, 0}, {GF_R_TERMINATED, 0, 0, 0}};
+    static constexpr int n_cmd = 1;
+    static constexpr int cmd_width[GF_POST_MAX_CMD] = {3, 0};
+    static constexpr int n_obs = 1;
+    static constexpr int obs_width[GF_POST_MAX_OBS] = {48, 0};
+    static constexpr int obs_history[GF_POST_MAX_OBS] = {1, 0};
+    static constexpr int obs_items[GF_POST_MAX_OBS] = {7, 0};
+    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {{{GF_O_COMMAND, 3, 0, false, false},
+                                                                      {GF_O_ANG_VEL_BODY, 3, 0, false, false},
+                                                                      {GF_O_LIN_VEL_BODY, 3, 0, false, false},
+                                                                      {GF_O_PROJ_GRAVITY, 3, 0, false, false},
+                                                                      {GF_O_DOF_POS, 12, 0, false, false},
+                                                                      {GF_O_DOF_VEL, 12, 0, true, false},
+                                                                      {GF_O_ACTIONS, 12, 0, false, false}},
+                                                                     {}};
+    static constexpr int n_air = 1;
+};
+
+// examples/berkeley_humanoid (12 actuated joints, BASELINE config 4): torso contact termination, clamped feet_air_time
+struct ProgBerkeleyHumanoid {
+    static constexpr bool kStatic = true;
+    static constexpr const char* name = "berkeley_humanoid";
+    static constexpr int DV = 3;
+    static constexpr int n_term = 2;
+    static constexpr TermSig term[n_term] = {{GF_T_TIMEOUT, GF_TERM_FLAG_TIME_OUT}, {GF_T_CONTACT_FORCE, 0}};
+    static constexpr int n_rew = 7;
+    static constexpr RewSig rew[n_rew] = {{GF_R_CMD_TRACK_LIN_VEL, 0, 0, 0}, {GF_R_CMD_TRACK_ANG_VEL, 0, 0, 2}, {GF_R_LIN_VEL_Z_L2, 0, 0, 0}, {GF_R_ANG_VEL_XY_L2, 0, 0, 0},
+                                          {GF_R_ACTION_RATE_L2, 0, 0, 0}, {GF_R_DOF_SIMILAR_TO_DEFAULT, 0, 0, 0}, {GF_R_FEET_AIR_TIME, GF_RW_FLAG_MAX, 1, 0}};
+    static constexpr int n_cmd = 1;
+    static constexpr int cmd_width[GF_POST_MAX_CMD] = {3, 0};
+    static constexpr int n_obs = 1;
+    static constexpr int obs_width[GF_POST_MAX_OBS] = {48, 0};
+    static constexpr int obs_history[GF_POST_MAX_OBS] = {1, 0};
+    static constexpr int obs_items[GF_POST_MAX_OBS] = {7, 0};
+    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {{{GF_O_COMMAND, 3, 0, false, false},
+                                                                      {GF_O_ANG_VEL_BODY, 3, 0, false, false},
+                                                                      {GF_O_LIN_VEL_BODY, 3, 0, false, false},
+                                                                      {GF_O_PROJ_GRAVITY, 3, 0, false, false},
+                                                                      {GF_O_DOF_POS, 12, 0, false, false},
+                                                                      {GF_O_DOF_VEL, 12, 0, true, false},
+                                                                      {GF_O_ACTIONS, 12, 0, false, false}},
+                                                                     {}};
+    static constexpr int n_air = 1;
+};
+
 // ---- matching -------------------------------------------------------------------------------------------------------------------
 template <class P>
 bool program_matches(const GfPostArgs& a) {
