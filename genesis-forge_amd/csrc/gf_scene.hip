@@ -109,9 +109,9 @@ __global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSce
 
 // Per-link outputs (orientation, velocity, position of every scene link), one lane per (env, link): the base state the main
 // kernel just wrote is read back (stream order), so consecutive lanes write consecutive floats instead of one lane walking NL rows.
-__global__ __launch_bounds__(256) void synth_links_kernel(const GfSynthSceneArgs a) {
+__device__ __forceinline__ void synth_links_body(const GfSynthSceneArgs& a, const int64_t block) {
     const int NL = a.num_scene_links;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t gid = block * 256 + threadIdx.x;
     if (gid >= (int64_t)a.num_envs * NL) return;
     const int64_t n = gid / NL;
     const int l = (int)(gid - n * NL);
@@ -134,9 +134,9 @@ __global__ __launch_bounds__(256) void synth_links_kernel(const GfSynthSceneArgs
 }
 
 // Sampled contacts, one lane per (env, contact slot): two Philox blocks per slot, 32 B of output per lane, coalesced.
-__global__ __launch_bounds__(256) void synth_contacts_kernel(const GfSynthSceneArgs a) {
+__device__ __forceinline__ void synth_contacts_body(const GfSynthSceneArgs& a, const int64_t block) {
     const int C = a.num_contacts, NL = a.num_scene_links;
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t k = block * 256 + threadIdx.x;
     if (k >= (int64_t)a.num_envs * C) return;
     const int64_t n = k / C;
     const int c = (int)(k - n * C);
@@ -159,6 +159,12 @@ __global__ __launch_bounds__(256) void synth_contacts_kernel(const GfSynthSceneA
     a.contact_pos_out[k * 3 + 0] = active ? p0 + fx * 0.2f : 0.0f;
     a.contact_pos_out[k * 3 + 1] = active ? p1 + fy * 0.2f : 0.0f;
     a.contact_pos_out[k * 3 + 2] = 0.0f;
+}
+
+// one launch for both per-(env, link) and per-(env, slot) outputs: the first `link_blocks` workgroups do the links
+__global__ __launch_bounds__(256) void synth_derived_kernel(const GfSynthSceneArgs a, const uint32_t link_blocks) {
+    if (blockIdx.x < link_blocks) synth_links_body(a, (int64_t)blockIdx.x);
+    else synth_contacts_body(a, (int64_t)(blockIdx.x - link_blocks));
 }
 
 }  // namespace gf
@@ -193,9 +199,10 @@ extern "C" __attribute__((visibility("default"))) int gf_synth_scene_step(const 
     if (rows16 && a->num_dofs == 12) gf::klaunch(gf::synth_scene_kernel<3>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
     else if (rows16 && a->num_dofs == 28) gf::klaunch(gf::synth_scene_kernel<7>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
     else gf::klaunch(gf::synth_scene_kernel<0>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
-    if ((a->links_quat_out || a->links_vel_out || a->links_pos_out) && a->num_scene_links > 0)
-        gf::klaunch(gf::synth_links_kernel, dim3(gf::env_grid((int64_t)a->num_envs * a->num_scene_links, 256)), dim3(256), 0, s, *a);
-    if (a->num_contacts > 0 && a->contact_force_out)
-        gf::klaunch(gf::synth_contacts_kernel, dim3(gf::env_grid((int64_t)a->num_envs * a->num_contacts, 256)), dim3(256), 0, s, *a);
+    const bool links = (a->links_quat_out || a->links_vel_out || a->links_pos_out) && a->num_scene_links > 0;
+    const bool contacts = a->num_contacts > 0 && a->contact_force_out;
+    const unsigned lb = links ? gf::env_grid((int64_t)a->num_envs * a->num_scene_links, 256) : 0u;
+    const unsigned cb = contacts ? gf::env_grid((int64_t)a->num_envs * a->num_contacts, 256) : 0u;
+    if (lb + cb > 0) gf::klaunch(gf::synth_derived_kernel, dim3(lb + cb), dim3(256), 0, s, *a, lb);
     return gf::launch_status();
 }
