@@ -202,3 +202,50 @@ def test_reference_fixture_cpu_oracle(oracle_backend, what):
 @pytest.mark.parametrize("what", list(CHECKS))
 def test_reference_fixture_hip(hip_backend, what):
     CHECKS[what]("cuda")
+
+
+def _check_entity_obs(dev):
+    """utils.entity_*, EntityManager getters and every mdp.observations getter against outputs recorded from the reference
+    (tests/golden/entity_obs.npz; a third of the quaternions are not unit length)."""
+    from genesis_forge_amd import utils
+    from genesis_forge_amd.mdp import observations
+
+    fix = helpers.load("entity_obs")
+    n = fix["in_pos"].shape[0]
+    env = Go2CommandDirectionEnv(num_envs=n, contacts=True)
+    env.build()
+    _load_state(env, fix, "in_", dev)
+    env.robot.dof_force[:] = _t(fix["in_dof_force"], dev)
+    for em in env.managers["entity"]:
+        em.step()
+    env.action_manager._actions[:] = _t(fix["in_targets"], dev)
+    em, am, foot = env.robot_manager, env.action_manager, env.foot_contacts
+    got = {
+        "utils_lin_vel": utils.entity_lin_vel(env.robot), "utils_ang_vel": utils.entity_ang_vel(env.robot),
+        "utils_projected_gravity": utils.entity_projected_gravity(env.robot),
+        "em_lin_vel": em.get_linear_velocity(), "em_ang_vel": em.get_angular_velocity(), "em_projected_gravity": em.get_projected_gravity(),
+        "obs_lin_vel_mgr": observations.entity_linear_velocity(env, entity_manager=em),
+        "obs_lin_vel_attr": observations.entity_linear_velocity(env, entity_attr="robot"),
+        "obs_ang_vel_mgr": observations.entity_angular_velocity(env, entity_manager=em),
+        "obs_ang_vel_attr": observations.entity_angular_velocity(env, entity_attr="robot"),
+        "obs_projected_gravity_mgr": observations.entity_projected_gravity(env, entity_manager=em),
+        "obs_dofs_position_mgr": observations.entity_dofs_position(env, action_manager=am),
+        "obs_dofs_position_idx": observations.entity_dofs_position(env, dofs_idx=[7, 9, 12]),
+        "obs_dofs_velocity_mgr": observations.entity_dofs_velocity(env, action_manager=am),
+        "obs_dofs_velocity_idx": observations.entity_dofs_velocity(env, dofs_idx=[6, 17]),
+        "obs_dofs_force_mgr": observations.entity_dofs_force(env, action_manager=am),
+        "obs_dofs_force_idx": observations.entity_dofs_force(env, dofs_idx=[8, 10]),
+        "obs_current_actions_mgr": observations.current_actions(env, action_manager=am),
+        "obs_contact_force": observations.contact_force(env, contact_manager=foot),
+    }
+    for k, v in got.items():
+        np.testing.assert_allclose(v.cpu().numpy(), fix["out_" + k], atol=helpers.FLOAT_TOL, rtol=0, err_msg=k)
+
+
+def test_entity_and_observation_getters_cpu_oracle(oracle_backend):
+    _check_entity_obs("cpu")
+
+
+@pytest.mark.gpu
+def test_entity_and_observation_getters_hip(hip_backend):
+    _check_entity_obs("cuda")

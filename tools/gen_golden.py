@@ -605,6 +605,51 @@ def gen_air_time():
     print("air_time: ok")
 
 
+def gen_entity_obs():
+    """utils.entity_* (utils.py:13-55), EntityManager getters (entity_manager.py:130-146,189-195) and every mdp.observations
+    getter (observations.py:16-193) on a random state whose quaternions are deliberately NOT all unit length."""
+    from genesis_forge import utils as rutils
+
+    n = 97
+    env = RefGo2Env(n, contacts=True, obs_noise=False)
+    env.build()
+    rng = np.random.RandomState(31)
+    random_state(env, rng, n)
+    q = env.robot.quat.clone()
+    q[::3] *= torch.from_numpy(rng.uniform(0.9, 1.1, (len(q[::3]), 1)).astype(np.float32))   # non-unit rows
+    env.robot.quat[:] = q
+    env.robot.dof_force[:] = torch.from_numpy((30.0 * rng.standard_normal((n, 12))).astype(np.float32))
+    for em in env.managers["entity"]:
+        em.step()
+    env.action_manager.step(torch.from_numpy(rng.standard_normal((n, 12)).astype(np.float32)))
+    em, am, foot = env.robot_manager, env.action_manager, env.foot_contacts
+    out = {"in_" + k: v for k, v in state_dict(env).items()}
+    out["in_dof_force"] = env.robot.dof_force.numpy().copy()
+    out["in_targets"] = am.get_actions().numpy().copy()
+    O = {
+        "utils_lin_vel": rutils.entity_lin_vel(env.robot), "utils_ang_vel": rutils.entity_ang_vel(env.robot),
+        "utils_projected_gravity": rutils.entity_projected_gravity(env.robot),
+        "em_lin_vel": em.get_linear_velocity(), "em_ang_vel": em.get_angular_velocity(), "em_projected_gravity": em.get_projected_gravity(),
+        "obs_lin_vel_mgr": observations.entity_linear_velocity(env, entity_manager=em),
+        "obs_lin_vel_attr": observations.entity_linear_velocity(env, entity_attr="robot"),
+        "obs_ang_vel_mgr": observations.entity_angular_velocity(env, entity_manager=em),
+        "obs_ang_vel_attr": observations.entity_angular_velocity(env, entity_attr="robot"),
+        "obs_projected_gravity_mgr": observations.entity_projected_gravity(env, entity_manager=em),
+        "obs_dofs_position_mgr": observations.entity_dofs_position(env, action_manager=am),
+        "obs_dofs_position_idx": observations.entity_dofs_position(env, dofs_idx=[7, 9, 12]),
+        "obs_dofs_velocity_mgr": observations.entity_dofs_velocity(env, action_manager=am),
+        "obs_dofs_velocity_idx": observations.entity_dofs_velocity(env, dofs_idx=[6, 17]),
+        "obs_dofs_force_mgr": observations.entity_dofs_force(env, action_manager=am),
+        "obs_dofs_force_idx": observations.entity_dofs_force(env, dofs_idx=[8, 10]),
+        "obs_current_actions_mgr": observations.current_actions(env, action_manager=am),
+        "obs_contact_force": observations.contact_force(env, contact_manager=foot),
+    }
+    for k, v in O.items():
+        out["out_" + k] = v.detach().numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "entity_obs.npz"), **out)
+    print("entity_obs:", len(O), "outputs")
+
+
 CONTACT_CASES = [  # ContactManager ctor kwargs of the contact-kernel fixture (tests/test_contact_kernel.py builds the same three)
     dict(link_names=[".*_foot"], track_air_time=True, air_time_contact_threshold=3.0),
     dict(link_names=[".*_thigh", "base"], with_entity_attr="terrain"),
@@ -818,6 +863,9 @@ def run_example(name):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "entity_obs":
+        gen_entity_obs()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "contact_kernel":
         gen_contact_kernel()
         sys.exit(0)
@@ -828,6 +876,7 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_terrain()
     gen_contact_kernel()
+    gen_entity_obs()
     run_trajectory("traj_go2_rough", n=16, steps=170, contacts=False, history=None, episode_s=1.5, variant="rough",
                    scene_kwargs=dict(ang_noise=0.4, lin_noise=0.05, seed=41, contact_prob=0.3, contact_force=30.0))
     gen_terms()
