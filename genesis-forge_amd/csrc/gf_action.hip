@@ -164,7 +164,8 @@ extern "C" __attribute__((visibility("default"))) int gf_action_step(const GfAct
         // (measured in the benchmark loop at 65 536 envs: action kernel 8.6 → 7.1 µs, step 22.8 → 20.4 µs; GF_ACTION_BLOCK256=1 restores
         // the flat 256-lane mapping for comparison)
         static const bool flat256 = getenv("GF_ACTION_BLOCK256") != nullptr;
-        const int block = (a->num_dofs == 12 && !flat256) ? 192 : 256;
+        static const int forced = getenv("GF_ACTION_BLOCK") ? atoi(getenv("GF_ACTION_BLOCK")) : 0;   // experiments only
+        const int block = forced > 0 ? forced : ((a->num_dofs == 12 && !flat256) ? 192 : 256);
         if (const4) gf::klaunch(gf::action_kernel<true, true>, dim3(gf::env_grid(lanes, block)), dim3(block), 0, s, *a, total);
         else gf::klaunch(gf::action_kernel<true>, dim3(gf::env_grid(lanes, block)), dim3(block), 0, s, *a, total);
     } else {

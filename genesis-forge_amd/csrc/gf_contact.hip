@@ -240,6 +240,8 @@ int contact_launch(const GfContactArgs* const* mgrs, int num, hipStream_t s) {
     if (E < 1) return GF_E_RANGE;  // more than ~2 000 contact slots per env
     // small problems: keep at least ~2 workgroups per CU busy rather than 64-env tiles on a quarter of the chip
     while (E > 8 && ((int64_t)a0->num_envs + E - 1) / E < 512) E >>= 1;
+    static const int forced_e = getenv("GF_CONTACT_E") ? atoi(getenv("GF_CONTACT_E")) : 0;   // experiments only
+    if (forced_e > 0 && forced_e <= kContactLdsBytes / per_env) E = forced_e;
     k.envs_per_block = E;
     int threads = ((E * total + GF_WAVE - 1) / GF_WAVE) * GF_WAVE;
     if (threads > kContactBlock) threads = kContactBlock;
