@@ -358,6 +358,7 @@ class HipBackend(Backend):
 
         self._torch = torch
         self._gpu_checked = False
+        self._raw_stream = None
         self.lib = C.CDLL(path)
         check_abi(self.lib, "gf_")
         self._fn = {}
@@ -406,6 +407,11 @@ class HipBackend(Backend):
             if not torch.cuda.is_available():
                 raise GfError("no ROCm device visible: genesis_forge_amd runs its manager phases as HIP kernels only")
             self._gpu_checked = True
+            # torch.cuda.current_stream() builds a Stream object (≈ 3.4 µs per call — a sixth of a 20 µs step); the raw
+            # handle of the current stream of the current device is what the C ABI wants
+            self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if self._raw_stream is not None:
+            return self._raw_stream(torch.cuda.current_device())
         return torch.cuda.current_stream().cuda_stream
 
     def _raise(self, fn: str, rc: int):

@@ -160,10 +160,18 @@ class CommandManager(BaseManager):
         command_manager.py:293-298) and the Philox stream id advances exactly as in the unrecorded path."""
         env = self.env
 
-        def patch(_actions, a=args, env=env, self=self):
-            for i, r in enumerate(self._ranges()):
-                a.lo[i], a.hi[i] = float(r[0]), float(r[1])
-            a.resample_steps = self._resample_steps   # `resample_time_sec` is a live property (command_manager.py:121-130)
+        seen = [None]
+
+        def patch(_actions, a=args, env=env, self=self, seen=seen):
+            # ranges and the resample period are live (curricula edit the range lists in place): compare cheaply, rewrite the
+            # descriptor only when something changed
+            rng = self._range
+            key = (self._resample_steps, *[v for r in (rng.values() if type(rng) is dict else (rng,)) for v in r])
+            if key != seen[0]:
+                seen[0] = key
+                for i, r in enumerate(self._ranges()):
+                    a.lo[i], a.hi[i] = float(r[0]), float(r[1])
+                a.resample_steps = self._resample_steps   # `resample_time_sec` is a live property (command_manager.py:121-130)
             a.stream = env.next_stream()
 
         return patch
