@@ -28,6 +28,16 @@ int main() {
     printf("small-arg launch <<<>>>        %.2f us\n", burst([&] { k_small<<<64, 64, 0, s>>>(sm); }));
     printf("3.8KB-arg launch <<<>>>        %.2f us\n", burst([&] { k_big<<<64, 64, 0, s>>>(bg); }));
     printf("1024-WG small launch           %.2f us\n", burst([&] { k_small<<<1024, 256, 0, s>>>(sm); }));
+    {   // pre-resolved function handle + hipModuleLaunchKernel (skips the host-stub -> device-function lookup of hipLaunchKernel)
+        hipFunction_t fs = nullptr, fb = nullptr;
+        CK(hipGetFuncBySymbol(&fs, reinterpret_cast<const void*>(k_small)));
+        CK(hipGetFuncBySymbol(&fb, reinterpret_cast<const void*>(k_big)));
+        void* ps[] = {&sm};
+        void* pb[] = {&bg};
+        printf("small-arg hipModuleLaunchKernel %.2f us\n", burst([&] { hipModuleLaunchKernel(fs, 64, 1, 1, 64, 1, 1, 0, s, ps, nullptr); }));
+        printf("3.8KB-arg hipModuleLaunchKernel %.2f us\n", burst([&] { hipModuleLaunchKernel(fb, 64, 1, 1, 64, 1, 1, 0, s, pb, nullptr); }));
+        printf("small-arg hipLaunchKernel       %.2f us\n", burst([&] { hipLaunchKernel(reinterpret_cast<const void*>(k_small), dim3(64), dim3(64), ps, 0, s); }));
+    }
     // graph of 3 kernels
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
