@@ -150,3 +150,33 @@ def test_recorded_step_equals_ordinary_hip(hip_backend, name):
     if name != "gait_trainer":
         assert env._trace.post_refs is not None, "the post-physics phases of this config should run as the fused launch"
     _same_runs(a, b)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="the reference's example files exist only in the build container")
+@pytest.mark.parametrize("name", EXAMPLES)
+def test_reference_example_file_takes_the_fast_path(oracle_backend, name):
+    """The unchanged example files are not only correct on this package, they get the recorded step and the fused post-physics
+    launch (observation lambdas are fused by provenance) — except gait_trainer, whose user-level Python manager and
+    step / reset overrides keep it on the reference's call-by-call path."""
+    from genesis_forge_amd import compat
+
+    case = example_cases.CASES[name]
+    try:
+        compat.SCENE_OVERRIDES.clear()
+        compat.SCENE_OVERRIDES.update(case["scene"])
+        cls, _mod = _load_reference_example(name)
+        env = cls(num_envs=64)
+        compat.SCENE_OVERRIDES.clear()
+        env.build()
+        env.reset()
+        d = env.action_space.shape[0]
+        for _ in range(6):
+            env.step(torch.zeros(64, d))
+        if name == "gait_trainer":
+            assert env._trace is None
+        else:
+            assert env._trace is not None and env._trace.post_refs is not None
+            assert env._trace.n_ops <= 5
+    finally:
+        compat.SCENE_OVERRIDES.clear()
+        _unalias()
