@@ -345,3 +345,40 @@ def test_recorded_step_follows_live_manager_attributes(oracle_backend):
             assert torch.equal(x[k], y[k]), f"output {k} differs at step {t}"
         assert x[5] == y[5], f"log differs at step {t}"
     assert not any(k.startswith("Rewards /") for k in a[-1][5]) and int(a[-1][4].min()) < 30
+
+
+@pytest.mark.parametrize("dofs", [7, 16])
+def test_other_dof_counts_use_phase_chains_cpu(oracle_backend, dofs):
+    """A DOF count without a fused variant (neither 12 nor 28): the step is still recorded; on the GPU its phases run as chains."""
+    a, _ = _run_humanoid("cpu", "ordinary", 50, dofs)
+    b, env = _run_humanoid("cpu", "fused", 50, dofs)
+    assert env._trace is not None
+    _same_h(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dofs,n", [(7, 300), (10, 65), (16, 1000), (20, 129)])
+def test_other_dof_counts_hip(hip_backend, oracle_lib_path, dofs, n):
+    """Scalar-row (D % 4 != 0) and other vector-row variants of the reward / action / scene kernels, through the phase chains:
+    recorded == ordinary on HIP, and HIP == oracle."""
+    from genesis_forge_amd import _native as nat
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+
+    a, _ = _run_humanoid("cuda", "ordinary", n, dofs)
+    b, env = _run_humanoid("cuda", "fused", n, dofs)
+    assert env._trace is not None and env._trace.post_refs is None, "no fused variant for this DOF count: phase chains"
+    _same_h(a, b)
+    torch.cuda.synchronize()
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(oracle_lib_path))
+    try:
+        ref, _ = _run_humanoid("cpu", "ordinary", n, dofs)
+    finally:
+        nat.set_backend(None)
+        gs.set_device("cuda:0")
+    for t, (x, y) in enumerate(zip(a, ref)):
+        for k in (2, 3, 8):
+            assert torch.equal(x[k], y[k]), f"integer state {k} differs at step {t}"
+        for k in (0, 1, 5, 6, 7, 9, 10):
+            assert torch.allclose(x[k], y[k], atol=1e-5, rtol=0), f"float state {k} differs at step {t}: {(x[k] - y[k]).abs().max()}"
