@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--num-envs", type=int, default=65536, help="envs per GPU (weak scaling)")
     ap.add_argument("--reduce-every", type=int, default=16, help="recorded steps per logging all-reduce (world > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 4096 / 16384-env side measurements")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stamping of the dominant kernel")
     ap.add_argument("--profile-stride", type=int, default=0,
                     help="stamp every k-th launch of the dominant kernel in the timed region; 0 (default) = steps // 10, at least 8: "
@@ -247,6 +248,27 @@ def main():
                        "stats_allreduce_every_steps": (args.reduce_every if world > 1 else None)},
             "roofline": roof,
         }
+        if world == 1 and not args.no_sweep:
+            # BASELINE.json quotes the metric "@ 4096–65536 envs": the other end of the range (and the middle), same workload, measured
+            # after the timed region above, without launch stamps (informational; `value` is the 65 536-env figure unless --num-envs)
+            out["sweep"] = []
+            for n_s in (4096, 16384):
+                if n_s == N:
+                    continue
+                env_s = make_env(n_s)
+                env_s.seed(1234)
+                env_s.reset()
+                acts_s = [torch.randn(n_s, 12, generator=g).to(gs.device) for _ in range(4)]
+                for i in range(args.warmup):
+                    env_s.step(acts_s[i % 4])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    env_s.step(acts_s[i % 4])
+                torch.cuda.synchronize()
+                dt_s = time.perf_counter() - t0
+                out["sweep"].append({"num_envs": n_s, "value": n_s * args.steps / dt_s, "unit": "env-steps/s", "ms_per_step": dt_s / args.steps * 1e3})
+                del env_s
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N)
             workers = min(16, os.cpu_count() or 1)   # the GPU box gives one GPU's share of the host: 16 cores
