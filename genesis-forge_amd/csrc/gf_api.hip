@@ -10,8 +10,9 @@ Profiler g_prof;
 thread_local LaunchSink g_sink;
 bool contact_compatible(const GfContactArgs* x, const GfContactArgs* y);          // gf_contact.hip
 int contact_launch(const GfContactArgs* const* mgrs, int num, hipStream_t s);
-int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc);   // gf_chain.hip
-int chain_b_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc);
+int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc, DeferredFlags* deferred);   // gf_chain.hip
+int chain_b_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc, DeferredFlags* deferred);
+int gait_launch(const GfGaitArgs* a, hipStream_t s, bool flags_all);                                      // gf_gait.hip
 }
 
 #define GF_EXPORT __attribute__((visibility("default")))
@@ -157,6 +158,7 @@ GF_EXPORT int gf_run_ops_graph(void** cache, const GfOp* ops, int num_ops, void*
 GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed_index) {
     if (!ops || num_ops < 0) return GF_E_NULL;
     hipStream_t s = (hipStream_t)stream;
+    gf::DeferredFlags deferred;
     for (int i = 0; i < num_ops; ++i) {
         int rc = GF_OK;
         const void* a = ops[i].args;
@@ -176,14 +178,14 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
                 if (rc == GF_OK) i += cnt - 1;
             } break;
             case GF_PHASE_TERMINATION: {
-                const int used = gf::chain_a_try(ops, i, num_ops, s, &rc);   // termination → reward → command.step … in one launch
+                const int used = gf::chain_a_try(ops, i, num_ops, s, &rc, &deferred);   // termination → reward → command.step … in one launch
                 if (used > 0) { if (rc == GF_OK) i += used - 1; break; }
                 rc = gf_termination_step((const GfTerminationArgs*)a, stream);
             } break;
             case GF_PHASE_REWARD: rc = gf_reward_step((const GfRewardArgs*)a, stream); break;
             case GF_PHASE_COMMAND: rc = gf_command_step((const GfCommandArgs*)a, stream); break;
             case GF_PHASE_RESET: {
-                const int used = gf::chain_b_try(ops, i, num_ops, s, &rc);   // reset → command.reset … → observe … in one launch
+                const int used = gf::chain_b_try(ops, i, num_ops, s, &rc, &deferred);   // reset → command.reset … → observe … in one launch
                 if (used > 0) { if (rc == GF_OK) i += used - 1; break; }
                 rc = gf_masked_reset((const GfResetArgs*)a, stream);
             } break;
@@ -191,7 +193,12 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
             case GF_PHASE_ROTATE: rc = gf_entity_rotate((const GfRotateArgs*)a, stream); break;
             case GF_PHASE_SCENE: rc = gf_synth_scene_step((const GfSynthSceneArgs*)a, stream); break;
             case GF_PHASE_TERRAIN: rc = gf_terrain_height((const GfTerrainHeightArgs*)a, stream); break;
-            case GF_PHASE_GAIT: rc = gf_gait_step((const GfGaitArgs*)a, stream); break;
+            case GF_PHASE_GAIT: {
+                const GfGaitArgs* g = (const GfGaitArgs*)a;
+                const bool all = g && g->mode != GF_CMD_STEP && deferred.has(g->state);
+                rc = gf::gait_launch(g, s, all);
+                if (all) deferred.pop(g->state);
+            } break;
             case GF_OP_STATS_CLEAR: rc = gf_stats_clear((GfStepStats*)const_cast<void*>(a), stream); break;
             case GF_OP_POST_PHYSICS: rc = gf_post_physics_step((const GfPostRefs*)a, stream); break;
             case GF_OP_STATS_PACK: rc = gf_stats_pack((const GfStatsPackArgs*)a, stream); break;

@@ -9,6 +9,11 @@
 // earlier phase's global stores visible to the whole workgroup: all its waves share one L1):
 //   chain A  (64 lanes / workgroup):   termination → reward → command.step / gait.step of every command manager
 //   chain B  (256 lanes / workgroup):  masked reset → command.reset / gait.reset (wave 0) → every ObservationManager (4 waves)
+// One value crosses workgroups: the gait manager's per-block swing / stance bytes, which the reward terms of the workgroup
+// that owns env 0 read for ALL blocks (GfRewardArgs.gait_wave_flags).  Inside chain A that reader would share a launch with
+// gait.step, the bytes' writer, in other workgroups.  So chain A folds a gait.step op only when a masked gait launch over the
+// same state follows in the op list: gait.step then leaves the bytes alone and that later launch (chain B or stand-alone)
+// rewrites every block's byte from the post-step, post-reset rows — reader and writer never share a launch.
 // The phase bodies are the very functions the stand-alone kernels run (gf_*.hip, compiled here with GF_BODIES_ONLY), and the
 // descriptors are the ordinary per-phase ones, validated by the same *_prep functions: a chain is by construction "the phases
 // in sequence".  gf_run_ops folds a matching run of ops into a chain; anything else launches phase by phase as before.
@@ -49,7 +54,8 @@ struct ChainBArgs {
     GfObservationArgs obs[kChainObs];
     uint32_t needs_o[kChainObs];
     int32_t vec[kChainObs];
-    int32_t n_cmd, n_gait, n_obs, _pad;
+    int32_t n_cmd, n_gait, n_obs;
+    int32_t gait_flags_all;   // bit g: gait[g] rewrites the swing / stance byte of every block (its step ran in chain A)
 };
 static_assert(sizeof(ChainBArgs) <= 4096, "kernarg segment");
 
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(kEnvBlock) void chain_a_kernel(const ChainAArgs a) 
 template <int M>
 __device__ __forceinline__ void chain_observe(const ChainBArgs& a, float* tile) {
     if (M >= a.n_obs) return;
-    observe_body(a.vec[M], a.obs[M], a.needs_o[M], tile);
+    observe_body(a.vec[M], a.obs[M], a.needs_o[M], tile, (uint32_t)(offsetof(ChainBArgs, obs) + M * sizeof(GfObservationArgs)));
 }
 
 __global__ __launch_bounds__(kObsBlock) void chain_b_kernel(const ChainBArgs a) {
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(kObsBlock) void chain_b_kernel(const ChainBArgs a) 
             if (c < a.n_cmd) command_body(a.cmd[c]);
 #pragma unroll
         for (int g = 0; g < kChainGait; ++g)
-            if (g < a.n_gait) gait_body(a.gait[g]);
+            if (g < a.n_gait) gait_body(a.gait[g], ((a.gait_flags_all >> g) & 1) != 0);
     }
     __syncthreads();  // observations read the post-reset state and the new commands (managed_env.py:322-326)
     chain_observe<0>(a, tile);
@@ -100,7 +106,7 @@ static bool profiled(int phase) { return g_prof.phase == phase; }
 
 // ops[i] is a termination op: fold it with the reward / command.step / gait.step ops that follow.  Returns the number of ops
 // consumed (0 = not a chain: launch phase by phase), *rc = launch status.
-int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc) {
+int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc, DeferredFlags* deferred) {
     if (!g_options[GF_OPT_CHAIN] || profiled(GF_PHASE_TERMINATION) || profiled(GF_PHASE_REWARD) || profiled(GF_PHASE_COMMAND) || profiled(GF_PHASE_GAIT)) return 0;
     ChainAArgs k{};
     const GfTerminationArgs* t = (const GfTerminationArgs*)ops[i].args;
@@ -121,7 +127,21 @@ int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc) {
         } else if (ops[j].phase == GF_PHASE_GAIT) {
             const GfGaitArgs* g = (const GfGaitArgs*)ops[j].args;
             if (!g || g->mode != GF_CMD_STEP || g->num_envs != N || k.n_gait >= kChainGait || gait_prep(g) != GF_OK) break;
-            k.gait[k.n_gait++] = *g;
+            GfGaitArgs& kg = k.gait[k.n_gait];
+            kg = *g;
+            if (g->wave_flags) {
+                // the bytes are read across workgroups by this very launch's reward terms: hand their update to the masked
+                // gait launch that follows, or keep gait.step out of the chain
+                bool later = false;
+                for (int q = j + 1; q < num_ops && !later; ++q)
+                    if (ops[q].phase == GF_PHASE_GAIT && ops[q].args) {
+                        const GfGaitArgs* m = (const GfGaitArgs*)ops[q].args;
+                        later = m->mode != GF_CMD_STEP && m->state == g->state && m->wave_flags == g->wave_flags && m->num_envs == N;
+                    }
+                if (!later || !deferred->push(g->state)) break;
+                kg.wave_flags = nullptr;
+            }
+            ++k.n_gait;
         } else {
             break;
         }
@@ -139,7 +159,7 @@ int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc) {
 }
 
 // ops[i] is a masked-reset op: fold it with the command.reset / gait.reset and observe ops that follow.
-int chain_b_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc) {
+int chain_b_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc, DeferredFlags* deferred) {
     if (!g_options[GF_OPT_CHAIN] || profiled(GF_PHASE_RESET) || profiled(GF_PHASE_COMMAND) || profiled(GF_PHASE_GAIT) || profiled(GF_PHASE_OBSERVE)) return 0;
     ChainBArgs k{};
     const GfResetArgs* r = (const GfResetArgs*)ops[i].args;
@@ -155,6 +175,7 @@ int chain_b_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc) {
         } else if (ops[j].phase == GF_PHASE_GAIT && k.n_obs == 0) {
             const GfGaitArgs* g = (const GfGaitArgs*)ops[j].args;
             if (!g || g->mode != GF_CMD_MASKED || g->num_envs != N || k.n_gait >= kChainGait || gait_prep(g) != GF_OK) break;
+            if (deferred->has(g->state)) k.gait_flags_all |= 1 << k.n_gait;
             k.gait[k.n_gait++] = *g;
         } else if (ops[j].phase == GF_PHASE_OBSERVE) {
             const GfObservationArgs* o = (const GfObservationArgs*)ops[j].args;
@@ -167,6 +188,8 @@ int chain_b_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc) {
         }
     }
     if (j - i < 2) return 0;
+    for (int g = 0; g < k.n_gait; ++g)
+        if ((k.gait_flags_all >> g) & 1) deferred->pop(k.gait[g].state);
     k.reset = *r;
     klaunch(chain_b_kernel, dim3(env_grid(N)), dim3(kObsBlock), lds, s, k);
     *rc = launch_status();

@@ -17,7 +17,9 @@
 
 namespace gf {
 
-__device__ __forceinline__ void gait_body(const GfGaitArgs& a) {
+// `flags_all` (masked launches only): rewrite the swing / stance byte of EVERY block, not only of the blocks that hold a reset
+// env — the phase chains use it to keep the flags' only writer in a different launch from their reader (gf_chain.hip).
+__device__ __forceinline__ void gait_body(const GfGaitArgs& a, const bool flags_all = false) {
     const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
     const bool live = n < a.num_envs;
     const int64_t m = live ? n : (int64_t)a.num_envs - 1;  // tail lanes shadow the last env and never store
@@ -29,9 +31,12 @@ __device__ __forceinline__ void gait_body(const GfGaitArgs& a) {
         else go = true;
     }
     // a masked launch touches only the 64-env blocks that contain a reset env (resets are sparse): 2 B/env for the rest
-    if (!step && __ballot(go) == 0ull) return;
+    const bool rows = step || __ballot(go) != 0ull;  // wave-uniform
+    const bool flags = a.wave_flags != nullptr && (rows || flags_all);
+    if (!rows && !flags) return;
     const GF_GLOBAL float* row = G(a.state) + m * GF_GAIT_ROW;
-    float4 r0 = ldg4(row), r1 = ldg4(row + 4), r2 = ldg4(row + 8), r3 = ldg4(row + 12);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 r0 = ldg4(row), r1 = rows ? ldg4(row + 4) : z4, r2 = rows ? ldg4(row + 8) : z4, r3 = ldg4(row + 12);  // flags need offsets + phase only
     int sel = (step || go) ? (int)G(a.selected)[m] : 0;
     float off[4] = {r0.x, r0.y, r0.z, r0.w};
     float height = r1.x, period = r1.y;
@@ -78,7 +83,7 @@ __device__ __forceinline__ void gait_body(const GfGaitArgs& a) {
             sincos_det(a.two_pi * fp, &clock[f], &clock[4 + f]);
         }
     }
-    if (a.wave_flags) {  // this block's "any env in swing / stance" byte, from the rows as they are after this launch
+    if (flags) {  // this block's "any env in swing / stance" byte, from the rows as they are after this launch
         const float pi = 0.5f * a.two_pi;  // exact halving: (float)(2π)/2 == (float)π
         uint32_t byte = 0;
 #pragma unroll
@@ -101,7 +106,7 @@ __device__ __forceinline__ void gait_body(const GfGaitArgs& a) {
 }
 
 #ifndef GF_BODIES_ONLY
-__global__ __launch_bounds__(kEnvBlock) void gait_kernel(const GfGaitArgs a) { gait_body(a); }
+__global__ __launch_bounds__(kEnvBlock) void gait_kernel(const GfGaitArgs a, const int flags_all) { gait_body(a, flags_all != 0); }
 #endif
 
 }  // namespace gf
@@ -124,13 +129,18 @@ int gait_prep(const GfGaitArgs* a) {
 }
 }  // namespace gf
 
-extern "C" __attribute__((visibility("default"))) int gf_gait_step(const GfGaitArgs* a, void* stream) {
-    const int rc = gf::gait_prep(a);
+namespace gf {
+int gait_launch(const GfGaitArgs* a, hipStream_t s, bool flags_all) {
+    const int rc = gait_prep(a);
     if (rc) return rc;
     if (a->num_envs == 0) return GF_OK;
-    hipStream_t s = (hipStream_t)stream;
-    gf::PhaseScope scope(GF_PHASE_GAIT, s);
-    GF_LAUNCH(scope, gf::gait_kernel, gf::env_grid(a->num_envs), gf::kEnvBlock, 0, s, *a);
-    return gf::launch_status();
+    PhaseScope scope(GF_PHASE_GAIT, s);
+    GF_LAUNCH(scope, gait_kernel, env_grid(a->num_envs), kEnvBlock, 0, s, *a, (int)(flags_all && a->mode != GF_CMD_STEP));
+    return launch_status();
+}
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_gait_step(const GfGaitArgs* a, void* stream) {
+    return gf::gait_launch(a, (hipStream_t)stream, false);
 }
 #endif

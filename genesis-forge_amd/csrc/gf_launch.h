@@ -150,4 +150,24 @@ inline int launch_status() {
     return e == hipSuccess ? GF_OK : (int)e;
 }
 
+// gait states whose swing / stance bytes chain A left for a later masked gait launch of the same gf_run_ops call (gf_chain.hip)
+struct DeferredFlags {
+    const float* state[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool push(const float* p) {
+        for (auto& q : state)
+            if (!q || q == p) { q = p; return true; }
+        return false;
+    }
+    bool has(const float* p) const {
+        for (auto q : state)
+            if (q == p && p) return true;
+        return false;
+    }
+    void pop(const float* p) {
+        for (auto& q : state)
+            if (q == p) q = nullptr;
+    }
+    bool empty() const { return !state[0] && !state[1] && !state[2] && !state[3]; }
+};
+
 }  // namespace gf

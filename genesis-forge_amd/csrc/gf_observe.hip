@@ -4,19 +4,21 @@
 // += uniform_(-1,1)*noise, then torch.cat; history list pop/insert + another cat: 29 aten ops /
 // 23 launches for the 7-item Go2 config) and the mdp/observations.py getters.
 //
-// One 256-thread workgroup owns a tile of 64 consecutive envs.  The tile's [64, O] frame is assembled in LDS
-// (row stride O+1 words, so the row-per-lane writes of the entity items and the flat cooperative
-// copies of the [N,w] items are both conflict-free), then streamed out with full-width coalesced
+// One 256-thread workgroup owns a tile of 64 consecutive envs.  The tile's [64, O] frame is assembled in LDS (row stride
+// O+1 words: conflict-free for row-per-lane and column-per-lane writes alike), then streamed out with full-width coalesced
 // stores — the [N,O] row-major result is written exactly once, never re-read.
-//   * [N,w] sources (commands, dof_pos, dof_vel, dof_force, targets, raw actions, external columns)
-//     are contiguous over the tile: lanes copy them flat, 16 B per lane when w % 4 == 0.
-//   * body-frame vectors (ang vel, lin vel, projected gravity) are computed once per env by the
-//     env's own lane from quat/vel/ang loaded up front.
-//   * scale and noise are applied on the way into LDS; noise is Philox(seed, stream, env, column)
-//     or a caller-supplied dense U[0,1) array (parity mode).
-//   * history (H > 1): the reference keeps a Python list of H tensors and re-concatenates them each
-//     step, newest first.  Here the previous output is the history: frame slots 1..H-1 of the new
-//     output are the previous output's slots 0..H-2 (flat coalesced copy), slot 0 is the new frame.
+//   * the item table is resolved once per workgroup, lane-parallel (lane i reads item i from the kernel-argument segment,
+//     lane c finds the source of column c); a walk of the table with scalar loads costs one load latency per item;
+//   * [N,w] sources (commands, dof_pos, dof_vel, dof_force, targets, raw actions, external columns, base pos / quat,
+//     contact-force norms) are gathered column-per-lane: every load a lane needs is in flight before the first LDS write;
+//   * body-frame vectors (ang vel, lin vel, projected gravity) are computed once per env by the env's own lane (wave 0) from
+//     quat / vel / ang requested before anything else;
+//   * scale and noise are applied on the way into LDS; noise is Philox(seed, stream, env, column) or a caller-supplied dense
+//     U[0,1) array (parity mode);
+//   * history (H > 1): the reference keeps a Python list of H tensors and re-concatenates them each step, newest first.
+//     Here the previous output is the history: frame slots 1..H-1 of the new output are the previous output's slots 0..H-2,
+//     moved as 16-byte units of the tile's contiguous run (HistBatch) in batches whose loads are issued before the table and
+//     the gather are waited for, so that wait is spent with history traffic in flight.
 // Algorithmic traffic (Go2 command config, O=48, H=1): R 196 + W 192 = 388 B/env.
 #include "gf_launch.h"
 
@@ -24,13 +26,15 @@ namespace gf {
 
 enum : uint32_t { ON_QUAT = 1, ON_LIN = 2, ON_ANG = 4 };
 
-// Four waves share a 64-env tile: wave 0 computes the per-env (body-frame) items, all 256 lanes do the flat copies into the
-// LDS tile, the write-out and the history shift.  (One wave per tile left a 310-wide frame with 300 dependent
-// load → store round trips per lane.)
+// Four waves share a 64-env tile: wave 0 computes the per-env (body-frame) items, all 256 lanes gather the [N,w] items into
+// the LDS tile, write it out and shift the history.
 constexpr int kObsBlock = 256;
+#define GF_OBS_INLINE __attribute__((always_inline))
+constexpr int kObsGather = 12;  // tile elements per lane whose loads are in flight together
+constexpr int kObsShift = 8;    // history units per lane in flight together
 
-// floor(i / d) by multiply-shift with m = ceil(2^40 / d): exact for i < 2^40 / d (here i < 64·d and d < 2^17) — the flat copies
-// turn an element index into (row, column) once per element, and d (an item or frame width) is a run-time value
+// floor(i / d) by multiply-shift with m = ceil(2^40 / d): exact for i < 2^40 / d (here i < 64·d and d < 2^17) — an element index
+// becomes (row, column) once per element, and d (a frame or history width) is a run-time value
 struct FastDiv {
     uint64_t m;
     uint32_t d;
@@ -38,91 +42,112 @@ struct FastDiv {
     __device__ __forceinline__ int div(int i) const { return d > 1 ? (int)(((uint64_t)(uint32_t)i * m) >> 40) : i; }
 };
 
-struct TileCtx {
-    float* tile;      // LDS, [64][S]
-    int S;            // row stride in words (O+1)
-    int64_t n0;       // first env of the tile
-    int rows;         // live rows in the tile (<= 64)
-    int tid;
-    const GfObservationArgs* a;
+// Where a frame's columns come from.  The item table is resolved ONCE per workgroup, lane-parallel: lane i reads item i
+// straight from the kernel-argument segment (a vector load: no serial walk of scalar loads), lane c then finds the item that
+// owns column c.  Both tables live in LDS because lanes of one wave look up different columns.
+enum : int32_t { OS_ROWS = 0, OS_OWNER = 1, OS_NORM3 = 2 };
+struct ObsItemRec {
+    const float* src;   // OS_ROWS: element (n, j) = src[n·stride + j];  OS_NORM3: |src[n·stride + 3j .. 3j+2]|
+    int32_t stride, width, kind, op;
+    float scale, noise;
+};
+struct ObsCol {
+    const float* p;     // source of row 0's element of this column (src + j or src + 3j)
+    int32_t stride, kind;
+    float scale, noise;
 };
 
-__device__ __forceinline__ float finish(const GfObservationArgs& a, const GfObsItem& it, float v, int64_t n, int col) {
-    if (it.scale != 1.0f) v = v * it.scale;  // observation_manager.py:242-244
-    if (it.noise != 0.0f) {                  // observation_manager.py:247-250
+__device__ __forceinline__ float finish(const GfObservationArgs& a, const float scale, const float noise, float v, int64_t n, int col) {
+    if (scale != 1.0f) v = v * scale;  // observation_manager.py:242-244
+    if (noise != 0.0f) {               // observation_manager.py:247-250
         const float u = draw_u(a.noise_draws, n * a.obs_width + col, a.seed, a.stream, (uint32_t)n + a.env_offset, (uint32_t)col);
-        v = v + uniform_range(u, -1.0f, 1.0f) * it.noise;
+        v = v + uniform_range(u, -1.0f, 1.0f) * noise;
     }
     return v;
 }
 
-// Flat cooperative copy of a [rows, w] source block (row stride = src_stride words) into tile columns [col0, col0+w).
-__device__ __forceinline__ void copy_rows(const int V, const TileCtx& c, const GfObsItem& it, const float* __restrict__ src, int src_stride, int w, int col0) {
-    const GfObservationArgs& a = *c.a;
-    const float* base = src + c.n0 * src_stride;
-    const int total = c.rows * w;
-    const FastDiv dw(w);
-    int done = 0;
-    if (V == 4 && src_stride == w && (reinterpret_cast<uintptr_t>(base) & 15u) == 0) {
-        const int total4 = total >> 2;
-        for (int i = c.tid; i < total4; i += kObsBlock) {
-            const float4 x = reinterpret_cast<const float4*>(base)[i];
-            const float xs[4] = {x.x, x.y, x.z, x.w};
-            const int e = i * 4;
-            int row = dw.div(e), cc = e - row * w;
+typedef float f32x4a __attribute__((ext_vector_type(4)));               // 16-byte aligned
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword aligned: one global_load_dwordx4 all the same
+
+// History shift.  The [rows, O·H] block of a tile is one contiguous run of floats in `out` and in `prev`, and
+// out[k] = prev[k - O] wherever column (k mod O·H) >= O.  Cut the run into 16-byte units aligned on `out`: a unit that lies
+// entirely in history columns is one (dword-aligned) 16-byte load and one aligned 16-byte store, whatever O is — rows of an
+// odd-width frame are not 16-byte aligned, the run is.  Units that touch a new-frame column wait for the LDS tile
+// (write_mixed_units).  A batch = kObsShift units per lane, loads first, stores later: the caller puts other work between
+// the two so the lane never sits on an empty queue.
+struct HistBatch {
+    f32x4u v[kObsShift];
+    uint32_t pure;   // bit k: unit k of the batch is a pure history unit of this lane
+};
+__device__ __forceinline__ void hist_load(HistBatch& b, const float* __restrict__ prev, int first, int units, int O, int OH, const FastDiv& dr) {
+    b.pure = 0u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                c.tile[row * c.S + col0 + cc] = finish(a, it, xs[j], c.n0 + row, col0 + cc);
-                if (++cc == w) { cc = 0; ++row; }
-            }
-        }
-        done = total4 << 2;  // ragged tail (partial tile, w % 4 != 0) falls through to the scalar loop
+    for (int k = 0; k < kObsShift; ++k) {
+        const int u = first + k * kObsBlock, uu = u < units ? u : 0;
+        const int e = uu << 2, row = dr.div(e), c = e - row * OH;
+        const bool pure = u < units && c >= O && c + 3 < OH;
+        b.pure |= pure ? 1u << k : 0u;
+        b.v[k] = f32x4u{0.f, 0.f, 0.f, 0.f};
+        if (pure) b.v[k] = *reinterpret_cast<const f32x4u*>(prev + (e - O));
     }
-    for (int i = done + c.tid; i < total; i += kObsBlock) {
-        const int row = dw.div(i), cc = i - row * w;
-        c.tile[row * c.S + col0 + cc] = finish(a, it, base[row * src_stride + cc], c.n0 + row, col0 + cc);
+}
+__device__ __forceinline__ void hist_store(const HistBatch& b, float* __restrict__ out, int first) {
+#pragma unroll
+    for (int k = 0; k < kObsShift; ++k)
+        if ((b.pure >> k) & 1u) *reinterpret_cast<f32x4a*>(out + ((first + k * kObsBlock) << 2)) = f32x4a{b.v[k].x, b.v[k].y, b.v[k].z, b.v[k].w};
+}
+
+// … and the units the history batches left: every unit with at least one new-frame column (frame from the LDS tile, the
+// history elements it shares a unit with from `prev`), plus the run's last rows·O·H mod 4 floats.
+__device__ __forceinline__ void write_mixed_units(float* __restrict__ out, const float* __restrict__ prev, const float* tile, int S, int rows, int O,
+                                                  int OH, int tid) {
+    const int total = rows * OH, units = total >> 2;
+    const int upr = ((O + 3) >> 2) + 1;  // units that can touch one row's frame columns
+    const FastDiv du(upr);
+    auto element = [&](int k, int r) -> float {
+        const int rr = k >= r * OH ? r : r - 1, c = k - rr * OH;   // the unit's leading floats can be the previous row's history
+        return c < O ? tile[rr * S + c] : prev[k - O];
+    };
+    constexpr int kU = 5;  // units per lane whose boundary loads are in flight together
+    for (int i0 = tid; i0 < rows * upr; i0 += kU * kObsBlock) {
+        f32x4a v[kU];
+        int at[kU];
+#pragma unroll
+        for (int b = 0; b < kU; ++b) {
+            const int i = i0 + b * kObsBlock;
+            const int ii = i < rows * upr ? i : i0, r = du.div(ii), j = ii - r * upr;
+            const int u = ((r * OH) >> 2) + j;
+            // two frames are O·(H-1) >= 4 floats apart: a unit touches one frame at most, so each is written once
+            const bool on = i < rows * upr && u <= ((r * OH + O - 1) >> 2) && u < units;
+            at[b] = on ? u << 2 : -1;
+            v[b] = f32x4a{0.f, 0.f, 0.f, 0.f};
+            if (on) v[b] = f32x4a{element(u << 2, r), element((u << 2) + 1, r), element((u << 2) + 2, r), element((u << 2) + 3, r)};
+        }
+#pragma unroll
+        for (int b = 0; b < kU; ++b)
+            if (at[b] >= 0) *reinterpret_cast<f32x4a*>(out + at[b]) = v[b];
+    }
+    const int tail = total & 3;
+    if (tid < tail) {
+        const int k = (units << 2) + tid, r = rows - 1, c = k - r * OH;
+        out[k] = c < O ? tile[r * S + c] : prev[k - O];
     }
 }
 
-// History shift: frame slots 1..H-1 of the new rows are slots 0..H-2 of the previous output.  `hw` units per row, rows
-// OHu units apart, `T` = float4 / float2 / float.  Four independent loads are in flight per lane before the first store.
-template <typename T>
-__device__ __forceinline__ void shift_history(T* __restrict__ dst, const T* __restrict__ src, int rows, int hw, int64_t OHu, int tid) {
-    const FastDiv dh(hw);
-    const int total = rows * hw;
-    int i = tid;
-    for (; i + 3 * kObsBlock < total; i += 4 * kObsBlock) {
-        T v[4];
-        int64_t o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = i + k * kObsBlock, row = dh.div(e);
-            o[k] = (int64_t)row * OHu + (e - row * hw);
-            v[k] = src[o[k]];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dst[o[k]] = v[k];
-    }
-    for (; i < total; i += kObsBlock) {
-        const int row = dh.div(i);
-        const int64_t o = (int64_t)row * OHu + (i - row * hw);
-        dst[o] = src[o];
-    }
-}
-
-// V = floats per memory operation of the write-out and the history shift: 4 when O % 4 == 0, 2 when O is even, else 1.
+// V = floats per memory operation of the frame write-out and the history shift: 4 when O % 4 == 0, 2 when O is even, else 1.
 // A run-time value here (wave-uniform branches); the stand-alone kernels pass a constant, which folds the branches away.
-__device__ __forceinline__ void observe_body(const int V, const GfObservationArgs& a, const uint32_t needs, float* tile) {
+__device__ __forceinline__ void observe_body(const int V, const GfObservationArgs& a, const uint32_t needs, float* tile, const uint32_t karg_off) {
+    __shared__ ObsItemRec s_item[GF_MAX_OBS_ITEMS];
+    __shared__ ObsCol s_col[GF_MAX_OBS_WIDTH];
     const int tid = threadIdx.x;
     const int64_t n0 = (int64_t)blockIdx.x * kEnvBlock;
     const int64_t N = a.num_envs;
     const int rows = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
     const int O = a.obs_width, H = a.history_len, S = O + 1, D = a.num_dofs;
+    const int num_items = a.num_items;
     const bool owner = tid < kEnvBlock;      // wave 0: lane = env
     const bool live = owner && tid < rows;
     const int64_t n = live ? n0 + tid : n0;
-
-    TileCtx c{tile, S, n0, rows, tid, &a};
 
     // per-env entity state, requested before anything else (wave 0 only; the other waves read the zero pad)
     const uint32_t e = (uint32_t)n;
@@ -136,56 +161,147 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
     const GF_GLOBAL float* ap = gsel(owner && (needs & ON_ANG) != 0, a.entity.ang_vel, 3u * e);
     const V3 lin{lp[0], lp[1], lp[2]}, ang{ap[0], ap[1], ap[2]};
 
-    int col = 0;
-    for (int i = 0; i < a.num_items; ++i) {
-        const GfObsItem& it = a.items[i];
-        const int w = it.width;
-        switch (it.op) {
-            case GF_O_COMMAND: copy_rows(V, c, it, a.command[it.i0].command, cmd_stride(a.command[it.i0]), w, col); break;
-            case GF_O_DOF_POS: copy_rows(V, c, it, a.dof_pos, D, w, col); break;
-            case GF_O_DOF_VEL: copy_rows(V, c, it, a.dof_vel, D, w, col); break;
-            case GF_O_DOF_FORCE: copy_rows(V, c, it, a.dof_force, D, w, col); break;
-            case GF_O_ACTIONS: copy_rows(V, c, it, a.targets, D, w, col); break;
-            case GF_O_RAW_ACTIONS: copy_rows(V, c, it, a.env_actions, D, w, col); break;
-            case GF_O_EXTERNAL: copy_rows(V, c, it, a.ext[it.i0], w, w, col); break;
-            case GF_O_BASE_POS: copy_rows(1, c, it, a.entity.pos, 3, 3, col); break;
-            case GF_O_BASE_QUAT: copy_rows(V, c, it, a.entity.quat, 4, 4, col); break;
-            case GF_O_ANG_VEL_BODY:
-            case GF_O_LIN_VEL_BODY:
-            case GF_O_PROJ_GRAVITY: {
-                if (live) {
-                    const V3 v = it.op == GF_O_ANG_VEL_BODY ? rot_inv(q, ang) : (it.op == GF_O_LIN_VEL_BODY ? rot_inv(q, lin) : rot_inv(q, V3{0.f, 0.f, -1.f}));
-                    float* r = tile + tid * S + col;
-                    r[0] = finish(a, it, v.x, n, col);
-                    r[1] = finish(a, it, v.y, n, col + 1);
-                    r[2] = finish(a, it, v.z, n, col + 2);
-                }
-            } break;
-            case GF_O_CONTACT_FORCE_NORM: {
-                const GfContactView& cv = a.contact[it.i0];
-                if (live) {
-                    const float* r = cv.contacts + n * cv.num_links * 3;
-                    for (int l = 0; l < w; ++l) tile[tid * S + col + l] = finish(a, it, norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]), n, col + l);
-                }
-            } break;
-            default: break;
-        }
-        col += w;
-    }
-
     const int64_t OH = (int64_t)O * H;
     float* out = a.obs + n0 * OH;
-    // the history shift does not depend on the tile: issue it before the barrier so its loads overlap the assembly
-    if (H > 1) {
-        const float* prev = a.prev_obs + n0 * OH;
-        const int hw = O * (H - 1);
-        if (V == 4) shift_history(reinterpret_cast<float4*>(out + O), reinterpret_cast<const float4*>(prev), rows, hw >> 2, OH >> 2, tid);
-        else if (V == 2) shift_history(reinterpret_cast<float2*>(out + O), reinterpret_cast<const float2*>(prev), rows, hw >> 1, OH >> 1, tid);
-        else shift_history(out + O, prev, rows, hw, OH, tid);
+    const float* prev = H > 1 ? a.prev_obs + n0 * OH : nullptr;
+    // 16-byte units over the tile's contiguous run (see HistBatch); otherwise (a frame narrower than 4, an output that is not
+    // 16-byte aligned) element by element
+    const bool flat = H > 1 && O >= 4 && (reinterpret_cast<uintptr_t>(a.obs) & 15u) == 0;
+    const bool hist = flat;
+    const int units = (rows * (int)OH) >> 2;
+    const FastDiv dr((int)OH);
+    constexpr int kHistStep = kObsShift * kObsBlock;
+    HistBatch hb;
+    int hfirst = tid;
+    // the history shift depends on nothing this kernel computes: its first batch of loads goes out before the item table is
+    // even read, and every later wait (table, gather) is spent with history traffic in flight
+    if (hist) hist_load(hb, prev, hfirst, units, O, (int)OH, dr);
+
+    // item i → its source (lane i); `a` sits `karg_off` bytes into the kernel-argument segment
+    if (tid < num_items) {
+        const auto* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+        const auto* ip = (const __attribute__((address_space(4))) int32_t*)(kp + karg_off + offsetof(GfObservationArgs, items) + (size_t)tid * sizeof(GfObsItem));
+        const int op = ip[0], w = ip[1], i0 = ip[2];
+        const float scale = __int_as_float(ip[4]), noise = __int_as_float(ip[5]);
+        const float* src = nullptr;
+        int stride = 0, kind = OS_ROWS;
+        switch (op) {
+            case GF_O_COMMAND:   // static slot loops: a lane-dependent index into the by-value descriptor would spill it to scratch
+#pragma unroll
+                for (int v = 0; v < GF_MAX_COMMAND_VIEWS; ++v)
+                    if (i0 == v) { src = a.command[v].command; stride = cmd_stride(a.command[v]); }
+                break;
+            case GF_O_DOF_POS: src = a.dof_pos; stride = D; break;
+            case GF_O_DOF_VEL: src = a.dof_vel; stride = D; break;
+            case GF_O_DOF_FORCE: src = a.dof_force; stride = D; break;
+            case GF_O_ACTIONS: src = a.targets; stride = D; break;
+            case GF_O_RAW_ACTIONS: src = a.env_actions; stride = D; break;
+            case GF_O_EXTERNAL:
+#pragma unroll
+                for (int v = 0; v < GF_MAX_EXT; ++v)
+                    if (i0 == v) src = a.ext[v];
+                stride = w;
+                break;
+            case GF_O_BASE_POS: src = a.entity.pos; stride = 3; break;
+            case GF_O_BASE_QUAT: src = a.entity.quat; stride = 4; break;
+            case GF_O_CONTACT_FORCE_NORM:
+#pragma unroll
+                for (int v = 0; v < GF_MAX_CONTACT_VIEWS; ++v)
+                    if (i0 == v) { src = a.contact[v].contacts; stride = 3 * a.contact[v].num_links; }
+                kind = OS_NORM3;
+                break;
+            default: kind = OS_OWNER; break;  // body-frame vectors: computed per env by wave 0
+        }
+        s_item[tid] = ObsItemRec{src, stride, w, kind, op, scale, noise};
+    }
+    __syncthreads();
+    // column c → its source (lane c)
+    if (tid < O) {
+        int acc = 0, it = 0, st = 0;
+        for (int i = 0; i < num_items; ++i) {
+            if (tid >= acc) { it = i; st = acc; }
+            acc += s_item[i].width;
+        }
+        const ObsItemRec r = s_item[it];
+        const int j = tid - st;
+        s_col[tid] = ObsCol{r.src + (r.kind == OS_NORM3 ? 3 * j : j), r.stride, r.kind, r.scale, r.noise};
     }
     __syncthreads();
 
-    if (V == 4) {
+    // gather: every [N,w] element of the tile.  A lane keeps ONE column (its source is looked up once) and walks rows: with
+    // P = the power of two >= O, lane t has column t mod P and rows t/P, t/P + 256/P, … — consecutive lanes read consecutive
+    // columns of one row, the address advances by a constant, and the LDS writes (row stride O+1) are conflict-free.
+    // kObsGather loads per lane are in flight per pass; a pass = loads, then (later) the LDS writes, and the history batches
+    // run between the two halves of the first pass.
+    const int lgP = O > 1 ? 32 - __builtin_clz((unsigned)(O - 1)) : 0;
+    const int gcol = tid & ((1 << lgP) - 1), grow0 = tid >> lgP, grstep = kObsBlock >> lgP;
+    const ObsCol gc = s_col[gcol < O ? gcol : 0];
+    const bool gactive = gcol < O && gc.kind != OS_OWNER;
+    const int64_t gstep = (int64_t)grstep * gc.stride;
+    float gx[kObsGather];
+    auto gather_load = [&](int row) GF_OBS_INLINE {
+        const float* p = gc.p + (n0 + row) * gc.stride;
+#pragma unroll
+        for (int u = 0; u < kObsGather; ++u) {
+            gx[u] = 0.f;
+            if (gactive && row + u * grstep < rows) gx[u] = p[u * gstep];
+        }
+    };
+    auto gather_store = [&](int row) GF_OBS_INLINE {
+#pragma unroll
+        for (int u = 0; u < kObsGather; ++u) {
+            const int r = row + u * grstep;
+            if (!(gactive && r < rows)) continue;
+            float v = gx[u];
+            if (gc.kind == OS_NORM3) {  // the other two components share the first one's cache line
+                const float* q3 = gc.p + (n0 + r) * gc.stride;
+                v = norm3(v, q3[1], q3[2]);
+            }
+            tile[r * S + gcol] = finish(a, gc.scale, gc.noise, v, n0 + r, gcol);
+        }
+    };
+    gather_load(grow0);
+    if (hist) {
+        for (;;) {
+            hist_store(hb, out, hfirst);
+            hfirst += kHistStep;
+            if (hfirst - tid >= units) break;  // wave-uniform: the batch's first unit index of lane 0
+            hist_load(hb, prev, hfirst, units, O, (int)OH, dr);
+        }
+    } else if (H > 1) {
+        const int hw = O * (H - 1);
+        const FastDiv dh(hw);
+        for (int i = tid; i < rows * hw; i += kObsBlock) {
+            const int row = dh.div(i);
+            const int64_t o = (int64_t)row * OH + (i - row * hw);
+            out[O + o] = prev[o];
+        }
+    }
+    gather_store(grow0);
+    for (int row = grow0 + kObsGather * grstep; row - grow0 < rows; row += kObsGather * grstep) {  // the rows one pass does not reach
+        gather_load(row);
+        gather_store(row);
+    }
+    // per-env items (their inputs were requested first and have long landed)
+    if (live && needs) {
+        int col = 0;
+        for (int i = 0; i < num_items; ++i) {
+            const ObsItemRec it = s_item[i];
+            if (it.op == GF_O_ANG_VEL_BODY || it.op == GF_O_LIN_VEL_BODY || it.op == GF_O_PROJ_GRAVITY) {
+                const V3 v = it.op == GF_O_ANG_VEL_BODY ? rot_inv(q, ang) : (it.op == GF_O_LIN_VEL_BODY ? rot_inv(q, lin) : rot_inv(q, V3{0.f, 0.f, -1.f}));
+                float* r = tile + tid * S + col;
+                r[0] = finish(a, it.scale, it.noise, v.x, n, col);
+                r[1] = finish(a, it.scale, it.noise, v.y, n, col + 1);
+                r[2] = finish(a, it.scale, it.noise, v.z, n, col + 2);
+            }
+            col += it.width;
+        }
+    }
+    __syncthreads();
+
+    if (flat) {
+        write_mixed_units(out, prev, tile, S, rows, O, (int)OH, tid);
+    } else if (V == 4) {
         const int o4 = O >> 2;
         const FastDiv d4(o4);
         for (int i = tid; i < rows * o4; i += kObsBlock) {
@@ -215,7 +331,7 @@ template <int V>
 __global__ __launch_bounds__(kObsBlock) void observe_kernel(const GfObservationArgs a, const uint32_t needs) {
     prefetch_args<GfObservationArgs>();
     extern __shared__ __attribute__((aligned(16))) float tile[];
-    observe_body(V, a, needs, tile);
+    observe_body(V, a, needs, tile, 0u);
 }
 #endif
 

@@ -30,10 +30,21 @@ __device__ __forceinline__ void reset_body(const GfResetArgs& a) {
     if (a.episode_seconds) {
         if (a.reward_logging && a.episode_sums) {
             const float secs = go ? a.episode_seconds[n] : 1.0f;
+            // every row first: the loads are independent of each other, but each would wait behind the previous term's
+            // atomic and store if it were issued inside the loop below (one memory latency per term).  Staged through LDS
+            // (lane-private slots) so that loop can keep its run-time trip count.
+            __shared__ float s_sum[GF_MAX_TERMS][kEnvBlock];
+            {
+                float sum[GF_MAX_TERMS];
+#pragma unroll
+                for (int t = 0; t < GF_MAX_TERMS; ++t) sum[t] = (go && t < a.num_reward_terms) ? a.episode_sums[(int64_t)t * N + n] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < GF_MAX_TERMS; ++t) s_sum[t][threadIdx.x & (kEnvBlock - 1)] = sum[t];
+            }
             for (int t = 0; t < a.num_reward_terms; ++t) {
                 float* v = a.episode_sums + (int64_t)t * N + (live ? n : 0);
                 if (a.reward_log_mask & (1u << t)) {
-                    const float per_sec = go ? (*v / secs) : 0.0f;  // value[envs_idx] /= episode_seconds
+                    const float per_sec = go ? (s_sum[t][threadIdx.x & (kEnvBlock - 1)] / secs) : 0.0f;  // value[envs_idx] /= episode_seconds
                     if (a.stats) {
                         const double s = wave_sum((double)per_sec);
                         if (threadIdx.x == 0) unsafeAtomicAdd(&stats_shard(a.stats)->reward_episode_sum[t], s);  // native global_atomic_add_f64
