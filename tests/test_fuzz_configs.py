@@ -1,0 +1,243 @@
+"""Randomised task configs: the HIP path against the CPU oracle on configs nobody wrote by hand.
+
+Each seed draws a task config from the whole mdp catalogue — which reward / termination terms, with what weights and parameters,
+which observation items in what order with what scales / noise / history, how many ContactManagers and ObservationManagers (a
+third one takes the recorded step off the fused kernel and onto the phase chains), whether a user-level (Python)
+reward term is present (Python between the phases: such a step cannot be recorded and runs phase by phase) — and an env count
+around the 64-env tile size.  The same config then runs 48 steps on the GPU and on the oracle in Philox mode; masks and integer state must be
+bit-exact, floats within 1e-5 (helpers.FLOAT_TOL), log keys identical.  A second leg replays the GPU run with the recorded step
+disabled: recorded (fused or chained) and phase-by-phase execution must agree bit for bit.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FLOAT_TOL
+
+SEEDS = list(range(28))
+STEPS = 48
+
+
+def make_fuzz_env(seed: int):
+    from genesis_forge_amd import ManagedEnvironment
+    from genesis_forge_amd.managers import (ContactManager, EntityManager, ObservationManager, PositionActionManager, RewardManager,
+                                            TerminationManager, VelocityCommandManager)
+    from genesis_forge_amd.mdp import observations, reset, rewards, terminations
+    from genesis_forge_amd.scene import SyntheticScene, morphs
+    from envs import GO2_DEFAULT_POS, GO2_JOINTS
+
+    rnd = random.Random(1000 + seed)
+    n = rnd.choice([1, 63, 64, 65, 130, 257, 1000])
+    pick = lambda p: rnd.random() < p
+    uni = lambda lo, hi: round(rnd.uniform(lo, hi), 3)
+
+    class FuzzEnv(ManagedEnvironment):
+        def __init__(self):
+            super().__init__(num_envs=n, dt=1 / 50, max_episode_length_sec=uni(0.4, 0.7), max_episode_random_scaling=rnd.choice([0.0, 0.1, 0.2]))
+            self.scene = SyntheticScene(dt=self.dt, substeps=2, ang_noise=uni(0.1, 0.3), seed=seed, max_collision_pairs=rnd.choice([8, 12, 30]),
+                                        contact_prob=uni(0.05, 0.3), contact_force=uni(10.0, 60.0))
+            self.terrain = self.scene.add_entity(morphs.Plane())
+            self.robot = self.scene.add_entity(morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=[0.0, 0.0, 0.4], quat=[1.0, 0.0, 0.0, 0.0]))
+
+        def config(self):
+            em = self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={
+                "position": {"fn": reset.position, "params": {"position": [0.0, 0.0, uni(0.3, 0.45)], "quat": [1.0, 0.0, 0.0, 0.0],
+                                                              "zero_velocity": pick(0.7)}}})
+            am = self.action_manager = PositionActionManager(
+                self, joint_names=GO2_JOINTS, default_pos=GO2_DEFAULT_POS, scale=rnd.choice([0.25, 0.5, 1.0]),
+                clip=rnd.choice([None, (-100.0, 100.0), (-1.5, 1.5)]), use_default_offset=pick(0.8), pd_kp=20, pd_kv=0.5)
+            vc = self.velocity_command = VelocityCommandManager(
+                self, range={"lin_vel_x": [-1.0, uni(0.2, 1.5)], "lin_vel_y": rnd.choice([[0, 0], [-0.5, 0.5]]), "ang_vel_z": [-uni(0.2, 1.0), 1.0]},
+                standing_probability=0.0, resample_time_sec=uni(0.15, 0.5))
+            feet = body = None
+            if pick(0.7):
+                feet = self.foot_contacts = ContactManager(self, link_names=[".*_foot"], track_air_time=True, air_time_contact_threshold=uni(1.0, 8.0))
+            if pick(0.6):
+                body = self.body_contacts = ContactManager(self, link_names=rnd.choice([["base"], [".*_thigh", "base"], [".*_calf"]]))
+
+            catalogue = {
+                "base_height": lambda: {"fn": rewards.base_height, "params": {"target_height": uni(0.25, 0.4), "entity_attr": "robot"}},
+                "track_lin": lambda: {"fn": rewards.command_tracking_lin_vel, "params": {"vel_cmd_manager": vc, "entity_manager": em, "sensitivity": uni(0.1, 0.5)}},
+                "track_ang": lambda: {"fn": rewards.command_tracking_ang_vel, "params": {"vel_cmd_manager": vc, "entity_manager": em}},
+                "lin_vel_z": lambda: {"fn": rewards.lin_vel_z_l2, "params": {"entity_manager": em}},
+                "ang_vel_xy": lambda: {"fn": rewards.ang_vel_xy_l2, "params": {"entity_manager": em}},
+                "flat": lambda: {"fn": rewards.flat_orientation_l2, "params": {"entity_manager": em}},
+                "action_rate": lambda: {"fn": rewards.action_rate_l2},
+                "similar": lambda: {"fn": rewards.dof_similar_to_default, "params": {"action_manager": am}},
+                "stand_still": lambda: {"fn": rewards.stand_still_joint_deviation_l1, "params": {"vel_cmd_manager": vc, "action_manager": am,
+                                                                                                 "command_threshold": uni(0.05, 0.6)}},
+                "alive": lambda: {"fn": rewards.is_alive},
+                "terminated": lambda: {"fn": rewards.terminated},
+                "body_accel": lambda: {"fn": rewards.body_acceleration_exp, "params": {"entity_manager": em}},
+            }
+            if feet is not None:
+                catalogue["air_time"] = lambda: {"fn": rewards.feet_air_time, "params": {
+                    "contact_manager": feet, "time_threshold": uni(0.02, 0.2), "vel_cmd_manager": vc if pick(0.5) else None,
+                    "time_threshold_max": uni(0.2, 0.5) if pick(0.4) else None}}
+                catalogue["feet_slide"] = lambda: {"fn": rewards.feet_slide, "params": {"contact_manager": feet}}
+            if body is not None:
+                catalogue["undesired"] = lambda: {"fn": rewards.has_contact, "params": {"contact_manager": body, "threshold": uni(1.0, 20.0)}}
+                catalogue["body_force"] = lambda: {"fn": rewards.contact_force, "params": {"contact_manager": body, "threshold": uni(1.0, 20.0)}}
+            names = rnd.sample(sorted(catalogue), rnd.randint(1, min(10, len(catalogue))))
+            rcfg = {}
+            for name in names:
+                item = catalogue[name]()
+                item["params"] = {k: v for k, v in item.get("params", {}).items() if v is not None}
+                item["weight"] = 0.0 if pick(0.08) else rnd.choice([-1, 1]) * uni(0.01, 3.0)
+                rcfg[name] = item
+            self.has_user_term = pick(0.3)
+            if self.has_user_term:  # a user-level Python term: evaluated in torch on both sides; such a step is not recorded
+                rcfg["user_height"] = {"weight": 0.3, "fn": lambda env: torch.tanh(env.robot.get_pos()[:, 2])}
+            self.reward_manager = RewardManager(self, logging_enabled=pick(0.85), cfg=rcfg)
+
+            tcfg = {"timeout": {"fn": terminations.timeout, "time_out": True}}
+            if pick(0.8):
+                tcfg["fall_over"] = {"fn": terminations.bad_orientation, "params": {"limit_angle": rnd.choice([10.0, 20.0, 30.0, 40.0]), "entity_manager": em,
+                                                                                    "grace_steps": rnd.choice([0, 0, 5])}}
+            if pick(0.3):
+                tcfg["too_low"] = {"fn": terminations.base_height_below_minimum, "params": {"minimum_height": uni(0.05, 0.3), "entity_manager": em}}
+            if body is not None and pick(0.6):
+                kind = rnd.choice(["force", "has", "grace"])
+                if kind == "force":
+                    tcfg["body_contact"] = {"fn": terminations.contact_force, "params": {"contact_manager": body, "threshold": uni(20.0, 50.0)}}
+                elif kind == "has":
+                    tcfg["body_contact"] = {"fn": terminations.has_contact, "params": {"contact_manager": body, "threshold": uni(20.0, 50.0),
+                                                                                       "min_contacts": rnd.choice([1, 2])}}
+                else:
+                    tcfg["body_contact"] = {"fn": terminations.contact_force_with_grace_period,
+                                            "params": {"contact_manager": body, "threshold": uni(20.0, 50.0), "grace_steps": rnd.choice([3, 10])}}
+            self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg=tcfg)
+
+            items = {
+                "velocity_cmd": lambda: {"fn": vc.observation},
+                "angle_velocity": lambda: {"fn": lambda env: em.get_angular_velocity()},
+                "linear_velocity": lambda: {"fn": lambda env: em.get_linear_velocity()},
+                "projected_gravity": lambda: {"fn": lambda env: em.get_projected_gravity()},
+                "dof_position": lambda: {"fn": lambda env: am.get_dofs_position()},
+                "dof_velocity": lambda: {"fn": lambda env: am.get_dofs_velocity()},
+                "actions": lambda: {"fn": lambda env: am.get_actions()},
+                "dof_force": lambda: {"fn": observations.entity_dofs_force, "params": {"action_manager": am}},
+            }
+            if feet is not None:
+                items["foot_force"] = lambda: {"fn": observations.contact_force, "params": {"contact_manager": feet}}
+
+            def obs_cfg(k_min):
+                chosen = rnd.sample(sorted(items), rnd.randint(k_min, len(items)))
+                cfg = {}
+                for name in chosen:
+                    it = items[name]()
+                    if pick(0.4):
+                        it["scale"] = rnd.choice([0.05, 0.1, 0.25, 2.0])
+                    if pick(0.25):
+                        it["noise"] = rnd.choice([0.01, 0.05])
+                    cfg[name] = it
+                return cfg
+
+            self.observation_manager = ObservationManager(self, name="policy", cfg=obs_cfg(2), history_len=rnd.choice([None, None, 2, 3, 5]),
+                                                          noise=0.02 if pick(0.15) else None)
+            self.third_obs = False
+            if pick(0.35):
+                ObservationManager(self, name="critic", cfg=obs_cfg(1), history_len=rnd.choice([None, 4]))
+                self.third_obs = pick(0.4)
+                if self.third_obs:  # more observation managers than the fused kernel takes: the recorded step runs as phase chains
+                    ObservationManager(self, name="extra", cfg=obs_cfg(1), history_len=rnd.choice([None, 2]))
+
+    return FuzzEnv()
+
+
+def _run(seed, dev, steps=STEPS):
+    env = make_fuzz_env(seed)
+    env.build()
+    env.seed(seed)
+    obs, _ = env.reset()
+    n = env.num_envs
+    g = torch.Generator().manual_seed(seed)
+    f = lambda t: t.detach().cpu().clone()
+    out = [({"obs": f(obs)}, {})]
+    for t in range(steps):
+        act = torch.randn(n, 12, generator=g)
+        obs, rew, term, trunc, extras = env.step(act.to(dev))
+        state = {"obs": obs, "reward": rew, "terminated": term, "truncated": trunc, "command": env.velocity_command.command,
+                 "episode_length": env.episode_length, "max_episode_length": env.max_episode_length,
+                 "episode_sums": env.reward_manager._episode_sums, "episode_seconds": env.reward_manager._episode_seconds,
+                 "pos": env.robot.get_pos(), "quat": env.robot.get_quat()}
+        for name, o in extras["observations"].items():
+            if name != "policy":
+                state["obs_" + name] = o
+        for cm in env.managers["contact"]:
+            state[f"contacts_{len([k for k in state if k.startswith('contacts_')])}"] = cm.contacts
+        out.append(({k: f(v) for k, v in state.items()}, {k: float(v) for k, v in extras["episode"].items()}))
+    info = {"n": n, "recorded": env._trace is not None, "fused": bool(env._trace is not None and env._trace.post_refs is not None),
+            "user_term": env.has_user_term, "third_obs": env.third_obs}
+    return out, info
+
+
+EXACT = ("terminated", "truncated", "episode_length", "max_episode_length")
+
+
+def _compare(a, b, tol, what):
+    resets = 0
+    for t, ((sa, la), (sb, lb)) in enumerate(zip(a, b)):
+        assert set(sa) == set(sb)
+        for k in sa:
+            if k in EXACT or tol == 0:
+                assert torch.equal(sa[k], sb[k]) or (tol == 0 and torch.allclose(sa[k].float(), sb[k].float(), atol=0, rtol=0, equal_nan=True)), \
+                    f"{what}: {k} differs at step {t}"
+            else:
+                assert torch.allclose(sa[k], sb[k], atol=tol, rtol=0, equal_nan=True), f"{what}: {k} differs at step {t}: {(sa[k] - sb[k]).abs().max()}"
+        assert set(la) == set(lb), f"{what}: log keys differ at step {t}: {sorted(set(la) ^ set(lb))}"
+        for key in la:
+            assert (np.isnan(la[key]) and np.isnan(lb[key])) or abs(la[key] - lb[key]) <= tol + 1e-5 * abs(lb[key]), (what, t, key, la[key], lb[key])
+        if "terminated" in sa:
+            resets += int(sa["terminated"].sum() + sa["truncated"].sum())
+    return resets
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_config_hip_equals_oracle(hip_backend, oracle_lib_path, seed):
+    from genesis_forge_amd import _native as nat
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+
+    hip, info = _run(seed, "cuda")
+    torch.cuda.synchronize()
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(oracle_lib_path))
+    try:
+        ref, _ = _run(seed, "cpu")
+    finally:
+        nat.set_backend(None)
+        gs.set_device("cuda:0")
+    resets = _compare(hip, ref, FLOAT_TOL, f"seed {seed} {info}")
+    if info["n"] >= 63:
+        assert resets > 0, "the config never reset an env: the reset path went untested"
+    # catalogue terms only: recorded and fused; a user-level Python term needs the interpreter between the phases
+    assert info["recorded"] == (not info["user_term"]), info
+    assert info["fused"] == (info["recorded"] and not info["third_obs"]), info
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS[::2])
+def test_random_config_recorded_equals_phase_by_phase(hip_backend, seed):
+    fast, info = _run(seed, "cuda")
+    if info["user_term"]:
+        pytest.skip("a config with a user-level term is never recorded")
+    os.environ["GF_NO_TRACE"] = "1"
+    try:
+        slow, info2 = _run(seed, "cuda")
+    finally:
+        del os.environ["GF_NO_TRACE"]
+    assert info["recorded"] and not info2["recorded"]
+    _compare(fast, slow, 0, f"seed {seed} {info}")
+
+
+def test_fuzz_configs_build_on_cpu(oracle_backend):
+    """CPU leg: every fuzz config builds and steps on the oracle backend (host logic of rarely combined options)."""
+    for seed in SEEDS:
+        out, info = _run(seed, "cpu", steps=6)
+        assert len(out) == 7 and out[-1][0]["obs"].shape[0] == info["n"]
+        assert torch.isfinite(out[-1][0]["reward"]).all()
