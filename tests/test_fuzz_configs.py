@@ -217,7 +217,8 @@ def test_random_config_hip_equals_oracle(hip_backend, oracle_lib_path, seed):
         assert resets > 0, "the config never reset an env: the reset path went untested"
     # catalogue terms only: recorded and fused; a user-level Python term needs the interpreter between the phases
     assert info["recorded"] == (not info["user_term"]), info
-    assert info["fused"] == (info["recorded"] and not info["third_obs"]), info
+    if os.environ.get("GF_NO_FUSE", "0") != "1":  # (the whole suite is also run with every config forced onto the phase chains)
+        assert info["fused"] == (info["recorded"] and not info["third_obs"]), info
 
 
 @pytest.mark.gpu
