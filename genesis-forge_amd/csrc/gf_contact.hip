@@ -27,6 +27,8 @@ constexpr int kContactMaxMgr = 4;
 constexpr int kContactMaxTargets = 64;   // tracked links over all managers of one launch
 constexpr int kContactBlock = 256;
 constexpr int kContactLdsBytes = 16 * 1024;
+constexpr int kContactSelect = 16;      // up to this many tracked links the target table is read with constant indices
+#define GF_CONTACT_INLINE __attribute__((always_inline))
 
 struct ContactMgr {
     int32_t num_targets, num_with, has_with_filter, track_air_time;
@@ -60,16 +62,66 @@ struct FastDivC {
     __device__ __forceinline__ int div(int i) const { return d > 1 ? (int)(((uint64_t)(uint32_t)i * m) >> 40) : i; }
 };
 
+// the per-manager fields a lane needs, picked by its manager index with constant-index selects: the four descriptors sit in
+// SGPRs (one batch of scalar loads), where a lane-dependent index into the kernel argument would be a chain of vector loads
+struct MgrSel {
+    int32_t num_targets, num_with, has_with_filter, track_air_time;
+    float air_time_threshold;
+    float *contacts, *contact_positions, *position_counts, *link_vel_out, *link_pos_out;
+    float *last_air_time, *current_air_time, *last_contact_time, *current_contact_time;
+};
+__device__ __forceinline__ MgrSel pick_mgr(const ContactMultiArgs& a, int mi) {
+    auto of = [](const ContactMgr& m) {
+        return MgrSel{m.num_targets, m.num_with, m.has_with_filter, m.track_air_time, m.air_time_threshold, m.contacts, m.contact_positions,
+                      m.position_counts, m.link_vel_out, m.link_pos_out, m.last_air_time, m.current_air_time, m.last_contact_time,
+                      m.current_contact_time};
+    };
+    MgrSel r = of(a.m[0]);
+#pragma unroll
+    for (int m = 1; m < kContactMaxMgr; ++m)
+        if (mi == m) r = of(a.m[m]);
+    return r;
+}
+
 __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMultiArgs a) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds_raw[];
+    __shared__ int32_t s_with[kContactMaxMgr][GF_MAX_LINK_IDS];
     const int C = a.num_contacts, T = a.total_targets, E = a.envs_per_block;
     const int MW = (C + 31) >> 5;  // 32-bit words of one env's "slot holds a contact" mask
     const int64_t n0 = (int64_t)blockIdx.x * E;
     const int envs_here = (int)((int64_t)a.num_envs - n0 < E ? (int64_t)a.num_envs - n0 : E);
     const int slots = envs_here * C;
+    const int pairs = envs_here * T;
     int32_t* sa = lds_raw;                                                  // [E*C] link_a
     int32_t* sb = lds_raw + E * C;                                          // [E*C] link_b
     uint32_t* smask = reinterpret_cast<uint32_t*>(lds_raw + 2 * E * C);     // [E][MW]
+    const auto* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+
+    // The kernel is a chain of memory round trips at the env counts of a real run (a few hundred workgroups), so everything
+    // that does not depend on an earlier load goes out first: this lane's (env, tracked link) row of the target table — a
+    // vector load from the kernel-argument segment — together with the slot ids and the with-filter tables.
+    auto pair_meta = [&](int pr, int& e, int& t, int& target, int& mi, int& lt) GF_CONTACT_INLINE {
+        const bool live = pr < pairs;
+        e = live ? pr / T : 0;
+        t = live ? pr - e * T : 0;
+        if (T <= kContactSelect) {  // the usual handful of tracked links: constant-index selects out of SGPRs, no memory round trip
+            target = a.target_ids[0]; mi = a.mgr_of[0]; lt = a.local_of[0];
+#pragma unroll
+            for (int x = 1; x < kContactSelect; ++x)
+                if (t == x) { target = a.target_ids[x]; mi = a.mgr_of[x]; lt = a.local_of[x]; }
+        } else {
+            target = *(const __attribute__((address_space(4))) int32_t*)(kp + offsetof(ContactMultiArgs, target_ids) + 4 * t);
+            mi = *(const __attribute__((address_space(4))) uint8_t*)(kp + offsetof(ContactMultiArgs, mgr_of) + t);
+            lt = *(const __attribute__((address_space(4))) uint8_t*)(kp + offsetof(ContactMultiArgs, local_of) + t);
+        }
+    };
+    int e0, t0, target0, mi0, lt0;
+    pair_meta((int)threadIdx.x, e0, t0, target0, mi0, lt0);
+    for (int i = threadIdx.x; i < kContactMaxMgr * GF_MAX_LINK_IDS; i += blockDim.x) {
+        const int m = i / GF_MAX_LINK_IDS, w = i - m * GF_MAX_LINK_IDS;
+        (&s_with[0][0])[i] = *(const __attribute__((address_space(4))) int32_t*)(kp + offsetof(ContactMultiArgs, m) + (size_t)m * sizeof(ContactMgr) +
+                                                                                 offsetof(ContactMgr, with_link_ids) + 4 * w);
+    }
     for (int i = threadIdx.x; i < envs_here * MW; i += blockDim.x) smask[i] = 0u;
     __syncthreads();
     {   // phase 1: the E rows of slot ids are contiguous — flat coalesced copy; slots that hold a contact set their bit
@@ -87,18 +139,15 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
         }
     }
     // phase 2: one lane per (env, tracked link) walks ONLY the occupied slots of its env, in slot order
-    const int pairs = envs_here * T;
     int flag_mask = 0;  // bit m: this lane sanitised a non-finite force for manager m
     for (int pr0 = 0; pr0 < pairs; pr0 += blockDim.x) {
         const int pr = pr0 + (int)threadIdx.x;
         const bool live = pr < pairs;
-        const int e = live ? pr / T : 0;
-        const int t = live ? pr - e * T : 0;
-        const int mi = a.mgr_of[t];
-        const ContactMgr& mg = a.m[mi];
+        int e = e0, t = t0, target = target0, mi = mi0, lt = lt0;
+        if (pr0 > 0) pair_meta(pr, e, t, target, mi, lt);
+        const MgrSel mg = pick_mgr(a, mi);
         const int64_t n = n0 + e;
-        const int lt = a.local_of[t], L = mg.num_targets, W = mg.num_with;
-        const int target = a.target_ids[t];
+        const int L = mg.num_targets, W = mg.num_with;
         const int64_t k = n * L + lt;
         // loop-invariant loads first: a matching slot always involves the target link itself, so its quaternion is the only
         // one this lane can need (kernel.py:74-78); the air-time state is read before the scan as well
@@ -106,6 +155,10 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
         if (live && C > 0) q = ldg4(G(a.links_quat) + (n * a.num_scene_links + target) * 4);
         float cur_air = 0.f, cur_con = 0.f;
         if (live && mg.track_air_time) { cur_air = G(mg.current_air_time)[k]; cur_con = G(mg.current_contact_time)[k]; }
+        V3 lvel{0.f, 0.f, 0.f}, lpos{0.f, 0.f, 0.f};
+        const bool copy_vel = live && a.links_vel && mg.link_vel_out, copy_pos = live && a.links_pos && mg.link_pos_out;
+        if (copy_vel) lvel = load3(a.links_vel, n * a.num_scene_links + target);
+        if (copy_pos) lpos = load3(a.links_pos, n * a.num_scene_links + target);
         if (pr0 == 0) __syncthreads();  // phase 1's LDS writes
         if (!live) continue;
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, cnt = 0.f;
@@ -123,7 +176,7 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
                 if (mg.has_with_filter) {
                     include = false;
                     for (int w = 0; w < W; ++w) {
-                        const int wl = mg.with_link_ids[w];
+                        const int wl = s_with[mi][w];
                         if ((is_a && lb == wl) || (is_b && la == wl)) { include = true; break; }
                     }
                 }
@@ -152,15 +205,13 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
             po[2] = cnt > 0.f ? p2 / cnt : p2;
         }
         if (mg.position_counts) G(mg.position_counts)[k] = cnt;
-        if (a.links_vel && mg.link_vel_out) {  // compact per-manager copy of the tracked links' velocities (feet_slide)
-            const GF_GLOBAL float* sv = G(a.links_vel) + (n * a.num_scene_links + target) * 3;
+        if (copy_vel) {  // compact per-manager copy of the tracked links' velocities (feet_slide)
             GF_GLOBAL float* o = G(mg.link_vel_out) + 3 * k;
-            o[0] = sv[0]; o[1] = sv[1]; o[2] = sv[2];
+            o[0] = lvel.x; o[1] = lvel.y; o[2] = lvel.z;
         }
-        if (a.links_pos && mg.link_pos_out) {  // … and of their positions (the gait manager's foot_height_reward)
-            const GF_GLOBAL float* sp = G(a.links_pos) + (n * a.num_scene_links + target) * 3;
+        if (copy_pos) {  // … and of their positions (the gait manager's foot_height_reward)
             GF_GLOBAL float* o = G(mg.link_pos_out) + 3 * k;
-            o[0] = sp[0]; o[1] = sp[1]; o[2] = sp[2];
+            o[0] = lpos.x; o[1] = lpos.y; o[2] = lpos.z;
         }
         if (mg.track_air_time) {  // contact_manager.py:441-477
             const float dt = a.dt;
