@@ -13,8 +13,14 @@ checks that they are the same objects in the same order, and from then on a step
 Results are bit-identical to the ordinary path (tests/test_trace.py).  Anything the trace cannot see
 invalidates it and the env falls back to the ordinary path until two clean steps have been recorded
 again: a mutated weight/param/scale (ConfigItem dirty hooks), parity-mode draws, an external command
-controller, ``enabled`` toggles, a re-seed.  Configs with Python-evaluated terms, user-overridden
-manager methods, or a scene without static buffers are never traced.
+controller, ``enabled`` toggles, a re-seed.  Configs with user-overridden manager methods or a scene
+without static buffers are never traced.
+
+Python-level terms (a lambda as a reward / termination term, an observation item no opcode covers) do not
+stop a step from being recorded: the op list is cut in front of the op that consumes them, and the replay
+runs ``gf_run_ops`` on the ops before the cut, then evaluates the callables — at exactly the point of the
+step where the ordinary path (and the reference) calls them, on the same stream, no host sync — hands the
+fresh columns to the descriptor, and continues with the next run of ops.
 """
 from __future__ import annotations
 
@@ -44,7 +50,9 @@ class StepTrace:
         self.backend = env.backend
         self.epoch = env._trace_epoch
         self.patches: list[Callable] = []
-        self.afters: list[Callable] = []
+        self.afters: list = []   # (index of the op it follows, callable)
+        self.splits: list = []   # (index of the op it precedes, callable): Python that must run in the middle of the step
+        self._cur_op = 0
         n = len(calls) + 2
         self.ops = (nat.GfOp * n)()
         self.keep = [c[1] for c in calls]
@@ -63,7 +71,12 @@ class StepTrace:
                 self.ops[k].phase = nat.GF_OP_POST_PHYSICS
                 self.ops[k].args = C.addressof(self.post_refs)
                 k += 1
+            self._cur_op = k - 2  # index of this call's op once the leading STATS_CLEAR op is dropped (below)
             self._hooks(fn, args, owner)
+            pre = owner._trace_pre(args) if hasattr(owner, "_trace_pre") else None
+            if pre is not None:
+                assert idx < first_post, "a phase with Python-level terms cannot be part of the fused launch"
+                self.splits.append((self._cur_op, pre))
         # single process: statistics go to a device ring slot per step (no memset, no copy); with a process group the
         # per-step all-reduce path is kept (clear op here, packed + reduced + copied by StepStats.snapshot)
         self.use_ring = stats.group is None
@@ -87,7 +100,15 @@ class StepTrace:
                 k += 1
         self.n_ops = k
         #: hipGraph of this step's launches (built by the library on first replay; HIP backend only)
-        self.graph = C.c_void_p() if hasattr(self.backend, "run_ops_graph") else None
+        self.graph = C.c_void_p() if hasattr(self.backend, "run_ops_graph") and not self.splits else None
+        #: the op list cut at the splits: (first op, count, callable to run before it or None)
+        self.segments = []
+        if self.splits:
+            cuts = [0] + [i for i, _ in self.splits] + [k]
+            pres = [None] + [f for _, f in self.splits]
+            for (a0, a1), pre in zip(zip(cuts[:-1], cuts[1:]), pres):
+                sub = (nat.GfOp * (a1 - a0)).from_buffer(self.ops, a0 * C.sizeof(nat.GfOp)) if a1 > a0 else None
+                self.segments.append((a0, a1 - a0, sub, pre))
 
     def __del__(self):
         g = getattr(self, "graph", None)
@@ -113,6 +134,8 @@ class StepTrace:
         fns = [c[0] for c in tail]
         if not fns or fns[0] != "termination_step":
             return None
+        if any(hasattr(c[2], "_trace_pre") and c[2]._trace_pre(c[1]) is not None for c in tail):
+            return None  # Python runs between these phases: they stay separate ops
         refs = nat.GfPostRefs()
         refs.termination = C.addressof(tail[0][1])
         j = 1
@@ -157,14 +180,14 @@ class StepTrace:
                 owner._raw_actions = actions
             self.patches.append(patch)
             if not owner._quiet_action_errors:
-                self.afters.append(owner._watch_flags)
+                self.afters.append((self._cur_op, owner._watch_flags))
         elif fn == "synth_scene_step":
             def patch(_actions, a=args, scene=owner):
                 a.tick = scene.tick
                 scene.tick += 1
             self.patches.append(patch)
         elif fn == "termination_step":
-            self.afters.append(owner.manager._publish)
+            self.afters.append((self._cur_op, owner.manager._publish))
         elif fn == "reward_step":
             pass
         elif fn in ("command_step", "gait_step"):
@@ -176,7 +199,7 @@ class StepTrace:
                 if rm is not None and rm.enabled and rm.logging_enabled:
                     rm._register_log()
             self.patches.append(patch)
-            self.afters.append(env._after_masked_reset_traced)
+            self.afters.append((self._cur_op, env._after_masked_reset_traced))
         elif fn == "observe":
             self.patches.append(owner._trace_patch(args))
         elif fn == "contact_step":
@@ -210,14 +233,27 @@ class StepTrace:
         for a in self.stat_fields:
             a.stats = cur
         self.action_args.stats_zero = nxt
-        if self.graph is not None:
+        done = 0  # afters already run
+        if self.segments:
+            for first, count, sub, pre in self.segments:
+                if pre is not None:
+                    # the ordinary path has finished every earlier phase — launch AND Python bookkeeping — when it calls a
+                    # Python-level term: views of the scene are stale after the scene op, earlier phases' hooks have run
+                    env._tick += 1
+                    while done < len(self.afters) and self.afters[done][0] < first:
+                        self.afters[done][1]()
+                        done += 1
+                    pre()
+                if count:
+                    self.backend.run_ops(sub, count)
+        elif self.graph is not None:
             self.backend.run_ops_graph(self.graph, self.ops, self.n_ops)
         else:
             self.backend.run_ops(self.ops, self.n_ops)
         if not self.use_ring:
             snap = env.stats.vec_ring_reduce(slot)  # the single collective of the path, asynchronous
         env._tick += 1  # scene advanced
-        for f in self.afters:
+        for _, f in self.afters[done:]:
             f()
         env._finish_step_light(snap)
         tm, rm = env.managers["termination"], env.managers["reward"]

@@ -69,8 +69,10 @@ class _Slots:
         self.exts: list = []
         self.states: list = []
         self.terrain = None        # the one TerrainManager a phase may sample
-        #: True when a launch bound a per-step temporary (Python-evaluated column, link velocities fetched through a
-        #: Genesis getter, an external command controller): such a descriptor must never be frozen into a recorded step
+        #: True when a launch bound a per-step temporary the recorded step cannot refresh (link velocities fetched through a
+        #: Genesis getter, an external command controller, a converted copy of a command tensor): such a descriptor must never
+        #: be frozen into a recorded step.  Python-evaluated columns (``exts``) are NOT volatile in this sense: the recorded step
+        #: re-evaluates them at the point of the step where the ordinary path does (rebind_exts, _trace.StepTrace.splits).
         self.volatile = False
 
     def cmd(self, src) -> int:
@@ -127,7 +129,7 @@ class _Slots:
     def bind(self, args, ext_dtype, keep: list) -> None:
         """Refresh the pointers of every slot for this launch."""
         n = self.env.num_envs
-        self.volatile = len(self.exts) > 0
+        self.volatile = False
         for k, src in enumerate(self.cmds):
             if getattr(src, "_external_controller", None) is not None:
                 self.volatile = True
@@ -158,15 +160,36 @@ class _Slots:
                 if tmp:
                     self.volatile = True  # link velocities are a fresh tensor every step
                 keep.extend(tmp)
-        for k, prov in enumerate(self.exts):
-            t = _col(prov(), n, ext_dtype)
-            keep.append(t)
-            args.ext[k] = t.data_ptr()
+        self.rebind_exts(args, ext_dtype, keep)
         if hasattr(args, "state"):
             for k, t in enumerate(self.states):
                 args.state[k] = t.data_ptr()
         if self.terrain is not None and hasattr(args, "terrain"):
             self.terrain.gf_view(args.terrain)
+
+
+def _rebind_exts(self, args, ext_dtype, keep: list) -> None:
+    """Evaluate every Python-level term now (exactly the call the reference makes at this point of the step) and hand the
+    columns to the descriptor."""
+    n = self.env.num_envs
+    for k, prov in enumerate(self.exts):
+        t = _col(call_untraced(self.env, prov), n, ext_dtype)
+        keep.append(t)
+        args.ext[k] = t.data_ptr()
+
+
+def call_untraced(env, fn):
+    """Run a user callable with step recording suspended: native launches it makes itself (an EntityManager getter, a direct
+    ``mdp.*`` call) belong to the callable — the recorded step re-runs the callable, not a frozen copy of its launches."""
+    backend = env.backend
+    tracer, backend.tracer = backend.tracer, None
+    try:
+        return fn()
+    finally:
+        backend.tracer = tracer
+
+
+_Slots.rebind_exts = _rebind_exts
 
 
 def spec_of(fn, env, params) -> Optional[TermSpec]:
@@ -249,6 +272,22 @@ class RewardProgram:
         self._keep = keep
 
 
+def _program_trace_pre(prog, ext_dtype):
+    """Recorded step: what must run in Python right before this program's op — its Python-level terms."""
+    if not prog.slots.exts:
+        return None
+
+    def pre(prog=prog, ext_dtype=ext_dtype):
+        keep: list = []
+        prog.slots.rebind_exts(prog.args, ext_dtype, keep)
+        prog._keep_ext = keep
+
+    return pre
+
+
+RewardProgram._trace_pre = lambda self, args: _program_trace_pre(self, torch.float32)
+
+
 def eval_reward_spec(env, spec: TermSpec) -> torch.Tensor:
     """Direct call of an ``mdp.rewards.*`` function: one-term program in EVAL mode → ``[N]`` tensor."""
     prog = RewardProgram(env)
@@ -297,6 +336,9 @@ class TerminationProgram:
         self.slots.bind(a, torch.bool, keep)
         env.backend.call("termination_step", a, owner=self)
         self._keep = keep
+
+
+TerminationProgram._trace_pre = lambda self, args: _program_trace_pre(self, torch.bool)
 
 
 def eval_termination_spec(env, spec: TermSpec) -> torch.Tensor:

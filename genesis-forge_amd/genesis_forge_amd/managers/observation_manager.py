@@ -22,7 +22,7 @@ import torch
 from .. import _native as nat
 from .. import gs
 from ..spaces import Box
-from ._program import _Slots, _col
+from ._program import _Slots, _col, call_untraced
 from .base import BaseManager, LiveAttr
 from .config import ObservationConfigItem
 
@@ -207,11 +207,7 @@ class ObservationManager(BaseManager):
             a.command[k].command, a.command[k].width, a.command[k].stride = t.data_ptr(), t.shape[1], 0
         for k, (mgr, lv, _lp) in enumerate(self._slots.contacts):
             keep.extend(mgr.view(a.contact[k], need_link_vel=False))
-        for k, prov in enumerate(self._slots.exts):
-            t = prov()
-            t = _col(t.unsqueeze(-1) if t.dim() == 1 else t, n, torch.float32)
-            keep.append(t)
-            a.ext[k] = t.data_ptr()
+        self._bind_exts(a, keep)
         draws = env.take_draws(f"obs:{self._name}")
         keep.append(draws)
         a.noise_draws = None if draws is None else draws.data_ptr()
@@ -229,9 +225,30 @@ class ObservationManager(BaseManager):
         a.obs = out.data_ptr()
         return out
 
+    def _bind_exts(self, a, keep: list) -> None:
+        """Evaluate the items no kernel opcode covers (user callables) and hand their [N,w] columns to the descriptor."""
+        n = self.env.num_envs
+        for k, prov in enumerate(self._slots.exts):
+            t = call_untraced(self.env, prov)
+            t = _col(t.unsqueeze(-1) if t.dim() == 1 else t, n, torch.float32)
+            keep.append(t)
+            a.ext[k] = t.data_ptr()
+
     def _traceable(self) -> bool:
-        return self.enabled and not self._dirty and len(self._slots.exts) == 0 and len(self._slots.contacts) >= 0 and all(
+        return self.enabled and not self._dirty and all(
             not hasattr(s, "_external_controller") or s._external_controller is None for s in self._slots.cmds)
+
+    def _trace_pre(self, args):
+        """Recorded step: Python-level items are evaluated right before this manager's op, where the ordinary path calls them."""
+        if not self._slots.exts:
+            return None
+
+        def pre(self=self, a=args):
+            keep: list = []
+            self._bind_exts(a, keep)
+            self._keep_ext = keep
+
+        return pre
 
     def _trace_patch(self, args):
         env = self.env

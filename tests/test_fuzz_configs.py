@@ -3,8 +3,7 @@
 Each seed draws a task config from the whole mdp catalogue — which reward / termination terms, with what weights and parameters,
 which observation items in what order with what scales / noise / history, how many ContactManagers and ObservationManagers (a
 third one takes the recorded step off the fused kernel and onto the phase chains), whether a user-level (Python)
-reward term is present (Python between the phases: such a step cannot be recorded and runs phase by phase) — and an env count
-around the 64-env tile size.  The same config then runs 48 steps on the GPU and on the oracle in Philox mode; masks and integer state must be
+reward term is present (the recorded step is then cut in two around the call) — and an env count around the 64-env tile size.  The same config then runs 48 steps on the GPU and on the oracle in Philox mode; masks and integer state must be
 bit-exact, floats within 1e-5 (helpers.FLOAT_TOL), log keys identical.  A second leg replays the GPU run with the recorded step
 disabled: recorded (fused or chained) and phase-by-phase execution must agree bit for bit.
 """
@@ -89,7 +88,7 @@ def make_fuzz_env(seed: int):
                 item["weight"] = 0.0 if pick(0.08) else rnd.choice([-1, 1]) * uni(0.01, 3.0)
                 rcfg[name] = item
             self.has_user_term = pick(0.3)
-            if self.has_user_term:  # a user-level Python term: evaluated in torch on both sides; such a step is not recorded
+            if self.has_user_term:  # a user-level Python term: evaluated in torch on both sides, in the middle of the recorded step
                 rcfg["user_height"] = {"weight": 0.3, "fn": lambda env: torch.tanh(env.robot.get_pos()[:, 2])}
             self.reward_manager = RewardManager(self, logging_enabled=pick(0.85), cfg=rcfg)
 
@@ -109,6 +108,9 @@ def make_fuzz_env(seed: int):
                 else:
                     tcfg["body_contact"] = {"fn": terminations.contact_force_with_grace_period,
                                             "params": {"contact_manager": body, "threshold": uni(20.0, 50.0), "grace_steps": rnd.choice([3, 10])}}
+            if pick(0.15):  # a user-level termination term (evaluated in front of the termination op)
+                self.has_user_term = True
+                tcfg["user_far"] = {"fn": lambda env: env.robot.get_pos()[:, :2].abs().sum(dim=1) > 0.35}
             self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg=tcfg)
 
             items = {
@@ -127,6 +129,9 @@ def make_fuzz_env(seed: int):
             def obs_cfg(k_min):
                 chosen = rnd.sample(sorted(items), rnd.randint(k_min, len(items)))
                 cfg = {}
+                if pick(0.15):  # a user-level observation item (evaluated in front of this manager's op)
+                    self.has_user_term = True
+                    cfg["user_xy"] = {"fn": lambda env: env.robot.get_pos()[:, :2] * 2.0}
                 for name in chosen:
                     it = items[name]()
                     if pick(0.4):
@@ -215,21 +220,33 @@ def test_random_config_hip_equals_oracle(hip_backend, oracle_lib_path, seed):
     resets = _compare(hip, ref, FLOAT_TOL, f"seed {seed} {info}")
     if info["n"] >= 63:
         assert resets > 0, "the config never reset an env: the reset path went untested"
-    # catalogue terms only: recorded and fused; a user-level Python term needs the interpreter between the phases
-    assert info["recorded"] == (not info["user_term"]), info
+    # every config is recorded; a user-level Python term or a third ObservationManager keeps it off the fused kernel
+    assert info["recorded"], info
     if os.environ.get("GF_NO_FUSE", "0") != "1":  # (the whole suite is also run with every config forced onto the phase chains)
-        assert info["fused"] == (info["recorded"] and not info["third_obs"]), info
+        assert info["fused"] == (not info["user_term"] and not info["third_obs"]), info
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", SEEDS[::2])
 def test_random_config_recorded_equals_phase_by_phase(hip_backend, seed):
     fast, info = _run(seed, "cuda")
-    if info["user_term"]:
-        pytest.skip("a config with a user-level term is never recorded")
     os.environ["GF_NO_TRACE"] = "1"
     try:
         slow, info2 = _run(seed, "cuda")
+    finally:
+        del os.environ["GF_NO_TRACE"]
+    assert info["recorded"] and not info2["recorded"]
+    _compare(fast, slow, 0, f"seed {seed} {info}")
+
+
+@pytest.mark.parametrize("seed", [s for s in SEEDS if s % 3 == 0])
+def test_random_config_recorded_equals_phase_by_phase_cpu(oracle_backend, seed):
+    """The same on the CPU oracle's gfo_run_ops: the recorded step (cut around Python-level terms where there are any)
+    against the phase-by-phase step."""
+    fast, info = _run(seed, "cpu", steps=30)
+    os.environ["GF_NO_TRACE"] = "1"
+    try:
+        slow, info2 = _run(seed, "cpu", steps=30)
     finally:
         del os.environ["GF_NO_TRACE"]
     assert info["recorded"] and not info2["recorded"]

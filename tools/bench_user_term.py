@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Step time of a config with one user-level (Python) reward term: recorded step (cut around the call) vs phase by phase.
+    python tools/bench_user_term.py [num_envs]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "genesis-forge_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from genesis_forge_amd import gs
+from envs import Go2CommandDirectionEnv
+
+
+def run(n, trace, steps=400):
+    if trace:
+        os.environ.pop("GF_NO_TRACE", None)
+    else:
+        os.environ["GF_NO_TRACE"] = "1"
+
+    env = Go2CommandDirectionEnv(num_envs=n, scene_kwargs=dict(ang_noise=0.05, seed=1))
+    cfg_add = {"user_height": {"weight": 0.3, "fn": lambda env: torch.tanh(env.robot.get_pos()[:, 2])}}
+    orig = env.config
+
+    def config():
+        orig()
+        from genesis_forge_amd.managers import RewardManager
+        rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in env.reward_manager.cfg.items()}
+        rc.update(cfg_add)
+        env.managers["reward"] = None
+        env.reward_manager = RewardManager(env, logging_enabled=True, cfg=rc)
+
+    env.config = config
+    env.build()
+    env.seed(1)
+    env.reset()
+    acts = [torch.randn(n, 12, device=gs.device) for _ in range(4)]
+    for i in range(30):
+        env.step(acts[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        env.step(acts[i % 4])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps * 1e6
+    tr = env._trace
+    return dt, (tr is not None), (len(tr.splits) if tr else None), (tr.n_ops if tr else None)
+
+
+if __name__ == "__main__":
+    gs.set_device("cuda:0")
+    for n in ([int(sys.argv[1])] if len(sys.argv) > 1 else [4096, 65536]):
+        for trace in (True, False):
+            dt, rec, splits, ops = run(n, trace)
+            print(f"N={n:6d} recorded={rec!s:5s} cuts={splits} ops={ops}  {dt:8.1f} us/step  {n / dt:8.1f} M env-steps/s", flush=True)

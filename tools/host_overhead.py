@@ -38,7 +38,7 @@ def py_only():
     env._begin_step_light()
     for p in tr.patches: p(act)
     cur, nxt, prev, prev_vec, snap = env.stats.ring_next()
-    for f in tr.afters: f()
+    for _, f in tr.afters: f()
     env._finish_step_light(snap)
 print("python bookkeeping only  %.1f us" % timeit(py_only))
 # host-side enqueue cost alone: time a short burst before the queue can fill, without waiting for the GPU
