@@ -182,7 +182,11 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
                 if (used > 0) { if (rc == GF_OK) i += used - 1; break; }
                 rc = gf_termination_step((const GfTerminationArgs*)a, stream);
             } break;
-            case GF_PHASE_REWARD: rc = gf_reward_step((const GfRewardArgs*)a, stream); break;
+            case GF_PHASE_REWARD: {
+                const int used = gf::chain_a_try(ops, i, num_ops, s, &rc, &deferred);   // reward → command.step … (no termination op in front)
+                if (used > 0) { if (rc == GF_OK) i += used - 1; break; }
+                rc = gf_reward_step((const GfRewardArgs*)a, stream);
+            } break;
             case GF_PHASE_COMMAND: rc = gf_command_step((const GfCommandArgs*)a, stream); break;
             case GF_PHASE_RESET: {
                 const int used = gf::chain_b_try(ops, i, num_ops, s, &rc, &deferred);   // reset → command.reset … → observe … in one launch

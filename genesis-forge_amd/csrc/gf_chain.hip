@@ -43,7 +43,9 @@ struct ChainAArgs {
     GfCommandArgs cmd[kChainCmd];
     GfGaitArgs gait[kChainGait];
     uint32_t needs_t, needs_r;
-    int32_t has_reward, n_cmd, n_gait, _pad;
+    int32_t has_reward, n_cmd, n_gait;
+    int32_t has_term;   // 0: the chain starts at the reward op (the termination op ran in an earlier launch: a recorded step cut
+                        // in front of a reward manager with Python-level terms)
 };
 static_assert(sizeof(ChainAArgs) <= 4096, "kernarg segment");
 
@@ -62,7 +64,7 @@ static_assert(sizeof(ChainBArgs) <= 4096, "kernarg segment");
 template <int DV>
 __global__ __launch_bounds__(kEnvBlock) void chain_a_kernel(const ChainAArgs a) {
     __shared__ float lds_sums[GF_MAX_TERMS * kEnvBlock];
-    termination_body(a.term, a.needs_t);
+    if (a.has_term) termination_body(a.term, a.needs_t);
     __syncthreads();  // the masks this workgroup just wrote are read by its reward terms
     if (a.has_reward) reward_body<DV>(a.rew, a.needs_r, lds_sums);
     __syncthreads();  // reward terms read the commands BEFORE this step's resample (managed_env.py:312-319)
@@ -104,21 +106,27 @@ __global__ __launch_bounds__(kObsBlock) void chain_b_kernel(const ChainBArgs a) 
 
 static bool profiled(int phase) { return g_prof.phase == phase; }
 
-// ops[i] is a termination op: fold it with the reward / command.step / gait.step ops that follow.  Returns the number of ops
-// consumed (0 = not a chain: launch phase by phase), *rc = launch status.
+// ops[i] is a termination op (or a reward op whose termination op ran earlier): fold it with the reward / command.step /
+// gait.step ops that follow.  Returns the number of ops consumed (0 = not a chain: launch phase by phase), *rc = launch status.
 int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc, DeferredFlags* deferred) {
     if (!g_options[GF_OPT_CHAIN] || profiled(GF_PHASE_TERMINATION) || profiled(GF_PHASE_REWARD) || profiled(GF_PHASE_COMMAND) || profiled(GF_PHASE_GAIT)) return 0;
     ChainAArgs k{};
-    const GfTerminationArgs* t = (const GfTerminationArgs*)ops[i].args;
-    if (!t || termination_prep(t, &k.needs_t) != GF_OK || t->num_envs <= 0) return 0;
-    const int N = t->num_envs;
-    int j = i + 1, dv = 0;
+    const GfTerminationArgs* t = nullptr;
+    int j = i, dv = 0, N = 0;
+    if (ops[i].phase == GF_PHASE_TERMINATION) {
+        t = (const GfTerminationArgs*)ops[i].args;
+        if (!t || termination_prep(t, &k.needs_t) != GF_OK || t->num_envs <= 0) return 0;
+        N = t->num_envs;
+        ++j;
+    }
     const GfRewardArgs* r = nullptr;
     if (j < num_ops && ops[j].phase == GF_PHASE_REWARD) {
         r = (const GfRewardArgs*)ops[j].args;
-        if (!r || r->num_envs != N || r->mode != GF_REWARD_MODE_STEP || reward_prep(r, &k.needs_r, &dv) != GF_OK) return 0;
+        if (!r || (t && r->num_envs != N) || r->num_envs <= 0 || r->mode != GF_REWARD_MODE_STEP || reward_prep(r, &k.needs_r, &dv) != GF_OK) return 0;
+        N = r->num_envs;
         ++j;
     }
+    if (!t && !r) return 0;
     for (; j < num_ops; ++j) {
         if (ops[j].phase == GF_PHASE_COMMAND) {
             const GfCommandArgs* c = (const GfCommandArgs*)ops[j].args;
@@ -147,7 +155,8 @@ int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc, Def
         }
     }
     if (j - i < 2) return 0;
-    k.term = *t;
+    k.has_term = t ? 1 : 0;
+    if (t) k.term = *t;
     k.has_reward = r ? 1 : 0;
     if (r) k.rew = *r;
     const dim3 grid(env_grid(N)), block(kEnvBlock);
