@@ -233,13 +233,16 @@ class StepTrace:
         for a in self.stat_fields:
             a.stats = cur
         self.action_args.stats_zero = nxt
-        done = 0  # afters already run
+        done = 0        # afters already run
+        ticked = False  # the scene op has been enqueued and the views cache invalidated for it
         if self.segments:
             for first, count, sub, pre in self.segments:
                 if pre is not None:
                     # the ordinary path has finished every earlier phase — launch AND Python bookkeeping — when it calls a
                     # Python-level term: views of the scene are stale after the scene op, earlier phases' hooks have run
-                    env._tick += 1
+                    if not ticked:
+                        env._tick += 1
+                        ticked = True
                     while done < len(self.afters) and self.afters[done][0] < first:
                         self.afters[done][1]()
                         done += 1
@@ -252,7 +255,8 @@ class StepTrace:
             self.backend.run_ops(self.ops, self.n_ops)
         if not self.use_ring:
             snap = env.stats.vec_ring_reduce(slot)  # the single collective of the path, asynchronous
-        env._tick += 1  # scene advanced
+        if not ticked:
+            env._tick += 1  # scene advanced
         for _, f in self.afters[done:]:
             f()
         env._finish_step_light(snap)

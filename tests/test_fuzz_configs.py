@@ -168,7 +168,9 @@ def _run(seed, dev, steps=STEPS):
         state = {"obs": obs, "reward": rew, "terminated": term, "truncated": trunc, "command": env.velocity_command.command,
                  "episode_length": env.episode_length, "max_episode_length": env.max_episode_length,
                  "episode_sums": env.reward_manager._episode_sums, "episode_seconds": env.reward_manager._episode_seconds,
-                 "pos": env.robot.get_pos(), "quat": env.robot.get_quat()}
+                 "pos": env.robot.get_pos(), "quat": env.robot.get_quat(),
+                 # a manager getter BETWEEN steps: just-reset envs are still rotated by their pre-reset orientation (quirk q-stale)
+                 "gravity_between_steps": env.robot_manager.get_projected_gravity()}
         for name, o in extras["observations"].items():
             if name != "policy":
                 state["obs_" + name] = o
