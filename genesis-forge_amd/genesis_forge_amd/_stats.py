@@ -130,10 +130,13 @@ class StepStats:
         self._slot = 0
         self.group = None       # torch.distributed process group (distributed.attach); None = single process
         self._vring = None
+        #: a recorded step whose tail runs in Python (an env that overrides reset()) points the phase-by-phase launches of that
+        #: tail at the step's ring slot, so that the whole step's statistics end up in one block
+        self.ptr_override: Optional[int] = None
 
     @property
     def ptr(self) -> int:
-        return self.dev.data_ptr()
+        return self.ptr_override if self.ptr_override is not None else self.dev.data_ptr()
 
     def clear(self, backend: nat.Backend) -> None:
         backend.stats_clear(self.ptr)

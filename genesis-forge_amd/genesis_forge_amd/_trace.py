@@ -36,17 +36,25 @@ class Recorder:
 
     def __init__(self):
         self.calls: list = []
+        self.tail_python = False
 
     def record(self, fn, args, owner):
-        self.calls.append((fn, args, owner))
+        if not self.tail_python:
+            self.calls.append((fn, args, owner))
+
+    def cut_tail(self):
+        """Everything the step does from here on stays Python in the recorded step (an env that overrides ``reset()``: the
+        index-list reset with its host sync, then the observations, run phase by phase exactly as in an ordinary step)."""
+        self.tail_python = True
 
     def signature(self):
-        return [(fn, C.addressof(args), id(owner)) for fn, args, owner in self.calls]
+        return [(fn, C.addressof(args), id(owner)) for fn, args, owner in self.calls] + ([("tail",)] if self.tail_python else [])
 
 
 class StepTrace:
-    def __init__(self, env, calls: list):
+    def __init__(self, env, calls: list, tail_python: bool = False):
         self.env = env
+        self.tail_python = tail_python
         self.backend = env.backend
         self.epoch = env._trace_epoch
         self.patches: list[Callable] = []
@@ -100,7 +108,7 @@ class StepTrace:
                 k += 1
         self.n_ops = k
         #: hipGraph of this step's launches (built by the library on first replay; HIP backend only)
-        self.graph = C.c_void_p() if hasattr(self.backend, "run_ops_graph") and not self.splits else None
+        self.graph = C.c_void_p() if hasattr(self.backend, "run_ops_graph") and not self.splits and not tail_python else None
         #: the op list cut at the splits: (first op, count, callable to run before it or None)
         self.segments = []
         if self.splits:
@@ -259,20 +267,34 @@ class StepTrace:
             env._tick += 1  # scene advanced
         for _, f in self.afters[done:]:
             f()
-        env._finish_step_light(snap)
         tm, rm = env.managers["termination"], env.managers["reward"]
+        obs_tail = None
+        if self.tail_python:
+            # reset (the user's override, by index list, behind the same nonzero() sync the reference pays) and observations,
+            # phase by phase; their launches write their statistics into this step's ring slot
+            env.stats.ptr_override, env._in_step = cur, True
+            try:
+                env._reset_done(tm._terminated_buf, tm._truncated_buf)
+                obs_tail = env.get_observations()
+            finally:
+                env.stats.ptr_override, env._in_step = None, False
+        env._finish_step_light(snap)
         extras = env._extras
-        obs = extras["observations"].get("policy") if len(env.managers["observation"]) > 0 else None
+        obs = extras["observations"].get("policy") if len(env.managers["observation"]) > 0 else obs_tail
         return obs, rm._reward_buf if rm is not None else env._reward_buf, tm._terminated_buf, tm._truncated_buf, extras
 
 
-def traceable(env) -> bool:
+def traceable(env, tail_python: bool = False) -> bool:
     """Static conditions under which an env's step may be recorded (see module docstring)."""
     from .managed_env import ManagedEnvironment, _most_derived_is_ours
     from .managers.action import PositionActionManager
 
-    if type(env).step is not ManagedEnvironment.step or type(env).reset is not ManagedEnvironment.reset:
+    if type(env).step is not ManagedEnvironment.step:
         return False
+    if (type(env).reset is not ManagedEnvironment.reset) != tail_python:
+        return False
+    if tail_python and env.stats.group is not None:
+        return False  # the per-step pack / all-reduce of a process group closes the statistics before the Python tail adds to them
     if type(env).get_observations is not ManagedEnvironment.get_observations:
         return False
     if not getattr(env.scene, "gf_static_buffers", False):
@@ -296,6 +318,8 @@ def traceable(env) -> bool:
     for c in env.managers["contact"]:
         if not c.enabled:
             return False
+    if tail_python:
+        return True  # reset and observations run phase by phase: nothing about them is frozen
     for om in env.managers["observation"]:
         if not om._traceable():
             return False

@@ -175,8 +175,8 @@ class ManagedEnvironment(GenesisEnv):
             backend.tracer = None
         if epoch == self._trace_epoch:  # nothing was invalidated while the step ran
             sig = rec.signature()
-            if sig == self._last_signature and _trace.traceable(self):
-                self._trace = _trace.StepTrace(self, rec.calls)
+            if sig == self._last_signature and _trace.traceable(self, rec.tail_python):
+                self._trace = _trace.StepTrace(self, rec.calls, rec.tail_python)
             self._last_signature = sig
         return out
 
@@ -230,6 +230,8 @@ class ManagedEnvironment(GenesisEnv):
             m.step()
 
         if tm is not None:
+            if type(self).reset is not ManagedEnvironment.reset and self.backend.tracer is not None:
+                self.backend.tracer.cut_tail()  # a user reset(): the rest of the step stays Python in the recorded step
             self._reset_done(terminated, truncated)
 
         obs = self.get_observations()

@@ -228,7 +228,8 @@ def _gait_reset_with_curriculum(self, envs_idx=None):
 
 class Go2GaitTrainingCurriculumEnv(Go2GaitTrainingEnv):
     """The example's ``reset`` override (examples/gait_trainer/environment.py:347-352).  Kept in a subclass: an env that
-    overrides ``reset`` gets the reference's index-list reset path and is never recorded."""
+    overrides ``reset`` gets the reference's index-list reset path: its step is recorded up to the reset, the reset and the
+    observations run phase by phase (_trace.StepTrace.tail_python)."""
 
     reset = _gait_reset_with_curriculum
 

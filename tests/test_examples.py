@@ -124,6 +124,60 @@ def _philox_run(name, dev, trace, n, steps=45):
     return out, env
 
 
+def _override_run(dev, trace, n, steps=45):
+    """The gait task WITH the example's reset() override (examples/gait_trainer/environment.py:347-352: curriculum update after
+    every reset) and, on top, a counter the override bumps — user code in reset() must run exactly as often as in an ordinary step."""
+    import envs
+
+    case = dict(example_cases.CASES["gait_trainer"], n=n, episode_s=1.0)
+
+    class Env(envs.Go2GaitTrainingCurriculumEnv):
+        user_resets = 0
+        user_reset_envs = 0
+
+        def reset(self, envs_idx=None):
+            out = envs.Go2GaitTrainingCurriculumEnv.reset(self, envs_idx)
+            if envs_idx is not None:
+                self.user_resets += 1
+                self.user_reset_envs += int(len(envs_idx))
+            return out
+
+    env = Env(num_envs=n, max_episode_length_s=1.0, scene_kwargs=dict(case["scene"]))
+    env.trace_enabled = trace
+    env.build()
+    env.seed(17)
+    for attr, sec in case["resample"].items():
+        getattr(env, attr).resample_time_sec = sec
+    env.reset()
+    g = torch.Generator().manual_seed(5)
+    d = env.action_space.shape[0]
+    out = []
+    for _ in range(steps):
+        o, r, te, tr, ex = env.step(torch.randn(n, d, generator=g).to(dev))
+        others = [v.cpu().clone() for k, v in ex["observations"].items() if k != "policy"]
+        out.append(([o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone()] + others,
+                    {k: float(v) for k, v in ex["episode"].items()}))
+    return out, env
+
+
+def _check_override(dev, n):
+    a, e0 = _override_run(dev, False, n)
+    b, env = _override_run(dev, True, n)
+    tr = env._trace
+    assert tr is not None and tr.tail_python, "an env that overrides reset() is recorded up to the reset; the rest of the step stays Python"
+    assert (env.user_resets, env.user_reset_envs) == (e0.user_resets, e0.user_reset_envs) and env.user_resets > 0
+    _same_runs(a, b)
+
+
+def test_reset_override_env_is_recorded_up_to_the_reset_cpu(oracle_backend):
+    _check_override("cpu", 70)
+
+
+@pytest.mark.gpu
+def test_reset_override_env_is_recorded_up_to_the_reset_hip(hip_backend):
+    _check_override("cuda", 1000)
+
+
 def _same_runs(a, b):
     for t, ((x, lx), (y, ly)) in enumerate(zip(a, b)):
         assert len(x) == len(y)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Step time of an env that overrides reset() (the gait task with the example's curriculum hook): recorded up to the reset
+(tail in Python) vs phase by phase.      python tools/bench_reset_override.py [num_envs]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "genesis-forge_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from genesis_forge_amd import gs
+import envs
+
+
+def run(n, trace, steps=300):
+    env = envs.Go2GaitTrainingCurriculumEnv(num_envs=n, scene_kwargs=dict(ang_noise=0.05, seed=1234, contact_prob=0.001, contact_force=40.0))
+    env.trace_enabled = trace
+    env.build()
+    env.seed(1)
+    env.reset()
+    acts = [torch.randn(n, 12, device=gs.device) for _ in range(4)]
+    for i in range(30):
+        env.step(acts[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        env.step(acts[i % 4])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps * 1e6
+    tr = env._trace
+    return dt, tr is not None and tr.tail_python, (tr.n_ops if tr else None)
+
+
+if __name__ == "__main__":
+    gs.set_device("cuda:0")
+    for n in ([int(sys.argv[1])] if len(sys.argv) > 1 else [8192, 65536]):
+        for trace in (True, False):
+            dt, tail, ops = run(n, trace)
+            print(f"N={n:6d} recorded-with-python-tail={tail!s:5s} ops={ops}  {dt:8.1f} us/step  {n / dt:8.1f} M env-steps/s", flush=True)
