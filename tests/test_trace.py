@@ -60,17 +60,27 @@ def test_parity_draws_disable_trace(oracle_backend):
     assert env._trace is None  # the step that consumed draws ran the ordinary path and is not a recording candidate twice yet
 
 
-def test_user_override_is_never_traced(oracle_backend):
-    class MyEnv(Go2CommandDirectionEnv):
+def test_user_overrides_limit_what_is_recorded(oracle_backend):
+    """A reset() override is honoured by index list: the step is recorded only up to the reset (the rest stays Python).
+    A step() override is user code around the whole step: never recorded."""
+    class ResetEnv(Go2CommandDirectionEnv):
         def reset(self, env_ids=None):
             return super().reset(env_ids)
 
-    env = MyEnv(num_envs=8)
-    env.build()
-    env.reset()
-    for _ in range(5):
-        env.step(torch.zeros(8, 12))
-    assert env._trace is None
+    class StepEnv(Go2CommandDirectionEnv):
+        def step(self, actions):
+            return super().step(actions)
+
+    for cls, recorded in ((ResetEnv, True), (StepEnv, False)):
+        env = cls(num_envs=8)
+        env.build()
+        env.reset()
+        for _ in range(5):
+            env.step(torch.zeros(8, 12))
+        if recorded:
+            assert env._trace is not None and env._trace.tail_python and env._trace.post_refs is None
+        else:
+            assert env._trace is None
 
 
 @pytest.mark.gpu
