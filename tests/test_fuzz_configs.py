@@ -150,6 +150,9 @@ def make_fuzz_env(seed: int):
                 if self.third_obs:  # more observation managers than the fused kernel takes: the recorded step runs as phase chains
                     ObservationManager(self, name="extra", cfg=obs_cfg(1), history_len=rnd.choice([None, 2]))
 
+    FuzzEnv.overrides_reset = pick(0.2)
+    if FuzzEnv.overrides_reset:  # a user reset(): honoured by index list; the step is recorded up to the reset only
+        FuzzEnv.reset = lambda self, envs_idx=None: ManagedEnvironment.reset(self, envs_idx)
     return FuzzEnv()
 
 
@@ -178,7 +181,7 @@ def _run(seed, dev, steps=STEPS):
             state[f"contacts_{len([k for k in state if k.startswith('contacts_')])}"] = cm.contacts
         out.append(({k: f(v) for k, v in state.items()}, {k: float(v) for k, v in extras["episode"].items()}))
     info = {"n": n, "recorded": env._trace is not None, "fused": bool(env._trace is not None and env._trace.post_refs is not None),
-            "user_term": env.has_user_term, "third_obs": env.third_obs}
+            "user_term": env.has_user_term, "third_obs": env.third_obs, "overrides_reset": env.overrides_reset}
     return out, info
 
 
@@ -225,7 +228,7 @@ def test_random_config_hip_equals_oracle(hip_backend, oracle_lib_path, seed):
     # every config is recorded; a user-level Python term or a third ObservationManager keeps it off the fused kernel
     assert info["recorded"], info
     if os.environ.get("GF_NO_FUSE", "0") != "1":  # (the whole suite is also run with every config forced onto the phase chains)
-        assert info["fused"] == (not info["user_term"] and not info["third_obs"]), info
+        assert info["fused"] == (not info["user_term"] and not info["third_obs"] and not info["overrides_reset"]), info
 
 
 @pytest.mark.gpu
