@@ -368,10 +368,41 @@ static int check_term_table(const GfTerm* terms, int n, int is_reward) {
 }
 
 /* termination_manager.py:151-190 */
+/* The boundary's refusals (include/gf_step.h:44-51): a term that addresses an unbound view, an input a term needs and the
+ * descriptor does not carry.  Same codes, same precedence as the library (tests/test_error_codes.py). */
+static int check_termination_inputs(const GfTerminationArgs* a) {
+    int need_quat = 0, need_pos = 0, need_eplen = 0;
+    for (int k = 0; k < a->num_terms; ++k) {
+        const GfTerm* t = &a->terms[k];
+        switch (t->op) {
+            case GF_T_TIMEOUT: if (a->max_episode_length) need_eplen = 1; break;
+            case GF_T_BAD_ORIENTATION: need_quat = need_eplen = 1; break;
+            case GF_T_BASE_HEIGHT_BELOW:
+            case GF_T_OUT_OF_BOUNDS: need_pos = 1; break;
+            case GF_T_CONTACT_FORCE_GRACE: need_eplen = 1; /* fallthrough */
+            case GF_T_HAS_CONTACT:
+            case GF_T_CONTACT_FORCE:
+                if (t->i[0] < 0 || t->i[0] >= GF_MAX_CONTACT_VIEWS || !a->contact[t->i[0]].contacts) return GF_E_SLOT;
+                if (a->contact[t->i[0]].num_links <= 0) return GF_E_RANGE;
+                break;
+            case GF_T_EXTERNAL:
+                if (t->i[0] < 0 || t->i[0] >= GF_MAX_EXT || !a->ext[t->i[0]]) return GF_E_SLOT;
+                break;
+            default: return GF_E_OPCODE;
+        }
+    }
+    if (need_quat && !a->entity.quat) return GF_E_NULL;
+    if (need_pos && !a->entity.pos) return GF_E_NULL;
+    if (need_eplen && !a->episode_length) return GF_E_NULL;
+    return GF_OK;
+}
+
 GFO_EXPORT int gfo_termination_step(const GfTerminationArgs* a) {
     if (!a || !a->terminated || !a->truncated) return GF_E_NULL;
     if (a->num_terms < 0 || a->num_terms > GF_MAX_TERM_TERMS) return GF_E_RANGE;
     int rc = check_term_table(a->terms, a->num_terms, 0);
+    if (rc) return rc;
+    rc = check_termination_inputs(a);
     if (rc) return rc;
     const int64_t N = a->num_envs;
     for (int64_t n = 0; n < N; ++n) {
@@ -556,10 +587,83 @@ static float eval_reward(const GfRewardArgs* a, const GfTerm* t, int64_t n) {
 }
 
 /* reward_manager.py:166-195 */
+static int reward_need_cmd(const GfRewardArgs* a, int idx, int min_width) {
+    if (idx < 0 || idx >= GF_MAX_COMMAND_VIEWS || !a->command[idx].command) return GF_E_SLOT;
+    return a->command[idx].width >= min_width ? GF_OK : GF_E_RANGE;
+}
+static int reward_need_contact(const GfRewardArgs* a, int idx) {
+    if (idx < 0 || idx >= GF_MAX_CONTACT_VIEWS || !a->contact[idx].contacts) return GF_E_SLOT;
+    return a->contact[idx].num_links > 0 ? GF_OK : GF_E_RANGE;
+}
+static int check_reward_inputs(const GfRewardArgs* a) {
+    int quat = 0, pos = 0, lin = 0, ang = 0, term = 0, dofs = 0, acts = 0;
+    for (int k = 0; k < a->num_terms; ++k) {
+        const GfTerm* t = &a->terms[k];
+        int rc = GF_OK;
+        if (t->row < 0 || t->row >= GF_MAX_TERMS) return GF_E_RANGE;
+        switch (t->op) {
+            case GF_R_IS_ALIVE:
+            case GF_R_TERMINATED: term = 1; break;
+            case GF_R_BASE_HEIGHT:
+                pos = 1;
+                if (t->flags & GF_RW_FLAG_CMD) rc = reward_need_cmd(a, t->i[0], 1);
+                if ((t->flags & GF_RW_FLAG_TERRAIN) && a->terrain.height_field && (a->terrain.rows < 1 || a->terrain.cols < 1)) rc = GF_E_RANGE;
+                break;
+            case GF_R_DOF_SIMILAR_TO_DEFAULT: dofs = 1; break;
+            case GF_R_LIN_VEL_Z_L2: quat = lin = 1; break;
+            case GF_R_ANG_VEL_XY_L2: quat = ang = 1; break;
+            case GF_R_FLAT_ORIENTATION_L2: quat = 1; break;
+            case GF_R_BODY_ACCEL_EXP:
+                quat = lin = ang = 1;
+                if (t->i[0] < 0 || t->i[0] >= 4 || !a->state[t->i[0]]) rc = GF_E_SLOT;
+                break;
+            case GF_R_ACTION_RATE_L2: acts = 1; break;
+            case GF_R_CMD_TRACK_LIN_VEL: quat = lin = 1; rc = reward_need_cmd(a, t->i[0], 2); break;
+            case GF_R_CMD_TRACK_ANG_VEL: quat = ang = 1; rc = reward_need_cmd(a, t->i[0], t->i[1] + 1); if (t->i[1] < 0) rc = GF_E_RANGE; break;
+            case GF_R_STAND_STILL: dofs = 1; rc = reward_need_cmd(a, t->i[0], 2); break;
+            case GF_R_HAS_CONTACT:
+            case GF_R_CONTACT_FORCE: rc = reward_need_contact(a, t->i[0]); break;
+            case GF_R_FEET_AIR_TIME:
+                rc = reward_need_contact(a, t->i[0]);
+                if (!rc && (!a->contact[t->i[0]].last_air_time || !a->contact[t->i[0]].current_contact_time)) rc = GF_E_SLOT;
+                if (!rc && t->i[1] >= 0) rc = reward_need_cmd(a, t->i[1], 2);
+                break;
+            case GF_R_FEET_SLIDE:
+                rc = reward_need_contact(a, t->i[0]);
+                if (!rc && !a->contact[t->i[0]].link_vel) rc = GF_E_SLOT;
+                break;
+            case GF_R_EXTERNAL:
+                if (t->i[0] < 0 || t->i[0] >= GF_MAX_EXT || !a->ext[t->i[0]]) rc = GF_E_SLOT;
+                break;
+            case GF_R_GAIT_PHASE:
+            case GF_R_FOOT_HEIGHT:
+                rc = reward_need_contact(a, t->i[0]);
+                if (!rc) rc = reward_need_cmd(a, t->i[1], GF_GAIT_OBS_WIDTH);
+                if (!rc && (a->command[t->i[1]].stride < GF_GAIT_ROW || !a->contact[t->i[0]].link_vel)) rc = GF_E_SLOT;
+                if (!rc && t->op == GF_R_FOOT_HEIGHT && !a->contact[t->i[0]].link_pos) rc = GF_E_SLOT;
+                for (int f = 0; !rc && f < 4; ++f)
+                    if (((t->i[2] >> (8 * f)) & 0xff) >= a->contact[t->i[0]].num_links) rc = GF_E_RANGE;
+                break;
+            default: return GF_E_OPCODE;
+        }
+        if (rc) return rc;
+    }
+    if (quat && !a->entity.quat) return GF_E_NULL;
+    if (pos && !a->entity.pos) return GF_E_NULL;
+    if (lin && !a->entity.lin_vel) return GF_E_NULL;
+    if (ang && !a->entity.ang_vel) return GF_E_NULL;
+    if (term && !a->terminated) return GF_E_NULL;
+    if (dofs && (!a->dof_pos || !a->default_dof_pos || a->num_dofs <= 0)) return GF_E_NULL;
+    if (acts && (!a->actions || !a->last_actions || a->num_dofs <= 0)) return GF_E_NULL;
+    return GF_OK;
+}
+
 GFO_EXPORT int gfo_reward_step(const GfRewardArgs* a) {
     if (!a) return GF_E_NULL;
     if (a->num_terms < 0 || a->num_terms > GF_MAX_TERMS) return GF_E_RANGE;
     int rc = check_term_table(a->terms, a->num_terms, 1);
+    if (rc) return rc;
+    rc = check_reward_inputs(a);
     if (rc) return rc;
     const int64_t N = a->num_envs;
     if (a->mode == GF_REWARD_MODE_EVAL) {
@@ -670,6 +774,8 @@ GFO_EXPORT int gfo_masked_reset(const GfResetArgs* a) {
     const int64_t N = a->num_envs, D = a->num_dofs;
     if (a->num_reward_terms < 0 || a->num_reward_terms > GF_MAX_TERMS) return GF_E_RANGE;
     if (a->num_contact < 0 || a->num_contact > GF_MAX_CONTACT_VIEWS) return GF_E_RANGE;
+    if (a->env_actions && !a->env_last_actions) return GF_E_NULL;
+    if (a->scene_dof_pos && !a->default_dof_pos) return GF_E_NULL;
     int count = 0;
     for (int64_t n = 0; n < N; ++n) {
         if (!(a->mask[n] || (a->mask2 && a->mask2[n]))) continue;
@@ -773,9 +879,55 @@ GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
     if (a->num_items <= 0 || a->num_items > GF_MAX_OBS_ITEMS) return GF_E_RANGE;
     if (a->history_len < 1 || (a->history_len > 1 && !a->prev_obs)) return a->history_len < 1 ? GF_E_RANGE : GF_E_NULL;
     const int64_t N = a->num_envs, D = a->num_dofs, O = a->obs_width, H = a->history_len;
+    if (O <= 0 || O >= GF_MAX_OBS_WIDTH) return GF_E_RANGE;
     int64_t wsum = 0;
-    for (int i = 0; i < a->num_items; ++i) wsum += a->items[i].width;
-    if (wsum != O || O > GF_MAX_OBS_WIDTH) return GF_E_RANGE;
+    int need_quat = 0, need_lin = 0, need_ang = 0;
+    for (int i = 0; i < a->num_items; ++i) {  /* the boundary's refusals, item by item (tests/test_error_codes.py) */
+        const GfObsItem* it = &a->items[i];
+        const float* src = NULL;
+        int stride = 0;
+        if (it->width <= 0) return GF_E_RANGE;
+        switch (it->op) {
+            case GF_O_COMMAND:
+                if (it->i0 < 0 || it->i0 >= GF_MAX_COMMAND_VIEWS || !a->command[it->i0].command) return GF_E_SLOT;
+                if (it->width != a->command[it->i0].width) return GF_E_RANGE;
+                src = a->command[it->i0].command; stride = cmd_stride(&a->command[it->i0]);
+                break;
+            case GF_O_DOF_POS: src = a->dof_pos; stride = (int)D; break;
+            case GF_O_DOF_VEL: src = a->dof_vel; stride = (int)D; break;
+            case GF_O_DOF_FORCE: src = a->dof_force; stride = (int)D; break;
+            case GF_O_ACTIONS: src = a->targets; stride = (int)D; break;
+            case GF_O_RAW_ACTIONS: src = a->env_actions; stride = (int)D; break;
+            case GF_O_EXTERNAL:
+                if (it->i0 < 0 || it->i0 >= GF_MAX_EXT || !a->ext[it->i0]) return GF_E_SLOT;
+                break;
+            case GF_O_BASE_POS:
+                if (!a->entity.pos) return GF_E_NULL;
+                if (it->width != 3) return GF_E_RANGE;
+                break;
+            case GF_O_BASE_QUAT:
+                if (it->width != 4) return GF_E_RANGE;
+                src = a->entity.quat; stride = 4;
+                break;
+            case GF_O_ANG_VEL_BODY: need_quat = need_ang = 1; if (it->width != 3) return GF_E_RANGE; break;
+            case GF_O_LIN_VEL_BODY: need_quat = need_lin = 1; if (it->width != 3) return GF_E_RANGE; break;
+            case GF_O_PROJ_GRAVITY: need_quat = 1; if (it->width != 3) return GF_E_RANGE; break;
+            case GF_O_CONTACT_FORCE_NORM:
+                if (it->i0 < 0 || it->i0 >= GF_MAX_CONTACT_VIEWS || !a->contact[it->i0].contacts) return GF_E_SLOT;
+                if (it->width != a->contact[it->i0].num_links) return GF_E_RANGE;
+                break;
+            default: return GF_E_OPCODE;
+        }
+        if (stride) {
+            if (!src) return GF_E_NULL;
+            if (it->width > stride) return GF_E_RANGE;
+        }
+        wsum += it->width;
+    }
+    if (wsum != O) return GF_E_RANGE;
+    if (need_quat && !a->entity.quat) return GF_E_NULL;
+    if (need_lin && !a->entity.lin_vel) return GF_E_NULL;
+    if (need_ang && !a->entity.ang_vel) return GF_E_NULL;
     for (int64_t n = 0; n < N; ++n) {
         float* row = a->obs + n * O * H;
         int64_t col = 0;
