@@ -125,6 +125,39 @@ def _cases(dev):
     return out, keep
 
 
+def _empty_cases(dev):
+    """Well-formed descriptors over ZERO envs: accepted, nothing to do (GF_OK), on both sides."""
+    cases, keep = _cases(dev)
+    seen, out = set(), []
+    for fn, a, _want, _what in cases:
+        if fn in seen:
+            continue
+        seen.add(fn)
+    # rebuild one valid descriptor per phase from the malformed ones' builders: undo the single defect
+    from genesis_forge_amd import _native as nat
+
+    p = {k: v.data_ptr() for k, v in keep.items()}
+    t = nat.GfTerminationArgs(); t.num_terms = 1; t.terms[0].op = nat.GF_T_TIMEOUT
+    t.episode_length, t.terminated, t.truncated = p["ep"], p["term"], p["trunc"]
+    r = nat.GfRewardArgs(); r.num_dofs, r.num_terms, r.mode, r.dt = 12, 1, nat.GF_REWARD_MODE_STEP, 0.02
+    r.terms[0].op, r.terms[0].w = nat.GF_R_IS_ALIVE, 1.0
+    r.terminated, r.reward, r.episode_seconds = p["term"], p["rew"], p["secs"]
+    o = nat.GfObservationArgs(); o.num_dofs, o.num_items, o.obs_width, o.history_len = 12, 1, 12, 1
+    o.items[0].op, o.items[0].width, o.items[0].scale = nat.GF_O_DOF_POS, 12, 1.0
+    o.dof_pos, o.obs = p["dof"], p["obs"]
+    c = nat.GfCommandArgs(); c.num_ranges, c.mode, c.resample_steps = 3, nat.GF_CMD_STEP, 10
+    c.episode_length, c.command = p["ep"], p["cmd"]
+    g = nat.GfGaitArgs(); g.mode, g.resample_steps, g.num_gaits = nat.GF_CMD_STEP, 10, 1
+    g.episode_length, g.state, g.selected = p["ep"], p["state"], p["sel"]
+    m = nat.GfResetArgs(); m.num_dofs, m.mask = 12, p["term"]
+    ac = nat.GfActionArgs(); ac.num_dofs, ac.mode = 12, nat.GF_ACTION_POSITION
+    ac.actions_in, ac.scale, ac.offset, ac.clip_lo, ac.clip_hi, ac.targets = p["act"], p["scale"], p["scale"], p["scale"], p["scale"], p["tgt"]
+    for fn, a in (("termination_step", t), ("reward_step", r), ("observe", o), ("command_step", c), ("gait_step", g), ("masked_reset", m), ("action_step", ac)):
+        a.num_envs = 0
+        out.append((fn, a, 0, "zero envs"))
+    return out, keep
+
+
 def _codes(lib, prefix, cases, stream):
     from genesis_forge_amd import _native as nat
 
@@ -139,6 +172,8 @@ def _codes(lib, prefix, cases, stream):
 
 def test_oracle_refuses_malformed_descriptors(oracle_lib_path):
     cases, _keep = _cases("cpu")
+    empty, _keep2 = _empty_cases("cpu")
+    cases = cases + empty
     got = _codes(C.CDLL(oracle_lib_path), "gfo_", cases, None)
     for (fn, _a, want, what), rc in zip(cases, got):
         assert rc == want, f"gfo_{fn}: {what}: returned {rc}, the header documents {want}"
@@ -147,6 +182,8 @@ def test_oracle_refuses_malformed_descriptors(oracle_lib_path):
 @pytest.mark.gpu
 def test_library_refuses_malformed_descriptors_like_the_oracle(hip_backend, oracle_lib_path):
     cases, _keep = _cases("cuda")
+    empty, _keep2 = _empty_cases("cuda")
+    cases = cases + empty
     got = _codes(hip_backend.lib, "gf_", cases, C.c_void_p(0))
     torch.cuda.synchronize()
     for (fn, _a, want, what), rc in zip(cases, got):

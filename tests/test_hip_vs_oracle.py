@@ -71,3 +71,87 @@ def test_pipeline_hip_equals_oracle(hip_backend, oracle_lib_path, n, contacts, h
         resets += int(a[2].sum() + a[3].sum())
     if n >= 63:
         assert resets > 0
+
+
+def _run_max_tables(dev, n=130, steps=40, seed=3):
+    """Every table at its maximum: GF_MAX_TERMS (24) reward terms, GF_MAX_TERM_TERMS (16) termination terms."""
+    from genesis_forge_amd import _native as nat
+    from genesis_forge_amd.managers import RewardManager, TerminationManager
+    from genesis_forge_amd.mdp import rewards, terminations
+    from envs import Go2CommandDirectionEnv
+
+    class Env(Go2CommandDirectionEnv):
+        def config(self):
+            super().config()
+            em, vc, am = self.robot_manager, self.velocity_command, self.action_manager
+            base = [
+                ("lin_z", rewards.lin_vel_z_l2, {"entity_manager": em}), ("ang_xy", rewards.ang_vel_xy_l2, {"entity_manager": em}),
+                ("flat", rewards.flat_orientation_l2, {"entity_manager": em}), ("rate", rewards.action_rate_l2, {}),
+                ("similar", rewards.dof_similar_to_default, {"action_manager": am}), ("alive", rewards.is_alive, {}),
+                ("track_lin", rewards.command_tracking_lin_vel, {"vel_cmd_manager": vc, "entity_manager": em}),
+                ("track_ang", rewards.command_tracking_ang_vel, {"vel_cmd_manager": vc, "entity_manager": em}),
+            ]
+            rcfg = {}
+            for k in range(nat.GF_MAX_TERMS):
+                name, fn, params = base[k % len(base)]
+                p = dict(params)
+                if fn is rewards.command_tracking_lin_vel:
+                    p["sensitivity"] = 0.1 + 0.05 * k
+                rcfg[f"{name}_{k}"] = {"weight": (-1) ** k * (0.1 + 0.07 * k), "fn": fn, "params": p}
+            self.managers["reward"] = None
+            self.reward_manager = RewardManager(self, logging_enabled=True, cfg=rcfg)
+            tcfg = {"timeout": {"fn": terminations.timeout, "time_out": True}}
+            for k in range(1, nat.GF_MAX_TERM_TERMS):
+                if k % 2:
+                    tcfg[f"tilt_{k}"] = {"fn": terminations.bad_orientation, "params": {"limit_angle": 25.0 + 3.0 * k, "entity_manager": em, "grace_steps": k % 4}}
+                else:
+                    tcfg[f"low_{k}"] = {"fn": terminations.base_height_below_minimum, "params": {"minimum_height": 0.02 * k, "entity_manager": em}}
+            self.managers["termination"] = None
+            self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg=tcfg)
+
+    env = Env(num_envs=n, max_episode_length_s=0.6, cmd_resample_s=0.3, scene_kwargs=dict(ang_noise=0.3, seed=seed))
+    env.build()
+    env.seed(seed)
+    env.reset()
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(steps):
+        obs, rew, term, trunc, extras = env.step(torch.randn(n, 12, generator=g).to(dev))
+        out.append(([x.cpu().clone() for x in (obs, rew, term, trunc, env.reward_manager._episode_sums, env.episode_length)],
+                    {k: float(v) for k, v in extras["episode"].items()}))
+    assert env.reward_manager._program.n == nat.GF_MAX_TERMS and env.termination_manager._program.n == nat.GF_MAX_TERM_TERMS
+    return out, env
+
+
+@pytest.mark.gpu
+def test_maximum_table_sizes_hip_equals_oracle(hip_backend, oracle_lib_path):
+    from genesis_forge_amd import _native as nat
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+
+    hip, env = _run_max_tables("cuda")
+    torch.cuda.synchronize()
+    assert env._trace is not None, "the step should be recorded"
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(oracle_lib_path))
+    try:
+        ref, _ = _run_max_tables("cpu")
+    finally:
+        nat.set_backend(None)
+        gs.set_device("cuda:0")
+    resets = 0
+    for t, ((a, la), (b, lb)) in enumerate(zip(hip, ref)):
+        for k in (2, 3, 5):
+            assert torch.equal(a[k], b[k]), f"mask / counter {k} differs at step {t}"
+        for k in (0, 1, 4):
+            assert torch.allclose(a[k], b[k], atol=1e-5, rtol=0), f"float output {k} differs at step {t}: {(a[k] - b[k]).abs().max()}"
+        assert set(la) == set(lb)
+        for key in la:
+            assert abs(la[key] - lb[key]) <= 1e-5 + 1e-5 * abs(lb[key]), (t, key, la[key], lb[key])
+        resets += int(a[2].sum() + a[3].sum())
+    assert resets > 0
+
+
+def test_maximum_table_sizes_run_on_the_oracle(oracle_backend):
+    out, env = _run_max_tables("cpu", n=40, steps=12)
+    assert torch.isfinite(out[-1][0][1]).all()
