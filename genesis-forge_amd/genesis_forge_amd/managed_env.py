@@ -292,6 +292,9 @@ class ManagedEnvironment(GenesisEnv):
         """Reset one or more environments and every registered manager (managed_env.py:336-371)."""
         outside = not self._in_step
         if outside:
+            # a reset the training script calls between steps refills the persistent reset / masked-resample descriptors with
+            # ITS masks — the ones a recorded step replays in place: drop the recording (two ordinary steps, then recorded again)
+            self.invalidate_trace()
             self.stats.clear(self.backend)
         mask = self._ids_to_mask(env_ids)
         ids = env_ids if env_ids is not None else torch.arange(self.num_envs, device=gs.device)

@@ -392,3 +392,51 @@ def test_other_dof_counts_hip(hip_backend, oracle_lib_path, dofs, n):
             assert torch.equal(x[k], y[k]), f"integer state {k} differs at step {t}"
         for k in (0, 1, 5, 6, 7, 9, 10):
             assert torch.allclose(x[k], y[k], atol=1e-5, rtol=0), f"float state {k} differs at step {t}: {(x[k] - y[k]).abs().max()}"
+
+
+def _run_with_user_resets(dev, trace, n=70, steps=60):
+    """A training script's own resets between steps: the whole batch (env.reset()), and some envs by index list
+    (env.reset([…]), managed_env.py:336-371), while the step is recorded."""
+    env = Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, contacts=True, history=2, obs_noise=True,
+                                 scene_kwargs=dict(ang_noise=0.3, seed=3))
+    env.trace_enabled = trace
+    env.build()
+    env.seed(5)
+    env.reset()
+    g = torch.Generator().manual_seed(0)
+    outs = []
+    for t in range(steps):
+        if t == 20:
+            obs, _ = env.reset()
+            outs.append((obs.cpu().clone(),))
+        if t in (33, 34, 50):
+            env.reset([1, 5, n - 1] if t != 34 else torch.tensor([0, 2]))
+        o, r, te, tr, ex = env.step(torch.randn(n, 12, generator=g).to(dev))
+        outs.append((o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone(), {k: float(v) for k, v in ex["episode"].items()},
+                     env.velocity_command._command.cpu().clone(), env.episode_length.cpu().clone(), env.reward_manager._episode_sums.cpu().clone()))
+    return outs, env
+
+
+def _same_user_resets(a, b):
+    for t, (x, y) in enumerate(zip(a, b)):
+        assert len(x) == len(y)
+        for k, (u, v) in enumerate(zip(x, y)):
+            if isinstance(u, dict):
+                assert u == v, f"log differs at entry {t}: {u} vs {v}"
+            else:
+                assert torch.equal(u, v), f"output {k} differs at entry {t}"
+
+
+def test_user_resets_between_recorded_steps_cpu(oracle_backend):
+    a, _ = _run_with_user_resets("cpu", False)
+    b, env = _run_with_user_resets("cpu", True)
+    assert env._trace is not None
+    _same_user_resets(a, b)
+
+
+@pytest.mark.gpu
+def test_user_resets_between_recorded_steps_hip(hip_backend):
+    a, _ = _run_with_user_resets("cuda", False, n=1000)
+    b, env = _run_with_user_resets("cuda", True, n=1000)
+    assert env._trace is not None and env._trace.post_refs is not None
+    _same_user_resets(a, b)
