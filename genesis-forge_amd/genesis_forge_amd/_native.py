@@ -311,6 +311,17 @@ class Backend:
 
     tracer = None  # set by _trace.StepTrace while it records a step
 
+    def _note_call(self, args) -> None:
+        """A phase call outside a recorded step's replay.  If its descriptor belongs to a live recorded step (`watched`), that
+        step's frozen copy of it is no longer what the ordinary path would launch — a manager method called between steps
+        (``resample_command([…])``, ``reset([…])``) has refilled it — and the recording must go (`dirty`, checked by
+        StepTrace.fresh before every replay)."""
+        w = self.__dict__.get("watched")
+        if w:
+            a = C.addressof(args)
+            if a in w:
+                self.__dict__.setdefault("dirty", set()).add(a)
+
     def call(self, fn: str, args, owner=None) -> None:  # pragma: no cover - interface
         raise NotImplementedError
 
@@ -421,6 +432,7 @@ class HipBackend(Backend):
     def call(self, fn: str, args, owner=None) -> None:
         if self.tracer is not None:
             self.tracer.record(fn, args, owner)
+        self._note_call(args)
         rc = self._fn[fn](C.byref(args), self._stream())
         if rc != 0:
             self._raise(fn, rc)

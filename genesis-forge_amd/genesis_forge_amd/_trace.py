@@ -107,6 +107,12 @@ class StepTrace:
                 self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_PACK, C.addressof(self.pack_args)
                 k += 1
         self.n_ops = k
+        #: the descriptors this recording froze: a phase call that goes through one of them from now on (a manager method the
+        #: training script calls between steps) makes the recording stale (Backend._note_call, fresh())
+        self.arg_set = {C.addressof(c[1]) for c in calls}
+        b = self.backend
+        b.__dict__.setdefault("dirty", set()).difference_update(self.arg_set)
+        b.__dict__.setdefault("watched", set()).update(self.arg_set)
         #: hipGraph of this step's launches (built by the library on first replay; HIP backend only)
         self.graph = C.c_void_p() if hasattr(self.backend, "run_ops_graph") and not self.splits and not tail_python else None
         #: the op list cut at the splits: (first op, count, callable to run before it or None)
@@ -118,7 +124,18 @@ class StepTrace:
                 sub = (nat.GfOp * (a1 - a0)).from_buffer(self.ops, a0 * C.sizeof(nat.GfOp)) if a1 > a0 else None
                 self.segments.append((a0, a1 - a0, sub, pre))
 
+    def fresh(self) -> bool:
+        """No descriptor of this recording has been used by a phase call outside its replay since it was made."""
+        d = self.backend.__dict__.get("dirty")
+        return not d or d.isdisjoint(self.arg_set)
+
     def __del__(self):
+        b, mine = getattr(self, "backend", None), getattr(self, "arg_set", None)
+        if b is not None and mine:
+            for name in ("watched", "dirty"):
+                st = b.__dict__.get(name)
+                if st:
+                    st.difference_update(mine)
         g = getattr(self, "graph", None)
         if g is not None and g.value:
             try:

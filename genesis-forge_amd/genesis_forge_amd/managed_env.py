@@ -161,8 +161,12 @@ class ManagedEnvironment(GenesisEnv):
         tr = self._trace
         if tr is not None:
             if tr.epoch == self._trace_epoch and not self._draws:
-                return tr.replay(actions)
-            self._trace = None
+                if tr.fresh():
+                    return tr.replay(actions)
+                tr = None
+                self.invalidate_trace()  # a manager method called between steps went through one of its descriptors
+            else:
+                self._trace = None
         if not self.trace_enabled or self._draws:
             return self._step_ordinary(actions)
         rec = _trace.Recorder()

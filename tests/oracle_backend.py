@@ -29,6 +29,7 @@ class OracleBackend(nat.Backend):
         self.calls.append(fn)
         if self.tracer is not None:
             self.tracer.record(fn, args, owner)
+        self._note_call(args)
         rc = self._fn[fn](C.byref(args))
         if rc != 0:
             raise nat.GfError(f"gfo_{fn} failed: {nat.GF_ERRORS.get(rc, rc)}")

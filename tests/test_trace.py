@@ -411,6 +411,8 @@ def _run_with_user_resets(dev, trace, n=70, steps=60):
             outs.append((obs.cpu().clone(),))
         if t in (33, 34, 50):
             env.reset([1, 5, n - 1] if t != 34 else torch.tensor([0, 2]))
+        if t == 42:  # a manager method of the public API, through the very descriptor the recorded step replays
+            env.velocity_command.resample_command([0, 3, n - 2])
         o, r, te, tr, ex = env.step(torch.randn(n, 12, generator=g).to(dev))
         outs.append((o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone(), {k: float(v) for k, v in ex["episode"].items()},
                      env.velocity_command._command.cpu().clone(), env.episode_length.cpu().clone(), env.reward_manager._episode_sums.cpu().clone()))
