@@ -413,6 +413,16 @@ def _run_with_user_resets(dev, trace, n=70, steps=60):
             env.reset([1, 5, n - 1] if t != 34 else torch.tensor([0, 2]))
         if t == 42:  # a manager method of the public API, through the very descriptor the recorded step replays
             env.velocity_command.resample_command([0, 3, n - 2])
+        if t == 45:
+            env.seed(99)                                  # a re-seed in mid-run
+        if t == 47:
+            env.foot_contacts.enabled = False             # manager toggles (base_manager.py: `enabled`)
+            env.velocity_command.enabled = False
+        if t == 52:
+            env.foot_contacts.enabled = True
+            env.velocity_command.enabled = True
+        if t in (30, 48):
+            outs.append((env.get_observations().cpu().clone(),))   # between steps: the last step's observation, nothing is launched
         o, r, te, tr, ex = env.step(torch.randn(n, 12, generator=g).to(dev))
         outs.append((o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone(), {k: float(v) for k, v in ex["episode"].items()},
                      env.velocity_command._command.cpu().clone(), env.episode_length.cpu().clone(), env.reward_manager._episode_sums.cpu().clone()))
