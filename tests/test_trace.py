@@ -452,3 +452,40 @@ def test_user_resets_between_recorded_steps_hip(hip_backend):
     b, env = _run_with_user_resets("cuda", True, n=1000)
     assert env._trace is not None and env._trace.post_refs is not None
     _same_user_resets(a, b)
+
+
+def test_two_recorded_envs_interleaved(oracle_backend):
+    """A training env and an evaluation env alive at once (one backend, two recorded steps replayed alternately, one of them reset by
+    its script in mid-run) behave exactly as each would alone."""
+    def make(seed):
+        env = Go2CommandDirectionEnv(num_envs=40, max_episode_length_s=0.6, cmd_resample_s=0.3, contacts=seed % 2 == 0,
+                                     scene_kwargs=dict(ang_noise=0.3, seed=seed))
+        env.build()
+        env.seed(seed)
+        env.reset()
+        return env
+
+    def drive(env, t, g):
+        if t == 15 and env is not None and getattr(env, "_is_eval", False):
+            env.reset()
+        o, r, te, tr, ex = env.step(torch.randn(40, 12, generator=g))
+        return (o.clone(), r.clone(), te.clone(), tr.clone(), {k: float(v) for k, v in ex["episode"].items()})
+
+    alone = []
+    for seed in (2, 3):
+        env, g = make(seed), torch.Generator().manual_seed(seed)
+        env._is_eval = seed == 3
+        alone.append([drive(env, t, g) for t in range(30)])
+    envs = [make(2), make(3)]
+    envs[1]._is_eval = True
+    gens = [torch.Generator().manual_seed(2), torch.Generator().manual_seed(3)]
+    both = [[], []]
+    for t in range(30):
+        for i in (0, 1):
+            both[i].append(drive(envs[i], t, gens[i]))
+    assert envs[0]._trace is not None and envs[1]._trace is not None
+    for i in (0, 1):
+        for t, (x, y) in enumerate(zip(alone[i], both[i])):
+            for k in range(4):
+                assert torch.equal(x[k], y[k]), f"env {i}: output {k} differs at step {t}"
+            assert x[4] == y[4], f"env {i}: log differs at step {t}"
