@@ -489,3 +489,28 @@ def test_two_recorded_envs_interleaved(oracle_backend):
             for k in range(4):
                 assert torch.equal(x[k], y[k]), f"env {i}: output {k} differs at step {t}"
             assert x[4] == y[4], f"env {i}: log differs at step {t}"
+
+
+def test_logs_read_late_across_ring_wraps(oracle_backend):
+    """The statistics ring has 64 slots and logs are lazy: extras dicts kept from steps 10, 70, 100 and 149 of a 150-step recorded
+    run, read only at the end (two wrap-arounds later), hold what the ordinary path logged at those steps; dicts nobody kept cost
+    nothing."""
+    def run(trace):
+        env = Go2CommandDirectionEnv(num_envs=70, max_episode_length_s=0.5, cmd_resample_s=0.3, scene_kwargs=dict(ang_noise=0.3, seed=8))
+        env.trace_enabled = trace
+        env.build()
+        env.seed(8)
+        env.reset()
+        g = torch.Generator().manual_seed(8)
+        kept = {}
+        for t in range(150):
+            _, _, _, _, ex = env.step(torch.randn(70, 12, generator=g))
+            if t in (10, 70, 100, 149):
+                kept[t] = ex["episode"] if trace else {k: float(v) for k, v in ex["episode"].items()}
+        return {t: {k: float(v) for k, v in d.items()} for t, d in kept.items()}, env
+
+    want, _ = run(False)
+    got, env = run(True)
+    assert env._trace is not None
+    assert want == got
+    assert any(len(d) > 0 for d in want.values())
