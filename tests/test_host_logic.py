@@ -251,3 +251,27 @@ def test_rl_library_wrappers_over_the_recorded_step(oracle_backend):
         else:
             obs, rew, term, trunc, extras = last
             assert rew.shape == (33, 1) and term.shape == (33, 1) and trunc.shape == (33, 1)
+
+
+def test_external_command_controller(oracle_backend):
+    """use_external_controller (command_manager.py:176-207): the controller's tensor IS the command — in the observation, in the
+    tracking rewards — nothing is resampled, and such a step is never recorded (the tensor is the controller's to replace)."""
+    from genesis_forge_amd.mdp import rewards
+
+    env = Go2CommandDirectionEnv(num_envs=16, max_episode_length_s=0.4, cmd_resample_s=0.1, scene_kwargs=dict(ang_noise=0.2, seed=2))
+    env.build()
+    env.reset()
+    buf = torch.zeros(16, 3)
+    env.velocity_command.use_external_controller(lambda step: buf)
+    g = torch.Generator().manual_seed(0)
+    for t in range(30):
+        buf[:, 0], buf[:, 2] = 0.1 * t, -0.05 * t
+        obs, rew, term, trunc, extras = env.step(torch.randn(16, 12, generator=g))
+        assert env._trace is None
+        assert torch.equal(obs[:, :3], buf), "the observation's command columns are the controller's values, also for just-reset envs"
+        assert torch.equal(env.velocity_command.command, buf)
+    # the tracking term reads the controller's values too (the step's reward was computed from them)
+    direct = rewards.command_tracking_lin_vel(env, vel_cmd_manager=env.velocity_command, entity_manager=env.robot_manager)
+    lin = env.robot_manager.get_linear_velocity()
+    want = torch.exp(-torch.sum(torch.square(buf[:, :2] - lin[:, :2]), dim=1) / 0.25)
+    assert torch.allclose(direct, want, atol=1e-6)
