@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "genesis-forge_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every=1, read_lag=0, mutate_at=None):
+def run_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every=1, read_lag=0, mutate_at=None, user_term=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from genesis_forge_amd import _native as nat
     from genesis_forge_amd import distributed as gfd
@@ -26,6 +26,18 @@ def run_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every=1
     count = sizes[rank]
     env = Go2CommandDirectionEnv(num_envs=count, max_episode_length_s=1, cmd_resample_s=0.3, contacts=True, history=2, obs_noise=True,
                                  scene_kwargs=dict(ang_noise=0.3, seed=3))
+    if user_term:  # a Python-level reward term: the recorded step is cut around the call (per-env state only, so sharding commutes)
+        from genesis_forge_amd.managers import RewardManager
+        base_config = env.config
+
+        def config():
+            base_config()
+            rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in env.reward_manager.cfg.items()}
+            rc["user_height"] = {"weight": 0.3, "fn": lambda e: torch.tanh(e.robot.get_pos()[:, 2])}
+            env.managers["reward"] = None
+            env.reward_manager = RewardManager(env, logging_enabled=True, cfg=rc)
+
+        env.config = config
     env.build()
     env.seed(5)
     gfd.attach(env, reduce_every=reduce_every)
@@ -44,7 +56,8 @@ def run_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every=1
         while held and (len(held) > read_lag or t == steps - 1):
             h = held.pop(0)
             outs.append(h[:4] + ({k: float(v) for k, v in h[4].items()},))
-    torch.save({"start": start, "count": count, "outs": outs, "traced": env._trace is not None}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save({"start": start, "count": count, "outs": outs, "traced": env._trace is not None,
+                "cuts": len(env._trace.splits) if env._trace is not None else 0}, os.path.join(out_dir, f"rank{rank}.pt"))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

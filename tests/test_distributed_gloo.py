@@ -22,19 +22,21 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("reduce_every,read_lag,mutate_at", [(1, 0, None), (8, 11, None), (16, 0, 20), (4, 3, 17)])
-def test_sharded_run_equals_unsharded(oracle_lib_path, reduce_every, read_lag, mutate_at):
+@pytest.mark.parametrize("reduce_every,read_lag,mutate_at,user_term", [(1, 0, None, False), (8, 11, None, False), (16, 0, 20, False), (4, 3, 17, False),
+                                                                       (1, 0, None, True), (8, 2, 19, True)])
+def test_sharded_run_equals_unsharded(oracle_lib_path, reduce_every, read_lag, mutate_at, user_term):
     """reduce_every = K > 1: the statistics rows of K steps travel in one all-reduce (folded by the following step's action
     kernel, no pack launch).  Logs read later than K steps hit closed batches (no extra collective); logs read at once close
-    the open batch on both ranks every step; a curriculum mutation drops and re-records the step on both ranks."""
+    the open batch on both ranks every step; a curriculum mutation drops and re-records the step on both ranks.  With a Python-level
+    reward term the recorded step is cut around the call on every rank alike."""
     n_global, steps, sizes = 70, 40, [33, 37]
     with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
         ctx = mp.get_context("spawn")
-        p = ctx.Process(target=run_shard, args=(0, 1, _free_port(), d1, n_global, steps, [n_global], 1, 0, mutate_at))
+        p = ctx.Process(target=run_shard, args=(0, 1, _free_port(), d1, n_global, steps, [n_global], 1, 0, mutate_at, user_term))
         p.start(); p.join(240)
         assert p.exitcode == 0
         port = _free_port()
-        procs = [ctx.Process(target=run_shard, args=(r, 2, port, d2, n_global, steps, sizes, reduce_every, read_lag, mutate_at)) for r in range(2)]
+        procs = [ctx.Process(target=run_shard, args=(r, 2, port, d2, n_global, steps, sizes, reduce_every, read_lag, mutate_at, user_term)) for r in range(2)]
         for q in procs:
             q.start()
         for q in procs:
@@ -43,6 +45,7 @@ def test_sharded_run_equals_unsharded(oracle_lib_path, reduce_every, read_lag, m
         full = torch.load(os.path.join(d1, "rank0.pt"))
         shards = [torch.load(os.path.join(d2, f"rank{r}.pt")) for r in range(2)]
     assert all(s["traced"] for s in shards), "the sharded env should still record its step"
+    assert all((s["cuts"] == 1) == user_term for s in shards)
     for t in range(steps):
         ref = full["outs"][t]
         for k in range(4):
