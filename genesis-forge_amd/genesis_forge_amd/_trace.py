@@ -21,6 +21,11 @@ stop a step from being recorded: the op list is cut in front of the op that cons
 runs ``gf_run_ops`` on the ops before the cut, then evaluates the callables — at exactly the point of the
 step where the ordinary path (and the reference) calls them, on the same stream, no host sync — hands the
 fresh columns to the descriptor, and continues with the next run of ops.
+
+An env that overrides ``reset()`` is recorded up to the reset (``tail_python``): the reset — user code, by index list, behind
+the ``nonzero()`` sync the reference pays too — and the observations that follow run phase by phase, with their launches
+pointed at the step's statistics slot.  A recording also watches its descriptors: a phase call outside the replay that goes
+through one of them (``reset([…])`` or ``resample_command([…])`` called by the training script between steps) drops it.
 """
 from __future__ import annotations
 
