@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--num-envs", type=int, default=65536, help="envs per GPU (weak scaling)")
-    ap.add_argument("--reduce-every", type=int, default=16, help="recorded steps per logging all-reduce (world > 1)")
+    ap.add_argument("--reduce-every", type=int, default=32, help="recorded steps per logging all-reduce (world > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 4096 / 16384-env side measurements")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stamping of the dominant kernel")
@@ -156,7 +156,7 @@ def main():
 
     N = args.num_envs
     env = make_env(N)
-    # multi-GPU: the statistics rows of 16 steps share one all-reduce (fewer, larger collectives; bench reads its log on every
+    # multi-GPU: the statistics rows of 32 steps share one all-reduce (fewer, larger collectives; bench reads its log on every
     # rank at the same step, which is what reduce_every > 1 asks for — see distributed.attach)
     gfd.attach(env, global_num_envs=N * world, reduce_every=args.reduce_every)
     env.seed(1234 + rank)

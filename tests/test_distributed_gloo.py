@@ -23,7 +23,7 @@ def _free_port():
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("reduce_every,read_lag,mutate_at,user_term", [(1, 0, None, False), (8, 11, None, False), (16, 0, 20, False), (4, 3, 17, False),
-                                                                       (1, 0, None, True), (8, 2, 19, True)])
+                                                                       (1, 0, None, True), (8, 2, 19, True), (32, 5, None, False)])
 def test_sharded_run_equals_unsharded(oracle_lib_path, reduce_every, read_lag, mutate_at, user_term):
     """reduce_every = K > 1: the statistics rows of K steps travel in one all-reduce (folded by the following step's action
     kernel, no pack launch).  Logs read later than K steps hit closed batches (no extra collective); logs read at once close
