@@ -2,32 +2,47 @@
 """
 bench.py — env-steps/sec of the ManagedEnvironment manager-step pipeline on MI355X.
 
-A "step" is one full ManagedEnvironment.step() (action → synthetic scene tick → termination → reward →
-command → masked reset → observation) over one batch of envs resident in HBM: BASELINE.json's
-Go2 12-DOF config with the full Reward/Termination/Command manager stack (6 reward terms, 2 termination
-terms, velocity command, 48-wide observation), synthetic data.  Weak scaling: every rank owns
-``--num-envs`` envs; the only cross-rank traffic is the per-step logging all-reduce (RCCL).
+A "step" is one full ManagedEnvironment.step() (action → synthetic scene tick → termination → reward → command → masked
+reset → observation) over one batch of envs resident in HBM: BASELINE.json's Go2 12-DOF config with the full Reward /
+Termination / Command manager stack (6 reward terms, 2 termination terms, velocity command, 48-wide observation), synthetic
+data.  The path shards by env: every rank owns its own envs, the only cross-rank traffic is the logging all-reduce (RCCL).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py                                   # 1 GPU, 65 536 envs
+    python bench.py --gpus 8                          # starts 8 ranks itself (one per GPU), weak scaling: 65 536 envs per GPU
+    python bench.py --gpus 8 --scaling strong --global-envs 65536 --config gait     # BASELINE config 5 sharded over 8 GPUs
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel — the fused post-physics launch that
-contains the reward fold (566 algorithmic B/env for this config; 268 B/env if the step runs unfused and
-the stand-alone reward kernel is the one measured) — bytes ÷ its average duration measured with HIP events on the launch
-stream during the timed region.  ``cpu_baseline`` times the CPU oracle (oracle/, a scalar C port of the
-reference algorithm) on the host cores of the same box, on a bounded sample of the same workload.
+Timing: W warm-up steps, then BATCHES of exactly K steps, each bracketed by barrier + synchronize on both sides and taken as
+the max over ranks, repeated until at least 0.3 s has been timed; the MEDIAN batch is reported (``ms_per_step`` = median / K).
+Nothing else runs inside a timed batch: the HIP-event stamping of the dominant kernel (``roofline``) is a separate loop after
+the timed batches, and every figure in the JSON line is measured by this run (committed rocprofv3 / PMC summaries live under
+profiles/ and are quoted in DESIGN.md, not here).
+
+Prints ONE JSON line (rank 0).  ``roofline``: the fused post-physics launch that contains the reward fold (566 algorithmic
+B/env for this config), bytes ÷ its average duration from dispatch-timestamp HIP events on the launch stream.
+``roofline_hbm``: the same kernel measured in this run at 1 048 576 envs, where the working set (0.85 GB) no longer fits the
+256 MiB Infinity Cache.  ``cpu_baseline``: the CPU oracle (oracle/, a scalar C port of the reference algorithm) on the host
+cores of the same box over the N x D grid of BASELINE.md §3 (plan B2).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "genesis-forge_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+MIN_TIMED_S = 0.3
+PRIMING_STEPS = 8      # setup, not warm-up: an env records its step over its first two steps and the first replay loads the
+#                        fused kernel's code object — done before the W warm-up steps so that even `--warmup 0` times the steady state
+HBM_POINT_ENVS = 1 << 20
+GRID_N = (64, 4096, 16384, 65536)
+GRID_D = (12, 28)
+OBS_OUTPUT = os.environ.get("GF_OBS_OUTPUT", "static")
 
 
 def reward_bytes_per_env(D: int, T: int, cmd_width: int) -> int:
@@ -46,217 +61,322 @@ def post_bytes_per_env(D: int, T: int, cmd_width: int, O: int, H: int = 1) -> in
     return reads + writes
 
 
-def make_env(num_envs: int):
-    from envs import Go2CommandDirectionEnv
+def make_env(num_envs: int, config: str = "go2_cmd", dofs: int = 12):
+    from genesis_forge_amd import tasks
+    from genesis_forge_amd.managers import ObservationManager
 
-    env = Go2CommandDirectionEnv(num_envs=num_envs, max_episode_length_s=20, scene_kwargs=dict(ang_noise=0.05, seed=1234))
+    # observations are returned in persistent output slots (hipGraph-style static outputs, ObservationManager(output="static"));
+    # the package default ("fresh": the reference's contract, a private copy per call) costs one extra copy launch per step
+    ObservationManager.default_output = OBS_OUTPUT
+
+    if config == "go2_cmd":
+        env = tasks.bench_env(num_envs, dofs=dofs)
+    else:
+        env = tasks.BASELINE_CONFIGS[config][1](num_envs)
     env.build()
     return env
 
 
-def cpu_baseline(num_envs: int, budget_s: float = 12.0) -> dict:
-    """Time the oracle (kind "port": scalar C restatement of the reference managers, 1 thread) on this box's host."""
+# ------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = "port"; BASELINE.md §3 plan B2): N x D grid, one thread and all host cores
+# ------------------------------------------------------------------------------------------------------------------------------
+def _oracle_env(num_envs: int, dofs: int):
+    """The bench workload on CPU tensors with the oracle as the compute backend — the checker timed as the CPU baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     from genesis_forge_amd import _native as nat
     from genesis_forge_amd import gs
     from oracle_backend import OracleBackend
 
-    old_dev, old_backend = gs.device, nat._backend
-    gs.set_device("cpu")
-    nat.set_backend(OracleBackend(os.path.join(ROOT, "oracle", "libgf_oracle.so")))
-    try:
-        env = make_env(num_envs)
-        env.reset()
-        g = torch.Generator().manual_seed(0)
-        acts = [torch.randn(num_envs, 12, generator=g) for _ in range(4)]
-        for i in range(2):
-            env.step(acts[i % 4])
+    if not isinstance(nat._backend, OracleBackend):
+        gs.set_device("cpu")
+        nat.set_backend(OracleBackend(os.path.join(ROOT, "oracle", "libgf_oracle.so")))
+    env = make_env(num_envs, dofs=dofs)
+    env.seed(1234)
+    env.reset()
+    g = torch.Generator().manual_seed(0)
+    acts = [torch.randn(num_envs, dofs, generator=g) for _ in range(4)]
+    for i in range(3):
+        env.step(acts[i % 4])
+    return env, acts
+
+
+def _cpu_point(env, acts, num_envs, min_iters, budget_s):
+    """Step until `min_iters` iterations AND `budget_s` seconds have passed (at most 4 x budget); median iteration time."""
+    ts = []
+    t_end = time.perf_counter() + budget_s
+    hard = time.perf_counter() + 4 * budget_s + 3.0
+    while (len(ts) < min_iters or time.perf_counter() < t_end) and time.perf_counter() < hard:
         t0 = time.perf_counter()
-        steps = 0
-        while True:
-            env.step(acts[steps % 4])
-            steps += 1
-            if time.perf_counter() - t0 > budget_s or steps >= 2000:
-                break
-        dt = time.perf_counter() - t0
-    finally:
-        nat.set_backend(old_backend)
-        gs.device = old_dev
-    return {"value": num_envs * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} steps x {num_envs} envs of the same Go2 full-stack workload, oracle/libgf_oracle.so single thread, "
-                      f"{os.cpu_count()} host cores present"}
+        env.step(acts[len(ts) % 4])
+        ts.append(time.perf_counter() - t0)
+    med = statistics.median(ts)
+    return {"iters": len(ts), "us_per_step_median": med * 1e6, "value": num_envs / med}
 
 
-def cpu_baseline_multicore(num_envs: int, workers: int, budget_s: float = 8.0) -> dict | None:
-    """The same port on `workers` host cores: the path shards by env, so each worker process steps its own shard of
-    num_envs / workers envs with the single-threaded oracle (no GPU in the workers); the figure is the sum."""
-    import subprocess
-
-    shard = max(1, num_envs // workers)
-    # GF_DEVICE=cpu: the workers never call torch.cuda.is_available() (which opens the GPU; the box allows few processes on it)
-    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", GF_DEVICE="cpu", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
-               CUDA_VISIBLE_DEVICES="")
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(shard), str(budget_s)], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(workers)]
-    total, ok = 0.0, 0
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=budget_s * 4 + 120)
-            total += float(out.strip().splitlines()[-1])
-            ok += 1
-        except Exception:
-            p.kill()
-    if ok != workers:
-        return None
-    return {"value": total, "unit": "env-steps/s", "cores": workers,
-            "sample": f"{workers} worker processes x {shard} envs each, ~{budget_s:.0f} s, oracle single-threaded per worker"}
-
-
-def cpu_worker(shard: int, budget_s: float) -> None:
+def cpu_worker(shard_div: int, budget_s: float) -> None:
+    """One host core: builds every grid point at num_envs / shard_div envs, reports "ready", waits for "go" on stdin (so all
+    workers measure the same point at the same time), then prints one JSON line with its per-point throughput."""
     import torch
 
     torch.set_num_threads(1)
-    print(cpu_baseline(shard, budget_s)["value"], flush=True)
+    points = []
+    for d in GRID_D:
+        for n in GRID_N:
+            shard = max(1, n // shard_div)
+            points.append((n, d, shard) + _oracle_env(shard, d))
+    print("ready", flush=True)
+    sys.stdin.readline()
+    out = []
+    for n, d, shard, env, acts in points:
+        t_end = time.perf_counter() + budget_s
+        steps = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() < t_end:
+            env.step(acts[steps % 4])
+            steps += 1
+        out.append({"num_envs": n, "dofs": d, "value": shard * steps / (time.perf_counter() - t0)})
+    print(json.dumps(out), flush=True)
+
+
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(headline_envs: int, workers: int) -> dict:
+    """Runs in helper processes that never open the GPU (GF_DEVICE=cpu, no visible devices)."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", GF_DEVICE="cpu", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
+               CUDA_VISIBLE_DEVICES="")
+    me = os.path.abspath(__file__)
+    # (1) one thread: median of >= 200 iterations per grid point
+    single = subprocess.run([sys.executable, me, "--cpu-single"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
+    grid = json.loads(single.stdout.strip().splitlines()[-1])
+    # (2) all host cores of this GPU's share: the path shards by env on the CPU exactly as across GPUs — `workers` processes, each
+    # stepping num_envs / workers envs with the single-threaded oracle; the figure is the sum over workers
+    multi = None
+    if workers > 1:
+        procs = [subprocess.Popen([sys.executable, me, "--cpu-worker", str(workers), "0.8"], env=env, stdin=subprocess.PIPE,
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(workers)]
+        try:
+            for p in procs:
+                assert p.stdout.readline().strip() == "ready"
+            for p in procs:
+                p.stdin.write("go\n")
+                p.stdin.flush()
+            rows = [json.loads(p.stdout.readline()) for p in procs]
+            for p in procs:
+                p.wait(timeout=60)
+            multi = [{"num_envs": r0["num_envs"], "dofs": r0["dofs"], "cores": workers, "value": sum(r[i]["value"] for r in rows)}
+                     for i, r0 in enumerate(rows[0])]
+        except Exception:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    head = next(g for g in grid if g["num_envs"] == (headline_envs if headline_envs in GRID_N else 65536) and g["dofs"] == 12)
+    return {"value": head["value"], "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{head['iters']} steps x {head['num_envs']} envs of the same Go2 full-stack workload (median step), oracle/libgf_oracle.so, one thread",
+            "cpu_model": _cpu_model(), "nproc": os.cpu_count(),
+            "grid": [dict(g, cores=1, unit="env-steps/s") for g in grid],
+            "grid_multicore": multi,
+            "grid_note": "BASELINE.md plan B2: N in {64, 4096, 16384, 65536} x D in {12, 28}; D = 28 is the same manager stack over a synthetic "
+                         "28-joint robot (O = 96); one thread = median of >= 200 steps; multicore = sum over worker processes each stepping "
+                         "N / workers envs for 0.8 s, all workers on the same grid point at the same time"}
+
+
+def cpu_single() -> None:
+    import torch
+
+    torch.set_num_threads(1)
+    out = []
+    for d in GRID_D:
+        for n in GRID_N:
+            env, acts = _oracle_env(n, d)
+            out.append(dict({"num_envs": n, "dofs": d}, **_cpu_point(env, acts, n, 200, 0.5)))
+            del env
+    print(json.dumps(out), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+def parse_args(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; > 1 without WORLD_SIZE in the environment: bench.py starts the ranks itself")
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --num-envs envs per GPU; strong: --global-envs envs in total, sharded contiguously over the GPUs")
+    ap.add_argument("--num-envs", type=int, default=65536, help="envs per GPU (weak scaling)")
+    ap.add_argument("--global-envs", type=int, default=65536, help="total envs (strong scaling)")
+    ap.add_argument("--config", default="go2_cmd", help="workload: go2_cmd (BASELINE.json's headline config) or another key of "
+                                                        "genesis_forge_amd.tasks.BASELINE_CONFIGS (gait = config 5, humanoid = config 4)")
+    ap.add_argument("--reduce-every", type=int, default=1,
+                    help="recorded steps per logging all-reduce (world > 1).  1 = one asynchronous all-reduce per step, log reads rank-local")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 4096 / 16384-env side measurements")
+    ap.add_argument("--no-hbm-point", action="store_true", help="skip the 1 048 576-env roofline_hbm measurement")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stamping pass (roofline)")
+    ap.add_argument("--profile-samples", type=int, default=64, help="stamped launches of the dominant kernel in the stamping pass")
+    ap.add_argument("--profile-stride", type=int, default=4,
+                    help="the stamping pass stamps every k-th launch: a stamped launch blocks the host for ~12 us and drains the queue, "
+                         "so the launches between two stamps let the pipeline refill")
+    return ap.parse_args(argv)
 
 
 def main():
-    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":
-        return cpu_worker(int(sys.argv[2]), float(sys.argv[3]))
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--num-envs", type=int, default=65536, help="envs per GPU (weak scaling)")
-    ap.add_argument("--reduce-every", type=int, default=32, help="recorded steps per logging all-reduce (world > 1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the 4096 / 16384-env side measurements")
-    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stamping of the dominant kernel")
-    ap.add_argument("--profile-stride", type=int, default=0,
-                    help="stamp every k-th launch of the dominant kernel in the timed region; 0 (default) = steps // 10, at least 8: "
-                         "a stamped launch drains the queue and costs ≈ 35 µs of a ≈ 20 µs step, so ten samples per run keep the "
-                         "throughput being measured within a few per cent of an unstamped run (1 = every launch)")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    if argv and argv[0] == "--cpu-worker":
+        return cpu_worker(int(argv[1]), float(argv[2]))
+    if argv and argv[0] == "--cpu-single":
+        return cpu_single()
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Start one rank per GPU ourselves.  Nothing in this process has touched the GPU (torch is not even imported): the
+        # ranks are fresh interpreters, this one only relays rank 0's line and exits with their status.
+        from genesis_forge_amd.launch import spawn_ranks
 
+        sys.exit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + argv, args.gpus))
+    run_rank(args)
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
     from genesis_forge_amd import _native as nat
     from genesis_forge_amd import distributed as gfd
     from genesis_forge_amd import gs
 
-    if not torch.cuda.is_available():
+    # A test harness may have injected a CPU backend (tests/test_bench_launch.py rehearses the multi-rank path over gloo with
+    # the oracle); bench.py itself never does: without it the manager phases only exist as HIP kernels.
+    rehearsal = nat._backend is not None and nat._backend.device_type == "cpu"
+    if not rehearsal and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the manager phases only exist as HIP kernels")
     # one rank per GPU over RCCL ("nccl" on ROCm).  GF_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer
     # GPUs than ranks (ranks then share devices; RCCL refuses that)
-    dist_backend = os.environ.get("GF_DIST_BACKEND", "nccl")
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
-    os.environ["LOCAL_RANK"] = str(local) if dist_backend != "nccl" else os.environ.get("LOCAL_RANK", "0")
+    dist_backend = os.environ.get("GF_DIST_BACKEND", "gloo" if rehearsal else "nccl")
+    if rehearsal:
+        gs.set_device("cpu")
+    else:
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        os.environ["LOCAL_RANK"] = str(local) if dist_backend != "nccl" else os.environ.get("LOCAL_RANK", "0")
+        gs.set_device(f"cuda:{local}")
     rank, world = gfd.init_from_env(dist_backend)
-    gs.set_device(f"cuda:{local}")
+    if world > 1:
+        assert dist.get_world_size() == world
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     backend = nat.get_backend()
+    sync = (lambda: None) if rehearsal else torch.cuda.synchronize
 
-    N = args.num_envs
-    env = make_env(N)
-    # multi-GPU: the statistics rows of 32 steps share one all-reduce (fewer, larger collectives; bench reads its log on every
-    # rank at the same step, which is what reduce_every > 1 asks for — see distributed.attach)
-    gfd.attach(env, global_num_envs=N * world, reduce_every=args.reduce_every)
-    env.seed(1234 + rank)
+    if args.scaling == "strong":
+        start, N = gfd.shard(args.global_envs, rank, world)
+        global_envs = args.global_envs
+    else:
+        N, global_envs = args.num_envs, args.num_envs * world
+    env = make_env(N, args.config)
+    D = env.action_space.shape[0]
+    gfd.attach(env, global_num_envs=global_envs, reduce_every=args.reduce_every)
+    env.seed(1234)          # one seed for all ranks: Philox is keyed by the GLOBAL env id, so shards draw different numbers
     env.reset()
     g = torch.Generator().manual_seed(1234 + rank)
-    acts = [torch.randn(N, 12, generator=g).to(gs.device) for _ in range(8)]
+    acts = [torch.randn(N, D, generator=g).to(gs.device) for _ in range(8)]
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    # setup, not warm-up: an env records its step over its first two steps and the first replay loads the fused kernel's code
-    # object — done here so that even `--warmup 0` times the steady state (the W warm-up steps below are run on top, as asked)
-    PRIMING_STEPS = 8
+    def timed_batches(e, a, steps):
+        """Batches of exactly `steps` steps, barrier + synchronize on both sides, max over ranks, until MIN_TIMED_S is covered."""
+        times = []
+        while True:
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                e.step(a[i % len(a)])
+            sync()
+            dt = time.perf_counter() - t0
+            barrier()
+            if world > 1:
+                t = torch.tensor([dt], device=gs.device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            times.append(dt)
+            if sum(times) >= MIN_TIMED_S or len(times) >= 1000:
+                return times
+
+    def stamp_pass(e, a, bytes_per_launch):
+        """HIP-event (dispatch timestamp) durations of the dominant kernel, in a loop of its own after the timed batches."""
+        fused_ = e._trace is not None and e._trace.post_refs is not None
+        phase = nat.GF_PHASE_POST if fused_ else nat.GF_PHASE_REWARD
+        stride = max(1, args.profile_stride)
+        backend.set_option(nat.GF_OPT_PROFILE_STRIDE, stride)
+        backend.profile_begin(phase, args.profile_samples)
+        for i in range(stride * args.profile_samples):
+            e.step(a[i % len(a)])
+        sync()
+        ms, cnt = backend.profile_end()
+        if cnt <= 0:
+            return None
+        avg_s = ms / cnt / 1e3
+        achieved = bytes_per_launch / avg_s / 1e9
+        return {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "avg_launch_us": avg_s * 1e6, "launches": cnt}
+
     for i in range(PRIMING_STEPS):
         env.step(acts[i % 8])
     for i in range(args.warmup):
         env.step(acts[i % 8])
-    barrier()
-    fused = env._trace is not None and env._trace.post_refs is not None
-    prof_phase = nat.GF_PHASE_POST if fused else nat.GF_PHASE_REWARD
-    if args.profile_stride <= 0:
-        args.profile_stride = max(8, args.steps // 10)
-    if not args.no_profile:
-        backend.set_option(nat.GF_OPT_PROFILE_STRIDE, max(1, args.profile_stride))
-        backend.profile_begin(prof_phase, args.steps)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        env.step(acts[i % 8])
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    prof_ms, prof_n = (0.0, 0)
-    if not args.no_profile:
-        prof_ms, prof_n = backend.profile_end()
-    if world > 1:
-        t = torch.tensor([elapsed], device=gs.device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    times = timed_batches(env, acts, args.steps)
+    batch = statistics.median(times)
+    _ = dict(env.extras["episode"])   # keep the logging path honest: read one step's global statistics (on every rank)
 
-    # keep the logging path honest: read one step's global statistics
-    _ = dict(env.extras["episode"])
+    fused = env._trace is not None and env._trace.post_refs is not None
+    rm = env.managers["reward"]
+    T = sum(1 for c in rm.cfg.values() if c.weight != 0)
+    go2 = args.config == "go2_cmd"
+    O = 12 + 3 * D
+    per_env = (post_bytes_per_env(D, T, 3, O, 1) if fused else reward_bytes_per_env(D, T, 3)) if go2 else None
+    kernel = "gf::reward_kernel"
+    if fused and not rehearsal:
+        what = backend.post_describe(env._trace.post_refs).split(":")[0]   # "program <id> (<name>)"
+        kernel = f"gf::post_ws_kernel, {what} (termination+reward+command+reset+observe fused)"
+    roof = None
+    if not args.no_profile and not rehearsal and per_env is not None:
+        m = stamp_pass(env, acts, per_env * N)   # on every rank (the steps contain the logging collective); rank 0 reports its own
+        if m is not None:
+            roof = dict({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel": kernel,
+                         "algorithmic_bytes_per_env": per_env, "algorithmic_bytes_per_launch": per_env * N, "num_envs": N,
+                         "launch_sampling": f"every {max(1, args.profile_stride)}th launch of a separate stamping loop after the timed batches",
+                         "note": "dispatch-timestamp HIP events; a stamped launch starts on a drained queue and runs ~1-2 us longer than in "
+                                 "the free-running loop (compare profiles/*kernel_stats.csv), so achieved / frac are lower bounds; "
+                                 "traffic (PMC) is collected by separate rocprofv3 --pmc passes, see profiles/ and DESIGN.md"}, **m)
 
     if rank == 0:
-        rm = env.managers["reward"]
-        T = sum(1 for c in rm.cfg.values() if c.weight != 0)
-        per_env = post_bytes_per_env(12, T, 3, 48, 1) if fused else reward_bytes_per_env(12, T, 3)
-        bytes_per_launch = per_env * N
-        kernel = "gf::reward_kernel<3>"
-        if fused:
-            # which kernel gf_post_physics_step launches for this config: "program <id> (<name>): <signature>"
-            what = backend.post_describe(env._trace.post_refs).split(":")[0]
-            kernel = f"gf::post_ws_kernel, {what} (termination+reward+command+reset+observe fused)"
-        roof = None
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if fused and os.path.exists(pmc_file):
-            # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected in
-            # separate rocprofv3 --pmc passes over this same command and committed under profiles/ (r01_pmc_traffic.md)
-            rec = json.load(open(pmc_file)).get(str(N))
-            if rec and ("Prog" in rec["kernel"]) == ("program 0" not in what):  # counters were taken on this same kernel
-                traffic, traffic_src = rec["traffic_bytes"], "profiles/r01_pmc_traffic.md"
-        # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary of this command (unperturbed by
-        # the event stamping: stamped launches start on a drained queue and run ≈ 2 µs longer, DESIGN.md §4.3)
-        rocprof_avg_us, rocprof_src = None, None
-        import csv
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_N{N}_*kernel_stats.csv")))[::-1]:
-            for row in csv.DictReader(open(path)):
-                if ("post_ws_kernel" in row["Name"] or "post_kernel" in row["Name"]) == fused and \
-                        (("post_" in row["Name"]) if fused else ("reward_kernel" in row["Name"])):
-                    rocprof_avg_us, rocprof_src = float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT)
-                    break
-            if rocprof_avg_us is not None:
-                break
-        if prof_n > 0:
-            avg_s = prof_ms / prof_n / 1e3
-            achieved = bytes_per_launch / avg_s / 1e9
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "algorithmic_bytes_per_env": per_env, "avg_launch_us": avg_s * 1e6, "launches": prof_n, "launch_sampling": f"every {max(1, args.profile_stride)}th launch of the timed region",
-                    "note": "stamped launches start on a drained queue and run ~2 us longer than the unstamped ones (DESIGN.md 4.3): "
-                            "achieved / frac are lower bounds, rocprof_avg_launch_us is the unperturbed average",
-                    "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "rocprof_avg_launch_us": rocprof_avg_us, "rocprof_source": rocprof_src}
         out = {
-            "metric": "env-steps/sec", "value": world * N * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "go2_12dof_full_manager_stack", "num_envs_per_gpu": N, "global_num_envs": N * world, "dofs": 12,
-                       "reward_terms": T, "termination_terms": 2, "command_managers": 1, "obs_width": 48,
-                       "scene": "synthetic (gf_synth_scene_step)", "parallelism": f"env-shard x{world}",
-                       "stats_allreduce_every_steps": (args.reduce_every if world > 1 else None),
-                       "setup_steps_before_warmup": PRIMING_STEPS},
+            "metric": "env-steps/sec", "value": global_envs * args.steps / batch, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": batch / args.steps * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "go2_12dof_full_manager_stack" if go2 else args.config, "num_envs_per_gpu": N, "global_num_envs": global_envs,
+                       "dofs": D, "reward_terms": T, "termination_terms": len(env.managers["termination"].term_cfg), "command_managers": len(env.managers["command"]),
+                       "obs_width": int(env.observation_space.shape[0]), "scene": "synthetic (gf_synth_scene_step)", "parallelism": f"env-shard x{world}",
+                       "stats_allreduce_every_steps": (args.reduce_every if world > 1 else None), "dist_backend": (dist_backend if world > 1 else None),
+                       "setup_steps_before_warmup": PRIMING_STEPS, "fused_post_physics": fused, "observation_output": OBS_OUTPUT,
+                       "launches_per_step": env._trace.n_ops if env._trace is not None else None},
+            "timing": {"batches": len(times), "timed_s": sum(times), "batch_ms_median": batch * 1e3, "batch_ms_min": min(times) * 1e3,
+                       "batch_ms_max": max(times) * 1e3, "rule": f"batches of exactly {args.steps} steps (barrier + synchronize both sides, max over ranks) "
+                                                                  f"until >= {MIN_TIMED_S} s are timed; median batch reported"},
             "roofline": roof,
         }
-        if world == 1 and not args.no_sweep:
-            # BASELINE.json quotes the metric "@ 4096–65536 envs": the other end of the range (and the middle), same workload, measured
-            # after the timed region above, without launch stamps (informational; `value` is the 65 536-env figure unless --num-envs)
+    del env
+    if world == 1 and not rehearsal:
+        if not args.no_sweep and go2:
+            # BASELINE.json quotes the metric "@ 4096–65536 envs": the other end of the range and the middle, same workload, same
+            # timing rule (informational; `value` is the 65 536-env figure unless --num-envs says otherwise)
             out["sweep"] = []
             for n_s in (4096, 16384):
                 if n_s == N:
@@ -264,24 +384,39 @@ def main():
                 env_s = make_env(n_s)
                 env_s.seed(1234)
                 env_s.reset()
-                acts_s = [torch.randn(n_s, 12, generator=g).to(gs.device) for _ in range(4)]
-                for i in range(args.warmup):
-                    env_s.step(acts_s[i % 4])
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(args.steps):
-                    env_s.step(acts_s[i % 4])
-                torch.cuda.synchronize()
-                dt_s = time.perf_counter() - t0
-                out["sweep"].append({"num_envs": n_s, "value": n_s * args.steps / dt_s, "unit": "env-steps/s", "ms_per_step": dt_s / args.steps * 1e3})
+                acts_s = [torch.randn(n_s, 12, generator=g).to(gs.device) for _ in range(8)]
+                for i in range(PRIMING_STEPS + args.warmup):
+                    env_s.step(acts_s[i % 8])
+                ts = timed_batches(env_s, acts_s, args.steps)
+                b = statistics.median(ts)
+                out["sweep"].append({"num_envs": n_s, "value": n_s * args.steps / b, "unit": "env-steps/s", "ms_per_step": b / args.steps * 1e3, "batches": len(ts)})
                 del env_s
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N)
-            workers = min(16, os.cpu_count() or 1)   # the GPU box gives one GPU's share of the host: 16 cores
-            if workers > 1:
-                multi = cpu_baseline_multicore(N, workers)
-                if multi is not None:
-                    out["cpu_baseline"]["multicore"] = multi
+        if not args.no_hbm_point and not args.no_profile and go2 and N != HBM_POINT_ENVS:
+            # the HBM-honest point: at 65 536 envs a step's 53 MB working set stays in the 256 MiB Infinity Cache between kernels;
+            # at 1 048 576 envs (0.85 GB) every launch streams from HBM
+            n_h = HBM_POINT_ENVS
+            env_h = make_env(n_h)
+            env_h.seed(1234)
+            env_h.reset()
+            acts_h = [torch.randn(n_h, 12, generator=g).to(gs.device) for _ in range(4)]
+            for i in range(PRIMING_STEPS + 10):
+                env_h.step(acts_h[i % 4])
+            ts = timed_batches(env_h, acts_h, min(args.steps, 100))
+            b = statistics.median(ts) / min(args.steps, 100)
+            pe = post_bytes_per_env(12, T, 3, 48, 1)
+            m = stamp_pass(env_h, acts_h, pe * n_h)
+            if m is not None:
+                out["roofline_hbm"] = dict({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel": kernel, "num_envs": n_h,
+                                            "algorithmic_bytes_per_env": pe, "algorithmic_bytes_per_launch": pe * n_h,
+                                            "ms_per_step": b * 1e3, "value": n_h / b,
+                                            "note": "same run, same kernel, 1 048 576 envs: the working set no longer fits the Infinity Cache"}, **m)
+            del env_h
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, min(16, os.cpu_count() or 1))   # the GPU box gives one GPU's share of the host: 16 cores
+            except Exception as ex:  # the baseline is a reported side figure: never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": f"failed: {ex!r}"}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

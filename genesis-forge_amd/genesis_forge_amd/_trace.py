@@ -232,6 +232,7 @@ class StepTrace:
             self.afters.append((self._cur_op, env._after_masked_reset_traced))
         elif fn == "observe":
             self.patches.append(owner._trace_patch(args))
+            self.afters.append((self._cur_op, owner._trace_after))
         elif fn == "contact_step":
             pass
         else:

@@ -11,9 +11,18 @@ the library's getters carry a provenance tag; if an item's result *is* such a ta
 is compiled to the matching opcode and its Python fn is never called again.  Anything else (a lambda
 that post-processes, user manager methods) stays an EXTERNAL item evaluated by Python each step.
 Pass ``fused=False`` to force the EXTERNAL path for every item.
+
+Returned tensors (``output=``).  The reference returns a fresh ``torch.cat`` every call and keeps its history list private
+(:218-226), so a caller may hold ``obs`` for as long as it likes and edit it in place.  ``output="fresh"`` (the default)
+keeps exactly that contract: the kernel writes into buffers only this manager sees and the caller gets a copy.
+``output="static"`` is the opt-in fast path in the style of CUDA/HIP-graph replays with static outputs: the returned tensor
+IS one of ``static_slots`` (3) persistent buffers the kernel writes in rotation — valid until this manager has been asked for
+``static_slots - 1`` further observations, read-only for the caller when ``history_len > 1`` (the next call reads its history
+frames from it).  No copy, no allocation, nothing that changes from step to step in a recorded step.
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Callable, Optional, TypedDict
 
 import numpy as np
@@ -41,18 +50,25 @@ _SRC_OPS = {
     "contact_norm": nat.GF_O_CONTACT_FORCE_NORM,
 }
 
-_OBS_RING = 3  # returned tensors stay valid for two further calls (rollout storages copy one step late)
+_OBS_RING = 3  # persistent output slots: output="static" hands them out directly (valid for two further calls)
 
 
 class ObservationManager(BaseManager):
     noise = LiveAttr("noise")   # manager-wide noise, read per step in the reference (observation_manager.py:246-250)
+    #: what get_observations() returns when the constructor is not told: "fresh" (reference contract) or "static" (see module
+    #: docstring).  GF_OBS_OUTPUT overrides the default for a whole process (unchanged task configs on the fast path).
+    default_output = os.environ.get("GF_OBS_OUTPUT", "fresh")
+    static_slots = _OBS_RING
 
     """Generates an observation tensor from a dict of items (ctor as observation_manager.py:134-156)."""
 
     def __init__(self, env, cfg: dict[str, ObservationConfig], name: str = "policy", history_len: int | None = None,
-                 noise: float | None = None, fused: bool = True):
+                 noise: float | None = None, fused: bool = True, output: str | None = None):
         super().__init__(env, "observation")
         self._name = name
+        self._output = output if output is not None else type(self).default_output
+        if self._output not in ("fresh", "static"):
+            raise ValueError("output must be 'fresh' or 'static'")
         self.noise = noise
         self._observation_size = 1
         self._observation_space = None
@@ -215,7 +231,11 @@ class ObservationManager(BaseManager):
         out = self._rotate_ring(a)
         env.backend.call("observe", a, owner=self)
         self._keep = keep
-        return out
+        return self._hand_out(out)
+
+    def _hand_out(self, out: torch.Tensor) -> torch.Tensor:
+        """The caller's tensor: a copy nobody else holds (reference contract), or the persistent slot itself (static)."""
+        return out.clone() if self._output == "fresh" else out
 
     def _rotate_ring(self, a) -> torch.Tensor:
         prev = self._bufs[self._cur]
@@ -255,7 +275,10 @@ class ObservationManager(BaseManager):
 
         def patch(_actions, a=args, env=env, self=self):
             a.stream = env.next_stream()
-            out = self._rotate_ring(a)
-            env._extras["observations"][self._name] = out
+            self._pending_out = self._rotate_ring(a)
 
         return patch
+
+    def _trace_after(self) -> None:
+        """Recorded step, after the launches have been enqueued: publish this step's observation (a fresh copy by default)."""
+        self.env._extras["observations"][self._name] = self._hand_out(self._pending_out)

@@ -41,6 +41,21 @@ CASES = {
                                  92: "more_gaits", 93: "wider_ranges"}),
 }
 
+# The same example files at more than one 64-env tile (fixtures traj_ex_<key>.npz, `example` names the reference directory):
+# the n = 8 cases above only ever exercise one partial tile of the HIP kernels.  130 envs = two full tiles + a 2-env tail,
+# 70 = one full tile + 6; short episodes (0.5 s = 25 steps +- jitter) so time-outs, resets and resamples all occur.
+for _ex, _n, _steps in (("command_direction", 130, 56), ("rough_terrain", 130, 56), ("berkeley_humanoid", 130, 48), ("gait_trainer", 70, 44)):
+    _base = CASES[_ex]
+    CASES[f"{_ex}_n{_n}"] = dict(_base, example=_ex, n=_n, steps=_steps, episode_s=0.5,
+                                  resample={k: 0.2 + 0.1 * i for i, k in enumerate(_base["resample"])},
+                                  events={5: "more_gaits", 6: "more_gaits", 7: "wider_ranges", 20: "more_gaits"} if _base["events"] else {})
+
+
+def example_of(key: str) -> str:
+    """The reference example directory (and restated task config) a case runs."""
+    return CASES[key].get("example", key)
+
+
 GOLDEN_SEED = 20251017
 
 

@@ -1,0 +1,64 @@
+"""bench.py --gpus N starts its ranks itself: rehearsed here with 2 ranks over gloo on the CPU.
+
+The children are ordinary `python bench.py …` processes; tests/inject/sitecustomize.py (on their PYTHONPATH) installs the oracle
+as the compute backend before bench.py runs, so everything except the kernels is the real thing: the parent that never touches
+the GPU, the rendezvous environment, one process group, contiguous env shards, the per-batch max over ranks, one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=os.path.join(ROOT, "tests", "inject") + os.pathsep + env.get("PYTHONPATH", ""), GF_TEST_INJECT_ORACLE="1",
+               GF_DEVICE="cpu", OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]   # gloo's C++ side greets on stdout
+    assert len(lines) == 1, f"exactly one JSON line expected, got {len(lines)}: {p.stdout[-500:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_gpus_2_self_launch_weak():
+    out = _bench("--gpus", "2", "--steps", "6", "--warmup", "2", "--num-envs", "96", "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 6
+    assert out["config"]["num_envs_per_gpu"] == 96 and out["config"]["global_num_envs"] == 192
+    assert out["config"]["parallelism"] == "env-shard x2" and out["config"]["dist_backend"] == "gloo"
+    assert out["value"] > 0 and abs(out["value"] - 192 * 6 / (out["ms_per_step"] * 6e-3)) < 1e-6 * out["value"]
+    assert out["timing"]["batches"] >= 1 and out["timing"]["timed_s"] >= 0.3
+
+
+@pytest.mark.timeout(300)
+def test_gpus_2_self_launch_strong_gait():
+    """BASELINE config 5's shape: a global env count split over the ranks (65 536 over 8 on the real node; 130 over 2 here)."""
+    out = _bench("--gpus", "2", "--steps", "5", "--warmup", "2", "--scaling", "strong", "--global-envs", "130", "--config", "gait", "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["global_num_envs"] == 130 and out["config"]["num_envs_per_gpu"] == 65 and out["config"]["workload"] == "gait"
+    assert out["value"] > 0
+
+
+@pytest.mark.timeout(300)
+def test_single_rank_line_and_torchrun_env():
+    """N = 1 is unchanged (no process group), and ranks started by an external launcher (WORLD_SIZE set) do not self-launch."""
+    out = _bench("--gpus", "1", "--steps", "4", "--warmup", "1", "--num-envs", "64", "--no-cpu-baseline")
+    assert out["n_gpus"] == 1 and out["config"]["parallelism"] == "env-shard x1" and out["config"]["dist_backend"] is None
+
+
+def test_spawn_ranks_propagates_failure_and_environment(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "genesis-forge_amd"))
+    from genesis_forge_amd.launch import spawn_ranks
+
+    code = ("import os, sys; open(os.path.join(sys.argv[1], 'r' + os.environ['RANK']), 'w').write(' '.join(os.environ[k] for k in "
+            "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR'))); import time; time.sleep(1.5 if os.environ['RANK'] == '1' else 0); "
+            "sys.exit(3 if os.environ['RANK'] == '1' else 0)")
+    rc = spawn_ranks([sys.executable, "-c", code, str(tmp_path)], 3)
+    assert rc == 3
+    for r in range(3):
+        assert (tmp_path / f"r{r}").read_text() == f"{r} {r} 3 127.0.0.1"

@@ -20,8 +20,9 @@ import torch
 import example_cases
 import helpers
 
-EXAMPLES = list(example_cases.CASES)
-RESTATED = EXAMPLES  # gait_trainer runs on the native GaitCommandManager
+CASE_KEYS = list(example_cases.CASES)   # the six examples at n = 8 plus the multi-tile cases (<example>_n<envs>)
+EXAMPLES = [k for k in CASE_KEYS if example_cases.example_of(k) == k]
+RESTATED = CASE_KEYS  # gait_trainer runs on the native GaitCommandManager
 REF_EXAMPLES = "/root/reference/examples"
 
 
@@ -57,7 +58,7 @@ def _unalias():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="the reference's example files exist only in the build container")
-@pytest.mark.parametrize("name", EXAMPLES)
+@pytest.mark.parametrize("name", CASE_KEYS)
 def test_reference_example_file_drops_in(oracle_backend, name):
     from genesis_forge_amd import compat
 
@@ -66,7 +67,7 @@ def test_reference_example_file_drops_in(oracle_backend, name):
     try:
         compat.SCENE_OVERRIDES.clear()
         compat.SCENE_OVERRIDES.update(case["scene"])
-        cls, mod = _load_reference_example(name)
+        cls, mod = _load_reference_example(example_cases.example_of(name))
         env = cls(num_envs=case["n"], max_episode_length_s=case["episode_s"])
         compat.SCENE_OVERRIDES.clear()
         user_gait = getattr(mod, "GaitCommandManager", None)
@@ -83,7 +84,7 @@ def test_restated_config_cpu_oracle(oracle_backend, name):
 
     case = example_cases.CASES[name]
     fix = helpers.load(f"traj_ex_{name}")
-    env = envs.make_example(name, case)
+    env = envs.make_example(example_cases.example_of(name), case)
     res = helpers.replay_example(fix, case, env, "cpu")
     helpers.compare_example(fix, res)
 
@@ -95,7 +96,7 @@ def test_restated_config_hip(hip_backend, name):
 
     case = example_cases.CASES[name]
     fix = helpers.load(f"traj_ex_{name}")
-    env = envs.make_example(name, case)
+    env = envs.make_example(example_cases.example_of(name), case)
     res = helpers.replay_example(fix, case, env, "cuda")
     helpers.compare_example(fix, res)
 

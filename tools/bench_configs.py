@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""env-steps/s of every BASELINE.json config (tests/envs.py restatements of the reference's examples) on one GPU.
+"""env-steps/s of every BASELINE.json config (genesis_forge_amd/tasks.py restatements of the reference's examples) on one GPU.
 
 bench.py measures the headline config only (its JSON contract); this tool gives the per-config table of DESIGN.md:
     python tools/bench_configs.py [--steps 200] [--configs simple,go2_cmd,...] [--num-envs N]
@@ -14,27 +14,11 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "genesis-forge_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# (name, BASELINE.json size, factory)
 def _configs():
-    import envs
+    from genesis_forge_amd.tasks import BASELINE_CONFIGS   # (name -> (BASELINE.json size, factory)), shared with the parity tests
 
-    # stand-in physics settings: small attitude noise (≈ 0.2 % of the envs fall over per step) and, where a config terminates
-    # on body / torso contact, a contact density that resets ≈ 0.3–0.5 % of the envs per step (an episode of a few hundred
-    # steps) — a scene that reset several per cent of its envs every step would time the reset path, not the step
-    sc = dict(ang_noise=0.05, seed=1234)
-    con = dict(sc, contact_prob=0.15, contact_force=40.0)
-    return {
-        "simple": (4096, lambda n: envs.Go2SimpleEnv(num_envs=n, scene_kwargs=dict(sc))),
-        "go2_cmd": (4096, lambda n: envs.Go2CommandDirectionEnv(num_envs=n, scene_kwargs=dict(sc))),
-        "go2_cmd_65536": (65536, lambda n: envs.Go2CommandDirectionEnv(num_envs=n, scene_kwargs=dict(sc))),
-        "contacts": (4096, lambda n: envs.Go2ContactsEnv(num_envs=n, scene_kwargs=dict(con))),
-        "rough_terrain": (16384, lambda n: envs.Go2RoughTerrainEnv(num_envs=n, height_reward=False, scene_kwargs=dict(con, max_collision_pairs=30))),
-        "humanoid": (8192, lambda n: envs.BerkeleyHumanoidEnv(num_envs=n, scene_kwargs=dict(con, contact_prob=0.002, max_collision_pairs=30))),
-        "gait": (65536, lambda n: envs.Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(con, contact_prob=0.001))),
-        "gait_8192": (8192, lambda n: envs.Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(con, contact_prob=0.001))),
-    }
+    return BASELINE_CONFIGS
 
 
 def main():
@@ -46,6 +30,9 @@ def main():
     args = ap.parse_args()
     import torch
     from genesis_forge_amd import gs
+    from genesis_forge_amd.managers import ObservationManager
+
+    ObservationManager.default_output = os.environ.get("GF_OBS_OUTPUT", "static")   # as bench.py: persistent output slots
 
     if not torch.cuda.is_available():
         raise SystemExit("needs a ROCm GPU")

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "genesis-forge_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from genesis_forge_amd import gs
-from envs import Go2CommandDirectionEnv
+from genesis_forge_amd.tasks import Go2CommandDirectionEnv
 
 
 def run(n, trace, steps=400):

@@ -9,7 +9,10 @@ stepped by the CPU oracle), its uniform_ calls are served from Philox draws (tes
 tests feed to the kernels in parity mode, so a fixture pins the reference's manager logic — phase
 order, which envs resample/reset, weights, op order — not torch's RNG stream.
 
-Usage: python tools/gen_golden.py            (rewrites every fixture)
+Usage: python tools/gen_golden.py                     rewrites the unit fixtures and the traj_go2_* trajectories
+       python tools/gen_golden.py examples [key ...]  rewrites traj_ex_<key>.npz — the reference's own example files
+                                                      (tests/example_cases.py: six examples at n = 8 + the multi-tile cases)
+       python tools/gen_golden.py entity_obs | contact_kernel   one unit fixture
 """
 import math
 import os
@@ -821,7 +824,7 @@ def run_example(name):
     compat.SCENE_OVERRIDES.clear()
     compat.SCENE_OVERRIDES.update(case["scene"])
     try:
-        cls, mod = load_example_class(name, ref.ManagedEnvironment)
+        cls, mod = load_example_class(example_cases.example_of(name), ref.ManagedEnvironment)
         env = cls(num_envs=n, max_episode_length_s=case["episode_s"])
     finally:
         compat.SCENE_OVERRIDES.clear()

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "genesis-forge_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from genesis_forge_amd import _native as nat, gs
-from envs import Go2CommandDirectionEnv
+from genesis_forge_amd.tasks import Go2CommandDirectionEnv
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 gs.set_device("cuda:0")
