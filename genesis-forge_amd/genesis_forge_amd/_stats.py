@@ -250,6 +250,11 @@ class StepStats:
         old = self._vec_snaps[i]
         if old is not None and old._value is None and (old._work is not None or self.reduce_every <= 1):
             self.materialize_vec_ring()   # an unread, already reduced row is about to be recycled: copy the ring out (local)
+        elif old is not None and old._work is not None and old._work is not True:
+            # the row is about to be rewritten by this step's fold / pack: order that behind the all-reduce that read it with an
+            # explicit stream dependency (64 steps later it has long finished, but ring distance is not a synchronisation)
+            old._work.wait()
+            old._work = None
         self.ring_pos = j
         prev = getattr(self, "_fold_slot", None)
         self._fold_slot = i

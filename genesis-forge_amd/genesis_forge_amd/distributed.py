@@ -50,7 +50,16 @@ def attach(env, group=None, global_num_envs: Optional[int] = None, reduce_every:
     ordering rules; with K > 1 reading the log of a step whose batch is still open closes the batch early — a collective —
     so all ranks must then read the same steps (training loops that log on every rank, curricula — which run on every rank
     by construction — and ``env.stats.flush_reduce()`` are fine; a rank-0-only logger should keep K = 1 or read only
-    steps older than K).  K must divide 64 and be at most 32."""
+    steps older than K).  K must divide 64 and be at most 32.
+
+    Collective discipline (what may NOT be rank-local once a group is attached).  With K = 1 every step — recorded or ordinary —
+    issues exactly one all-reduce of one GF_STATS_VECTOR_LEN row, so ranks may drop and re-record their steps independently
+    (a weight mutated on one rank only, a descriptor going dirty on one rank); the calls that add a collective of their own are
+    ``env.reset(...)`` OUTSIDE a step (its log needs the global means) and ``attach`` itself — call those on every rank.
+    With K > 1 the batches are tied to the recorded step: anything that invalidates it (``invalidate_trace``: a mutated weight /
+    param / range, ``reset([ids])`` or ``resample_command`` between steps, a re-seed) closes the open batch with a collective
+    and must therefore happen on every rank at the same step, as must reading the log of a step whose batch is still open.
+    K > 1 is for lock-step training loops only; it stays opt-in until RCCL scaling has been measured on a real node."""
     if reduce_every < 1 or reduce_every > 32 or 64 % reduce_every != 0:
         raise ValueError("reduce_every must divide 64 and be at most 32")
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

@@ -15,7 +15,13 @@ from typing import Callable, Optional
 
 
 class ParamsDict(dict):
-    """dict that reports item assignment / deletion to ``on_change``."""
+    """dict that reports every mutation to ``on_change``.
+
+    The reference hooks item assignment / deletion only (params_dict.py:4-22) and gets away with it because its term loops
+    re-read ``**params`` every step, so ``params.update(...)``, ``pop``, ``setdefault``, ``clear`` and ``|=`` take effect
+    there too.  Here params are compiled into a native term table (and frozen into a recorded step), so every mutating method
+    must mark the table dirty.  What no dict can see — editing a mutable VALUE in place (a list appended to, a tensor written
+    through a view the table copied) — still needs an explicit ``params[key] = params[key]``."""
 
     def __init__(self, params: dict, on_change: Callable[[], None]):
         super().__init__(params)
@@ -28,6 +34,36 @@ class ParamsDict(dict):
     def __delitem__(self, key):
         super().__delitem__(key)
         self._on_change()
+
+    def update(self, *args, **kwargs):
+        super().update(*args, **kwargs)
+        self._on_change()
+
+    def pop(self, *args):
+        out = super().pop(*args)
+        self._on_change()
+        return out
+
+    def popitem(self):
+        out = super().popitem()
+        self._on_change()
+        return out
+
+    def setdefault(self, key, default=None):
+        had = key in self
+        out = super().setdefault(key, default)
+        if not had:
+            self._on_change()
+        return out
+
+    def clear(self):
+        super().clear()
+        self._on_change()
+
+    def __ior__(self, other):
+        super().update(other)
+        self._on_change()
+        return self
 
 
 class MdpFnClass:

@@ -8,9 +8,14 @@
  *      0            success
  *      < 0          argument validation failure (GF_E_*)
  *      > 0          hipError_t of the failing runtime call
- * The library allocates nothing, keeps no global mutable state and never synchronises the
- * device: ownership never crosses the ABI.  No torch types appear here; the
- * Python host (genesis_forge_amd) hands over `tensor.data_ptr()` values via ctypes.
+ * The phase entry points allocate nothing, never synchronise the device and keep no state between
+ * calls: everything a launch reads or writes is named by its descriptor, so they are re-entrant per
+ * (device, stream) and ownership never crosses the ABI.  What IS process-global, and
+ * therefore not re-entrant, is diagnostic: the tuning switches of gf_set_option() (read once per
+ * launch) and the single-phase event profiler gf_profile_begin() / gf_profile_end().  The opaque
+ * handles of gf_run_ops_graph() / gf_event_create() belong to the caller that created them.
+ * No torch types appear here; the Python host (genesis_forge_amd) hands over `tensor.data_ptr()`
+ * values via ctypes.
  *
  * Conventions
  *   N = num_envs, D = controlled DOFs, L = tracked links of one ContactManager,

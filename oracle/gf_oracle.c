@@ -9,12 +9,16 @@
  * Parity status: PINNED against the reference itself — tests/golden/*.npz were generated in the
  * build container by importing /root/reference/genesis_forge (with stub genesis/gstaichi/
  * gymnasium/tensordict modules, tools/gen_golden.py) and recording its inputs/outputs; this
- * oracle is checked against every one of them by tests/test_oracle_golden.py.
+ * oracle is checked against every one of them on the CPU (`pytest -m "not gpu"`): tests/test_terms_golden.py (every mdp term,
+ * action managers, air time, orientation sweep, entity / observation getters), tests/test_golden_trajectory.py and
+ * tests/test_examples.py (whole trajectories, incl. the reference's six example files), tests/test_contact_kernel.py,
+ * tests/test_terrain.py.
  * UNPINNED sub-parts (third-party code absent from /root/reference):
  *   - genesis.utils.geom.transform_by_quat / inv_quat (genesis-world>=0.3.4): restated from
  *     the mathematical definition  v' = v + w*t + qv x t,  t = 2*(qv x v),  inv = conjugate;
- *   - the Taichi kernel kernel_get_contact_forces is not executable without gstaichi: restated
- *     from managers/contact/kernel.py:35-90 by reading, accumulation in contact-slot order;
+ *   - gstaichi's JIT semantics for kernel_get_contact_forces (the order of its atomic `+=`): the fixture was recorded by
+ *     executing the reference's kernel SOURCE under a serial emulation of ti.ndrange / ti.Vector / ti.static
+ *     (tools/ref_stubs.py), accumulation in contact-slot order (managers/contact/kernel.py:35-90);
  *   - torch's RNG stream: draws are inputs (dense U[0,1) arrays) or Philox4x32-10.
  *
  * It shares the POD descriptors of include/gf_step.h (host pointers instead of device

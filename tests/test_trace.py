@@ -47,6 +47,49 @@ def test_trace_invalidated_by_mutation_cpu(oracle_backend):
     assert env._trace is not None, "trace should have been re-recorded after the mutation"
 
 
+@pytest.mark.parametrize("trace", [False, True])
+def test_params_dict_bulk_mutations_take_effect(oracle_backend, trace):
+    """the reference re-reads **params every step, so params.update(...) / pop / setdefault / |= / clear take effect
+    there; here they must mark the compiled term table dirty (and drop a recorded step) just like item assignment does."""
+    def run(how):
+        env = Go2CommandDirectionEnv(num_envs=40, max_episode_length_s=1, scene_kwargs=dict(ang_noise=0.3, seed=3))
+        env.trace_enabled = trace
+        env.build()
+        env.seed(5)
+        env.reset()
+        g = torch.Generator().manual_seed(0)
+        out = []
+        for t in range(16):
+            if t == 8:
+                p = env.reward_manager.cfg["base_height_target"].params
+                q = env.reward_manager.cfg["tracking_lin_vel"].params
+                if how == "setitem":
+                    p["target_height"] = 0.37
+                    q["sensitivity"] = 0.5
+                elif how == "update":
+                    p.update(target_height=0.37)
+                    q.setdefault("sensitivity", 0.5)
+                elif how == "ior":
+                    p |= {"target_height": 0.37}
+                    q.update({"sensitivity": 0.5})
+                elif how == "pop":       # back to the term's defaults: target_height has none -> set again; sensitivity default 0.25
+                    p.pop("target_height")
+                    p["target_height"] = 0.37
+                    q["sensitivity"] = 0.9
+                    q.pop("sensitivity")
+                    q.update(sensitivity=0.5)
+            out.append(env.step(torch.randn(40, 12, generator=g))[1].clone())
+        assert (env._trace is not None) == trace
+        return out
+
+    want = run("setitem")
+    assert not torch.equal(want[7], want[9])
+    for how in ("update", "ior", "pop"):
+        got = run(how)
+        for t, (a, b) in enumerate(zip(want, got)):
+            assert torch.equal(a, b), f"{how}: reward differs at step {t} — the mutation did not reach the term table"
+
+
 def test_parity_draws_disable_trace(oracle_backend):
     env = Go2CommandDirectionEnv(num_envs=8)
     env.build()
