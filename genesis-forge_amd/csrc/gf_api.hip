@@ -49,6 +49,8 @@ GF_EXPORT int gf_sizeof(int which) {
         case 14: return (int)sizeof(GfGaitArgs);
         case 15: return (int)sizeof(GfContactView);
         case 16: return (int)sizeof(GfCommandView);
+        case 17: return (int)sizeof(GfPostRefs);
+        case 18: return (int)sizeof(GfRolloutArgs);
         default: return -1;
     }
 }
@@ -197,6 +199,7 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
             case GF_PHASE_ROTATE: rc = gf_entity_rotate((const GfRotateArgs*)a, stream); break;
             case GF_PHASE_SCENE: rc = gf_synth_scene_step((const GfSynthSceneArgs*)a, stream); break;
             case GF_PHASE_TERRAIN: rc = gf_terrain_height((const GfTerrainHeightArgs*)a, stream); break;
+            case GF_PHASE_ROLLOUT: rc = gf_rollout_write((const GfRolloutArgs*)a, stream); break;
             case GF_PHASE_GAIT: {
                 const GfGaitArgs* g = (const GfGaitArgs*)a;
                 const bool all = g && g->mode != GF_CMD_STEP && deferred.has(g->state);

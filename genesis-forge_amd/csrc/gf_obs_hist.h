@@ -1,0 +1,98 @@
+// gf_obs_hist.h — the observation history shift, shared by the stand-alone observation kernel / chain B (gf_observe.hip) and
+// the fused post-physics kernel (gf_post_ws.h): both run 256-thread workgroups over 64-env tiles.
+#pragma once
+
+#include "gf_device.h"
+
+namespace gf {
+
+constexpr int kObsBlock = 256;  // threads of a workgroup that owns one 64-env observation tile
+constexpr int kObsShift = 8;    // history units per lane in flight together
+
+// floor(i / d) by multiply-shift with m = ceil(2^40 / d): exact for i < 2^40 / d (here i < 64·d and d < 2^17) — an element index
+// becomes (row, column) once per element, and d (a frame or history width) is a run-time value
+struct FastDiv {
+    uint64_t m;
+    uint32_t d;
+    __device__ __forceinline__ explicit FastDiv(int div) : m(div > 1 ? ((1ull << 40) + (uint64_t)div - 1ull) / (uint64_t)div : 0ull), d((uint32_t)div) {}
+    __device__ __forceinline__ int div(int i) const { return d > 1 ? (int)(((uint64_t)(uint32_t)i * m) >> 40) : i; }
+};
+
+typedef float f32x2a __attribute__((ext_vector_type(2)));               // 8-byte aligned
+typedef float f32x4a __attribute__((ext_vector_type(4)));               // 16-byte aligned
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword aligned: one global_load_dwordx4 all the same
+
+// History shift.  The [rows, O·H] block of a tile is one contiguous run of floats in `out` and in `prev`, and
+// out[k] = prev[k - O] wherever column (k mod O·H) >= O.  Cut the run into 16-byte units aligned on `out`: a unit that lies
+// entirely in history columns is one (dword-aligned) 16-byte load and one aligned 16-byte store, whatever O is — rows of an
+// odd-width frame are not 16-byte aligned, the run is.  Units that touch a new-frame column wait for the LDS tile
+// (write_mixed_units).  A batch = kObsShift units per lane, loads first, stores later: the caller puts other work between
+// the two so the lane never sits on an empty queue.
+struct HistBatch {
+    f32x4u v[kObsShift];
+    uint32_t pure;   // bit k: unit k of the batch is a pure history unit of this lane
+};
+__device__ __forceinline__ void hist_load(HistBatch& b, const GF_GLOBAL float* __restrict__ prev, int first, int units, int O, int OH, const FastDiv& dr) {
+    b.pure = 0u;
+#pragma unroll
+    for (int k = 0; k < kObsShift; ++k) {
+        const int u = first + k * kObsBlock, uu = u < units ? u : 0;
+        const int e = uu << 2, row = dr.div(e), c = e - row * OH;
+        const bool pure = u < units && c >= O && c + 3 < OH;
+        b.pure |= pure ? 1u << k : 0u;
+        b.v[k] = f32x4u{0.f, 0.f, 0.f, 0.f};
+        if (pure) b.v[k] = *reinterpret_cast<const GF_GLOBAL f32x4u*>(prev + (e - O));
+    }
+}
+__device__ __forceinline__ void hist_store(const HistBatch& b, GF_GLOBAL float* out, int first) {
+#pragma unroll
+    for (int k = 0; k < kObsShift; ++k)
+        if ((b.pure >> k) & 1u) *reinterpret_cast<GF_GLOBAL f32x4a*>(out + ((first + k * kObsBlock) << 2)) = f32x4a{b.v[k].x, b.v[k].y, b.v[k].z, b.v[k].w};
+}
+
+// … and the units the history batches left: every unit with at least one new-frame column (frame from the LDS tile, the
+// history elements it shares a unit with from `prev`), plus the run's last rows·O·H mod 4 floats.
+// `out2` (optional, wave-uniform): a second destination with the same layout — the rollout-storage row of the RL library (§8f-5)
+__device__ __forceinline__ void write_mixed_units(GF_GLOBAL float* __restrict__ out, const GF_GLOBAL float* __restrict__ prev, const float* tile, int S, int rows, int O,
+                                                  int OH, int tid, GF_GLOBAL float* __restrict__ out2 = nullptr) {
+    const int total = rows * OH, units = total >> 2;
+    const int upr = ((O + 3) >> 2) + 1;  // units that can touch one row's frame columns
+    const FastDiv du(upr);
+    auto element = [&](int k, int r) -> float {
+        const int rr = k >= r * OH ? r : r - 1, c = k - rr * OH;   // the unit's leading floats can be the previous row's history
+        return c < O ? tile[rr * S + c] : prev[k - O];
+    };
+    constexpr int kU = 5;  // units per lane whose boundary loads are in flight together
+    for (int i0 = tid; i0 < rows * upr; i0 += kU * kObsBlock) {
+        f32x4a v[kU];
+        int at[kU];
+#pragma unroll
+        for (int b = 0; b < kU; ++b) {
+            const int i = i0 + b * kObsBlock;
+            const int ii = i < rows * upr ? i : i0, r = du.div(ii), j = ii - r * upr;
+            const int u = ((r * OH) >> 2) + j;
+            // two frames are O·(H-1) >= 4 floats apart: a unit touches one frame at most, so each is written once
+            const bool on = i < rows * upr && u <= ((r * OH + O - 1) >> 2) && u < units;
+            at[b] = on ? u << 2 : -1;
+            v[b] = f32x4a{0.f, 0.f, 0.f, 0.f};
+            if (on) v[b] = f32x4a{element(u << 2, r), element((u << 2) + 1, r), element((u << 2) + 2, r), element((u << 2) + 3, r)};
+        }
+#pragma unroll
+        for (int b = 0; b < kU; ++b)
+            if (at[b] >= 0) *reinterpret_cast<GF_GLOBAL f32x4a*>(out + at[b]) = v[b];
+        if (out2) {
+#pragma unroll
+            for (int b = 0; b < kU; ++b)
+                if (at[b] >= 0) *reinterpret_cast<GF_GLOBAL f32x4a*>(out2 + at[b]) = v[b];
+        }
+    }
+    const int tail = total & 3;
+    if (tid < tail) {
+        const int k = (units << 2) + tid, r = rows - 1, c = k - r * OH;
+        const float v = c < O ? tile[r * S + c] : prev[k - O];
+        out[k] = v;
+        if (out2) out2[k] = v;
+    }
+}
+
+}  // namespace gf

@@ -21,6 +21,7 @@
 //     the gather are waited for, so that wait is spent with history traffic in flight.
 // Algorithmic traffic (Go2 command config, O=48, H=1): R 196 + W 192 = 388 B/env.
 #include "gf_launch.h"
+#include "gf_obs_hist.h"
 
 namespace gf {
 
@@ -28,19 +29,8 @@ enum : uint32_t { ON_QUAT = 1, ON_LIN = 2, ON_ANG = 4 };
 
 // Four waves share a 64-env tile: wave 0 computes the per-env (body-frame) items, all 256 lanes gather the [N,w] items into
 // the LDS tile, write it out and shift the history.
-constexpr int kObsBlock = 256;
 #define GF_OBS_INLINE __attribute__((always_inline))
 constexpr int kObsGather = 12;  // tile elements per lane whose loads are in flight together
-constexpr int kObsShift = 8;    // history units per lane in flight together
-
-// floor(i / d) by multiply-shift with m = ceil(2^40 / d): exact for i < 2^40 / d (here i < 64·d and d < 2^17) — an element index
-// becomes (row, column) once per element, and d (a frame or history width) is a run-time value
-struct FastDiv {
-    uint64_t m;
-    uint32_t d;
-    __device__ __forceinline__ explicit FastDiv(int div) : m(div > 1 ? ((1ull << 40) + (uint64_t)div - 1ull) / (uint64_t)div : 0ull), d((uint32_t)div) {}
-    __device__ __forceinline__ int div(int i) const { return d > 1 ? (int)(((uint64_t)(uint32_t)i * m) >> 40) : i; }
-};
 
 // Where a frame's columns come from.  The item table is resolved ONCE per workgroup, lane-parallel: lane i reads item i
 // straight from the kernel-argument segment (a vector load: no serial walk of scalar loads), lane c then finds the item that
@@ -64,74 +54,6 @@ __device__ __forceinline__ float finish(const GfObservationArgs& a, const float 
         v = v + uniform_range(u, -1.0f, 1.0f) * noise;
     }
     return v;
-}
-
-typedef float f32x4a __attribute__((ext_vector_type(4)));               // 16-byte aligned
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword aligned: one global_load_dwordx4 all the same
-
-// History shift.  The [rows, O·H] block of a tile is one contiguous run of floats in `out` and in `prev`, and
-// out[k] = prev[k - O] wherever column (k mod O·H) >= O.  Cut the run into 16-byte units aligned on `out`: a unit that lies
-// entirely in history columns is one (dword-aligned) 16-byte load and one aligned 16-byte store, whatever O is — rows of an
-// odd-width frame are not 16-byte aligned, the run is.  Units that touch a new-frame column wait for the LDS tile
-// (write_mixed_units).  A batch = kObsShift units per lane, loads first, stores later: the caller puts other work between
-// the two so the lane never sits on an empty queue.
-struct HistBatch {
-    f32x4u v[kObsShift];
-    uint32_t pure;   // bit k: unit k of the batch is a pure history unit of this lane
-};
-__device__ __forceinline__ void hist_load(HistBatch& b, const float* __restrict__ prev, int first, int units, int O, int OH, const FastDiv& dr) {
-    b.pure = 0u;
-#pragma unroll
-    for (int k = 0; k < kObsShift; ++k) {
-        const int u = first + k * kObsBlock, uu = u < units ? u : 0;
-        const int e = uu << 2, row = dr.div(e), c = e - row * OH;
-        const bool pure = u < units && c >= O && c + 3 < OH;
-        b.pure |= pure ? 1u << k : 0u;
-        b.v[k] = f32x4u{0.f, 0.f, 0.f, 0.f};
-        if (pure) b.v[k] = *reinterpret_cast<const f32x4u*>(prev + (e - O));
-    }
-}
-__device__ __forceinline__ void hist_store(const HistBatch& b, float* __restrict__ out, int first) {
-#pragma unroll
-    for (int k = 0; k < kObsShift; ++k)
-        if ((b.pure >> k) & 1u) *reinterpret_cast<f32x4a*>(out + ((first + k * kObsBlock) << 2)) = f32x4a{b.v[k].x, b.v[k].y, b.v[k].z, b.v[k].w};
-}
-
-// … and the units the history batches left: every unit with at least one new-frame column (frame from the LDS tile, the
-// history elements it shares a unit with from `prev`), plus the run's last rows·O·H mod 4 floats.
-__device__ __forceinline__ void write_mixed_units(float* __restrict__ out, const float* __restrict__ prev, const float* tile, int S, int rows, int O,
-                                                  int OH, int tid) {
-    const int total = rows * OH, units = total >> 2;
-    const int upr = ((O + 3) >> 2) + 1;  // units that can touch one row's frame columns
-    const FastDiv du(upr);
-    auto element = [&](int k, int r) -> float {
-        const int rr = k >= r * OH ? r : r - 1, c = k - rr * OH;   // the unit's leading floats can be the previous row's history
-        return c < O ? tile[rr * S + c] : prev[k - O];
-    };
-    constexpr int kU = 5;  // units per lane whose boundary loads are in flight together
-    for (int i0 = tid; i0 < rows * upr; i0 += kU * kObsBlock) {
-        f32x4a v[kU];
-        int at[kU];
-#pragma unroll
-        for (int b = 0; b < kU; ++b) {
-            const int i = i0 + b * kObsBlock;
-            const int ii = i < rows * upr ? i : i0, r = du.div(ii), j = ii - r * upr;
-            const int u = ((r * OH) >> 2) + j;
-            // two frames are O·(H-1) >= 4 floats apart: a unit touches one frame at most, so each is written once
-            const bool on = i < rows * upr && u <= ((r * OH + O - 1) >> 2) && u < units;
-            at[b] = on ? u << 2 : -1;
-            v[b] = f32x4a{0.f, 0.f, 0.f, 0.f};
-            if (on) v[b] = f32x4a{element(u << 2, r), element((u << 2) + 1, r), element((u << 2) + 2, r), element((u << 2) + 3, r)};
-        }
-#pragma unroll
-        for (int b = 0; b < kU; ++b)
-            if (at[b] >= 0) *reinterpret_cast<f32x4a*>(out + at[b]) = v[b];
-    }
-    const int tail = total & 3;
-    if (tid < tail) {
-        const int k = (units << 2) + tid, r = rows - 1, c = k - r * OH;
-        out[k] = c < O ? tile[r * S + c] : prev[k - O];
-    }
 }
 
 // V = floats per memory operation of the frame write-out and the history shift: 4 when O % 4 == 0, 2 when O is even, else 1.
@@ -162,8 +84,8 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
     const V3 lin{lp[0], lp[1], lp[2]}, ang{ap[0], ap[1], ap[2]};
 
     const int64_t OH = (int64_t)O * H;
-    float* out = a.obs + n0 * OH;
-    const float* prev = H > 1 ? a.prev_obs + n0 * OH : nullptr;
+    GF_GLOBAL float* out = G(a.obs) + n0 * OH;
+    const GF_GLOBAL float* prev = H > 1 ? G(a.prev_obs) + n0 * OH : nullptr;
     // 16-byte units over the tile's contiguous run (see HistBatch); otherwise (a frame narrower than 4, an output that is not
     // 16-byte aligned) element by element
     const bool flat = H > 1 && O >= 4 && (reinterpret_cast<uintptr_t>(a.obs) & 15u) == 0;
@@ -307,7 +229,7 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
         for (int i = tid; i < rows * o4; i += kObsBlock) {
             const int row = d4.div(i), c4 = i - row * o4;
             const float* r = tile + row * S + c4 * 4;
-            reinterpret_cast<float4*>(out + row * OH)[c4] = make_float4(r[0], r[1], r[2], r[3]);
+            reinterpret_cast<GF_GLOBAL f32x4a*>(out + row * OH)[c4] = f32x4a{r[0], r[1], r[2], r[3]};
         }
     } else if (V == 2) {
         const int o2 = O >> 1;
@@ -315,7 +237,7 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
         for (int i = tid; i < rows * o2; i += kObsBlock) {
             const int row = d2.div(i), c2 = i - row * o2;
             const float* r = tile + row * S + c2 * 2;
-            reinterpret_cast<float2*>(out + row * OH)[c2] = make_float2(r[0], r[1]);
+            reinterpret_cast<GF_GLOBAL f32x2a*>(out + row * OH)[c2] = f32x2a{r[0], r[1]};
         }
     } else {
         const FastDiv d1(O);

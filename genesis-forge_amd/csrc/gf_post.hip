@@ -499,6 +499,7 @@ struct Packer {
         for (int k = 0; k < n_contact; ++k)
             if (a.contact[k].contacts == v.contacts) {
                 if (!a.contact[k].link_vel) a.contact[k].link_vel = v.link_vel;
+                if (!a.contact[k].link_pos) a.contact[k].link_pos = v.link_pos;
                 return k;
             }
         if (n_contact >= GF_MAX_CONTACT_VIEWS) return -1;
@@ -511,6 +512,12 @@ struct Packer {
         if (n_view >= GF_MAX_COMMAND_VIEWS) return -1;
         a.command[n_view] = v;
         a.cmd_of_view[n_view] = -1;
+        if (a.n_gait && v.command == a.gait.state) {
+            // a view of the gait manager's state rows (observation(): 14 columns of the 16-float row): travels through LDS
+            if (v.stride != GF_GAIT_ROW || v.width > GF_GAIT_ROW) return -1;
+            a.cmd_of_view[n_view] = kViewGait;
+            return n_view++;
+        }
         for (int c = 0; c < a.n_cmd; ++c)
             if (a.cmds[c].command == v.command) {
                 // a fused command manager's own buffer is dense and travels through registers / LDS: a strided alias of it
@@ -589,6 +596,34 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     }
     a.seed = RS.seed; a.env_offset = RS.env_offset; a.stream_reset = RS.stream;
 
+    // the GaitCommandManager (examples/gait_trainer): stepped and reset on wave 0's registers
+    UNSUP(r->num_gait < 0 || r->num_gait > GF_POST_MAX_GAIT);
+    a.n_gait = r->num_gait;
+    if (a.n_gait) {
+        const GfGaitArgs* gs = r->gait_step[0];
+        const GfGaitArgs* gm = r->gait_reset[0];
+        UNSUP(!gs || !gm || gs->mode != GF_CMD_STEP || gm->mode != GF_CMD_MASKED || !gs->state || gs->state != gm->state || !gs->selected || gs->selected != gm->selected);
+        UNSUP(gs->num_envs != N || gm->num_envs != N || gs->draws || gm->draws || gs->resample_steps <= 0 || gs->num_gaits < 1 || gs->num_gaits > GF_MAX_GAITS);
+        UNSUP(gm->mask != T.terminated || gm->mask2 != T.truncated || gs->episode_length != T.episode_length);
+        UNSUP(gs->seed != RS.seed || gm->seed != RS.seed || gs->env_offset != RS.env_offset || gm->env_offset != RS.env_offset);
+        UNSUP(gs->stats && a.stats && gs->stats != a.stats);
+        UNSUP(gs->wave_flags != gm->wave_flags || (gs->wave_flags != nullptr) != (r->gait_flags_next[0] != nullptr) || (gs->wave_flags && gs->wave_flags == r->gait_flags_next[0]));
+        UNSUP(reinterpret_cast<uintptr_t>(gs->state) & 15u);
+        // both descriptors are filled from the same manager state (curriculum values are re-read per launch)
+        UNSUP(gs->num_gaits != gm->num_gaits || gs->fixed_clearance_mask != gm->fixed_clearance_mask || gs->dt != gm->dt || gs->two_pi != gm->two_pi);
+        UNSUP(memcmp(gs->cum_weight, gm->cum_weight, sizeof(gs->cum_weight)) != 0 || memcmp(gs->gait_offsets, gm->gait_offsets, sizeof(gs->gait_offsets)) != 0);
+        UNSUP(gs->clearance_lo != gm->clearance_lo || gs->clearance_hi != gm->clearance_hi || gs->period_lo != gm->period_lo || gs->period_hi != gm->period_hi);
+        PostGait& pg = a.gait;
+        pg.state = gs->state; pg.selected = gs->selected; pg.flags_in = gs->wave_flags; pg.flags_out = r->gait_flags_next[0];
+        pg.stream_step = gs->stream; pg.stream_reset = gm->stream;
+        pg.resample_steps = gs->resample_steps; pg.num_gaits = gs->num_gaits; pg.fixed_clearance_mask = gs->fixed_clearance_mask;
+        memcpy(pg.cum_weight, gs->cum_weight, sizeof(pg.cum_weight));
+        memcpy(pg.gait_offsets, gs->gait_offsets, sizeof(pg.gait_offsets));
+        pg.clearance_lo = gs->clearance_lo; pg.clearance_hi = gs->clearance_hi; pg.period_lo = gs->period_lo; pg.period_hi = gs->period_hi;
+        pg.dt = gs->dt; pg.two_pi = gs->two_pi;
+        needs |= PN_EPLEN;
+    }
+
     // termination terms
     a.num_term = T.num_terms;
     for (int k = 0; k < T.num_terms; ++k) {
@@ -655,6 +690,22 @@ static int pack(const GfPostRefs* r, Packer& pk) {
                 case GF_R_CONTACT_FORCE:
                 case GF_R_FEET_AIR_TIME:
                 case GF_R_FEET_SLIDE: break;
+                case GF_R_GAIT_PHASE:
+                case GF_R_FOOT_HEIGHT: {
+                    // read the feet's contact / velocity / position buffers and the PRE-step gait rows straight from memory
+                    UNSUP(t.i[0] < 0 || t.i[0] >= GF_MAX_CONTACT_VIEWS || !RW->contact[t.i[0]].contacts || !RW->contact[t.i[0]].link_vel);
+                    UNSUP(t.op == GF_R_FOOT_HEIGHT && !RW->contact[t.i[0]].link_pos);
+                    UNSUP(t.i[1] < 0 || t.i[1] >= GF_MAX_COMMAND_VIEWS || !RW->command[t.i[1]].command || RW->command[t.i[1]].stride != GF_GAIT_ROW);
+                    for (int f = 0; f < 4; ++f) UNSUP(((t.i[2] >> (8 * f)) & 0xff) >= RW->contact[t.i[0]].num_links);
+                    const int cs2 = pk.contact_slot(RW->contact[t.i[0]]);
+                    const int vs2 = pk.view_slot(RW->command[t.i[1]]);
+                    UNSUP(cs2 < 0 || vs2 < 0);
+                    t.i[0] = cs2; t.i[1] = vs2;
+                    if (t.op == GF_R_GAIT_PHASE && RW->gait_wave_flags) {
+                        UNSUP(!a.n_gait || RW->gait_wave_flags != a.gait.flags_in);   // the bytes this launch may read are the ones it does not write
+                        a.gait_wave_flags = RW->gait_wave_flags;
+                    }
+                } break;
                 default: return GF_E_UNSUPPORTED;
             }
             if (t.op == GF_R_BASE_HEIGHT && (t.flags & GF_RW_FLAG_CMD)) {
@@ -668,8 +719,8 @@ static int pack(const GfPostRefs* r, Packer& pk) {
                 UNSUP(t.i[cs] >= GF_MAX_COMMAND_VIEWS || !RW->command[t.i[cs]].command);
                 const int s = pk.view_slot(RW->command[t.i[cs]]);
                 UNSUP(s < 0);
-                // terms read view 0 from registers and any other view from memory: a non-zero view must not be resampled this step
-                UNSUP(s != 0 && pk.a.cmd_of_view[s] >= 0);
+                // terms read view 0 from registers and any other view from memory — as it is BEFORE this step's resample: every
+                // command / gait row the launch rewrites is stored behind the barrier the reward wave passes after its fold
                 t.i[cs] = s;
             }
             if (reward_op_has_contact(t.op)) {
@@ -781,7 +832,8 @@ static int pack(const GfPostRefs* r, Packer& pk) {
                 case GF_O_COMMAND: {
                     UNSUP(it.i0 < 0 || it.i0 >= GF_MAX_COMMAND_VIEWS || !ob->command[it.i0].command || it.width != ob->command[it.i0].width);
                     const int s = pk.view_slot(ob->command[it.i0]);
-                    UNSUP(s < 0 || it.width > kPostMaxRanges);
+                    UNSUP(s < 0);
+                    UNSUP(pk.a.cmd_of_view[s] >= 0 && pk.a.cmd_of_view[s] != kViewGait && it.width > kPostMaxRanges);
                     it.i0 = s;
                 } break;
                 case GF_O_ANG_VEL_BODY: needs |= PN_QUAT | PN_ANG; uses_entity = true; break;
@@ -814,6 +866,20 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     }
     UNSUP(omax >= GF_MAX_OBS_WIDTH);
 
+    // rollout-storage rows (§8f-5): second stores of what the launch holds anyway
+    if (const GfRolloutArgs* ro = r->rollout) {
+        UNSUP(ro->num_envs != N);
+        UNSUP((ro->done_out && (ro->terminated != T.terminated || ro->truncated != T.truncated)) || (ro->reward_out && (!RW || ro->reward != RW->reward)));
+        a.roll_reward = ro->reward_out; a.roll_done = ro->done_out;
+        a.roll_obs = nullptr; a.roll_obs_index = -1;
+        if (ro->obs_out) {
+            for (int m = 0; m < a.n_obs; ++m)
+                if (a.obs[m].obs == ro->obs && a.obs[m].width * a.obs[m].history == ro->obs_width) a.roll_obs_index = m;
+            UNSUP(a.roll_obs_index < 0 || (reinterpret_cast<uintptr_t>(ro->obs_out) & 15u));
+            a.roll_obs = ro->obs_out;
+        }
+    }
+
     // everything the kernel dereferences must exist, be float4-aligned and agree on D
     a.num_dofs = D;
     a.needs = needs;
@@ -843,14 +909,14 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_check(cons
     return gf::pack(r, pk);
 }
 
-static size_t lds_ws_floats(int omax) {
-    return (size_t)(gf::X_FIELDS + gf::kPostMaxReward + gf::kPostAuxRows) * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock;
+static size_t lds_ws_floats(int omax, int n_gait) {
+    return (size_t)(gf::x_fields(n_gait) + gf::kPostMaxReward + gf::kPostAuxRows) * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock;
 }
 
 // Static programs in registration order; program id = 1 + index (0 = table interpreter).
 #define GF_POST_PROGRAMS(X)                                                                                                \
     X(1, gf::ProgGo2CommandDirection) X(2, gf::ProgGo2Simple) X(3, gf::ProgGo2Contacts) X(4, gf::ProgGo2RoughTerrain) \
-    X(5, gf::ProgBerkeleyHumanoid)
+    X(5, gf::ProgBerkeleyHumanoid) X(6, gf::ProgGo2GaitTrainer)
 
 static int select_program(const gf::GfPostArgs& a) {
     if (gf::g_options[GF_OPT_POST_VARIANT] < 2) return 0;
@@ -892,17 +958,18 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = gf::env_grid(a.num_envs);
     gf::PhaseScope scope(GF_PHASE_POST, s);
-    if (gf::g_options[GF_OPT_POST_VARIANT] == 0) {
+    const bool ws_only = a.n_gait || a.roll_obs || a.roll_reward || a.roll_done;   // the one-wave variant has neither a gait manager nor rollout stores
+    if (gf::g_options[GF_OPT_POST_VARIANT] == 0 && !ws_only) {
         if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid, gf::kEnvBlock, lds, s, a);
         else GF_LAUNCH(scope, gf::post_kernel<3>, grid, gf::kEnvBlock, lds, s, a);
     } else if (const int prog = select_program(a)) {
-        const size_t lds_st = lds_ws_floats(omax) * sizeof(float);
+        const size_t lds_st = lds_ws_floats(omax, a.n_gait) * sizeof(float);
 #define GF_RUN(id, P) \
         if (prog == id) GF_LAUNCH(scope, gf::post_ws_kernel<P>, grid, gf::kWsBlock, lds_st, s, a);
         GF_POST_PROGRAMS(GF_RUN)
 #undef GF_RUN
     } else {
-        const size_t lds_ws = sizeof(gf::GfPostArgs) + lds_ws_floats(omax) * sizeof(float);
+        const size_t lds_ws = sizeof(gf::GfPostArgs) + lds_ws_floats(omax, a.n_gait) * sizeof(float);
         if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<7>>, grid, gf::kWsBlock, lds_ws, s, a);
         else GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<3>>, grid, gf::kWsBlock, lds_ws, s, a);
     }

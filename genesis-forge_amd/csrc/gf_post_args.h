@@ -49,6 +49,20 @@ struct PostCmd {
     float hi[kPostMaxRanges];
 };
 
+// one GaitCommandManager stepped and reset inside the launch (gf_gait.hip's gait_body, both modes, on wave 0's registers)
+constexpr int kViewGait = GF_POST_MAX_CMD;   // cmd_of_view value: the view aliases the gait manager's state rows
+struct PostGait {
+    float* state;               // [N, GF_GAIT_ROW]
+    int64_t* selected;          // [N]
+    const uint8_t* flags_in;    // swing / stance bytes the previous step left (read by GF_R_GAIT_PHASE for env 0), or NULL
+    uint8_t* flags_out;         // every block's byte for the state this launch leaves (the caller swaps the two), or NULL
+    uint64_t stream_step, stream_reset;
+    int32_t resample_steps, num_gaits, fixed_clearance_mask, _pad;
+    float cum_weight[GF_MAX_GAITS];
+    float gait_offsets[GF_MAX_GAITS][4];
+    float clearance_lo, clearance_hi, period_lo, period_hi, dt, two_pi;
+};
+
 struct PostObs {
     float* obs;
     const float* prev;
@@ -102,7 +116,16 @@ struct alignas(16) GfPostArgs {
     float* air_state[GF_MAX_CONTACT_VIEWS][4];
     int32_t air_links[GF_MAX_CONTACT_VIEWS];
     int32_t n_air;
-    int32_t _pad0;
+    int32_t n_gait;
+    // rollout-storage rows of the RL library (GfRolloutArgs, §8f-5): the observation of manager `roll_obs_index`, the reward and
+    // terminated | truncated are stored a second time, there
+    float* roll_obs;
+    float* roll_reward;
+    uint8_t* roll_done;
+    int32_t roll_obs_index;
+    int32_t _pad1;
+    const uint8_t* gait_wave_flags;   // == gait.flags_in when the reward terms reproduce the env-0 quirk (GF_R_GAIT_PHASE)
+    PostGait gait;
     GfTerm tterms[kPostMaxTerm];
     GfTerm rterms[kPostMaxReward];
     PostCmd cmds[GF_POST_MAX_CMD];
@@ -118,6 +141,8 @@ enum : uint32_t {
     PN_POS = 1, PN_QUAT = 2, PN_LIN = 4, PN_ANG = 8, PN_DOFPOS = 16, PN_DOFVEL = 32, PN_TARGETS = 64, PN_ACTIONS = 128, PN_LAST = 256,
     PN_EPLEN = 512, PN_MAXLEN = 1024, PN_DOFDEV = 2048, PN_ACTRATE = 4096, PN_DOFFORCE = 8192,
 };
+
+template <> struct HasGaitTerms<GfPostArgs> { static constexpr bool value = true; };
 
 // scale / noise of one observation element (observation_manager.py:242-250); everything it needs arrives by value
 struct ObsFin {

@@ -37,6 +37,7 @@ struct ProgGo2CommandDirection {
                                                                       {GF_O_ACTIONS, 12, 0, false, false}},
                                                                      {}};
     static constexpr int n_air = 0;
+    static constexpr int n_gait = 0;
 };
 
 
@@ -64,6 +65,7 @@ struct ProgGo2Simple {
                                                                       {GF_O_ACTIONS, 12, 0, false, false}},
                                                                      {}};
     static constexpr int n_air = 0;
+    static constexpr int n_gait = 0;
 };
 
 // examples/contacts (Go2): feet_air_time on the calves (one air-time ContactManager), flat orientation
@@ -91,6 +93,7 @@ struct ProgGo2Contacts {
                                                                       {GF_O_ACTIONS, 12, 0, false, false}},
                                                                      {}};
     static constexpr int n_air = 1;
+    static constexpr int n_gait = 0;
 };
 
 // examples/rough_terrain (Go2, BASELINE config 3): out_of_bounds, undesired contacts, terminated penalty, terrain spawn on reset
@@ -119,6 +122,7 @@ struct ProgGo2RoughTerrain {
                                                                       {GF_O_ACTIONS, 12, 0, false, false}},
                                                                      {}};
     static constexpr int n_air = 1;
+    static constexpr int n_gait = 0;
 };
 
 // examples/berkeley_humanoid (12 actuated joints, BASELINE config 4): torso contact termination, clamped feet_air_time
@@ -146,12 +150,46 @@ struct ProgBerkeleyHumanoid {
                                                                       {GF_O_ACTIONS, 12, 0, false, false}},
                                                                      {}};
     static constexpr int n_air = 1;
+    static constexpr int n_gait = 0;
+};
+
+// examples/gait_trainer (Go2, BASELINE config 5): velocity + gait command managers (the gait manager stepped / reset in the
+// launch, its state row exchanged through LDS), the gait manager's two reward terms on the feet's contact / velocity / position
+// buffers, body acceleration, three contact managers, policy (62 x 5) and critic (16 x 5) observations with history
+struct ProgGo2GaitTrainer {
+    static constexpr bool kStatic = true;
+    static constexpr const char* name = "go2_gait_trainer";
+    static constexpr int DV = 3;
+    static constexpr int n_term = 3;
+    static constexpr TermSig term[n_term] = {{GF_T_TIMEOUT, GF_TERM_FLAG_TIME_OUT}, {GF_T_BAD_ORIENTATION, 0}, {GF_T_CONTACT_FORCE, 0}};
+    static constexpr int n_rew = 9;
+    static constexpr RewSig rew[n_rew] = {{GF_R_GAIT_PHASE, 0, 1, 0}, {GF_R_FOOT_HEIGHT, 0, 1, 0}, {GF_R_BASE_HEIGHT, 0, 0, 0}, {GF_R_CMD_TRACK_LIN_VEL, 0, 1, 0},
+                                          {GF_R_CMD_TRACK_ANG_VEL, 0, 1, 2}, {GF_R_BODY_ACCEL_EXP, 0, 0, 0}, {GF_R_LIN_VEL_Z_L2, 0, 0, 0}, {GF_R_ACTION_RATE_L2, 0, 0, 0},
+                                          {GF_R_CONTACT_FORCE, 0, 2, 0}};
+    static constexpr int n_cmd = 1;
+    static constexpr int cmd_width[GF_POST_MAX_CMD] = {3, 0};
+    static constexpr int n_obs = 2;
+    static constexpr int obs_width[GF_POST_MAX_OBS] = {62, 16};
+    static constexpr int obs_history[GF_POST_MAX_OBS] = {5, 5};
+    static constexpr int obs_items[GF_POST_MAX_OBS] = {8, 2};
+    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {{{GF_O_COMMAND, 14, 0, false, false},
+                                                                      {GF_O_COMMAND, 3, 1, false, false},
+                                                                      {GF_O_ANG_VEL_BODY, 3, 0, false, false},
+                                                                      {GF_O_LIN_VEL_BODY, 3, 0, false, false},
+                                                                      {GF_O_PROJ_GRAVITY, 3, 0, false, false},
+                                                                      {GF_O_DOF_POS, 12, 0, false, false},
+                                                                      {GF_O_DOF_VEL, 12, 0, true, false},
+                                                                      {GF_O_ACTIONS, 12, 0, false, false}},
+                                                                     {{GF_O_CONTACT_FORCE_NORM, 4, 1, false, false}, {GF_O_DOF_FORCE, 12, 0, true, false}}};
+    static constexpr int n_air = 0;
+    static constexpr int n_gait = 1;
 };
 
 // ---- matching -------------------------------------------------------------------------------------------------------------------
 template <class P>
 bool program_matches(const GfPostArgs& a) {
-    if (a.num_dofs != 4 * P::DV || a.num_term != P::n_term || a.num_rew != P::n_rew || a.n_cmd != P::n_cmd || a.n_obs != P::n_obs || a.n_air != P::n_air)
+    if (a.num_dofs != 4 * P::DV || a.num_term != P::n_term || a.num_rew != P::n_rew || a.n_cmd != P::n_cmd || a.n_obs != P::n_obs || a.n_air != P::n_air ||
+        a.n_gait != P::n_gait)
         return false;
     for (int k = 0; k < P::n_term; ++k)
         if (a.tterms[k].op != P::term[k].op || a.tterms[k].flags != P::term[k].flags) return false;
@@ -197,7 +235,7 @@ inline int describe_program(const GfPostArgs& a, char* buf, int cap) {
         }
         put("%s", "};");
     }
-    put(" n_air = %d", a.n_air);
+    put(" n_air = %d; n_gait = %d", a.n_air, a.n_gait);
     return n;
 }
 

@@ -26,12 +26,16 @@
 
 #include <utility>
 
+#include "gf_obs_hist.h"
 #include "gf_post_args.h"
 
 namespace gf {
 
+static_assert(kObsBlock == 4 * kEnvBlock, "the history helpers assume the 4-wave workgroup");
 constexpr int kWsBlock = 4 * kEnvBlock;
-enum : int { X_TERM = 0, X_TRUNC = 1, X_DONE = 2, X_BLIN = 3, X_BANG = 6, X_GRAV = 9, X_CMD = 12, X_DIRTY = 20, X_FIELDS = 21 };
+enum : int { X_TERM = 0, X_TRUNC = 1, X_DONE = 2, X_BLIN = 3, X_BANG = 6, X_GRAV = 9, X_CMD = 12, X_DIRTY = 20, X_FIELDS = 21,
+             X_GAIT = X_FIELDS /* the gait manager's post-step, post-reset state row: only laid out when the launch carries one */ };
+__host__ __device__ constexpr int x_fields(int n_gait) { return X_FIELDS + (n_gait > 0 ? GF_GAIT_ROW : 0); }
 
 // ---- signature rows of a static program ---------------------------------------------------------------------------------------
 struct TermSig { int op, flags; };
@@ -80,8 +84,11 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     }
     const GfPostArgs& a = pick_args<P>(karg, lds);
     GF_WSTAMP(1);
-    float* xch = lds + kArgVec * 4;                          // [X_FIELDS][64]
-    float* lds_sums = xch + X_FIELDS * kEnvBlock;            // [kPostMaxReward][64]
+    bool has_gait = false;
+    if constexpr (P::kStatic) has_gait = P::n_gait > 0;
+    else has_gait = UNI(a.n_gait) > 0;
+    float* xch = lds + kArgVec * 4;                          // [x_fields][64]
+    float* lds_sums = xch + x_fields(has_gait ? 1 : 0) * kEnvBlock;   // [kPostMaxReward][64]
     float* lds_aux = lds_sums + kPostMaxReward * kEnvBlock;  // [kPostAuxRows][64]
     float* tile = lds_aux + kPostAuxRows * kEnvBlock;        // [64][O+1]
 
@@ -126,6 +133,9 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     int ep_len = 0, term = 0, trunc = 0;                // wave 0
     float cmd[GF_POST_MAX_CMD][kPostMaxRanges] = {};    // wave 0
     bool cmd_dirty[GF_POST_MAX_CMD] = {false, false};   // wave 0
+    float grow[GF_GAIT_ROW] = {};                       // wave 0: the gait manager's state row, stored after the last barrier
+    int gait_sel = 0;                                   // wave 0
+    bool gait_resampled = false;                        // wave 0
     float dof_dev = 0.f, act_rate = 0.f, secs_in = 0.f; // wave 1
     float cmd0[3] = {0.f, 0.f, 0.f};                    // wave 1
     float4 r_a[R], r_b[R], r_c[R];                      // wave 1: dof_pos/actions/last; wave 2: dof_pos/dof_vel/default; wave 3: targets/actions
@@ -149,6 +159,13 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             const GF_GLOBAL float* cp = gsel(on, on ? UNI(a.cmds[c].command) : nullptr, e * w);
 #pragma unroll
             for (int j = 0; j < kPostMaxRanges; ++j) cmd[c][j] = cp[(uint32_t)j < w ? j : 0];
+        }
+        if (has_gait) {   // the gait state row: 4 x dwordx4, one wave = 4 KiB contiguous
+            const GF_GLOBAL float* gp = G(UNI(a.gait.state)) + (int64_t)e * GF_GAIT_ROW;
+            const float4 g0 = ldg4(gp), g1 = ldg4(gp + 4), g2 = ldg4(gp + 8), g3 = ldg4(gp + 12);
+            grow[0] = g0.x; grow[1] = g0.y; grow[2] = g0.z; grow[3] = g0.w; grow[4] = g1.x; grow[5] = g1.y; grow[6] = g1.z; grow[7] = g1.w;
+            grow[8] = g2.x; grow[9] = g2.y; grow[10] = g2.z; grow[11] = g2.w; grow[12] = g3.x; grow[13] = g3.y; grow[14] = g3.z; grow[15] = g3.w;
+            gait_sel = (int)G(UNI(a.gait.selected))[e];
         }
         // ---- body-frame vectors, termination -----------------------------------------------------------------------------
         const V3 blin = rot_inv(q, lin), bang = rot_inv(q, ang), grav = rot_inv(q, V3{0.f, 0.f, -1.f});
@@ -208,6 +225,70 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                     cmd_dirty[c] = true;
                 }
             }
+        }
+        // ---- GaitCommandManager.step, then .reset for done envs (gf_gait.hip: gait_body in both modes), on registers ------------
+        if (has_gait) {
+            const PostGait& gg = a.gait;
+            const float two_pi = UNI(gg.two_pi), g_dt = UNI(gg.dt);
+            const int num_gaits = UNI(gg.num_gaits), fixed_mask = UNI(gg.fixed_clearance_mask);
+            auto resample = [&](const uint64_t stream) GF_INLINE_LAMBDA {   // resample_command -> _set_gait (:185-211, 347-377)
+                const float4 u = draw_unit4(seed, stream, genv, 0u);
+                int g = 0;
+#pragma unroll
+                for (int k = 0; k + 1 < GF_MAX_GAITS; ++k) g += (k + 1 < num_gaits && u.x >= gg.cum_weight[k]) ? 1 : 0;
+                gait_sel = g;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    float o = gg.gait_offsets[0][f];
+#pragma unroll
+                    for (int k = 1; k < GF_MAX_GAITS; ++k) o = g == k ? gg.gait_offsets[k][f] : o;
+                    grow[GF_GAIT_OFFSET + f] = o;
+                }
+                grow[GF_GAIT_HEIGHT] = ((fixed_mask >> g) & 1) ? gg.clearance_lo : uniform_range(u.y, gg.clearance_lo, gg.clearance_hi);
+                grow[GF_GAIT_PERIOD] = uniform_range(u.z, gg.period_lo, gg.period_hi);
+                gait_resampled = true;
+            };
+            if (live && (ep_len % UNI(gg.resample_steps)) == 0) resample(gg.stream_step);
+            if (shard) {   // _log_metrics (:430-441): envs per gait, after this step's resample
+#pragma unroll
+                for (int g = 0; g < GF_MAX_GAITS; ++g) {
+                    const unsigned long long b = __ballot(live && gait_sel == g);
+                    if (b && lane == 0) atomicAdd(&shard->gait_count[g], popc64(b));
+                }
+            }
+            {   // the periodic clock (:231-239), for every env
+                const float period = grow[GF_GAIT_PERIOD];
+                const float gtime = torch_remainder(grow[GF_GAIT_TIME] + g_dt, period);
+                const float phase = gtime / period;
+                grow[GF_GAIT_TIME] = gtime;
+                grow[GF_GAIT_PHASE] = phase;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const float fp = torch_remainder(phase + grow[GF_GAIT_OFFSET + f], 1.0f);
+                    sincos_det(two_pi * fp, &grow[GF_GAIT_CLOCK + f], &grow[GF_GAIT_CLOCK + 4 + f]);
+                }
+            }
+            if (done0) {   // reset (:241-255): resample, zero the clock
+                resample(gg.stream_reset);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) grow[GF_GAIT_CLOCK + j] = 0.0f;
+                grow[GF_GAIT_TIME] = 0.0f;
+                grow[GF_GAIT_PHASE] = 0.0f;
+            }
+            uint8_t* const fout = UNI(gg.flags_out);
+            if (fout) {   // this block's "any env in swing / stance" byte for the state the launch leaves — into the OTHER buffer
+                const float pi = 0.5f * two_pi;
+                uint32_t byte = 0;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int fl = gait_foot_flags(grow[GF_GAIT_PHASE], grow[GF_GAIT_OFFSET + f], two_pi, pi);
+                    if (__ballot(live && (fl & 1))) byte |= 1u << (2 * f);
+                    if (__ballot(live && (fl & 2))) byte |= 2u << (2 * f);
+                }
+                if (lane == 0) G(fout)[blockIdx.x] = (uint8_t)byte;
+            }
+#pragma unroll
+            for (int j = 0; j < GF_GAIT_ROW; ++j) xch[(X_GAIT + j) * kEnvBlock + lane] = grow[j];
         }
         // ---- publish ---------------------------------------------------------------------------------------------------------
         xch[X_TERM * kEnvBlock + lane] = (float)term;
@@ -297,6 +378,8 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         if (live) {
             G(UNI(a.terminated))[n_raw] = (uint8_t)term;
             G(UNI(a.truncated))[n_raw] = (uint8_t)trunc;
+            uint8_t* const rd = UNI(a.roll_done);
+            if (rd) G(rd)[n_raw] = (uint8_t)((term | trunc) != 0);   // dones[t] of the rollout storage
         }
         if (shard && done_mask && lane == 0) atomicAdd(&shard->reset_count, popc64(done_mask));
         if (done) {
@@ -389,6 +472,8 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             if (live) {
                 G(k_reward)[n_raw] = buf;
                 G(UNI(a.episode_seconds))[n_raw] = done ? 1e-10f : secs_new;
+                float* const rr_out = UNI(a.roll_reward);
+                if (rr_out) G(rr_out)[n_raw] = buf;   // rewards[t] of the rollout storage
             }
             if (done && logging)
                 for (int row = 0; row < a.reward_rows; ++row)
@@ -465,7 +550,11 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                         case GF_O_RAW_ACTIONS: put_row<DV>(f, r_b, row, col); break;
                         case GF_O_COMMAND: {
                             const int owner = a.cmd_of_view[it.i0];
-                            if (owner >= 0) {
+                            if (owner == kViewGait) {   // the gait manager's post-step, post-reset row (observation(): columns 0..13)
+#pragma unroll
+                                for (int j = 0; j < GF_GAIT_ROW; ++j)
+                                    if (j < it_w) row[col + j] = obs_finish(f, xch[(X_GAIT + j) * kEnvBlock + lane], col + j);
+                            } else if (owner >= 0) {
 #pragma unroll
                                 for (int j = 0; j < kPostMaxRanges; ++j)
                                     if (j < it_w) row[col + j] = obs_finish(f, xch[(X_CMD + owner * kPostMaxRanges + j) * kEnvBlock + lane], col + j);
@@ -517,14 +606,31 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             const int rows = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
             const int64_t OH = (int64_t)O * H;
             GF_GLOBAL float* out = G(ob_out) + n0 * OH;
+            float* const roll_base = UNI(a.roll_obs);
+            GF_GLOBAL float* roll = (roll_base && UNI(a.roll_obs_index) == m) ? G(roll_base) + n0 * OH : nullptr;   // observations[t+1] of the rollout storage
             const int t = threadIdx.x;
-            if ((O & 3) == 0) {
+            // history (H > 1): 16-byte units over the tile's contiguous [rows, O·H] run, whatever O is (gf_obs_hist.h) — the
+            // gait task's 62-wide policy frame has no 16-byte aligned rows, the run has
+            const bool flat = H > 1 && O >= 4 && (reinterpret_cast<uintptr_t>(ob_out) & 15u) == 0;
+            if (flat) {
+                const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
+                const int units = (rows * (int)OH) >> 2;
+                const FastDiv dr((int)OH);
+                HistBatch hb;
+                for (int first = t; first - t < units; first += kObsShift * kObsBlock) {   // wave-uniform trip count
+                    hist_load(hb, prev, first, units, O, (int)OH, dr);
+                    hist_store(hb, out, first);
+                    if (roll) hist_store(hb, roll, first);
+                }
+                write_mixed_units(out, prev, tile, S, rows, O, (int)OH, t, roll);
+            } else if ((O & 3) == 0) {
                 const int o4 = O >> 2;
                 const int qstep = kWsBlock / o4, rstep = kWsBlock - qstep * o4;
                 int rw = t / o4, c4 = t - rw * o4;
                 for (int i = t; i < rows * o4; i += kWsBlock) {
                     const float* r = tile + rw * S + c4 * 4;
                     reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OH)[c4] = f32x4{r[0], r[1], r[2], r[3]};
+                    if (roll) reinterpret_cast<GF_GLOBAL f32x4*>(roll + rw * OH)[c4] = f32x4{r[0], r[1], r[2], r[3]};
                     rw += qstep; c4 += rstep;
                     if (c4 >= o4) { c4 -= o4; ++rw; }
                 }
@@ -533,20 +639,25 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                     const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
                     for (int i = t; i < rows * h4; i += kWsBlock) {
                         const int rw2 = i / h4, j = i - rw2 * h4;
-                        reinterpret_cast<GF_GLOBAL f32x4*>(out + rw2 * OH + O)[j] = reinterpret_cast<const GF_GLOBAL f32x4*>(prev + rw2 * OH)[j];
+                        const f32x4 hv = reinterpret_cast<const GF_GLOBAL f32x4*>(prev + rw2 * OH)[j];
+                        reinterpret_cast<GF_GLOBAL f32x4*>(out + rw2 * OH + O)[j] = hv;
+                        if (roll) reinterpret_cast<GF_GLOBAL f32x4*>(roll + rw2 * OH + O)[j] = hv;
                     }
                 }
             } else {
                 for (int i = t; i < rows * O; i += kWsBlock) {
                     const int rw = i / O, cc = i - rw * O;
                     out[rw * OH + cc] = tile[rw * S + cc];
+                    if (roll) roll[rw * OH + cc] = tile[rw * S + cc];
                 }
                 if (H > 1) {
                     const int hw = O * (H - 1);
                     const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
                     for (int i = t; i < rows * hw; i += kWsBlock) {
                         const int rw = i / hw, j = i - rw * hw;
-                        out[rw * OH + O + j] = prev[rw * OH + j];
+                        const float hv = prev[rw * OH + j];
+                        out[rw * OH + O + j] = hv;
+                        if (roll) roll[rw * OH + O + j] = hv;
                     }
                 }
             }
@@ -595,6 +706,14 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 for (int j = 0; j < kPostMaxRanges; ++j)
                     if (j < cm.width) crow[j] = xch[(X_CMD + c * kPostMaxRanges + j) * kEnvBlock + lane];
             }
+        }
+        if (has_gait && live) {   // the reward wave read the PRE-step row straight from memory (gait_phase / foot_height terms)
+            GF_GLOBAL f32x4* grw = reinterpret_cast<GF_GLOBAL f32x4*>(G(UNI(a.gait.state)) + n * GF_GAIT_ROW);
+            grw[0] = f32x4{grow[0], grow[1], grow[2], grow[3]};
+            grw[1] = f32x4{grow[4], grow[5], grow[6], grow[7]};
+            grw[2] = f32x4{grow[8], grow[9], grow[10], grow[11]};
+            grw[3] = f32x4{grow[12], grow[13], grow[14], grow[15]};
+            if (gait_resampled) G(UNI(a.gait.selected))[n] = (int64_t)gait_sel;
         }
         if (done) {
             const int n_air = UNI(a.n_air);

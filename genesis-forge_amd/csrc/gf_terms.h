@@ -66,7 +66,7 @@ struct RewardRegs {
     bool live;
 };
 
-// the gait opcodes exist only behind descriptors that can carry them (the fused post-physics kernel never sees one)
+// the gait opcodes exist only behind descriptors that can carry them (GfRewardArgs here, GfPostArgs in gf_post_args.h)
 template <class Args> struct HasGaitTerms { static constexpr bool value = false; };
 template <> struct HasGaitTerms<GfRewardArgs> { static constexpr bool value = true; };
 

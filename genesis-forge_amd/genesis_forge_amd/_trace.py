@@ -73,7 +73,10 @@ class StepTrace:
         k = 0
         self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_CLEAR, stats.ptr
         k += 1
+        self._gait_swaps: list = []
         self.post_refs = self._fuse_post(calls) if env.fuse_post_physics else None
+        if self.post_refs is None:
+            self._gait_swaps = []
         first_post = self._post_start(calls) if self.post_refs is not None else len(calls)
         for idx, (fn, args, owner) in enumerate(calls):
             if idx < first_post:
@@ -90,6 +93,7 @@ class StepTrace:
             if pre is not None:
                 assert idx < first_post, "a phase with Python-level terms cannot be part of the fused launch"
                 self.splits.append((self._cur_op, pre))
+        self.patches.extend(self._gait_swaps)   # after the gait managers' own patches (those refill the descriptors)
         # single process: statistics go to a device ring slot per step (no memset, no copy); with a process group the
         # per-step all-reduce path is kept (clear op here, packed + reduced + copied by StepStats.snapshot)
         self.use_ring = stats.group is None
@@ -172,27 +176,52 @@ class StepTrace:
         if j < len(fns) and fns[j] == "reward_step":
             refs.reward = C.addressof(tail[j][1])
             j += 1
-        steps = []
-        while j < len(fns) and fns[j] == "command_step" and tail[j][1].mode == nat.GF_CMD_STEP:
-            steps.append(tail[j])
+        steps, gsteps = [], []
+        while j < len(fns) and fns[j] in ("command_step", "gait_step") and tail[j][1].mode == nat.GF_CMD_STEP:
+            (steps if fns[j] == "command_step" else gsteps).append(tail[j])
             j += 1
         if j >= len(fns) or fns[j] != "masked_reset":
             return None
         refs.reset = C.addressof(tail[j][1])
+        reward_args = tail[1][1] if refs.reward else None
         j += 1
-        resets = []
-        while j < len(fns) and fns[j] == "command_step" and tail[j][1].mode == nat.GF_CMD_MASKED:
-            resets.append(tail[j])
+        resets, gresets = [], []
+        while j < len(fns) and fns[j] in ("command_step", "gait_step") and tail[j][1].mode == nat.GF_CMD_MASKED:
+            (resets if fns[j] == "command_step" else gresets).append(tail[j])
             j += 1
         obs = []
         while j < len(fns) and fns[j] == "observe":
             obs.append(tail[j])
             j += 1
+        if j < len(fns) and fns[j] == "rollout_write":   # learner.RolloutStorage: its rows are stored by the same launch
+            refs.rollout = C.addressof(tail[j][1])
+            j += 1
         if j != len(fns) or len(steps) != len(resets) or len(steps) > nat.GF_POST_MAX_CMD or len(obs) > nat.GF_POST_MAX_OBS:
             return None
-        for s, r in zip(steps, resets):
+        if len(gsteps) != len(gresets) or len(gsteps) > nat.GF_POST_MAX_GAIT:
+            return None
+        for s, r in zip(steps + gsteps, resets + gresets):
             if s[2] is not r[2]:
                 return None
+        refs.num_gait = len(gsteps)
+        self._gait_swaps = []
+        for g, (s, r) in enumerate(zip(gsteps, gresets)):
+            refs.gait_step[g] = C.addressof(s[1])
+            refs.gait_reset[g] = C.addressof(r[1])
+            mgr = s[2]
+            refs.gait_flags_next[g] = mgr._wave_flags_next.data_ptr()
+
+            # One launch reads the swing / stance bytes the previous step left and writes the bytes of the state it leaves into
+            # the manager's OTHER buffer (GfPostRefs): point the descriptors at the two buffers, then swap the manager's view
+            def swap(_actions, mgr=mgr, g=g, sa=s[1], ra=r[1], rw=reward_args, refs=refs):
+                cur, nxt = mgr._wave_flags, mgr._wave_flags_next
+                sa.wave_flags = ra.wave_flags = cur.data_ptr()
+                if rw is not None and rw.gait_wave_flags:
+                    rw.gait_wave_flags = cur.data_ptr()
+                refs.gait_flags_next[g] = nxt.data_ptr()
+                mgr._wave_flags, mgr._wave_flags_next = nxt, cur
+
+            self._gait_swaps.append(swap)
         refs.num_command, refs.num_observe = len(steps), len(obs)
         for c, (s, r) in enumerate(zip(steps, resets)):
             refs.command_step[c] = C.addressof(s[1])
@@ -235,6 +264,9 @@ class StepTrace:
             self.afters.append((self._cur_op, owner._trace_after))
         elif fn == "contact_step":
             pass
+        elif fn == "rollout_write":
+            pol = next(m for m in env.managers["observation"] if m.name == owner.obs_name)
+            self.patches.append(owner._trace_patch(args, pol._args))
         else:
             raise RuntimeError(f"untraceable phase {fn}")
 
@@ -299,6 +331,11 @@ class StepTrace:
             try:
                 env._reset_done(tm._terminated_buf, tm._truncated_buf)
                 obs_tail = env.get_observations()
+                ro = getattr(env, "_rollout", None)
+                if ro is not None:
+                    pol = next((m for m in env.managers["observation"] if m.name == ro.obs_name), None)
+                    ro.write(pol._last_out if pol is not None else obs_tail, rm._reward_buf if rm is not None else env._reward_buf,
+                             tm._terminated_buf, tm._truncated_buf)
             finally:
                 env.stats.ptr_override, env._in_step = None, False
         env._finish_step_light(snap)

@@ -239,6 +239,11 @@ class ManagedEnvironment(GenesisEnv):
             self._reset_done(terminated, truncated)
 
         obs = self.get_observations()
+        ro = getattr(self, "_rollout", None)
+        if ro is not None and tm is not None:
+            # the RL library's rollout rows (learner.RolloutStorage): written from the manager-owned buffers of this step
+            pol = next((m for m in self.managers["observation"] if m.name == ro.obs_name), None)
+            ro.write(pol._last_out if pol is not None else obs, rewards, terminated, truncated)
         self._end_step()
         return obs, rewards, terminated, truncated, self.extras
 

@@ -104,6 +104,8 @@ class GaitCommandManager(CommandManager):
         blocks = (n + 63) // 64
         self._wave_flags = torch.zeros((blocks + 3) // 4 * 4, dtype=torch.uint8, device=gs.device)
         self._wave_flags[:blocks] = 0x55
+        #: the fused post-physics launch writes the bytes of the state it leaves here and the two buffers swap (GfPostRefs)
+        self._wave_flags_next = self._wave_flags.clone()
         #: reproduce the reference's env-0 index-list quirk in gait_phase_reward (see GF_R_GAIT_PHASE in gf_step.h)
         self.reference_env0_quirk = True
         self._gait_args = {m: nat.GfGaitArgs() for m in (nat.GF_CMD_STEP, nat.GF_CMD_MASKED, nat.GF_CMD_ALL)}
@@ -186,8 +188,10 @@ class GaitCommandManager(CommandManager):
         env = self.env
         key = self._cfg_key()
         if getattr(a, "_gf_key", None) == key:
+            a.wave_flags = self._wave_flags.data_ptr()   # the current one of the two swing / stance buffers
             return
         a._gf_key = key
+        a.wave_flags = self._wave_flags.data_ptr()
         a.num_envs, a.mode, a.resample_steps = env.num_envs, mode, self._resample_steps
         g = self._num_gaits
         a.num_gaits = g
@@ -211,7 +215,6 @@ class GaitCommandManager(CommandManager):
         a.dt, a.two_pi = float(env.dt), 2 * math.pi
         a.seed, a.env_offset = env._rng_seed, env.env_offset
         a.state, a.selected = self._state.data_ptr(), self._gait_selected.data_ptr()
-        a.wave_flags = self._wave_flags.data_ptr()
         a.episode_length = env.episode_length.data_ptr()
 
     def _launch_gait(self, mode: int, mask=None, mask2=None, draws_key: Optional[str] = None) -> None:

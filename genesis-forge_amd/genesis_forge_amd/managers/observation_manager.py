@@ -231,6 +231,7 @@ class ObservationManager(BaseManager):
         out = self._rotate_ring(a)
         env.backend.call("observe", a, owner=self)
         self._keep = keep
+        self._last_out = out    # the buffer the kernel wrote (what a rollout storage copies from)
         return self._hand_out(out)
 
     def _hand_out(self, out: torch.Tensor) -> torch.Tensor:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 2
+#define GF_ABI_VERSION 3
 
 #define GF_MAX_TERMS 24          /* reward terms per manager          */
 #define GF_MAX_TERM_TERMS 16     /* termination terms per manager     */
@@ -562,6 +562,30 @@ typedef struct GfSynthSceneArgs {
 } GfSynthSceneArgs;
 
 /* ------------------------------------------------------------------------------------------
+ * Rollout storage write (first slice): what the RL library does with a step's outputs.
+ * rsl_rl's OnPolicyRunner (call site examples/simple/train.py:125-129, `num_steps_per_env` = 24, :75) copies every
+ * step's observation, reward and done flags into a time-major RolloutStorage with three `copy_` launches
+ * (`observations[step].copy_(obs)`, `rewards[step].copy_(rew)`, `dones[step].copy_(dones)`).  Here the step's own
+ * kernel stores them: the fused post-physics launch writes its observation tile, reward and masks a second time,
+ * straight into the storage rows (GfPostRefs.rollout), or gf_rollout_write does it as one launch.
+ * Layout (plain pointers, time-major, contiguous): observations [T+1, N, W] f32, rewards [T, N] f32, dones [T, N] u8.
+ * Step t of a rollout writes rewards[t], dones[t] = terminated | truncated, and observations[t+1] = the observation the
+ * step RETURNS (the policy's next input; row T is the bootstrap observation, row 0 the one the rollout started from).
+ * The caller passes the row addresses, so the library needs neither T nor t.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct GfRolloutArgs {
+    int32_t num_envs;
+    int32_t obs_width;          /* W: floats per env of `obs` (O·H of the policy ObservationManager) */
+    const float* obs;           /* [N, W] the observation this step returns */
+    const float* reward;        /* [N] */
+    const uint8_t* terminated;  /* [N] */
+    const uint8_t* truncated;   /* [N] */
+    float* obs_out;             /* &observations[t+1][0][0], or NULL */
+    float* reward_out;          /* &rewards[t][0], or NULL */
+    uint8_t* done_out;          /* &dones[t][0], or NULL */
+} GfRolloutArgs;
+
+/* ------------------------------------------------------------------------------------------
  * Entry points.  `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream).
  * ---------------------------------------------------------------------------------------- */
 int gf_abi_version(void);
@@ -579,7 +603,7 @@ int gf_abi_version(void);
  * chains — termination → reward → command.step…, and reset → command.reset… → observe… — one launch each (csrc/gf_chain.hip). */
 enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_GRAPH = 2, GF_OPT_CHAIN = 3, GF_OPT_COUNT = 4 };
 int gf_set_option(int option, int value);
-int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView): binding self-check */
+int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView, 17 GfPostRefs, 18 GfRolloutArgs): binding self-check */
 const char* gf_build_info(void);
 const char* gf_error_string(int code);
 
@@ -596,6 +620,7 @@ int gf_observe(const GfObservationArgs* a, void* stream);         /* replaces ob
 int gf_entity_rotate(const GfRotateArgs* a, void* stream);        /* replaces entity_manager.py:130-146 */
 int gf_terrain_height(const GfTerrainHeightArgs* a, void* stream);/* replaces terrain_manager.py:100-166 */
 int gf_synth_scene_step(const GfSynthSceneArgs* a, void* stream); /* stands in for scene.step() (managed_env.py:292) */
+int gf_rollout_write(const GfRolloutArgs* a, void* stream);       /* replaces the RolloutStorage copy_ launches of the RL library (examples/simple/train.py:125-129) */
 
 /* ------------------------------------------------------------------------------------------
  * Fused post-physics step: everything ManagedEnvironment.step() does after scene.step() and the
@@ -607,10 +632,11 @@ int gf_synth_scene_step(const GfSynthSceneArgs* a, void* stream); /* stands in f
  * definition those of calling the phases in sequence — which is what the oracle twin does); the call
  * packs them into one kernarg block.  Returns GF_E_UNSUPPORTED when the combination cannot be fused
  * (Python-evaluated terms, parity-mode draws, D not a built variant, phases reading different
- * buffers, more than 2 command / observation managers …): the caller then runs the phases one by one.
+ * buffers, more than 2 command / 1 gait / 2 observation managers …): the caller then runs the phases one by one.
  * ---------------------------------------------------------------------------------------- */
 #define GF_POST_MAX_CMD 2
 #define GF_POST_MAX_OBS 2
+#define GF_POST_MAX_GAIT 1
 
 typedef struct GfPostRefs {
     const GfTerminationArgs* termination;                 /* required */
@@ -621,6 +647,20 @@ typedef struct GfPostRefs {
     const GfCommandArgs* command_step[GF_POST_MAX_CMD];   /* mode GF_CMD_STEP  */
     const GfCommandArgs* command_reset[GF_POST_MAX_CMD];  /* mode GF_CMD_MASKED on the same masks, same buffers */
     const GfObservationArgs* observe[GF_POST_MAX_OBS];
+    /* GaitCommandManagers stepped / reset inside the same launch (examples/gait_trainer: BASELINE config 5).  The swing / stance
+     * bytes (GfGaitArgs.wave_flags) are read ACROSS 64-env blocks by GF_R_GAIT_PHASE (env-0 quirk) while every block rewrites its
+     * own byte, so a single launch needs two buffers: it reads gait_step->wave_flags (the state the previous step left; must be
+     * the reward descriptor's gait_wave_flags) and writes every block's byte for the state it leaves into gait_flags_next, which
+     * the caller makes the current buffer afterwards (ping-pong).  Sequentially the result is the same: gait.step rewrites every
+     * block's byte, gait.reset the blocks with a reset env, both from the rows they hold. */
+    int32_t num_gait;
+    int32_t _pad;
+    const GfGaitArgs* gait_step[GF_POST_MAX_GAIT];    /* mode GF_CMD_STEP */
+    const GfGaitArgs* gait_reset[GF_POST_MAX_GAIT];   /* mode GF_CMD_MASKED on the termination masks, same state */
+    uint8_t* gait_flags_next[GF_POST_MAX_GAIT];       /* same size as wave_flags; may be NULL when wave_flags is NULL */
+    /* optional: the launch also stores the step's observation / reward / done flags into rollout-storage rows (§8f-5).
+     * rollout->obs must be the obs buffer of one of `observe`, ->reward the reward buffer, the masks termination's outputs. */
+    const GfRolloutArgs* rollout;
 } GfPostRefs;
 
 int gf_post_physics_check(const GfPostRefs* r);               /* GF_OK if gf_post_physics_step can fuse this combination */
@@ -676,7 +716,8 @@ int gf_event_synchronize(void* event);   /* blocks the host until the event has 
 /* Optional per-phase HIP-event timing used by bench.py (events recorded on `stream`
  * immediately around the kernel launch of the selected phase). */
 enum { GF_PHASE_ACTION = 0, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
-       GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_COUNT };
+       GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_ROLLOUT,
+       GF_PHASE_COUNT };
 int gf_profile_begin(int phase, int max_samples);     /* start recording event pairs for `phase` */
 int gf_profile_end(double* total_ms, int* samples);    /* sync events, return Σ elapsed + count, free them */
 

@@ -1075,6 +1075,20 @@ GFO_EXPORT int gfo_synth_scene_step(const GfSynthSceneArgs* a) {
     return GF_OK;
 }
 
+/* Rollout-storage write: rsl_rl's `observations[t+1].copy_(obs)`, `rewards[t].copy_(rew)`,
+ * `dones[t].copy_(terminated | truncated)` (call site examples/simple/train.py:125-129). */
+GFO_EXPORT int gfo_rollout_write(const GfRolloutArgs* a) {
+    if (!a) return GF_E_NULL;
+    if (a->num_envs < 0 || a->obs_width < 0) return GF_E_RANGE;
+    if ((a->obs_out && !a->obs) || (a->reward_out && !a->reward) || (a->done_out && !a->terminated)) return GF_E_NULL;
+    const int64_t N = a->num_envs;
+    if (a->obs_out) memcpy(a->obs_out, a->obs, (size_t)N * (size_t)a->obs_width * sizeof(float));
+    if (a->reward_out) memcpy(a->reward_out, a->reward, (size_t)N * sizeof(float));
+    if (a->done_out)
+        for (int64_t n = 0; n < N; ++n) a->done_out[n] = (uint8_t)((a->terminated[n] != 0) | (a->truncated && a->truncated[n] != 0));
+    return GF_OK;
+}
+
 /* Host twin of gf_post_physics_step: BY DEFINITION the phases in the reference's order (managed_env.py:303-326). */
 GFO_EXPORT int gfo_post_physics_check(const GfPostRefs* r) { return (r && r->termination && r->reset) ? GF_OK : GF_E_NULL; }
 
@@ -1085,11 +1099,23 @@ GFO_EXPORT int gfo_post_physics_step(const GfPostRefs* r) {
     if (r->reward && (rc = gfo_reward_step(r->reward))) return rc;
     for (int c = 0; c < r->num_command; ++c)
         if ((rc = gfo_command_step(r->command_step[c]))) return rc;
+    for (int g = 0; g < r->num_gait; ++g)
+        if ((rc = gfo_gait_step(r->gait_step[g]))) return rc;
     if ((rc = gfo_masked_reset(r->reset))) return rc;
     for (int c = 0; c < r->num_command; ++c)
         if ((rc = gfo_command_step(r->command_reset[c]))) return rc;
+    for (int g = 0; g < r->num_gait; ++g)
+        if ((rc = gfo_gait_step(r->gait_reset[g]))) return rc;
     for (int o = 0; o < r->num_observe; ++o)
         if ((rc = gfo_observe(r->observe[o]))) return rc;
+    /* the single launch writes the swing / stance bytes of the state it leaves into the OTHER buffer (GfPostRefs); in sequence
+     * gait.step + gait.reset have just left exactly those bytes in wave_flags */
+    if (r->rollout && (rc = gfo_rollout_write(r->rollout))) return rc;
+    for (int g = 0; g < r->num_gait; ++g)
+        if (r->gait_flags_next[g] && r->gait_step[g]->wave_flags) {
+            const int64_t blocks = ((int64_t)r->gait_step[g]->num_envs + 63) / 64;
+            memcpy(r->gait_flags_next[g], r->gait_step[g]->wave_flags, (size_t)blocks);
+        }
     return GF_OK;
 }
 
@@ -1136,6 +1162,7 @@ GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
             case GF_PHASE_GAIT: rc = gfo_gait_step((const GfGaitArgs*)a); break;
             case GF_OP_STATS_CLEAR: rc = gfo_stats_clear((GfStepStats*)a); break;
             case GF_OP_POST_PHYSICS: rc = gfo_post_physics_step((const GfPostRefs*)a); break;
+            case GF_PHASE_ROLLOUT: rc = gfo_rollout_write((const GfRolloutArgs*)a); break;
             case GF_OP_STATS_PACK: rc = gfo_stats_pack((const GfStatsPackArgs*)a); break;
             case GF_OP_STATS_COPY: {
                 const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
@@ -1172,6 +1199,8 @@ GFO_EXPORT int gfo_sizeof(int which) {
         case 14: return (int)sizeof(GfGaitArgs);
         case 15: return (int)sizeof(GfContactView);
         case 16: return (int)sizeof(GfCommandView);
+        case 17: return (int)sizeof(GfPostRefs);
+        case 18: return (int)sizeof(GfRolloutArgs);
         default: return -1;
     }
 }
