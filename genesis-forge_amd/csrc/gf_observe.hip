@@ -84,11 +84,12 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
     const V3 lin{lp[0], lp[1], lp[2]}, ang{ap[0], ap[1], ap[2]};
 
     const int64_t OH = (int64_t)O * H;
-    GF_GLOBAL float* out = G(a.obs) + n0 * OH;
-    const GF_GLOBAL float* prev = H > 1 ? G(a.prev_obs) + n0 * OH : nullptr;
+    const bool ring = a.history_ring != 0;   // in-place ring: only the new frame is written, into its slot
+    GF_GLOBAL float* out = G(a.obs) + n0 * OH + (ring ? (int64_t)(a.history_ring - 1) * O : 0);
+    const GF_GLOBAL float* prev = (H > 1 && !ring) ? G(a.prev_obs) + n0 * OH : nullptr;
     // 16-byte units over the tile's contiguous run (see HistBatch); otherwise (a frame narrower than 4, an output that is not
     // 16-byte aligned) element by element
-    const bool flat = H > 1 && O >= 4 && (reinterpret_cast<uintptr_t>(a.obs) & 15u) == 0;
+    const bool flat = H > 1 && !ring && O >= 4 && (reinterpret_cast<uintptr_t>(a.obs) & 15u) == 0;
     const bool hist = flat;
     const int units = (rows * (int)OH) >> 2;
     const FastDiv dr((int)OH);
@@ -190,7 +191,7 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
             if (hfirst - tid >= units) break;  // wave-uniform: the batch's first unit index of lane 0
             hist_load(hb, prev, hfirst, units, O, (int)OH, dr);
         }
-    } else if (H > 1) {
+    } else if (H > 1 && !ring) {
         const int hw = O * (H - 1);
         const FastDiv dh(hw);
         for (int i = tid; i < rows * hw; i += kObsBlock) {
@@ -265,16 +266,17 @@ namespace gf {
 int observe_prep(const GfObservationArgs* a, uint32_t* needs_out, int* vec_out) {
     if (!a || !a->obs) return GF_E_NULL;
     if (a->num_items <= 0 || a->num_items > GF_MAX_OBS_ITEMS || a->num_envs < 0) return GF_E_RANGE;
-    if (a->history_len < 1) return GF_E_RANGE;
-    if (a->history_len > 1 && (!a->prev_obs || a->prev_obs == a->obs)) return GF_E_NULL;
+    if (a->history_len < 1 || a->history_ring < 0 || a->history_ring > a->history_len) return GF_E_RANGE;
+    const bool ring = a->history_ring != 0;
+    if (a->history_len > 1 && !ring && (!a->prev_obs || a->prev_obs == a->obs)) return GF_E_NULL;
     const int O = a->obs_width, D = a->num_dofs;
     if (O <= 0 || O >= GF_MAX_OBS_WIDTH) return GF_E_RANGE;
     int wsum = 0;
     uint32_t needs = 0;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
-    const bool vec4 = (O % 4 == 0) && al16(a->obs) && (a->history_len == 1 || al16(a->prev_obs));
-    const bool vec2 = (O % 2 == 0) && al8(a->obs) && (a->history_len == 1 || al8(a->prev_obs));
+    const bool vec4 = (O % 4 == 0) && al16(a->obs) && (a->history_len == 1 || ring || al16(a->prev_obs));
+    const bool vec2 = (O % 2 == 0) && al8(a->obs) && (a->history_len == 1 || ring || al8(a->prev_obs));
     for (int i = 0; i < a->num_items; ++i) {
         const GfObsItem& it = a->items[i];
         if (it.width <= 0) return GF_E_RANGE;

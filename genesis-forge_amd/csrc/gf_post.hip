@@ -818,11 +818,13 @@ static int pack(const GfPostRefs* r, Packer& pk) {
         const GfObservationArgs* ob = r->observe[m];
         UNSUP(!ob || ob->num_envs != N || ob->num_items > kPostMaxItems || ob->noise_draws || !ob->obs);
         UNSUP(ob->seed != RS.seed || ob->env_offset != RS.env_offset);
-        UNSUP(ob->history_len > 1 && !ob->prev_obs);
+        UNSUP(ob->history_ring < 0 || ob->history_ring > ob->history_len);
+        UNSUP(ob->history_len > 1 && !ob->history_ring && !ob->prev_obs);
         UNSUP((reinterpret_cast<uintptr_t>(ob->obs) & 15u) || (ob->prev_obs && (reinterpret_cast<uintptr_t>(ob->prev_obs) & 15u)));
         GfEntityView cur{a.pos, a.quat, a.lin_vel, a.ang_vel};
         PostObs& po = a.obs[m];
-        po.obs = ob->obs; po.prev = ob->history_len > 1 ? ob->prev_obs : nullptr; po.stream = ob->stream;
+        po.obs = ob->obs; po.prev = (ob->history_len > 1 && !ob->history_ring) ? ob->prev_obs : nullptr; po.stream = ob->stream;
+        po.ring = ob->history_ring;
         po.num_items = ob->num_items; po.width = ob->obs_width; po.history = ob->history_len;
         omax = ob->obs_width > omax ? ob->obs_width : omax;
         bool uses_entity = false;
@@ -876,6 +878,7 @@ static int pack(const GfPostRefs* r, Packer& pk) {
             for (int m = 0; m < a.n_obs; ++m)
                 if (a.obs[m].obs == ro->obs && a.obs[m].width * a.obs[m].history == ro->obs_width) a.roll_obs_index = m;
             UNSUP(a.roll_obs_index < 0 || (reinterpret_cast<uintptr_t>(ro->obs_out) & 15u));
+            UNSUP(a.obs[a.roll_obs_index].ring != 0);   // an in-place ring is not a newest-first row: nothing to copy from
             a.roll_obs = ro->obs_out;
         }
     }
@@ -958,7 +961,9 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = gf::env_grid(a.num_envs);
     gf::PhaseScope scope(GF_PHASE_POST, s);
-    const bool ws_only = a.n_gait || a.roll_obs || a.roll_reward || a.roll_done;   // the one-wave variant has neither a gait manager nor rollout stores
+    bool any_ring = false;
+    for (int m = 0; m < a.n_obs; ++m) any_ring = any_ring || a.obs[m].ring != 0;
+    const bool ws_only = a.n_gait || a.roll_obs || a.roll_reward || a.roll_done || any_ring;   // the one-wave variant has neither a gait manager nor rollout stores
     if (gf::g_options[GF_OPT_POST_VARIANT] == 0 && !ws_only) {
         if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid, gf::kEnvBlock, lds, s, a);
         else GF_LAUNCH(scope, gf::post_kernel<3>, grid, gf::kEnvBlock, lds, s, a);

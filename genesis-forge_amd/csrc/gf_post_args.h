@@ -70,7 +70,7 @@ struct PostObs {
     int32_t num_items;
     int32_t width;
     int32_t history;
-    int32_t _pad;
+    int32_t ring;      // GfObservationArgs.history_ring: 0 = shift, k+1 = in-place ring, the new frame goes to slot k
     GfObsItem items[kPostMaxItems];
 };
 

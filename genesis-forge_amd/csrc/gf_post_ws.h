@@ -605,13 +605,14 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         {
             const int rows = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
             const int64_t OH = (int64_t)O * H;
-            GF_GLOBAL float* out = G(ob_out) + n0 * OH;
+            const int ring = UNI(ob.ring);   // in-place history ring: only the new frame is written, into its slot
+            GF_GLOBAL float* out = G(ob_out) + n0 * OH + (ring ? (int64_t)(ring - 1) * O : 0);
             float* const roll_base = UNI(a.roll_obs);
             GF_GLOBAL float* roll = (roll_base && UNI(a.roll_obs_index) == m) ? G(roll_base) + n0 * OH : nullptr;   // observations[t+1] of the rollout storage
             const int t = threadIdx.x;
             // history (H > 1): 16-byte units over the tile's contiguous [rows, O·H] run, whatever O is (gf_obs_hist.h) — the
             // gait task's 62-wide policy frame has no 16-byte aligned rows, the run has
-            const bool flat = H > 1 && O >= 4 && (reinterpret_cast<uintptr_t>(ob_out) & 15u) == 0;
+            const bool flat = H > 1 && !ring && O >= 4 && (reinterpret_cast<uintptr_t>(ob_out) & 15u) == 0;
             if (flat) {
                 const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
                 const int units = (rows * (int)OH) >> 2;
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                     rw += qstep; c4 += rstep;
                     if (c4 >= o4) { c4 -= o4; ++rw; }
                 }
-                if (H > 1) {
+                if (H > 1 && !ring) {
                     const int h4 = (O * (H - 1)) >> 2;
                     const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
                     for (int i = t; i < rows * h4; i += kWsBlock) {
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                     out[rw * OH + cc] = tile[rw * S + cc];
                     if (roll) roll[rw * OH + cc] = tile[rw * S + cc];
                 }
-                if (H > 1) {
+                if (H > 1 && !ring) {
                     const int hw = O * (H - 1);
                     const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
                     for (int i = t; i < rows * hw; i += kWsBlock) {

@@ -198,7 +198,7 @@ class GfObsItem(C.Structure):
 
 class GfObservationArgs(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_dofs", C.c_int32), ("num_items", C.c_int32), ("obs_width", C.c_int32),
-                ("history_len", C.c_int32), ("_pad", C.c_int32), ("entity", GfEntityView),
+                ("history_len", C.c_int32), ("history_ring", C.c_int32), ("entity", GfEntityView),
                 ("dof_pos", P), ("dof_vel", P), ("dof_force", P), ("targets", P), ("env_actions", P),
                 ("contact", GfContactView * GF_MAX_CONTACT_VIEWS), ("command", GfCommandView * GF_MAX_COMMAND_VIEWS),
                 ("ext", P * GF_MAX_EXT), ("noise_draws", P), ("seed", C.c_uint64), ("stream", C.c_uint64),

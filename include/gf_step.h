@@ -464,7 +464,12 @@ typedef struct GfObservationArgs {
     int32_t num_items;
     int32_t obs_width;        /* O = Σ width */
     int32_t history_len;      /* H >= 1 */
-    int32_t _pad;
+    int32_t history_ring;     /* 0: `obs` = [new frame | the first H-1 frames of prev_obs] (newest first, observation_manager.py:218-226:
+                                 the previous OUTPUT is the history, so a launch moves (2H-1)·O floats per env);
+                                 k+1: IN-PLACE RING — `obs` is the persistent [N, H, O] history itself and the launch writes ONLY the new
+                                 frame, into frame slot k (0 <= k < H); prev_obs is unused.  O floats per env instead of (2H-1)·O; the
+                                 caller walks the slots from k upwards (wrapping) to read newest first: the host passes
+                                 k = (H - step % H) % H so that this walk is ascending in memory. */
     GfEntityView entity;
     const float* dof_pos;     /* [N,D] */
     const float* dof_vel;     /* [N,D] */

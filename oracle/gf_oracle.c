@@ -881,8 +881,10 @@ GFO_EXPORT int gfo_masked_reset(const GfResetArgs* a) {
 GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
     if (!a || !a->obs) return GF_E_NULL;
     if (a->num_items <= 0 || a->num_items > GF_MAX_OBS_ITEMS) return GF_E_RANGE;
-    if (a->history_len < 1 || (a->history_len > 1 && !a->prev_obs)) return a->history_len < 1 ? GF_E_RANGE : GF_E_NULL;
+    if (a->history_ring < 0 || a->history_ring > a->history_len) return GF_E_RANGE;
+    if (a->history_len < 1 || (a->history_len > 1 && !a->history_ring && !a->prev_obs)) return a->history_len < 1 ? GF_E_RANGE : GF_E_NULL;
     const int64_t N = a->num_envs, D = a->num_dofs, O = a->obs_width, H = a->history_len;
+    const int64_t frame_off = a->history_ring ? (int64_t)(a->history_ring - 1) * O : 0;   /* in-place ring: only this slot is written */
     if (O <= 0 || O >= GF_MAX_OBS_WIDTH) return GF_E_RANGE;
     int64_t wsum = 0;
     int need_quat = 0, need_lin = 0, need_ang = 0;
@@ -933,7 +935,7 @@ GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
     if (need_lin && !a->entity.lin_vel) return GF_E_NULL;
     if (need_ang && !a->entity.ang_vel) return GF_E_NULL;
     for (int64_t n = 0; n < N; ++n) {
-        float* row = a->obs + n * O * H;
+        float* row = a->obs + n * O * H + frame_off;
         int64_t col = 0;
         /* entity_manager.py:189-195: quaternion cached before the reset of this tick */
         GfEntityView ent = a->entity;
@@ -974,8 +976,9 @@ GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
                 row[col] = v;
             }
         }
-        /* history: newest first (:223-226) */
-        for (int64_t k = O; k < O * H; ++k) row[k] = a->prev_obs[n * O * H + (k - O)];
+        /* history: newest first (:223-226); in the in-place ring the older frames already sit in their slots */
+        if (!a->history_ring)
+            for (int64_t k = O; k < O * H; ++k) row[k] = a->prev_obs[n * O * H + (k - O)];
     }
     return GF_OK;
 }

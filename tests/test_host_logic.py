@@ -323,3 +323,33 @@ def test_static_observation_output_is_opt_in(oracle_backend):
     env.observation_manager._output = "fresh"
     ptrs = {env.step(torch.zeros(16, 12))[0].data_ptr() for _ in range(3)} & set(ptrs)
     assert not ptrs, "fresh outputs never alias the persistent slots"
+
+
+@pytest.mark.parametrize("trace", [False, True])
+def test_in_place_history_ring_holds_the_reference_frames(oracle_backend, trace):
+    """output="ring": one persistent [N, H, O] buffer, a call writes only the new frame into slot `history_head`; gathered
+    newest first (`ordered`) it is exactly the default output (observation_manager.py:218-226) at every step."""
+    def run(output):
+        env = Go2CommandDirectionEnv(num_envs=70, max_episode_length_s=0.4, cmd_resample_s=0.2, history=3, contacts=True,
+                                     scene_kwargs=dict(ang_noise=0.3, seed=3))
+        env.trace_enabled = trace
+        env.build()
+        om = env.observation_manager
+        om._output = output
+        env.seed(9)
+        obs0, _ = env.reset()
+        g = torch.Generator().manual_seed(1)
+        outs = [om.ordered(obs0).clone()]
+        ptrs = set()
+        for _ in range(11):
+            obs = env.step(torch.randn(70, 12, generator=g))[0]
+            ptrs.add(obs.data_ptr())
+            outs.append(om.ordered(obs).clone())
+        assert (env._trace is not None) == trace
+        return outs, ptrs
+
+    want, _ = run("fresh")
+    got, ptrs = run("ring")
+    assert len(ptrs) == 1, "the ring IS the returned tensor"
+    for t, (a, b) in enumerate(zip(want, got)):
+        assert torch.equal(a, b), f"frames differ at observation {t}"

@@ -557,3 +557,55 @@ def test_logs_read_late_across_ring_wraps(oracle_backend):
     assert env._trace is not None
     assert want == got
     assert any(len(d) > 0 for d in want.values())
+
+
+def _ring_run(dev, kind, output, n, steps=14):
+    from genesis_forge_amd import tasks
+    from genesis_forge_amd.managers import ObservationManager
+
+    old = ObservationManager.default_output
+    ObservationManager.default_output = output
+    try:
+        if kind == "gait":
+            env = tasks.Go2GaitTrainingEnv(num_envs=n, max_episode_length_s=0.4, scene_kwargs=dict(ang_noise=0.3, seed=3, contact_prob=0.05))
+        else:
+            env = Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=0.4, cmd_resample_s=0.2, history=3, contacts=True, obs_noise=True,
+                                         scene_kwargs=dict(ang_noise=0.3, seed=3))
+        env.build()
+    finally:
+        ObservationManager.default_output = old
+    env.seed(9)
+    env.reset()
+    g = torch.Generator().manual_seed(1)
+    d = env.action_space.shape[0]
+    outs = []
+    for _ in range(steps):
+        obs, rew, te, tr, ex = env.step(torch.randn(n, d, generator=g).to(dev))
+        frames = [m.ordered(ex["observations"][m.name]).cpu().clone() for m in env.managers["observation"]]
+        outs.append(frames + [rew.cpu().clone(), te.cpu().clone()])
+    return outs, env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["go2_hist", "gait"])
+def test_in_place_history_ring_hip(hip_backend, kind):
+    """The in-place ring through the fused post-physics kernel (interpreter for the noisy Go2 config, the gait static program):
+    only the new frame is written; gathered newest first it equals the default output bit for bit."""
+    want, _ = _ring_run("cuda", kind, "static", 1000)
+    got, env = _ring_run("cuda", kind, "ring", 1000)
+    assert env._trace is not None and env._trace.post_refs is not None
+    for t, (a, b) in enumerate(zip(want, got)):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), f"output {k} differs at step {t}"
+
+
+@pytest.mark.gpu
+def test_in_place_history_ring_stand_alone_kernel_hip(hip_backend, monkeypatch):
+    """… and through the stand-alone observation kernel (no recording: every phase its own launch)."""
+    monkeypatch.setenv("GF_NO_TRACE", "1")
+    want, e0 = _ring_run("cuda", "gait", "static", 130)
+    got, e1 = _ring_run("cuda", "gait", "ring", 130)
+    assert e0._trace is None and e1._trace is None
+    for t, (a, b) in enumerate(zip(want, got)):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), f"output {k} differs at step {t}"
