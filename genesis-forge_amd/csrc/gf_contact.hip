@@ -29,6 +29,13 @@ constexpr int kContactBlock = 256;
 constexpr int kContactLdsBytes = 16 * 1024;
 constexpr int kContactSelect = 16;      // up to this many tracked links the target table is read with constant indices
 #define GF_CONTACT_INLINE __attribute__((always_inline))
+typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));   // dword aligned; one global_{load,store}_dwordx3: a wave moves 768 contiguous bytes
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st3(float* p, float x, float y, float z) { *reinterpret_cast<GF_GLOBAL f32x3*>(G(p)) = f32x3{x, y, z}; }
+__device__ __forceinline__ V3 ld3(const float* p) {
+    const f32x3 v = *reinterpret_cast<const GF_GLOBAL f32x3*>(G(p));
+    return V3{v.x, v.y, v.z};
+}
 
 struct ContactMgr {
     int32_t num_targets, num_with, has_with_filter, track_air_time;
@@ -129,13 +136,26 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
         const GF_GLOBAL int32_t* ga = G(a.link_a) + n0 * C;
         const GF_GLOBAL int32_t* gb = G(a.link_b) + n0 * C;
         const FastDivC dc(C);
-        for (int i = threadIdx.x; i < slots; i += blockDim.x) {
-            const int la = ga[i], lb = gb[i];
-            sa[i] = la; sb[i] = lb;
+        auto mark = [&](int i, int la, int lb) GF_CONTACT_INLINE {
             if (la >= 0 || lb >= 0) {
                 const int e = dc.div(i), c = i - e * C;
                 atomicOr(&smask[e * MW + (c >> 5)], 1u << (c & 31));
             }
+        };
+        // four ids per lane and array (dwordx4: 1 KiB per wave instruction) when the block's rows start 16-byte aligned
+        const bool vec = ((E * C) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.link_a) | reinterpret_cast<uintptr_t>(a.link_b)) & 15u) == 0;
+        const int slots4 = vec ? (slots >> 2) : 0;
+        for (int i4 = threadIdx.x; i4 < slots4; i4 += blockDim.x) {
+            const i32x4 va = reinterpret_cast<const GF_GLOBAL i32x4*>(ga)[i4], vb = reinterpret_cast<const GF_GLOBAL i32x4*>(gb)[i4];
+            reinterpret_cast<i32x4*>(sa)[i4] = va;
+            reinterpret_cast<i32x4*>(sb)[i4] = vb;
+            const int i = i4 << 2;
+            mark(i, va.x, vb.x); mark(i + 1, va.y, vb.y); mark(i + 2, va.z, vb.z); mark(i + 3, va.w, vb.w);
+        }
+        for (int i = (slots4 << 2) + threadIdx.x; i < slots; i += blockDim.x) {
+            const int la = ga[i], lb = gb[i];
+            sa[i] = la; sb[i] = lb;
+            mark(i, la, lb);
         }
     }
     // phase 2: one lane per (env, tracked link) walks ONLY the occupied slots of its env, in slot order
@@ -157,8 +177,8 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
         if (live && mg.track_air_time) { cur_air = G(mg.current_air_time)[k]; cur_con = G(mg.current_contact_time)[k]; }
         V3 lvel{0.f, 0.f, 0.f}, lpos{0.f, 0.f, 0.f};
         const bool copy_vel = live && a.links_vel && mg.link_vel_out, copy_pos = live && a.links_pos && mg.link_pos_out;
-        if (copy_vel) lvel = load3(a.links_vel, n * a.num_scene_links + target);
-        if (copy_pos) lpos = load3(a.links_pos, n * a.num_scene_links + target);
+        if (copy_vel) lvel = ld3(a.links_vel + 3 * (n * a.num_scene_links + target));
+        if (copy_pos) lpos = ld3(a.links_pos + 3 * (n * a.num_scene_links + target));
         if (pr0 == 0) __syncthreads();  // phase 1's LDS writes
         if (!live) continue;
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, cnt = 0.f;
@@ -181,10 +201,9 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
                     }
                 }
                 if (!include) continue;
-                const GF_GLOBAL float* fr = G(a.force) + (n * C + c) * 3;
-                const GF_GLOBAL float* pr_ = G(a.position) + (n * C + c) * 3;
-                float fx = fr[0], fy = fr[1], fz = fr[2];
-                const float px = pr_[0], py = pr_[1], pz = pr_[2];
+                const V3 fv = ld3(a.force + (n * C + c) * 3), pv = ld3(a.position + (n * C + c) * 3);
+                float fx = fv.x, fy = fv.y, fz = fv.z;
+                const float px = pv.x, py = pv.y, pz = pv.z;
                 // torch.nan_to_num(force, nan=0, posinf=0, neginf=0)   contact_manager.py:401-403
                 if (isnan(fx) || isinf(fx)) { fx = 0.f; flag_mask |= 1 << mi; }
                 if (isnan(fy) || isinf(fy)) { fy = 0.f; flag_mask |= 1 << mi; }
@@ -196,23 +215,12 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
                 f0 += r.x; f1 += r.y; f2 += r.z;
             }
         }
-        GF_GLOBAL float* co = G(mg.contacts) + 3 * k;
-        co[0] = f0; co[1] = f1; co[2] = f2;
-        if (mg.contact_positions) {  // kernel.py:84-90
-            GF_GLOBAL float* po = G(mg.contact_positions) + 3 * k;
-            po[0] = cnt > 0.f ? p0 / cnt : p0;
-            po[1] = cnt > 0.f ? p1 / cnt : p1;
-            po[2] = cnt > 0.f ? p2 / cnt : p2;
-        }
+        st3(mg.contacts + 3 * k, f0, f1, f2);
+        if (mg.contact_positions)  // kernel.py:84-90
+            st3(mg.contact_positions + 3 * k, cnt > 0.f ? p0 / cnt : p0, cnt > 0.f ? p1 / cnt : p1, cnt > 0.f ? p2 / cnt : p2);
         if (mg.position_counts) G(mg.position_counts)[k] = cnt;
-        if (copy_vel) {  // compact per-manager copy of the tracked links' velocities (feet_slide)
-            GF_GLOBAL float* o = G(mg.link_vel_out) + 3 * k;
-            o[0] = lvel.x; o[1] = lvel.y; o[2] = lvel.z;
-        }
-        if (copy_pos) {  // … and of their positions (the gait manager's foot_height_reward)
-            GF_GLOBAL float* o = G(mg.link_pos_out) + 3 * k;
-            o[0] = lpos.x; o[1] = lpos.y; o[2] = lpos.z;
-        }
+        if (copy_vel) st3(mg.link_vel_out + 3 * k, lvel.x, lvel.y, lvel.z);  // compact per-manager copy of the tracked links' velocities (feet_slide)
+        if (copy_pos) st3(mg.link_pos_out + 3 * k, lpos.x, lpos.y, lpos.z);  // … and of their positions (the gait manager's foot_height_reward)
         if (mg.track_air_time) {  // contact_manager.py:441-477
             const float dt = a.dt;
             const bool is_contact = norm3(f0, f1, f2) > mg.air_time_threshold;

@@ -232,6 +232,30 @@ class GfGaitArgs(C.Structure):
                 ("state", P), ("selected", P), ("wave_flags", P), ("stats", P)]
 
 
+(GF_PATCH_ACTIONS, GF_PATCH_STREAM, GF_PATCH_COUNTER, GF_PATCH_ROTATE, GF_PATCH_PARAM, GF_PATCH_COPY, GF_PATCH_RING_SLOT) = range(1, 8)
+
+
+class GfRotor(C.Structure):
+    _fields_ = [("cur", C.c_int32), ("count", C.c_int32), ("slot", P * 8)]
+
+
+class GfRingClock(C.Structure):
+    _fields_ = [("calls", C.c_int32), ("length", C.c_int32)]
+
+
+class GfReplayPatch(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("index", C.c_int32), ("target", P), ("target2", P), ("aux", P)]
+
+
+class GfReplay(C.Structure):
+    _fields_ = [("ops", P), ("num_ops", C.c_int32), ("num_patches", C.c_int32), ("patches", P), ("rng_stream", P)]
+
+
+def field_addr(struct, name: str) -> int:
+    """Host address of ``struct.name`` (a patch target, see GfReplayPatch)."""
+    return C.addressof(struct) + getattr(type(struct), name).offset
+
+
 class GfStatsCopyArgs(C.Structure):
     _fields_ = [("src", P), ("dst", P), ("event", P)]
 
@@ -320,6 +344,7 @@ class Backend:
     device_type = "cuda"
 
     tracer = None  # set by _trace.StepTrace while it records a step
+    graph_enabled = False   # GF_GRAPH=1 (HipBackend): recorded steps replay as one hipGraphLaunch (measured slower, see gf_step.h)
 
     def _note_call(self, args) -> None:
         """A phase call outside a recorded step's replay.  If its descriptor belongs to a live recorded step (`watched`), that
@@ -339,6 +364,10 @@ class Backend:
         raise NotImplementedError
 
     def run_ops(self, ops, n: int) -> None:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def replay_step(self, replay, actions_ptr: int, params, num_params: int) -> None:  # pragma: no cover - interface
+        """Apply a recorded step's patch table, then replay its ops (gf_replay_step)."""
         raise NotImplementedError
 
     def event_create(self):
@@ -395,6 +424,9 @@ class HipBackend(Backend):
         self.lib.gf_build_info.restype = C.c_char_p
         self.lib.gf_run_ops.restype = C.c_int
         self.lib.gf_run_ops.argtypes = [C.POINTER(GfOp), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        self.lib.gf_replay_step.restype = C.c_int
+        self.lib.gf_replay_step.argtypes = [C.POINTER(GfReplay), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        self._failed = C.c_int(-1)
         self.lib.gf_run_ops_graph.restype = C.c_int
         self.lib.gf_run_ops_graph.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GfOp), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         self.lib.gf_graph_destroy.restype = C.c_int
@@ -403,6 +435,7 @@ class HipBackend(Backend):
             self.lib.gf_set_option(GF_OPT_CHAIN, 0)
         if os.environ.get("GF_GRAPH", "0") == "1":   # opt-in: measured slower than plain launches (gf_step.h, GF_OPT_GRAPH)
             self.lib.gf_set_option(GF_OPT_GRAPH, 1)
+            self.graph_enabled = True
         self.lib.gf_stats_pack.restype = C.c_int
         self.lib.gf_stats_pack.argtypes = [C.POINTER(GfStatsPackArgs), C.c_void_p]
         self.lib.gf_post_physics_check.restype = C.c_int
@@ -453,6 +486,11 @@ class HipBackend(Backend):
         if rc != 0:
             self._raise(f"run_ops[op {failed.value}]", rc)
 
+    def replay_step(self, replay, actions_ptr: int, params, num_params: int) -> None:
+        rc = self.lib.gf_replay_step(replay, actions_ptr, params, num_params, self._stream(), self._failed)
+        if rc != 0:
+            self._raise(f"replay_step[op {self._failed.value}]", rc)
+
     def run_ops_graph(self, cache, ops, n: int) -> None:
         """``cache``: a ctypes c_void_p owned by the caller (the recorded step); see gf_run_ops_graph."""
         failed = C.c_int(-1)
@@ -497,6 +535,8 @@ class HipBackend(Backend):
             self._raise("stats_clear", rc)
 
     def set_option(self, option: int, value: int) -> None:
+        if option == GF_OPT_GRAPH:
+            self.graph_enabled = bool(value)
         rc = self.lib.gf_set_option(option, value)
         if rc != 0:
             self._raise("set_option", rc)

@@ -62,7 +62,8 @@ class StepTrace:
         self.tail_python = tail_python
         self.backend = env.backend
         self.epoch = env._trace_epoch
-        self.patches: list[Callable] = []
+        self.patches: list[Callable] = []   # Python-side per-step work that has Python semantics (live ranges, log registration)
+        self.native: list = []              # GfReplayPatch entries: every per-step descriptor field, applied by gf_replay_step
         self.afters: list = []   # (index of the op it follows, callable)
         self.splits: list = []   # (index of the op it precedes, callable): Python that must run in the middle of the step
         self._cur_op = 0
@@ -93,7 +94,7 @@ class StepTrace:
             if pre is not None:
                 assert idx < first_post, "a phase with Python-level terms cannot be part of the fused launch"
                 self.splits.append((self._cur_op, pre))
-        self.patches.extend(self._gait_swaps)   # after the gait managers' own patches (those refill the descriptors)
+        self.native.extend(self._gait_swaps)   # after the gait managers' own patches (those refill the descriptors)
         # single process: statistics go to a device ring slot per step (no memset, no copy); with a process group the
         # per-step all-reduce path is kept (clear op here, packed + reduced + copied by StepStats.snapshot)
         self.use_ring = stats.group is None
@@ -116,6 +117,21 @@ class StepTrace:
                 self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_PACK, C.addressof(self.pack_args)
                 k += 1
         self.n_ops = k
+        # the statistics ring slots of a step arrive as call parameters (cur, next-to-zero, previous, its vector row, last_reset)
+        self.params = (C.c_void_p * 5)()
+        if self.use_ring:
+            P = nat.GfReplayPatch
+            for a in self.stat_fields:
+                self.native.append(P(nat.GF_PATCH_PARAM, 0, nat.field_addr(a, "stats"), None, None))
+            aa = self.action_args
+            for idx, name in ((1, "stats_zero"), (2, "stats_fold_src"), (3, "stats_fold_dst"), (4, "stats_last_reset")):
+                self.native.append(P(nat.GF_PATCH_PARAM, idx, nat.field_addr(aa, name), None, None))
+            self._last_reset_ptr = stats.last_reset.data_ptr()
+        # gf_replay_step: the whole table, then the ops, in ONE native call (the patch-only variant serves steps whose ops are
+        # replayed in pieces around Python-level terms, or as a hipGraph)
+        self.patch_table = (nat.GfReplayPatch * max(1, len(self.native)))(*self.native)
+        self.replay_desc = nat.GfReplay(C.addressof(self.ops), k, len(self.native), C.addressof(self.patch_table), C.addressof(env._rng_c))
+        self.patch_desc = nat.GfReplay(None, 0, len(self.native), C.addressof(self.patch_table), C.addressof(env._rng_c))
         #: the descriptors this recording froze: a phase call that goes through one of them from now on (a manager method the
         #: training script calls between steps) makes the recording stale (Backend._note_call, fresh())
         self.arg_set = {C.addressof(c[1]) for c in calls}
@@ -210,18 +226,15 @@ class StepTrace:
             refs.gait_reset[g] = C.addressof(r[1])
             mgr = s[2]
             refs.gait_flags_next[g] = mgr._wave_flags_next.data_ptr()
-
             # One launch reads the swing / stance bytes the previous step left and writes the bytes of the state it leaves into
-            # the manager's OTHER buffer (GfPostRefs): point the descriptors at the two buffers, then swap the manager's view
-            def swap(_actions, mgr=mgr, g=g, sa=s[1], ra=r[1], rw=reward_args, refs=refs):
-                cur, nxt = mgr._wave_flags, mgr._wave_flags_next
-                sa.wave_flags = ra.wave_flags = cur.data_ptr()
-                if rw is not None and rw.gait_wave_flags:
-                    rw.gait_wave_flags = cur.data_ptr()
-                refs.gait_flags_next[g] = nxt.data_ptr()
-                mgr._wave_flags, mgr._wave_flags_next = nxt, cur
-
-            self._gait_swaps.append(swap)
+            # the manager's OTHER buffer (GfPostRefs): rotate the manager's two buffers, the other descriptors follow
+            P = nat.GfReplayPatch
+            sw = [P(nat.GF_PATCH_ROTATE, 0, nat.field_addr(s[1], "wave_flags"), C.addressof(refs) + nat.GfPostRefs.gait_flags_next.offset + 8 * g,
+                    C.addressof(mgr._flags_rotor)),
+                  P(nat.GF_PATCH_COPY, 0, nat.field_addr(r[1], "wave_flags"), None, nat.field_addr(s[1], "wave_flags"))]
+            if reward_args is not None and reward_args.gait_wave_flags:
+                sw.append(P(nat.GF_PATCH_COPY, 0, nat.field_addr(reward_args, "gait_wave_flags"), None, nat.field_addr(s[1], "wave_flags")))
+            self._gait_swaps.extend(sw)
         refs.num_command, refs.num_observe = len(steps), len(obs)
         for c, (s, r) in enumerate(zip(steps, resets)):
             refs.command_step[c] = C.addressof(s[1])
@@ -233,40 +246,39 @@ class StepTrace:
     # -- per-phase hooks ----------------------------------------------------------------------------
     def _hooks(self, fn, args, owner):
         env = self.env
+        P = nat.GfReplayPatch
         if fn == "action_step":
-            def patch(actions, a=args, owner=owner):
-                a.actions_in = actions.data_ptr()
-                owner._raw_actions = actions
-            self.patches.append(patch)
+            self.action_owner = owner
+            self.native.append(P(nat.GF_PATCH_ACTIONS, 0, nat.field_addr(args, "actions_in"), None, None))
             if not owner._quiet_action_errors:
                 self.afters.append((self._cur_op, owner._watch_flags))
         elif fn == "synth_scene_step":
-            def patch(_actions, a=args, scene=owner):
-                a.tick = scene.tick
-                scene.tick += 1
-            self.patches.append(patch)
+            self.native.append(P(nat.GF_PATCH_COUNTER, 0, nat.field_addr(args, "tick"), None, C.addressof(owner._tick_c)))
         elif fn == "termination_step":
             self.afters.append((self._cur_op, owner.manager._publish))
         elif fn == "reward_step":
             pass
         elif fn in ("command_step", "gait_step"):
             self.patches.append(owner._trace_patch(args))
+            self.native.extend(owner._trace_native(args))
         elif fn == "masked_reset":
-            def patch(_actions, a=args, env=env):
-                a.stream = env.next_stream()
-                rm = env.managers["reward"]
-                if rm is not None and rm.enabled and rm.logging_enabled:
-                    rm._register_log()
-            self.patches.append(patch)
+            self.native.append(P(nat.GF_PATCH_STREAM, 0, nat.field_addr(args, "stream"), None, None))
+            rm = env.managers["reward"]
+            if rm is not None:
+                def patch(_actions, rm=rm):
+                    if rm.enabled and rm.logging_enabled:
+                        rm._register_log()
+                self.patches.append(patch)
             self.afters.append((self._cur_op, env._after_masked_reset_traced))
         elif fn == "observe":
-            self.patches.append(owner._trace_patch(args))
+            self.native.extend(owner._trace_native(args))
             self.afters.append((self._cur_op, owner._trace_after))
         elif fn == "contact_step":
             pass
         elif fn == "rollout_write":
             pol = next(m for m in env.managers["observation"] if m.name == owner.obs_name)
-            self.patches.append(owner._trace_patch(args, pol._args))
+            self.patches.append(owner._trace_patch(args))
+            self.native.extend(owner._trace_native(args, pol._args))
         else:
             raise RuntimeError(f"untraceable phase {fn}")
 
@@ -274,14 +286,15 @@ class StepTrace:
     def replay(self, actions):
         env = self.env
         env._begin_step_light()
+        self.action_owner._raw_actions = actions
         for p in self.patches:
             p(actions)
         snap = None
+        pr = self.params
         if self.use_ring:
             cur, nxt, prev, prev_vec, snap = env.stats.ring_next()
-            aa = self.action_args
-            aa.stats_fold_src, aa.stats_fold_dst = prev, prev_vec
-            aa.stats_last_reset = env.stats.last_reset.data_ptr() if prev is not None else None
+            pr[0], pr[1], pr[2], pr[3] = cur, nxt, prev, prev_vec
+            pr[4] = self._last_reset_ptr if prev is not None else None
         else:
             slot, cur, nxt, vec, fold = env.stats.vec_ring_next()
             if self.fold_mode:
@@ -293,12 +306,14 @@ class StepTrace:
                 aa.stats_last_reset = None
             else:
                 self.pack_args.src, self.pack_args.dst = cur, vec
-        for a in self.stat_fields:
-            a.stats = cur
-        self.action_args.stats_zero = nxt
+            for a in self.stat_fields:
+                a.stats = cur
+            self.action_args.stats_zero = nxt
+        aptr = actions.data_ptr()
         done = 0        # afters already run
         ticked = False  # the scene op has been enqueued and the views cache invalidated for it
         if self.segments:
+            self.backend.replay_step(self.patch_desc, aptr, pr, 5)
             for first, count, sub, pre in self.segments:
                 if pre is not None:
                     # the ordinary path has finished every earlier phase — launch AND Python bookkeeping — when it calls a
@@ -312,10 +327,11 @@ class StepTrace:
                     pre()
                 if count:
                     self.backend.run_ops(sub, count)
-        elif self.graph is not None:
+        elif self.graph is not None and self.backend.graph_enabled:
+            self.backend.replay_step(self.patch_desc, aptr, pr, 5)
             self.backend.run_ops_graph(self.graph, self.ops, self.n_ops)
         else:
-            self.backend.run_ops(self.ops, self.n_ops)
+            self.backend.replay_step(self.replay_desc, aptr, pr, 5)   # patch table + ops: the one native call of the step
         if not self.use_ring:
             snap = env.stats.vec_ring_reduce(slot)  # the single collective of the path, asynchronous
         if not ticked:

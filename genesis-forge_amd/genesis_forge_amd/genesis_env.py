@@ -14,6 +14,7 @@ kernels:
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import Any, Literal, Optional
 
@@ -95,7 +96,8 @@ class GenesisEnv:
         self._views_cache: dict = {}
         self._rng_seed = 0x5EED
         self.env_offset = 0            # global index of local env 0 when envs are sharded over ranks (distributed.attach)
-        self._rng_stream = 0           # every stochastic native call takes a fresh stream id
+        self._rng_c = C.c_uint64(0)    # every stochastic native call takes a fresh stream id; a ctypes cell so that a recorded
+        #                                step's native patch table (GfReplay.rng_stream) advances the very same counter
         self._draws: dict = {}         # parity mode: {"name": tensor of U[0,1)} consumed by the next call
         self._done_mask: Optional[torch.Tensor] = None
         self._trace = None
@@ -176,9 +178,18 @@ class GenesisEnv:
         self._trace_epoch += 1
         self._last_signature = None
 
+    @property
+    def _rng_stream(self) -> int:
+        return self._rng_c.value
+
+    @_rng_stream.setter
+    def _rng_stream(self, v: int) -> None:
+        self._rng_c.value = v
+
     def next_stream(self) -> int:
-        self._rng_stream += 1
-        return self._rng_stream
+        v = self._rng_c.value + 1
+        self._rng_c.value = v
+        return v
 
     def set_draws(self, **draws: torch.Tensor) -> None:
         """Parity mode: supply the U[0,1) draws the next stochastic phase calls consume instead of Philox.

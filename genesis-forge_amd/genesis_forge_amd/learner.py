@@ -87,12 +87,15 @@ class RolloutStorage:
         self._keep = (obs, reward, terminated, truncated)
         self.env.backend.call("rollout_write", a, owner=self)
 
-    def _trace_patch(self, args, obs_args):
-        def patch(_actions, a=args, oa=obs_args, self=self):
-            a.obs = oa.obs          # the slot the observation kernel writes this step (patched before this one runs)
+    def _trace_patch(self, args):
+        def patch(_actions, a=args, self=self):
             self._next_rows(a)
 
         return patch
+
+    def _trace_native(self, args, obs_args) -> list:
+        """`obs` follows the slot the observation kernel writes this step (that manager's rotation comes earlier in the table)."""
+        return [nat.GfReplayPatch(nat.GF_PATCH_COPY, 0, nat.field_addr(args, "obs"), None, nat.field_addr(obs_args, "obs"))]
 
 
 class ActorCriticMLP(torch.nn.Module):

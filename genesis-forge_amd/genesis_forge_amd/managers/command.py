@@ -172,9 +172,12 @@ class CommandManager(BaseManager):
                 for i, r in enumerate(self._ranges()):
                     a.lo[i], a.hi[i] = float(r[0]), float(r[1])
                 a.resample_steps = self._resample_steps   # `resample_time_sec` is a live property (command_manager.py:121-130)
-            a.stream = env.next_stream()
 
         return patch
+
+    def _trace_native(self, args) -> list:
+        """The launch's Philox stream as a native patch (what resample draws with env.next_stream())."""
+        return [nat.GfReplayPatch(nat.GF_PATCH_STREAM, 0, nat.field_addr(args, "stream"), None, None)]
 
     def use_gamepad(self, gamepad, range_axis):
         """Map gamepad axes onto the command ranges (command_manager.py:209-288).  The HID reader itself is

@@ -102,16 +102,30 @@ class GaitCommandManager(CommandManager):
         # per block of 64 envs: bit 2f / 2f+1 = some env has foot f in swing / stance (GfGaitArgs.wave_flags); the all-zero
         # initial state is "swing" for every foot.  Padded with zeros to whole 32-bit words.
         blocks = (n + 63) // 64
-        self._wave_flags = torch.zeros((blocks + 3) // 4 * 4, dtype=torch.uint8, device=gs.device)
-        self._wave_flags[:blocks] = 0x55
-        #: the fused post-physics launch writes the bytes of the state it leaves here and the two buffers swap (GfPostRefs)
-        self._wave_flags_next = self._wave_flags.clone()
+        flags = torch.zeros((blocks + 3) // 4 * 4, dtype=torch.uint8, device=gs.device)
+        flags[:blocks] = 0x55
+        #: two buffers: the fused post-physics launch reads the current one and writes the bytes of the state it leaves into the
+        #: other, then they swap (GfPostRefs.gait_flags_next); the rotor is shared with a recorded step's native patch table
+        self._flag_bufs = [flags, flags.clone()]
+        self._flags_rotor = nat.GfRotor()
+        self._flags_rotor.cur, self._flags_rotor.count = 0, 2
+        for i, b in enumerate(self._flag_bufs):
+            self._flags_rotor.slot[i] = b.data_ptr()
         #: reproduce the reference's env-0 index-list quirk in gait_phase_reward (see GF_R_GAIT_PHASE in gf_step.h)
         self.reference_env0_quirk = True
         self._gait_args = {m: nat.GfGaitArgs() for m in (nat.GF_CMD_STEP, nat.GF_CMD_MASKED, nat.GF_CMD_ALL)}
         self._feet_cm = None
         self.gait_phase_reward = _RewardMethod(self, "gait_phase_reward", self._spec_gait_phase, self._gait_phase_reward_torch)
         self.foot_height_reward = _RewardMethod(self, "foot_height_reward", self._spec_foot_height, self._foot_height_reward_torch)
+
+    @property
+    def _wave_flags(self) -> torch.Tensor:
+        """The swing / stance bytes of the current state."""
+        return self._flag_bufs[self._flags_rotor.cur]
+
+    @property
+    def _wave_flags_next(self) -> torch.Tensor:
+        return self._flag_bufs[1 - self._flags_rotor.cur]
 
     # -- buffers: views into the state rows (attribute names of gait_command_manager.py:110-125) ------------------------
     @property
@@ -266,11 +280,14 @@ class GaitCommandManager(CommandManager):
 
         def patch(_actions, a=args, self=self, mode=mode):
             self._fill(a, mode)
-            a.stream = self.env.next_stream()
             if mode == nat.GF_CMD_STEP:
                 self._log_metrics()
 
         return patch
+
+    def _trace_native(self, args) -> list:
+        """The launch's Philox stream as a native patch (what `_launch_gait` draws with env.next_stream())."""
+        return [nat.GfReplayPatch(nat.GF_PATCH_STREAM, 0, nat.field_addr(args, "stream"), None, None)]
 
     def use_gamepad(self, gamepad):
         raise NotImplementedError("gamepad HID input is outside the manager-step pipeline (SURVEY.md §2 row 19)")

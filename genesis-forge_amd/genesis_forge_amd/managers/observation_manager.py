@@ -27,6 +27,7 @@ traffic per env instead of the ``(2H-1)*O`` a newest-first concatenation costs (
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Any, Callable, Optional, TypedDict
 
@@ -74,7 +75,7 @@ class ObservationManager(BaseManager):
         self._output = output if output is not None else type(self).default_output
         if self._output not in ("fresh", "static", "ring"):
             raise ValueError("output must be 'fresh', 'static' or 'ring'")
-        self._ring_calls = 0      # observations produced in ring mode (slot = (H - calls % H) % H)
+
         self.noise = noise
         self._observation_size = 1
         self._observation_space = None
@@ -91,7 +92,8 @@ class ObservationManager(BaseManager):
         self._plan: list = []
         self._args = nat.GfObservationArgs()
         self._bufs: list[torch.Tensor] = []
-        self._cur = 0
+        self._rotor = nat.GfRotor()           # which output slot is current (shared with a recorded step's native patch table)
+        self._ring_clock = nat.GfRingClock()  # observations produced in ring mode (slot = (H - calls % H) % H)
 
     def _mark_dirty(self):
         self._dirty = True
@@ -130,7 +132,10 @@ class ObservationManager(BaseManager):
         self._observation_size = width * self._history_len
         self._observation_space = Box(low=-np.inf, high=np.inf, shape=(self._observation_size,), dtype=np.float32)
         self._bufs = [torch.zeros((env.num_envs, self._observation_size), device=gs.device, dtype=gs.tc_float) for _ in range(_OBS_RING)]
-        self._cur = 0
+        self._rotor.cur, self._rotor.count = 0, _OBS_RING
+        for i, b in enumerate(self._bufs):
+            self._rotor.slot[i] = b.data_ptr()
+        self._ring_clock.calls, self._ring_clock.length = 0, self._history_len
         self._dirty = True
 
     def _call_item(self, name, cfg) -> torch.Tensor:
@@ -253,7 +258,8 @@ class ObservationManager(BaseManager):
     def history_head(self) -> int:
         """Frame slot of the newest frame in the ``output="ring"`` buffer (after the most recent observation)."""
         H = self._history_len
-        return (H - (self._ring_calls - 1) % H) % H if self._ring_calls else 0
+        calls = self._ring_clock.calls
+        return (H - (calls - 1) % H) % H if calls else 0
 
     def history_order(self) -> list:
         """Frame slots newest first: ``history_head``, then upwards, wrapping."""
@@ -269,19 +275,23 @@ class ObservationManager(BaseManager):
 
     def _rotate_ring(self, a) -> torch.Tensor:
         if self._in_place:
-            H = self._history_len
-            a.history_ring = (H - self._ring_calls % H) % H + 1
-            self._ring_calls += 1
+            H, ck = self._history_len, self._ring_clock
+            a.history_ring = (H - ck.calls % H) % H + 1
+            ck.calls += 1
             a.prev_obs = None
             a.obs = self._bufs[0].data_ptr()
             return self._bufs[0]
         a.history_ring = 0
-        prev = self._bufs[self._cur]
-        self._cur = (self._cur + 1) % _OBS_RING
-        out = self._bufs[self._cur]
+        ro = self._rotor
+        prev = self._bufs[ro.cur]
+        ro.cur = (ro.cur + 1) % _OBS_RING
+        out = self._bufs[ro.cur]
         a.prev_obs = prev.data_ptr() if self._history_len > 1 else None
         a.obs = out.data_ptr()
         return out
+
+    def _current_out(self) -> torch.Tensor:
+        return self._bufs[0] if self._in_place else self._bufs[self._rotor.cur]
 
     def _bind_exts(self, a, keep: list) -> None:
         """Evaluate the items no kernel opcode covers (user callables) and hand their [N,w] columns to the descriptor."""
@@ -308,15 +318,22 @@ class ObservationManager(BaseManager):
 
         return pre
 
-    def _trace_patch(self, args):
-        env = self.env
-
-        def patch(_actions, a=args, env=env, self=self):
-            a.stream = env.next_stream()
-            self._pending_out = self._rotate_ring(a)
-
-        return patch
+    def _trace_native(self, args) -> list:
+        """Recorded step: the per-step fields of this manager's launch as native patches (GfReplayPatch) — the noise stream and
+        the output slot rotation / ring slot, exactly what the ordinary path does in get_observations()."""
+        P = nat.GfReplayPatch
+        out = [P(nat.GF_PATCH_STREAM, 0, nat.field_addr(args, "stream"), None, None)]
+        if self._in_place:
+            args.prev_obs, args.obs = None, self._bufs[0].data_ptr()
+            out.append(P(nat.GF_PATCH_RING_SLOT, 0, nat.field_addr(args, "history_ring"), None, C.addressof(self._ring_clock)))
+        else:
+            args.history_ring = 0
+            out.append(P(nat.GF_PATCH_ROTATE, 0, nat.field_addr(args, "prev_obs") if self._history_len > 1 else None,
+                         nat.field_addr(args, "obs"), C.addressof(self._rotor)))
+        return out
 
     def _trace_after(self) -> None:
         """Recorded step, after the launches have been enqueued: publish this step's observation (a fresh copy by default)."""
-        self.env._extras["observations"][self._name] = self._hand_out(self._pending_out)
+        out = self._current_out()
+        self._last_out = out
+        self.env._extras["observations"][self._name] = self._hand_out(out)

@@ -12,6 +12,8 @@ let the reset phase run without the ``nonzero()`` host sync real Genesis setters
 """
 from __future__ import annotations
 
+import ctypes as C
+
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -401,7 +403,7 @@ class SyntheticScene:
         self.entities: list = []
         self.robot: Optional[SyntheticEntity] = None
         self._n_links = 0
-        self.tick = 0
+        self._tick_c = C.c_uint64(0)   # a ctypes cell: a recorded step's native patch table advances it (GF_PATCH_COUNTER)
         self.rigid_solver = self
         self.collider = _Collider(self)
         self._args = nat.GfSynthSceneArgs()
@@ -488,6 +490,14 @@ class SyntheticScene:
             r.links_vel = self.links_vel_all[:, s:s + r.n_links]
             r.links_pos = self.links_pos_all[:, s:s + r.n_links]
         self.tick += 1
+
+    @property
+    def tick(self) -> int:
+        return self._tick_c.value
+
+    @tick.setter
+    def tick(self, v: int) -> None:
+        self._tick_c.value = v
 
     # viewer / debug API accepted and ignored
     def draw_debug_arrow(self, *a, **k):

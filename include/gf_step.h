@@ -707,6 +707,47 @@ typedef struct GfStatsCopyArgs {
 } GfStatsCopyArgs;
 
 int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed_index);
+
+/* Recorded step, patched natively: the few descriptor fields that change from one step to the next are described ONCE as a
+ * patch table (which host address receives what), and a step is a single call — apply the table, then gf_run_ops — instead of
+ * a Python closure per phase (managed_env.py:274-334 has no counterpart: the reference re-marshals every op every step).
+ * All state lives in caller-owned memory (the descriptors, the counters and rotors the table points at): the call itself is
+ * stateless and re-entrant per recorded step. */
+enum {
+    GF_PATCH_ACTIONS = 1,    /* *(const void**)target = actions                                    (the policy output of this step) */
+    GF_PATCH_STREAM = 2,     /* *(uint64_t*)target = ++*rng_stream                                 (Philox stream ids, in draw order) */
+    GF_PATCH_COUNTER = 3,    /* *(uint64_t*)target = (*(uint64_t*)aux)++                           (scene tick) */
+    GF_PATCH_ROTATE = 4,     /* r = (GfRotor*)aux: if target: *(void**)target = r->slot[r->cur]; r->cur = (r->cur + 1) % r->count;
+                                if target2: *(void**)target2 = r->slot[r->cur]                     (output slots, ping-pong buffers) */
+    GF_PATCH_PARAM = 5,      /* *(const void**)target = params[index]                              (statistics ring slots) */
+    GF_PATCH_COPY = 6,       /* *(uint64_t*)target = *(const uint64_t*)aux                         (a field that follows another) */
+    GF_PATCH_RING_SLOT = 7   /* c = (GfRingClock*)aux: *(int32_t*)target = (c->length - c->calls % c->length) % c->length + 1; ++c->calls
+                                                                                                   (GfObservationArgs.history_ring) */
+};
+typedef struct GfRotor {
+    int32_t cur;
+    int32_t count;           /* 1..8 */
+    void* slot[8];
+} GfRotor;
+typedef struct GfRingClock {
+    int32_t calls;
+    int32_t length;
+} GfRingClock;
+typedef struct GfReplayPatch {
+    int32_t kind;            /* GF_PATCH_* */
+    int32_t index;           /* GF_PATCH_PARAM */
+    void* target;
+    void* target2;
+    void* aux;
+} GfReplayPatch;
+typedef struct GfReplay {
+    const GfOp* ops;         /* may be NULL / num_ops 0: patch only (the caller then replays the ops in pieces) */
+    int32_t num_ops;
+    int32_t num_patches;
+    const GfReplayPatch* patches;
+    uint64_t* rng_stream;    /* the env's stream counter (GF_PATCH_STREAM pre-increments it) */
+} GfReplay;
+int gf_replay_step(const GfReplay* r, const void* actions, const void* const* params, int num_params, void* stream, int* failed_index);
 /* The same replay as ONE hipGraphLaunch: the first call builds a linear hipGraph of the step's kernel launches, later calls
  * refresh every node's kernel arguments in place (the descriptors change from step to step: action pointer, RNG streams,
  * ring slots) and launch the graph — the host pays one graph launch instead of one launch per kernel.  *cache is an opaque

@@ -1182,6 +1182,60 @@ GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
     return GF_OK;
 }
 
+
+/* the patch table of a recorded step (gf_step.h: GfReplay) */
+static int replay_patch(const GfReplay* r, const void* actions, const void* const* params, int num_params) {
+    if (!r || (r->num_patches > 0 && !r->patches)) return GF_E_NULL;
+    for (int i = 0; i < r->num_patches; ++i) {
+        const GfReplayPatch* p = &r->patches[i];
+        switch (p->kind) {
+            case GF_PATCH_ACTIONS:
+                if (!p->target) return GF_E_NULL;
+                *(const void**)p->target = actions;
+                break;
+            case GF_PATCH_STREAM:
+                if (!p->target || !r->rng_stream) return GF_E_NULL;
+                *(uint64_t*)p->target = ++*r->rng_stream;
+                break;
+            case GF_PATCH_COUNTER:
+                if (!p->target || !p->aux) return GF_E_NULL;
+                *(uint64_t*)p->target = (*(uint64_t*)p->aux)++;
+                break;
+            case GF_PATCH_ROTATE: {
+                GfRotor* ro = (GfRotor*)p->aux;
+                if (!ro || ro->count < 1 || ro->count > 8 || ro->cur < 0 || ro->cur >= ro->count) return GF_E_RANGE;
+                if (p->target) *(void**)p->target = ro->slot[ro->cur];
+                ro->cur = (ro->cur + 1) % ro->count;
+                if (p->target2) *(void**)p->target2 = ro->slot[ro->cur];
+            } break;
+            case GF_PATCH_PARAM:
+                if (!p->target) return GF_E_NULL;
+                if (p->index < 0 || p->index >= num_params || !params) return GF_E_RANGE;
+                *(const void**)p->target = params[p->index];
+                break;
+            case GF_PATCH_COPY:
+                if (!p->target || !p->aux) return GF_E_NULL;
+                *(uint64_t*)p->target = *(const uint64_t*)p->aux;
+                break;
+            case GF_PATCH_RING_SLOT: {
+                GfRingClock* c = (GfRingClock*)p->aux;
+                if (!p->target || !c || c->length < 1) return GF_E_RANGE;
+                *(int32_t*)p->target = (c->length - c->calls % c->length) % c->length + 1;
+                ++c->calls;
+            } break;
+            default: return GF_E_OPCODE;
+        }
+    }
+    return GF_OK;
+}
+
+GFO_EXPORT int gfo_replay_step(const GfReplay* r, const void* actions, const void* const* params, int num_params, int* failed_index) {
+    if (failed_index) *failed_index = -1;
+    const int rc = replay_patch(r, actions, params, num_params);
+    if (rc != GF_OK || !r->ops || r->num_ops <= 0) return rc;
+    return gfo_run_ops(r->ops, r->num_ops, failed_index);
+}
+
 GFO_EXPORT int gfo_abi_version(void) { return GF_ABI_VERSION; }
 GFO_EXPORT int gfo_sizeof(int which) {
     switch (which) {

@@ -22,6 +22,8 @@ class OracleBackend(nat.Backend):
         self.lib.gfo_stats_clear.argtypes = [C.c_void_p]
         self.lib.gfo_run_ops.restype = C.c_int
         self.lib.gfo_run_ops.argtypes = [C.POINTER(nat.GfOp), C.c_int, C.POINTER(C.c_int)]
+        self.lib.gfo_replay_step.restype = C.c_int
+        self.lib.gfo_replay_step.argtypes = [C.POINTER(nat.GfReplay), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         self.calls = []
         self.replays = 0
 
@@ -55,3 +57,11 @@ class OracleBackend(nat.Backend):
         rc = self.lib.gfo_run_ops(ops, n, C.byref(failed))
         if rc != 0:
             raise nat.GfError(f"gfo_run_ops failed at op {failed.value}: {nat.GF_ERRORS.get(rc, rc)}")
+
+    def replay_step(self, replay, actions_ptr, params, num_params):
+        if replay.num_ops > 0:
+            self.replays += 1
+        failed = C.c_int(-1)
+        rc = self.lib.gfo_replay_step(replay, actions_ptr, params, num_params, C.byref(failed))
+        if rc != 0:
+            raise nat.GfError(f"gfo_replay_step failed at op {failed.value}: {nat.GF_ERRORS.get(rc, rc)}")
