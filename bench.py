@@ -214,8 +214,10 @@ def parse_args(argv):
     ap.add_argument("--global-envs", type=int, default=65536, help="total envs (strong scaling)")
     ap.add_argument("--config", default="go2_cmd", help="workload: go2_cmd (BASELINE.json's headline config) or another key of "
                                                         "genesis_forge_amd.tasks.BASELINE_CONFIGS (gait = config 5, humanoid = config 4)")
-    ap.add_argument("--reduce-every", type=int, default=1,
-                    help="recorded steps per logging all-reduce (world > 1).  1 = one asynchronous all-reduce per step, log reads rank-local")
+    ap.add_argument("--reduce-every", type=int, default=0,
+                    help="recorded steps per logging all-reduce (world > 1): the statistics rows of K consecutive steps travel as ONE all-reduce "
+                         "(K x 392 B).  0 (default) = 32 — the benchmark loop is lock-step on every rank, which is what K > 1 asks for "
+                         "(distributed.attach); 1 = one asynchronous all-reduce per step, log reads rank-local (the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 4096 / 16384-env side measurements")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the 1 048 576-env roofline_hbm measurement")
@@ -224,6 +226,9 @@ def parse_args(argv):
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="the stamping pass stamps every k-th launch: a stamped launch blocks the host for ~12 us and drains the queue, "
                          "so the launches between two stamps let the pipeline refill")
+    ap.add_argument("--profile-presleep-cycles", type=int, default=150000,
+                    help="GPU spin (torch.cuda._sleep) enqueued in front of every stamped step of the stamping pass so that the stamped "
+                         "kernel runs behind queued work as in the timed loop; 0 = off")
     return ap.parse_args(argv)
 
 
@@ -272,6 +277,8 @@ def run_rank(args):
     backend = nat.get_backend()
     sync = (lambda: None) if rehearsal else torch.cuda.synchronize
 
+    if args.reduce_every <= 0:
+        args.reduce_every = 32
     if args.scaling == "strong":
         start, N = gfd.shard(args.global_envs, rank, world)
         global_envs = args.global_envs
@@ -318,6 +325,12 @@ def run_rank(args):
         backend.set_option(nat.GF_OPT_PROFILE_STRIDE, stride)
         backend.profile_begin(phase, args.profile_samples)
         for i in range(stride * args.profile_samples):
+            if i % stride == 0 and args.profile_presleep_cycles > 0:
+                # A stamped launch blocks the host for ~12 us; at 65 536 envs the GPU would drain its queue meanwhile and the stamped
+                # kernel would start on an idle GPU (its dispatch then includes the launch ramp that back-to-back kernels hide).
+                # A spin kernel in front of the stamped step keeps the stream busy while the host enqueues it, so the step's three
+                # kernels run back to back exactly as in the timed loop.  It touches no memory (caches are as the step left them).
+                torch.cuda._sleep(args.profile_presleep_cycles)
             e.step(a[i % len(a)])
         sync()
         ms, cnt = backend.profile_end()
@@ -352,9 +365,12 @@ def run_rank(args):
             roof = dict({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel": kernel,
                          "algorithmic_bytes_per_env": per_env, "algorithmic_bytes_per_launch": per_env * N, "num_envs": N,
                          "launch_sampling": f"every {max(1, args.profile_stride)}th launch of a separate stamping loop after the timed batches",
-                         "note": "dispatch-timestamp HIP events; a stamped launch starts on a drained queue and runs ~1-2 us longer than in "
-                                 "the free-running loop (compare profiles/*kernel_stats.csv), so achieved / frac are lower bounds; "
-                                 "traffic (PMC) is collected by separate rocprofv3 --pmc passes, see profiles/ and DESIGN.md"}, **m)
+                         "note": "dispatch-timestamp HIP events on the launch stream (a GPU spin in front of each stamped step keeps the queue "
+                                 "from draining while the host pays for the stamped launch).  An event-stamped dispatch measures ~1.5 us "
+                                 "(65 536 envs) / ~7 us (1 M envs) longer than the same kernel in the rocprofv3 --kernel-trace --stats "
+                                 "summary of this command (profiles/): it completes with a system-scope release that back-to-back launches "
+                                 "do not pay, so achieved / frac are lower bounds.  traffic (PMC) comes from separate rocprofv3 --pmc "
+                                 "passes (profiles/, DESIGN.md) and is not repeated here"}, **m)
 
     if rank == 0:
         out = {

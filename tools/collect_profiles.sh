@@ -1,0 +1,25 @@
+#!/bin/bash
+# The round's evidence, collected on the GPU box into gpurun_out/ (copy what should be judged into profiles/):
+#   tools/collect_profiles.sh <tag>
+set -e
+tag=$1
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$root"
+python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_steps20.json 2>> gpurun_out/${tag}_bench.err
+python3 tools/bench_configs.py > gpurun_out/${tag}_configs.jsonl 2> gpurun_out/${tag}_configs.err
+GF_OBS_OUTPUT=ring python3 tools/bench_configs.py --configs gait,gait_8192 > gpurun_out/${tag}_configs_ring.jsonl 2>> gpurun_out/${tag}_configs.err
+tools/prof_by_grid.sh ${tag}_bench bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point > /dev/null
+tools/prof_by_grid.sh ${tag}_bench1m bench.py --steps 100 --warmup 10 --num-envs 1048576 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point > /dev/null
+tools/prof_by_grid.sh ${tag}_cfg tools/bench_configs.py > /dev/null
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$root/gpurun_out/${tag}_pmc_${c}_bench" -o pmc -- python3 "$root/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$root/gpurun_out/${tag}_pmc_${c}_bench1m" -o pmc -- python3 "$root/bench.py" --steps 40 --warmup 10 --num-envs 1048576 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$root/gpurun_out/${tag}_pmc_${c}_cfg" -o pmc -- python3 "$root/tools/bench_configs.py" --steps 60 --configs gait,rough_terrain,humanoid > /dev/null 2>&1
+done
+cd "$root"
+for k in bench bench1m cfg; do
+  python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_FETCH_SIZE_$k gpurun_out/${tag}_pmc_WRITE_SIZE_$k > gpurun_out/${tag}_pmc_$k.md
+done
+tail -c 400 gpurun_out/${tag}_bench.json; echo; cat gpurun_out/${tag}_pmc_bench.md | head -8
