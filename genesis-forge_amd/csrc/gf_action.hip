@@ -27,21 +27,27 @@ __device__ __forceinline__ float action_target(float x, float s, float o, float 
     return t;
 }
 
+// `upkeep` leading workgroups do nothing but the statistics ring's housekeeping: zero the NEXT step's slot and fold the PREVIOUS
+// step's shards into its vector row.  The fold is a chain of two scattered loads and a dozen cross-lane shuffles per entry (≈ 2.5 µs):
+// inside the workgroups that also move actions it was those waves' tail, and with it the kernel's (5.8 µs in the benchmark loop at
+// 65 536 envs).  On workgroups of their own it runs beside the main work.  `upkeep` is a multiple of 8, so workgroup b + upkeep still
+// lands on the XCD workgroup b of the scene / post-physics kernels lands on (round-robin placement, see gf_action_step).
+constexpr int kActionUpkeepBlocks = 24;
+
 template <bool VEC4, bool CONST4 = false>
-__global__ __launch_bounds__(256) void action_kernel(const GfActionArgs a, const int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // zero the next step's statistics slot (nobody else touches it during this step)
-    if (a.stats_zero) {
-        constexpr int kWords = (int)(sizeof(GfStepStats) * GF_STATS_SHARDS / 4);
-        for (int64_t w = i; w < kWords; w += (int64_t)gridDim.x * blockDim.x) reinterpret_cast<uint32_t*>(a.stats_zero)[w] = 0u;
+__global__ __launch_bounds__(256) void action_kernel(const GfActionArgs a, const int64_t total, const int upkeep) {
+    if ((int)blockIdx.x < upkeep) {
+        const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x), nt = (int)(upkeep * blockDim.x);
+        if (a.stats_zero) {   // nobody else touches the next slot during this step
+            constexpr int kWords = (int)(sizeof(GfStepStats) * GF_STATS_SHARDS / 4);
+            for (int w = t; w < kWords; w += nt) reinterpret_cast<uint32_t*>(a.stats_zero)[w] = 0u;
+        }
+        if (a.stats_fold_src && a.stats_fold_dst) {   // the previous slot is complete by stream order: one entry per wave
+            for (int v = t / GF_WAVE; v < GF_STATS_VECTOR_LEN; v += nt / GF_WAVE) fold_stats_entry(a.stats_fold_src, a.stats_fold_dst, a.stats_last_reset, v);
+        }
+        return;
     }
-    // fold the previous step's statistics slot (complete by stream order) into its row of the vector ring: one entry per
-    // wave, spread over the first waves of the grid so no single workgroup becomes the kernel's tail
-    if (a.stats_fold_src && a.stats_fold_dst) {
-        const int waves = (int)(gridDim.x * (blockDim.x / GF_WAVE));
-        for (int v = (int)(blockIdx.x * (blockDim.x / GF_WAVE) + threadIdx.x / GF_WAVE); v < GF_STATS_VECTOR_LEN; v += waves)
-            fold_stats_entry(a.stats_fold_src, a.stats_fold_dst, a.stats_last_reset, v);
-    }
+    const int64_t i = (int64_t)(blockIdx.x - upkeep) * blockDim.x + threadIdx.x;
     const int D = a.num_dofs;
     const int mode = a.mode;
     int flags = 0;
@@ -151,6 +157,7 @@ extern "C" __attribute__((visibility("default"))) int gf_action_step(const GfAct
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_ACTION, s);
     scope.begin_bracket();
+    const int upkeep = (a->stats_zero || (a->stats_fold_src && a->stats_fold_dst)) ? gf::kActionUpkeepBlocks : 0;
     if (vec) {
         int64_t lanes = total >> 2;
         if (a->episode_length) {
@@ -166,11 +173,11 @@ extern "C" __attribute__((visibility("default"))) int gf_action_step(const GfAct
         static const bool flat256 = getenv("GF_ACTION_BLOCK256") != nullptr;
         static const int forced = getenv("GF_ACTION_BLOCK") ? atoi(getenv("GF_ACTION_BLOCK")) : 0;   // experiments only
         const int block = forced > 0 ? forced : ((a->num_dofs == 12 && !flat256) ? 192 : 256);
-        if (const4) gf::klaunch(gf::action_kernel<true, true>, dim3(gf::env_grid(lanes, block)), dim3(block), 0, s, *a, total);
-        else gf::klaunch(gf::action_kernel<true>, dim3(gf::env_grid(lanes, block)), dim3(block), 0, s, *a, total);
+        if (const4) gf::klaunch(gf::action_kernel<true, true>, dim3(gf::env_grid(lanes, block) + upkeep), dim3(block), 0, s, *a, total, upkeep);
+        else gf::klaunch(gf::action_kernel<true>, dim3(gf::env_grid(lanes, block) + upkeep), dim3(block), 0, s, *a, total, upkeep);
     } else {
         int64_t lanes = total > a->num_envs ? total : a->num_envs;
-        gf::klaunch(gf::action_kernel<false>, dim3(gf::env_grid(lanes, 256)), dim3(256), 0, s, *a, total);
+        gf::klaunch(gf::action_kernel<false>, dim3(gf::env_grid(lanes, 256) + upkeep), dim3(256), 0, s, *a, total, upkeep);
     }
     return gf::launch_status();
 }

@@ -32,11 +32,14 @@ struct HistBatch {
     f32x4u v[kObsShift];
     uint32_t pure;   // bit k: unit k of the batch is a pure history unit of this lane
 };
-__device__ __forceinline__ void hist_load(HistBatch& b, const GF_GLOBAL float* __restrict__ prev, int first, int units, int O, int OH, const FastDiv& dr) {
+// `stride` = lanes that share the run (the whole 256-thread workgroup, or the 192 lanes of the three waves that shift history while
+// the fourth folds rewards in the fused kernel)
+__device__ __forceinline__ void hist_load(HistBatch& b, const GF_GLOBAL float* __restrict__ prev, int first, int units, int O, int OH, const FastDiv& dr,
+                                          const int stride = kObsBlock) {
     b.pure = 0u;
 #pragma unroll
     for (int k = 0; k < kObsShift; ++k) {
-        const int u = first + k * kObsBlock, uu = u < units ? u : 0;
+        const int u = first + k * stride, uu = u < units ? u : 0;
         const int e = uu << 2, row = dr.div(e), c = e - row * OH;
         const bool pure = u < units && c >= O && c + 3 < OH;
         b.pure |= pure ? 1u << k : 0u;
@@ -44,10 +47,10 @@ __device__ __forceinline__ void hist_load(HistBatch& b, const GF_GLOBAL float* _
         if (pure) b.v[k] = *reinterpret_cast<const GF_GLOBAL f32x4u*>(prev + (e - O));
     }
 }
-__device__ __forceinline__ void hist_store(const HistBatch& b, GF_GLOBAL float* out, int first) {
+__device__ __forceinline__ void hist_store(const HistBatch& b, GF_GLOBAL float* out, int first, const int stride = kObsBlock) {
 #pragma unroll
     for (int k = 0; k < kObsShift; ++k)
-        if ((b.pure >> k) & 1u) *reinterpret_cast<GF_GLOBAL f32x4a*>(out + ((first + k * kObsBlock) << 2)) = f32x4a{b.v[k].x, b.v[k].y, b.v[k].z, b.v[k].w};
+        if ((b.pure >> k) & 1u) *reinterpret_cast<GF_GLOBAL f32x4a*>(out + ((first + k * stride) << 2)) = f32x4a{b.v[k].x, b.v[k].y, b.v[k].z, b.v[k].w};
 }
 
 // … and the units the history batches left: every unit with at least one new-frame column (frame from the LDS tile, the

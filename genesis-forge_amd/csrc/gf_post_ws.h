@@ -527,6 +527,39 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     }
     GF_WSTAMP(4);
 
+    // ---- history shift (H > 1) of every observation manager: it depends on nothing this launch computes, and the reward wave's
+    //      fold is the longest post-barrier role (a chain of per-term loads) — so waves 0, 2 and 3 move the pure history units
+    //      (gf_obs_hist.h) while wave 1 folds; the frame and the units that touch it follow from the LDS tile below
+    auto hist_early = [&](int m, const PostObs& ob, int O, int H) GF_INLINE_LAMBDA {
+        float* const ob_out = UNI(ob.obs);
+        const bool flat = H > 1 && !UNI(ob.ring) && O >= 4 && (reinterpret_cast<uintptr_t>(ob_out) & 15u) == 0;
+        if (!flat || wave == 1) return;
+        const int rows = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
+        const int64_t OH = (int64_t)O * H;
+        GF_GLOBAL float* out = G(ob_out) + n0 * OH;
+        const GF_GLOBAL float* prev = G(UNI(ob.prev)) + n0 * OH;
+        float* const roll_base = UNI(a.roll_obs);
+        GF_GLOBAL float* roll = (roll_base && UNI(a.roll_obs_index) == m) ? G(roll_base) + n0 * OH : nullptr;
+        const int units = (rows * (int)OH) >> 2;
+        const FastDiv dr((int)OH);
+        constexpr int kLanes = 3 * kEnvBlock;
+        const int lid = (wave == 0 ? 0 : wave - 1) * kEnvBlock + lane;
+        HistBatch hb;
+        for (int first = lid; first - lid < units; first += kObsShift * kLanes) {   // wave-uniform trip count
+            hist_load(hb, prev, first, units, O, (int)OH, dr, kLanes);
+            hist_store(hb, out, first, kLanes);
+            if (roll) hist_store(hb, roll, first, kLanes);
+        }
+    };
+    if constexpr (P::kStatic) {
+        static_for<P::n_obs>([&](auto M) GF_INLINE_LAMBDA {
+            constexpr int m_ = decltype(M)::value;
+            if constexpr (P::obs_history[m_] > 1) hist_early(m_, karg.obs[m_], P::obs_width[m_], P::obs_history[m_]);
+        });
+    } else {
+        for (int m = 0; m < n_obs; ++m) hist_early(m, a.obs[m], uni(a.obs[m].width), uni(a.obs[m].history));
+    }
+
     // ---- observations: waves 2 and 3 assemble the tile, all four stream it out ---------------------------------------------------
     auto obs_manager = [&](int m, const PostObs& ob, int O, int H, int n_items, auto&& each_item) GF_INLINE_LAMBDA {
         const int S = O + 1;
@@ -613,16 +646,8 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             // history (H > 1): 16-byte units over the tile's contiguous [rows, O·H] run, whatever O is (gf_obs_hist.h) — the
             // gait task's 62-wide policy frame has no 16-byte aligned rows, the run has
             const bool flat = H > 1 && !ring && O >= 4 && (reinterpret_cast<uintptr_t>(ob_out) & 15u) == 0;
-            if (flat) {
+            if (flat) {   // the pure history units went out above (hist_early); what touches the new frame comes from the tile
                 const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
-                const int units = (rows * (int)OH) >> 2;
-                const FastDiv dr((int)OH);
-                HistBatch hb;
-                for (int first = t; first - t < units; first += kObsShift * kObsBlock) {   // wave-uniform trip count
-                    hist_load(hb, prev, first, units, O, (int)OH, dr);
-                    hist_store(hb, out, first);
-                    if (roll) hist_store(hb, roll, first);
-                }
                 write_mixed_units(out, prev, tile, S, rows, O, (int)OH, t, roll);
             } else if ((O & 3) == 0) {
                 const int o4 = O >> 2;
