@@ -78,7 +78,15 @@ __device__ __forceinline__ void write_mixed_units(GF_GLOBAL float* __restrict__ 
             const bool on = i < rows * upr && u <= ((r * OH + O - 1) >> 2) && u < units;
             at[b] = on ? u << 2 : -1;
             v[b] = f32x4a{0.f, 0.f, 0.f, 0.f};
-            if (on) v[b] = f32x4a{element(u << 2, r), element((u << 2) + 1, r), element((u << 2) + 2, r), element((u << 2) + 3, r)};
+            if (on) {
+                const int c0 = (u << 2) - r * OH;   // the unit's first column in row r (negative: it starts in row r-1's history)
+                if (c0 >= 0 && c0 + 3 < O) {        // entirely inside the new frame (all but <= 2 units of a row): the LDS tile only
+                    const float* tp = tile + r * S + c0;
+                    v[b] = f32x4a{tp[0], tp[1], tp[2], tp[3]};
+                } else {                            // straddles a frame edge: the history elements come from `prev`
+                    v[b] = f32x4a{element(u << 2, r), element((u << 2) + 1, r), element((u << 2) + 2, r), element((u << 2) + 3, r)};
+                }
+            }
         }
 #pragma unroll
         for (int b = 0; b < kU; ++b)
