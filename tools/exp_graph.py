@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Step time of the Go2 command config at 4 096 / 16 384 / 65 536 envs, best of 5 x 1000 steps: plain launches (default) or, with
+GF_GRAPH=1, the recorded step as one hipGraphLaunch.  The third row of profiles/r02_b_hipgraph_static_experiment.jsonl
+(GF_GRAPH_STATIC=1: the instantiated graph replayed with FROZEN arguments, no SetParams, no host-side packing — the best case a
+device-resident step counter could reach) needed a one-line diagnostic change in gf_run_ops_graph that is not in the product:
+    if (getenv("GF_GRAPH_STATIC") && g && g->exec) return (int)hipGraphLaunch(g->exec, stream);
+Without it the variable is ignored."""
 import os, sys, time, json
 sys.path.insert(0, '/root/repo/genesis-forge_amd')
 import torch
