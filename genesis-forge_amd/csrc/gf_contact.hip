@@ -27,7 +27,6 @@ constexpr int kContactMaxMgr = 4;
 constexpr int kContactMaxTargets = 64;   // tracked links over all managers of one launch
 constexpr int kContactBlock = 256;
 constexpr int kContactLdsBytes = 16 * 1024;
-constexpr int kContactSelect = 16;      // up to this many tracked links the target table is read with constant indices
 #define GF_CONTACT_INLINE __attribute__((always_inline))
 typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));   // dword aligned; one global_{load,store}_dwordx3: a wave moves 768 contiguous bytes
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
@@ -69,30 +68,16 @@ struct FastDivC {
     __device__ __forceinline__ int div(int i) const { return d > 1 ? (int)(((uint64_t)(uint32_t)i * m) >> 40) : i; }
 };
 
-// the per-manager fields a lane needs, picked by its manager index with constant-index selects: the four descriptors sit in
-// SGPRs (one batch of scalar loads), where a lane-dependent index into the kernel argument would be a chain of vector loads
-struct MgrSel {
-    int32_t num_targets, num_with, has_with_filter, track_air_time;
-    float air_time_threshold;
-    float *contacts, *contact_positions, *position_counts, *link_vel_out, *link_pos_out;
-    float *last_air_time, *current_air_time, *last_contact_time, *current_contact_time;
-};
-__device__ __forceinline__ MgrSel pick_mgr(const ContactMultiArgs& a, int mi) {
-    auto of = [](const ContactMgr& m) {
-        return MgrSel{m.num_targets, m.num_with, m.has_with_filter, m.track_air_time, m.air_time_threshold, m.contacts, m.contact_positions,
-                      m.position_counts, m.link_vel_out, m.link_pos_out, m.last_air_time, m.current_air_time, m.last_contact_time,
-                      m.current_contact_time};
-    };
-    MgrSel r = of(a.m[0]);
-#pragma unroll
-    for (int m = 1; m < kContactMaxMgr; ++m)
-        if (mi == m) r = of(a.m[m]);
-    return r;
-}
-
 __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMultiArgs a) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds_raw[];
     __shared__ int32_t s_with[kContactMaxMgr][GF_MAX_LINK_IDS];
+    // The per-manager fields and the target table, staged once per workgroup: a lane's manager / tracked link is lane-dependent, and
+    // picking 14 fields x 4 managers (and 3 x 16 table entries) with constant-index select chains out of SGPRs cost ~250 of the
+    // kernel's ~1 100 instructions per wave and 127 spilled SGPRs — on a kernel PMC counters show to be issue-bound (r02_i).
+    constexpr int kMgrWords = (int)(offsetof(ContactMgr, with_link_ids) / 4);   // the scalar fields and pointers of one manager
+    __shared__ __attribute__((aligned(8))) int32_t s_mgr[kContactMaxMgr][kMgrWords];
+    __shared__ int32_t s_target[kContactMaxTargets];
+    __shared__ uint16_t s_meta[kContactMaxTargets];   // manager | local index << 8
     const int C = a.num_contacts, T = a.total_targets, E = a.envs_per_block;
     const int MW = (C + 31) >> 5;  // 32-bit words of one env's "slot holds a contact" mask
     const int64_t n0 = (int64_t)blockIdx.x * E;
@@ -107,23 +92,25 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
     // The kernel is a chain of memory round trips at the env counts of a real run (a few hundred workgroups), so everything
     // that does not depend on an earlier load goes out first: this lane's (env, tracked link) row of the target table — a
     // vector load from the kernel-argument segment — together with the slot ids and the with-filter tables.
+    const FastDivC dT(T);
     auto pair_meta = [&](int pr, int& e, int& t, int& target, int& mi, int& lt) GF_CONTACT_INLINE {
         const bool live = pr < pairs;
-        e = live ? pr / T : 0;
+        e = live ? dT.div(pr) : 0;
         t = live ? pr - e * T : 0;
-        if (T <= kContactSelect) {  // the usual handful of tracked links: constant-index selects out of SGPRs, no memory round trip
-            target = a.target_ids[0]; mi = a.mgr_of[0]; lt = a.local_of[0];
-#pragma unroll
-            for (int x = 1; x < kContactSelect; ++x)
-                if (t == x) { target = a.target_ids[x]; mi = a.mgr_of[x]; lt = a.local_of[x]; }
-        } else {
-            target = *(const __attribute__((address_space(4))) int32_t*)(kp + offsetof(ContactMultiArgs, target_ids) + 4 * t);
-            mi = *(const __attribute__((address_space(4))) uint8_t*)(kp + offsetof(ContactMultiArgs, mgr_of) + t);
-            lt = *(const __attribute__((address_space(4))) uint8_t*)(kp + offsetof(ContactMultiArgs, local_of) + t);
-        }
+        target = s_target[t];
+        const int meta = s_meta[t];
+        mi = meta & 0xff;
+        lt = meta >> 8;
     };
-    int e0, t0, target0, mi0, lt0;
-    pair_meta((int)threadIdx.x, e0, t0, target0, mi0, lt0);
+    for (int i = threadIdx.x; i < kContactMaxMgr * kMgrWords; i += blockDim.x) {
+        const int m = i / kMgrWords, w = i - m * kMgrWords;
+        (&s_mgr[0][0])[i] = *(const __attribute__((address_space(4))) int32_t*)(kp + offsetof(ContactMultiArgs, m) + (size_t)m * sizeof(ContactMgr) + 4 * w);
+    }
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+        s_target[i] = *(const __attribute__((address_space(4))) int32_t*)(kp + offsetof(ContactMultiArgs, target_ids) + 4 * i);
+        s_meta[i] = (uint16_t)(*(const __attribute__((address_space(4))) uint8_t*)(kp + offsetof(ContactMultiArgs, mgr_of) + i) |
+                               (*(const __attribute__((address_space(4))) uint8_t*)(kp + offsetof(ContactMultiArgs, local_of) + i) << 8));
+    }
     for (int i = threadIdx.x; i < kContactMaxMgr * GF_MAX_LINK_IDS; i += blockDim.x) {
         const int m = i / GF_MAX_LINK_IDS, w = i - m * GF_MAX_LINK_IDS;
         (&s_with[0][0])[i] = *(const __attribute__((address_space(4))) int32_t*)(kp + offsetof(ContactMultiArgs, m) + (size_t)m * sizeof(ContactMgr) +
@@ -149,8 +136,15 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
             const i32x4 va = reinterpret_cast<const GF_GLOBAL i32x4*>(ga)[i4], vb = reinterpret_cast<const GF_GLOBAL i32x4*>(gb)[i4];
             reinterpret_cast<i32x4*>(sa)[i4] = va;
             reinterpret_cast<i32x4*>(sb)[i4] = vb;
-            const int i = i4 << 2;
-            mark(i, va.x, vb.x); mark(i + 1, va.y, vb.y); mark(i + 2, va.z, vb.z); mark(i + 3, va.w, vb.w);
+            // contacts are sparse: one (rarely taken) branch per four slots instead of four
+            const int occ4 = ((va.x & vb.x) >= 0 ? 1 : 0) | ((va.y & vb.y) >= 0 ? 2 : 0) | ((va.z & vb.z) >= 0 ? 4 : 0) | ((va.w & vb.w) >= 0 ? 8 : 0);
+            if (occ4) {
+                const int i = i4 << 2;
+                if (occ4 & 1) mark(i, va.x, vb.x);
+                if (occ4 & 2) mark(i + 1, va.y, vb.y);
+                if (occ4 & 4) mark(i + 2, va.z, vb.z);
+                if (occ4 & 8) mark(i + 3, va.w, vb.w);
+            }
         }
         for (int i = (slots4 << 2) + threadIdx.x; i < slots; i += blockDim.x) {
             const int la = ga[i], lb = gb[i];
@@ -163,9 +157,9 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
     for (int pr0 = 0; pr0 < pairs; pr0 += blockDim.x) {
         const int pr = pr0 + (int)threadIdx.x;
         const bool live = pr < pairs;
-        int e = e0, t = t0, target = target0, mi = mi0, lt = lt0;
-        if (pr0 > 0) pair_meta(pr, e, t, target, mi, lt);
-        const MgrSel mg = pick_mgr(a, mi);
+        int e, t, target, mi, lt;
+        pair_meta(pr, e, t, target, mi, lt);
+        const ContactMgr& mg = *reinterpret_cast<const ContactMgr*>(&s_mgr[mi][0]);   // only the fields in front of with_link_ids
         const int64_t n = n0 + e;
         const int L = mg.num_targets, W = mg.num_with;
         const int64_t k = n * L + lt;
