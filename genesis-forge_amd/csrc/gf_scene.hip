@@ -35,11 +35,14 @@ __device__ __forceinline__ LinkOffset synth_link_offset(int l) {
     return {leg < 2 ? 0.19f : -0.19f, (leg & 1) ? -0.11f : 0.11f, -0.085f * (float)depth};
 }
 
+// the base state an env's tick leaves: position, quaternion, linear and angular velocity
+struct SynthBase {
+    float p[3], q[4], v[3], w[3];
+};
+
 template <int DV>
-__global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSceneArgs a) {
-    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
-    if (n >= a.num_envs) return;
-    const int D = a.num_dofs, C = a.num_contacts, NL = a.num_scene_links;
+__device__ __forceinline__ void synth_state_body(const GfSynthSceneArgs& a, const int64_t n, SynthBase& out) {
+    const int D = a.num_dofs;
     const float dt = a.dt;
     const uint32_t genv = (uint32_t)n + a.env_offset;
     // all loads first: joint rows as float4 (DV = D/4 when the rows are 16-byte tiles), base state, then one wait
@@ -102,21 +105,24 @@ __global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSce
 #pragma unroll
     for (int j = 0; j < 4; ++j) nq[j] = nq[j] / nrm;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { wp[j] = w[j]; vp[j] = v[j]; pp[j] = p[j]; }
+    for (int j = 0; j < 3; ++j) { wp[j] = w[j]; vp[j] = v[j]; pp[j] = p[j]; out.w[j] = w[j]; out.v[j] = v[j]; out.p[j] = p[j]; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) qp[j] = nq[j];
+    for (int j = 0; j < 4; ++j) { qp[j] = nq[j]; out.q[j] = nq[j]; }
 }
 
-// Per-link outputs (orientation, velocity, position of every scene link), one lane per (env, link): the base state the main
-// kernel just wrote is read back (stream order), so consecutive lanes write consecutive floats instead of one lane walking NL rows.
-__device__ __forceinline__ void synth_links_body(const GfSynthSceneArgs& a, const int64_t block) {
-    const int NL = a.num_scene_links;
-    const int64_t gid = block * 256 + threadIdx.x;
-    if (gid >= (int64_t)a.num_envs * NL) return;
-    const int64_t n = gid / NL;
-    const int l = (int)(gid - n * NL);
-    const V3 w = load3(a.ang_vel, n), v = load3(a.lin_vel, n), p = load3(a.pos, n);
-    if (a.links_quat_out) reinterpret_cast<float4*>(a.links_quat_out)[gid] = load_quat(a.quat, n);
+template <int DV>
+__global__ __launch_bounds__(kEnvBlock) void synth_scene_kernel(const GfSynthSceneArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
+    if (n >= a.num_envs) return;
+    SynthBase b;
+    synth_state_body<DV>(a, n, b);
+}
+
+// Per-link outputs (orientation, velocity, position of scene link l of env n; flat index gid = n·NL + l) from the base state the
+// tick just produced: consecutive lanes write consecutive floats.
+__device__ __forceinline__ void synth_link_one(const GfSynthSceneArgs& a, const int64_t gid, const int l, const float* b /* p3 q4 v3 w3 */) {
+    const V3 p{b[0], b[1], b[2]}, v{b[7], b[8], b[9]}, w{b[10], b[11], b[12]};
+    if (a.links_quat_out) reinterpret_cast<float4*>(a.links_quat_out)[gid] = make_float4(b[3], b[4], b[5], b[6]);
     if (a.links_vel_out) {
         float* o = a.links_vel_out + gid * 3;
         o[0] = v.x + (float)(l % 3 == 0 ? 1 : 0) * 0.05f * w.x;
@@ -133,22 +139,21 @@ __device__ __forceinline__ void synth_links_body(const GfSynthSceneArgs& a, cons
     }
 }
 
-// Sampled contacts, one lane per (env, contact slot): two Philox blocks per slot, 32 B of output per lane, coalesced.
-__device__ __forceinline__ void synth_contacts_body(const GfSynthSceneArgs& a, const int64_t block) {
-    const int C = a.num_contacts, NL = a.num_scene_links;
-    const int64_t k = block * 256 + threadIdx.x;
-    if (k >= (int64_t)a.num_envs * C) return;
-    const int64_t n = k / C;
-    const int c = (int)(k - n * C);
-    const uint32_t genv = (uint32_t)n + a.env_offset;
-    const float p0 = a.pos[3 * n], p1 = a.pos[3 * n + 1];
+// Sampled contact of slot c of env n (flat index k = n·C + c): 32 B of output per lane, coalesced.  The second Philox block only
+// feeds the z force of an ACTIVE slot; an empty slot's outputs are constants, so it is skipped for waves without an active slot.
+__device__ __forceinline__ void synth_contact_one(const GfSynthSceneArgs& a, const int64_t k, const uint32_t genv, const int c, const float p0, const float p1) {
+    const int NL = a.num_scene_links;
     const uint32_t col = (uint32_t)(8 + 8 * c);
     // columns col..col+3 share one Philox block, col+4 starts the next
     const U4 r0 = philox4x32_10(genv, col >> 2, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-    const U4 r1 = philox4x32_10(genv, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
     const float u_act = u24_to_unit(r0.x), u_link = u24_to_unit(r0.y);
-    const float fx = u24_to_unit(r0.z) * 2.0f - 1.0f, fy = u24_to_unit(r0.w) * 2.0f - 1.0f, fz = u24_to_unit(r1.x);
     const bool active = u_act < a.contact_prob;
+    float fz = 0.0f;
+    if (active) {
+        const U4 r1 = philox4x32_10(genv, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+        fz = u24_to_unit(r1.x);
+    }
+    const float fx = u24_to_unit(r0.z) * 2.0f - 1.0f, fy = u24_to_unit(r0.w) * 2.0f - 1.0f;
     int lb = 1 + (int)(u_link * (float)(NL - 1));
     if (lb > NL - 1) lb = NL - 1;
     a.link_a_out[k] = active ? 0 : -1;
@@ -161,10 +166,43 @@ __device__ __forceinline__ void synth_contacts_body(const GfSynthSceneArgs& a, c
     a.contact_pos_out[k * 3 + 2] = 0.0f;
 }
 
-// one launch for both per-(env, link) and per-(env, slot) outputs: the first `link_blocks` workgroups do the links
-__global__ __launch_bounds__(256) void synth_derived_kernel(const GfSynthSceneArgs a, const uint32_t link_blocks) {
-    if (blockIdx.x < link_blocks) synth_links_body(a, (int64_t)blockIdx.x);
-    else synth_contacts_body(a, (int64_t)(blockIdx.x - link_blocks));
+// A scene with per-link outputs and / or contacts, as ONE launch (two until round 2: the state tick, then a flat kernel over
+// (env, link) and (env, slot) pairs that read the new base state back): workgroup b owns envs [64b, 64b+64) — wave 0 ticks them
+// (lane = env) and leaves their new base state in LDS, then all four waves write the tile's link rows and contact slots, which are
+// contiguous in memory.  Same statements per element, so the outputs are bit-identical to the two-launch version and the oracle.
+// TE = envs per workgroup: 64 (the tile of the action / post-physics kernels, same XCD) when that still fills the chip, 16 below
+// ~32 k envs (4 096 envs are 64 tiles of 64 — a quarter of the CUs — but 256 tiles of 16).
+constexpr int kSynthTileBlock = 256;
+template <int DV, int TE>
+__global__ __launch_bounds__(kSynthTileBlock) void synth_tile_kernel(const GfSynthSceneArgs a, const int links, const int contacts) {
+    __shared__ float s_base[TE][13];   // p(3) q(4) v(3) w(3)
+    const int64_t n0 = (int64_t)blockIdx.x * TE;
+    const int rows = (int)((int64_t)a.num_envs - n0 < TE ? (int64_t)a.num_envs - n0 : TE);
+    const int tid = threadIdx.x;
+    if (tid < rows) {
+        SynthBase b;
+        synth_state_body<DV>(a, n0 + tid, b);
+        float* r = s_base[tid];
+        r[0] = b.p[0]; r[1] = b.p[1]; r[2] = b.p[2];
+        r[3] = b.q[0]; r[4] = b.q[1]; r[5] = b.q[2]; r[6] = b.q[3];
+        r[7] = b.v[0]; r[8] = b.v[1]; r[9] = b.v[2];
+        r[10] = b.w[0]; r[11] = b.w[1]; r[12] = b.w[2];
+    }
+    __syncthreads();
+    if (links) {
+        const int NL = a.num_scene_links;
+        for (int i = tid; i < rows * NL; i += kSynthTileBlock) {
+            const int e = i / NL, l = i - e * NL;
+            synth_link_one(a, n0 * NL + i, l, s_base[e]);
+        }
+    }
+    if (contacts) {
+        const int C = a.num_contacts;
+        for (int i = tid; i < rows * C; i += kSynthTileBlock) {
+            const int e = i / C, c = i - e * C;
+            synth_contact_one(a, n0 * C + i, (uint32_t)(n0 + e) + a.env_offset, c, s_base[e][0], s_base[e][1]);
+        }
+    }
 }
 
 }  // namespace gf
@@ -196,13 +234,20 @@ extern "C" __attribute__((visibility("default"))) int gf_synth_scene_step(const 
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const bool rows16 = (a->num_dofs % 4 == 0) && al16(a->targets) && al16(a->dof_pos) && al16(a->dof_vel);
     const unsigned grid = gf::env_grid(a->num_envs);
-    if (rows16 && a->num_dofs == 12) gf::klaunch(gf::synth_scene_kernel<3>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
-    else if (rows16 && a->num_dofs == 28) gf::klaunch(gf::synth_scene_kernel<7>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
-    else gf::klaunch(gf::synth_scene_kernel<0>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
     const bool links = (a->links_quat_out || a->links_vel_out || a->links_pos_out) && a->num_scene_links > 0;
     const bool contacts = a->num_contacts > 0 && a->contact_force_out;
-    const unsigned lb = links ? gf::env_grid((int64_t)a->num_envs * a->num_scene_links, 256) : 0u;
-    const unsigned cb = contacts ? gf::env_grid((int64_t)a->num_envs * a->num_contacts, 256) : 0u;
-    if (lb + cb > 0) gf::klaunch(gf::synth_derived_kernel, dim3(lb + cb), dim3(256), 0, s, *a, lb);
+    if (links || contacts) {   // tick + per-link rows + contact slots of a 64-env tile in one launch
+        const dim3 tb(gf::kSynthTileBlock);
+        const bool small = a->num_envs < 32768;
+        const dim3 tg(small ? gf::env_grid(a->num_envs, 16) : grid);
+        const int dv = !rows16 ? 0 : (a->num_dofs == 12 ? 3 : (a->num_dofs == 28 ? 7 : 0));
+#define GF_SYNTH_TILE(DVV)                                                                                              \
+        if (small) gf::klaunch(gf::synth_tile_kernel<DVV, 16>, tg, tb, 0, s, *a, (int)links, (int)contacts);          \
+        else gf::klaunch(gf::synth_tile_kernel<DVV, 64>, tg, tb, 0, s, *a, (int)links, (int)contacts)
+        if (dv == 3) { GF_SYNTH_TILE(3); } else if (dv == 7) { GF_SYNTH_TILE(7); } else { GF_SYNTH_TILE(0); }
+#undef GF_SYNTH_TILE
+    } else if (rows16 && a->num_dofs == 12) gf::klaunch(gf::synth_scene_kernel<3>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
+    else if (rows16 && a->num_dofs == 28) gf::klaunch(gf::synth_scene_kernel<7>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
+    else gf::klaunch(gf::synth_scene_kernel<0>, dim3(grid), dim3(gf::kEnvBlock), 0, s, *a);
     return gf::launch_status();
 }
