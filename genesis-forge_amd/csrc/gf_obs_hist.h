@@ -37,17 +37,21 @@ struct HistBatch {
 __device__ __forceinline__ void hist_load(HistBatch& b, const GF_GLOBAL float* __restrict__ prev, int first, int units, int O, int OH, const FastDiv& dr,
                                           const int stride = kObsBlock) {
     b.pure = 0u;
+    // UNCONDITIONAL loads (a unit that is not this lane's to move re-reads the run's first unit): eight loads back to back, no
+    // basic blocks in between.  With `if (pure) load` the compiler put every load and every store in a block of its own and — loads
+    // and stores share vmcnt on gfx9 and complete out of order with respect to each other — an `s_waitcnt vmcnt(0)` in front of
+    // EVERY store: eight serialised round trips per batch (ISA of r02's first gait kernel; 45 us for 164 MB at 65 536 envs).
 #pragma unroll
     for (int k = 0; k < kObsShift; ++k) {
         const int u = first + k * stride, uu = u < units ? u : 0;
         const int e = uu << 2, row = dr.div(e), c = e - row * OH;
         const bool pure = u < units && c >= O && c + 3 < OH;
         b.pure |= pure ? 1u << k : 0u;
-        b.v[k] = f32x4u{0.f, 0.f, 0.f, 0.f};
-        if (pure) b.v[k] = *reinterpret_cast<const GF_GLOBAL f32x4u*>(prev + (e - O));
+        b.v[k] = *reinterpret_cast<const GF_GLOBAL f32x4u*>(prev + (pure ? e - O : 0));
     }
 }
-__device__ __forceinline__ void hist_store(const HistBatch& b, GF_GLOBAL float* out, int first, const int stride = kObsBlock) {
+__device__ __forceinline__ void hist_store(const HistBatch& b, GF_GLOBAL float* out, int first, const int stride = kObsBlock, const bool wait = true) {
+    if (wait) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), once: every load of the batch has landed, the stores below need no further waits
 #pragma unroll
     for (int k = 0; k < kObsShift; ++k)
         if ((b.pure >> k) & 1u) *reinterpret_cast<GF_GLOBAL f32x4a*>(out + ((first + k * stride) << 2)) = f32x4a{b.v[k].x, b.v[k].y, b.v[k].z, b.v[k].w};

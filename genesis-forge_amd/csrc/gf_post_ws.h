@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         for (int first = lid; first - lid < units; first += kObsShift * kLanes) {   // wave-uniform trip count
             hist_load(hb, prev, first, units, O, (int)OH, dr, kLanes);
             hist_store(hb, out, first, kLanes);
-            if (roll) hist_store(hb, roll, first, kLanes);
+            if (roll) hist_store(hb, roll, first, kLanes, false);
         }
     };
     if constexpr (P::kStatic) {
