@@ -209,6 +209,9 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
                 f0 += r.x; f1 += r.y; f2 += r.z;
             }
         }
+        // every load of this pair has been consumed or was issued before the scan: say so once, or the compiler — loads and stores
+        // share vmcnt and complete out of order with respect to each other — puts waits between the conditional stores below
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         st3(mg.contacts + 3 * k, f0, f1, f2);
         if (mg.contact_positions)  // kernel.py:84-90
             st3(mg.contact_positions + 3 * k, cnt > 0.f ? p0 / cnt : p0, cnt > 0.f ? p1 / cnt : p1, cnt > 0.f ? p2 / cnt : p2);
