@@ -249,6 +249,13 @@ def main():
 
 
 def run_rank(args):
+    # stdout carries exactly ONE line, the JSON result of rank 0.  Libraries write there too (RCCL prints a five-line version banner
+    # on rank 0 when the first communicator is created; gloo a connection note), so the descriptor is kept aside and fd 1 points at
+    # stderr while the rank runs.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from genesis_forge_amd import _native as nat
@@ -270,7 +277,15 @@ def run_rank(args):
         os.environ["LOCAL_RANK"] = str(local) if dist_backend != "nccl" else os.environ.get("LOCAL_RANK", "0")
         gs.set_device(f"cuda:{local}")
     rank, world = gfd.init_from_env(dist_backend)
-    if world > 1:
+    # GF_DIST_FORCE=1: go through the process-group code (RCCL barrier, max over ranks, batched statistics all-reduce) even with one
+    # rank — how the multi-GPU path of this file is rehearsed on a one-GPU box; the numbers are then those of one GPU plus collectives
+    dist_on = world > 1
+    if world == 1 and os.environ.get("GF_DIST_FORCE") == "1" and not rehearsal:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29631")
+        dist.init_process_group(dist_backend, rank=0, world_size=1)
+        dist_on = True
+    if dist_on:
         assert dist.get_world_size() == world
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
@@ -286,7 +301,7 @@ def run_rank(args):
         N, global_envs = args.num_envs, args.num_envs * world
     env = make_env(N, args.config)
     D = env.action_space.shape[0]
-    gfd.attach(env, global_num_envs=global_envs, reduce_every=args.reduce_every)
+    gfd.attach(env, global_num_envs=global_envs, reduce_every=args.reduce_every, force=dist_on)
     env.seed(1234)          # one seed for all ranks: Philox is keyed by the GLOBAL env id, so shards draw different numbers
     env.reset()
     g = torch.Generator().manual_seed(1234 + rank)
@@ -294,7 +309,7 @@ def run_rank(args):
 
     def barrier():
         sync()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         sync()
 
@@ -309,7 +324,7 @@ def run_rank(args):
             sync()
             dt = time.perf_counter() - t0
             barrier()
-            if world > 1:
+            if dist_on:
                 t = torch.tensor([dt], device=gs.device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
@@ -380,7 +395,7 @@ def run_rank(args):
             "config": {"workload": "go2_12dof_full_manager_stack" if go2 else args.config, "num_envs_per_gpu": N, "global_num_envs": global_envs,
                        "dofs": D, "reward_terms": T, "termination_terms": len(env.managers["termination"].term_cfg), "command_managers": len(env.managers["command"]),
                        "obs_width": int(env.observation_space.shape[0]), "scene": "synthetic (gf_synth_scene_step)", "parallelism": f"env-shard x{world}",
-                       "stats_allreduce_every_steps": (args.reduce_every if world > 1 else None), "dist_backend": (dist_backend if world > 1 else None),
+                       "stats_allreduce_every_steps": (args.reduce_every if dist_on else None), "dist_backend": (dist_backend if dist_on else None),
                        "setup_steps_before_warmup": PRIMING_STEPS, "fused_post_physics": fused, "observation_output": OBS_OUTPUT,
                        "launches_per_step": env._trace.n_ops if env._trace is not None else None},
             "timing": {"batches": len(times), "timed_s": sum(times), "batch_ms_median": batch * 1e3, "batch_ms_min": min(times) * 1e3,
@@ -433,8 +448,10 @@ def run_rank(args):
             except Exception as ex:  # the baseline is a reported side figure: never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": f"failed: {ex!r}"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

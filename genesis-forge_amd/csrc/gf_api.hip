@@ -18,6 +18,16 @@ int gait_launch(const GfGaitArgs* a, hipStream_t s, bool flags_all);            
 #define GF_EXPORT __attribute__((visibility("default")))
 namespace gf {
 __global__ __launch_bounds__(256) void stats_pack_kernel(const GfStatsPackArgs a) { fold_stats_block256(a.src, a.dst, nullptr); }
+
+// One wave: lane r looks at row r's reset count, the ballot names the newest row that reset something, the lanes copy it.
+__global__ __launch_bounds__(GF_WAVE) void stats_last_reset_kernel(const double* rows, const int num_rows, double* dst) {
+    const int lane = (int)threadIdx.x;
+    const bool hit = lane < num_rows && rows[(size_t)lane * GF_STATS_VECTOR_LEN + GF_MAX_TERM_TERMS] > 0.0;
+    const unsigned long long m = __ballot(hit);
+    if (!m) return;
+    const int r = 63 - __builtin_clzll(m);
+    for (int v = lane; v < GF_STATS_VECTOR_LEN; v += GF_WAVE) dst[v] = rows[(size_t)r * GF_STATS_VECTOR_LEN + v];
+}
 }  // namespace gf
 
 extern "C" {
@@ -80,6 +90,14 @@ GF_EXPORT int gf_stats_clear(GfStepStats* stats, void* stream) {
 GF_EXPORT int gf_stats_pack(const GfStatsPackArgs* a, void* stream) {
     if (!a || !a->src || !a->dst) return GF_E_NULL;
     gf::klaunch(gf::stats_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a);
+    return gf::launch_status();
+}
+
+GF_EXPORT int gf_stats_last_reset(const double* rows, int num_rows, double* dst, void* stream) {
+    if (!rows || !dst) return GF_E_NULL;
+    if (num_rows < 0 || num_rows > GF_WAVE) return GF_E_RANGE;
+    if (num_rows == 0) return GF_OK;
+    gf::klaunch(gf::stats_last_reset_kernel, dim3(1), dim3(GF_WAVE), 0, (hipStream_t)stream, rows, num_rows, dst);
     return gf::launch_status();
 }
 

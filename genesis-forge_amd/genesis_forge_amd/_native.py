@@ -383,6 +383,9 @@ class Backend:
     def stats_pack(self, src_ptr: int, dst_ptr: int) -> None:  # pragma: no cover - interface
         raise NotImplementedError
 
+    def stats_last_reset(self, rows_ptr: int, num_rows: int, dst_ptr: int) -> None:  # pragma: no cover - interface
+        raise NotImplementedError
+
     def check_tensor(self, t, what: str = "tensor") -> None:
         if t is None:
             return
@@ -438,6 +441,8 @@ class HipBackend(Backend):
             self.graph_enabled = True
         self.lib.gf_stats_pack.restype = C.c_int
         self.lib.gf_stats_pack.argtypes = [C.POINTER(GfStatsPackArgs), C.c_void_p]
+        self.lib.gf_stats_last_reset.restype = C.c_int
+        self.lib.gf_stats_last_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         self.lib.gf_post_physics_check.restype = C.c_int
         self.lib.gf_post_physics_check.argtypes = [C.POINTER(GfPostRefs)]
         self.lib.gf_post_physics_describe.restype = C.c_int
@@ -517,6 +522,11 @@ class HipBackend(Backend):
         rc = self.lib.gf_stats_pack(C.byref(a), self._stream())
         if rc != 0:
             self._raise("stats_pack", rc)
+
+    def stats_last_reset(self, rows_ptr: int, num_rows: int, dst_ptr: int) -> None:
+        rc = self.lib.gf_stats_last_reset(rows_ptr, num_rows, dst_ptr, self._stream())
+        if rc != 0:
+            self._raise("stats_last_reset", rc)
 
     def event_create(self):
         ev = self.lib.gf_event_create()

@@ -118,6 +118,22 @@ class VecRingSnapshot:
         return self._value
 
 
+class GroupRingSnapshot:
+    """Statistics of one recorded step of the batched process-group ring (``reduce_every`` > 1): a row of the device vector
+    ring that is folded by the following step and all-reduced with its batch.  Held weakly by the ring, like RingSnapshot: a
+    log nobody kept is never copied out."""
+
+    __slots__ = ("_owner", "_slot", "_value", "__weakref__")
+
+    def __init__(self, owner, slot: int):
+        self._owner, self._slot, self._value = owner, slot, None
+
+    def wait(self) -> HostStats:
+        if self._value is None:
+            self._owner.materialize_group_ring(self._slot)
+        return self._value
+
+
 class StepStats:
     """Owns the device stats block and the pinned read-back ring."""
 
@@ -179,6 +195,10 @@ class StepStats:
             self._ring_prev = None      # slot written by the previous recorded step (not folded yet)
             self._ring_snaps = [None] * _RING
             self._vec_snaps = [None] * _RING
+            self._grp_refs = [None] * _RING   # batched group ring: weak references to the rows' snapshots,
+            self._grp_work = [None] * _RING   # the all-reduce that covered a row (True: finished synchronously), None = not reduced
+            self._grp_open: list[int] = []    # slots of the open batch, oldest first
+            self._fold_slot = None
 
     def ring_ptr(self, slot: int) -> int:
         return self.ring.data_ptr() + slot * STATS_BYTES
@@ -217,7 +237,11 @@ class StepStats:
 
     def read_last_reset(self) -> Optional["HostStats"]:
         """Statistics of the most recent recorded step that reset at least one env, or None (blocking, on demand)."""
-        if getattr(self, "ring", None) is None or self._ring_prev is None:
+        if getattr(self, "ring", None) is None:
+            return None
+        if self.group is not None and self.reduce_every > 1:
+            return self._group_last_reset()
+        if self._ring_prev is None:
             return None
         self._fold_latest(nat.get_backend())
         both = torch.stack([self.vec_ring[self._ring_prev], self.last_reset]).cpu().numpy()
@@ -230,8 +254,12 @@ class StepStats:
         """Called when a recorded step is dropped: hands back the last reset statistics and forgets the unfolded slot."""
         last = self.read_last_reset()
         if getattr(self, "ring", None) is not None:
-            self.materialize_ring()
-            self._ring_prev = None
+            if self.group is not None and self.reduce_every > 1:
+                self.materialize_group_ring(None)   # rows are all reduced by now (read_last_reset closed the open batch)
+                self._grp_work = [None] * _RING
+            else:
+                self.materialize_ring()
+                self._ring_prev = None
             self.last_reset.zero_()
         return last
 
@@ -242,23 +270,14 @@ class StepStats:
         self.ensure_ring()
 
     def vec_ring_next(self):
-        """(slot index, shard-slot pointer, next shard-slot pointer, vector-row pointer, slot this step's action kernel
-        should fold or None) for this step.  The fold slot is only used with reduce_every > 1: the previous step's shards are
-        folded into their vector row by this step's action kernel instead of a pack launch of their own."""
+        """reduce_every = 1: (slot index, shard-slot pointer, next shard-slot pointer, vector-row pointer) for this step."""
         i = self.ring_pos
         j = (i + 1) % _RING
         old = self._vec_snaps[i]
-        if old is not None and old._value is None and (old._work is not None or self.reduce_every <= 1):
+        if old is not None and old._value is None:
             self.materialize_vec_ring()   # an unread, already reduced row is about to be recycled: copy the ring out (local)
-        elif old is not None and old._work is not None and old._work is not True:
-            # the row is about to be rewritten by this step's fold / pack: order that behind the all-reduce that read it with an
-            # explicit stream dependency (64 steps later it has long finished, but ring distance is not a synchronisation)
-            old._work.wait()
-            old._work = None
         self.ring_pos = j
-        prev = getattr(self, "_fold_slot", None)
-        self._fold_slot = i
-        return i, self.ring_ptr(i), self.ring_ptr(j), self.vec_ptr(i), prev
+        return i, self.ring_ptr(i), self.ring_ptr(j), self.vec_ptr(i)
 
     #: Rows of the vector ring all-reduced per collective.  1 (default): one all-reduce per recorded step, enqueued behind the
     #: step's kernels — reading a log entry is then purely local, any rank may read any step at any time.  K > 1 (must divide
@@ -271,54 +290,13 @@ class StepStats:
     def vec_ring_reduce(self, slot: int) -> "VecRingSnapshot":
         import torch.distributed as dist
 
-        if self.reduce_every <= 1:
-            row = self.vec_ring[slot]
-            work = dist.all_reduce(row, op=dist.ReduceOp.SUM, group=self.group, async_op=self.device.type == "cuda")
-            snap = VecRingSnapshot(self, slot, work)
-            self._vec_snaps[slot] = snap
-            return snap
-        # The rows of the steps already pending were folded by the action kernels of the steps that followed them — the newest of
-        # them by the step that has just been enqueued — so a full batch (or one that would not stay contiguous across the
-        # ring's wrap) can go out now; this step's own row is folded by the next step and joins the next batch.
-        snap = VecRingSnapshot(self, slot, None)
+        row = self.vec_ring[slot]
+        work = dist.all_reduce(row, op=dist.ReduceOp.SUM, group=self.group, async_op=self.device.type == "cuda")
+        snap = VecRingSnapshot(self, slot, work)
         self._vec_snaps[slot] = snap
-        pend = getattr(self, "_pending", None)
-        if pend is None:
-            pend = self._pending = []
-        if pend and (len(pend) >= self.reduce_every or pend[-1]._slot + 1 != slot):
-            self._reduce_pending()
-            pend = self._pending
-        pend.append(snap)
         return snap
 
-    def flush_reduce(self) -> None:
-        """Close the open batch now (COLLECTIVE: every rank must call it at the same step): the newest pending step has not been
-        followed by another recorded step yet, so its shards are folded explicitly, then every pending row is all-reduced."""
-        pend = getattr(self, "_pending", None)
-        if not pend:
-            return
-        newest = pend[-1]._slot
-        if getattr(self, "_fold_slot", None) == newest:
-            nat.get_backend().stats_pack(self.ring_ptr(newest), self.vec_ptr(newest))
-            self._fold_slot = None   # folded and about to be reduced: the next step must not fold it again
-        self._reduce_pending()
-
-    def _reduce_pending(self) -> None:
-        import torch.distributed as dist
-
-        pend = getattr(self, "_pending", None)
-        if not pend:
-            return
-        i0, i1 = pend[0]._slot, pend[-1]._slot + 1
-        rows = self.vec_ring[i0:i1]   # contiguous rows of one batch
-        work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=self.device.type == "cuda")
-        for s in pend:
-            s._work = work if work is not None else True
-        self._pending = []
-
     def materialize_vec_ring(self) -> None:
-        if getattr(self, "_pending", None) and any(s._value is None for s in self._pending):
-            self.flush_reduce()   # somebody reads a step whose batch is still open
         for snap in self._vec_snaps:
             if snap is not None and snap._value is None and snap._work is not None and snap._work is not True:
                 snap._work.wait()
@@ -327,6 +305,118 @@ class StepStats:
             if snap is not None and snap._value is None:
                 snap._value = vector_to_stats(host[snap._slot])
                 snap._work = None
+
+    # -- reduce_every = K > 1: the batched group ring ---------------------------------------------------------------------
+    # The step is the single-process ring's step (cur / next-to-zero / previous slot and its vector row arrive as call
+    # parameters, the action kernel folds the previous slot) — the host adds an integer to a list per step.  Every K-th step
+    # one all-reduce covers the K rows folded so far.  A batch is recycled 64 - K steps after its all-reduce was issued: at
+    # that point the rows' unread live snapshots (normally none) are copied out and gf_stats_last_reset carries "the newest
+    # row that reset something" into ``last_reset`` on the device, so ``last_episode_mean_reward`` needs no host copy of rows
+    # nobody asked for.
+    def group_ring_next(self):
+        """(slot index, this step's slot pointer, slot pointer to zero, previous slot pointer or None, its vector row or None,
+        snapshot)."""
+        i = self.ring_pos
+        if self._grp_work[i] is not None:
+            self._recycle_batch(i)
+        prev = self._fold_slot
+        self._fold_slot = i
+        self.ring_pos = j = (i + 1) % _RING
+        snap = GroupRingSnapshot(self, i)
+        self._grp_refs[i] = weakref.ref(snap)
+        if prev is None:
+            return i, self.ring_ptr(i), self.ring_ptr(j), None, None, snap
+        return i, self.ring_ptr(i), self.ring_ptr(j), self.ring_ptr(prev), self.vec_ptr(prev), snap
+
+    def group_ring_after(self, slot: int) -> None:
+        """After step ``slot`` has been enqueued.  The rows of the steps already in the open batch were folded by the action
+        kernels of the steps that followed them — the newest of them by the step just enqueued — so a full batch (or one that
+        would not stay contiguous across the ring's wrap) goes out now; this step's own row is folded by the next step and
+        joins the next batch."""
+        pend = self._grp_open
+        if pend and (len(pend) >= self.reduce_every or pend[-1] + 1 != slot):
+            self._reduce_pending()
+        self._grp_open.append(slot)
+
+    def _grp_live(self, slot: int):
+        ref = self._grp_refs[slot]
+        snap = ref() if ref is not None else None
+        return snap if snap is not None and snap._value is None else None
+
+    def _recycle_batch(self, i: int) -> None:
+        w = self._grp_work[i]
+        n = 1
+        while i + n < _RING and self._grp_work[i + n] is w:
+            n += 1
+        if any(self._grp_live(i + k) is not None for k in range(n)):
+            self.materialize_group_ring(None)   # still referenced by a live extras dict and about to be recycled unread (local)
+        if w is not True:
+            w.wait()   # stream dependency: the fold that rewrites these rows and the pick below run behind the all-reduce
+        nat.get_backend().stats_last_reset(self.vec_ptr(i), n, self.last_reset.data_ptr())
+        for k in range(n):
+            self._grp_work[i + k] = None
+
+    def flush_reduce(self) -> None:
+        """Close the open batch now (COLLECTIVE: every rank must call it at the same step): the newest pending step has not been
+        followed by another recorded step yet, so its shards are folded explicitly, then every pending row is all-reduced."""
+        pend = getattr(self, "_grp_open", None)
+        if not pend:
+            return
+        newest = pend[-1]
+        if self._fold_slot == newest:
+            nat.get_backend().stats_pack(self.ring_ptr(newest), self.vec_ptr(newest))
+            self._fold_slot = None   # folded and about to be reduced: the next step must not fold it again
+        self._reduce_pending()
+
+    def _reduce_pending(self) -> None:
+        import torch.distributed as dist
+
+        pend = self._grp_open
+        if not pend:
+            return
+        i0, i1 = pend[0], pend[-1] + 1
+        rows = self.vec_ring[i0:i1]   # contiguous rows of one batch
+        work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=self.device.type == "cuda")
+        if work is None:
+            work = True
+        for s in pend:
+            self._grp_work[s] = work
+        self._grp_open = []
+
+    def materialize_group_ring(self, want: Optional[int]) -> None:
+        """Copy the reduced rows out and fill the snapshots somebody still holds.  ``want`` is the slot being read: if its batch
+        is still open the batch is closed first (a collective — the documented cost of reading a fresh step with K > 1);
+        whether that happens depends only on WHICH step is read, never on what else happens to be alive on this rank."""
+        if want is not None and want in self._grp_open:
+            self.flush_reduce()
+        seen = []
+        for w in self._grp_work:
+            if w is not None and w is not True and not any(w is x for x in seen):
+                w.wait()
+                seen.append(w)
+        host = self.vec_ring.cpu().numpy()
+        for slot in range(_RING):
+            snap = self._grp_live(slot)
+            if snap is not None and self._grp_work[slot] is not None:
+                snap._value = vector_to_stats(host[slot])
+
+    def _group_last_reset(self) -> Optional["HostStats"]:
+        """Batched group ring: global statistics of the most recent recorded step that reset at least one env (COLLECTIVE when a
+        batch is open — curricula read this on every rank at the same step)."""
+        self.flush_reduce()
+        seen = []
+        for w in self._grp_work:
+            if w is not None and w is not True and not any(w is x for x in seen):
+                w.wait()
+                seen.append(w)
+        host = torch.cat([self.vec_ring, self.last_reset[None]]).cpu().numpy()
+        for k in range(1, _RING + 1):   # newest first; rows already carried into ``last_reset`` are skipped
+            slot = (self.ring_pos - k) % _RING
+            if self._grp_work[slot] is not None and host[slot][_NT] > 0:
+                return vector_to_stats(host[slot])
+        if host[_RING][_NT] > 0:
+            return vector_to_stats(host[_RING])
+        return None
 
     def ensure_native_events(self, backend) -> None:
         if getattr(self, "_events", None) is None:

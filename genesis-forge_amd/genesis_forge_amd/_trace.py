@@ -110,23 +110,21 @@ class StepTrace:
             stats.ensure_ring()
         else:
             stats.ensure_vec_ring()
-            if self.fold_mode:
-                stats._fold_slot = None   # nothing recorded before this trace is waiting for a fold
-            else:
+            if not self.fold_mode:
                 self.pack_args = nat.GfStatsPackArgs()
                 self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_PACK, C.addressof(self.pack_args)
                 k += 1
         self.n_ops = k
         # the statistics ring slots of a step arrive as call parameters (cur, next-to-zero, previous, its vector row, last_reset)
         self.params = (C.c_void_p * 5)()
-        if self.use_ring:
+        if self.use_ring or self.fold_mode:
             P = nat.GfReplayPatch
             for a in self.stat_fields:
                 self.native.append(P(nat.GF_PATCH_PARAM, 0, nat.field_addr(a, "stats"), None, None))
             aa = self.action_args
             for idx, name in ((1, "stats_zero"), (2, "stats_fold_src"), (3, "stats_fold_dst"), (4, "stats_last_reset")):
                 self.native.append(P(nat.GF_PATCH_PARAM, idx, nat.field_addr(aa, name), None, None))
-            self._last_reset_ptr = stats.last_reset.data_ptr()
+            self._last_reset_ptr = stats.last_reset.data_ptr() if self.use_ring else None   # (group ring: gf_stats_last_reset)
         # gf_replay_step: the whole table, then the ops, in ONE native call (the patch-only variant serves steps whose ops are
         # replayed in pieces around Python-level terms, or as a hipGraph)
         self.patch_table = (nat.GfReplayPatch * max(1, len(self.native)))(*self.native)
@@ -295,17 +293,12 @@ class StepTrace:
             cur, nxt, prev, prev_vec, snap = env.stats.ring_next()
             pr[0], pr[1], pr[2], pr[3] = cur, nxt, prev, prev_vec
             pr[4] = self._last_reset_ptr if prev is not None else None
+        elif self.fold_mode:
+            slot, cur, nxt, prev, prev_vec, snap = env.stats.group_ring_next()
+            pr[0], pr[1], pr[2], pr[3] = cur, nxt, prev, prev_vec
         else:
-            slot, cur, nxt, vec, fold = env.stats.vec_ring_next()
-            if self.fold_mode:
-                aa = self.action_args
-                if fold is None:
-                    aa.stats_fold_src = aa.stats_fold_dst = None
-                else:
-                    aa.stats_fold_src, aa.stats_fold_dst = env.stats.ring_ptr(fold), env.stats.vec_ptr(fold)
-                aa.stats_last_reset = None
-            else:
-                self.pack_args.src, self.pack_args.dst = cur, vec
+            slot, cur, nxt, vec = env.stats.vec_ring_next()
+            self.pack_args.src, self.pack_args.dst = cur, vec
             for a in self.stat_fields:
                 a.stats = cur
             self.action_args.stats_zero = nxt
@@ -332,7 +325,9 @@ class StepTrace:
             self.backend.run_ops_graph(self.graph, self.ops, self.n_ops)
         else:
             self.backend.replay_step(self.replay_desc, aptr, pr, 5)   # patch table + ops: the one native call of the step
-        if not self.use_ring:
+        if self.fold_mode:
+            env.stats.group_ring_after(slot)   # every K-th step: the single collective of the path, asynchronous, K rows
+        elif not self.use_ring:
             snap = env.stats.vec_ring_reduce(slot)  # the single collective of the path, asynchronous
         if not ticked:
             env._tick += 1  # scene advanced

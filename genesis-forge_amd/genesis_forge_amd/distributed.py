@@ -40,7 +40,7 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int]:
     return rank, world
 
 
-def attach(env, group=None, global_num_envs: Optional[int] = None, reduce_every: int = 1) -> None:
+def attach(env, group=None, global_num_envs: Optional[int] = None, reduce_every: int = 1, force: bool = False) -> None:
     """Make ``env``'s logging statistics global: sums over the ranks of ``group`` (default group if None).
     ``env.num_envs`` stays the local shard size; ``env.global_num_envs`` is the denominator of fractions.
 
@@ -62,9 +62,9 @@ def attach(env, group=None, global_num_envs: Optional[int] = None, reduce_every:
     K > 1 is for lock-step training loops only; it stays opt-in until RCCL scaling has been measured on a real node."""
     if reduce_every < 1 or reduce_every > 32 or 64 % reduce_every != 0:
         raise ValueError("reduce_every must divide 64 and be at most 32")
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         env.global_num_envs = env.num_envs if global_num_envs is None else global_num_envs
-        return
+        return   # (``force``: take the collective path even in a group of one — how the RCCL calls are exercised on a one-GPU box)
     env.stats.group = group if group is not None else dist.group.WORLD
     env.stats.reduce_every = reduce_every
     if global_num_envs is None:

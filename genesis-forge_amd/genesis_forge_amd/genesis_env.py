@@ -165,15 +165,15 @@ class GenesisEnv:
         """Drop the recorded step (something its frozen descriptors depend on has changed)."""
         if not hasattr(self, "_trace_epoch"):
             return  # still inside __init__: nothing has been recorded
-        if self._trace is not None and self._stats is not None and getattr(self._stats, "ring", None) is not None and self._stats.group is None:
-            last = self._stats.end_recording()
+        st = self._stats
+        if self._trace is not None and st is not None and getattr(st, "ring", None) is not None and (st.group is None or st.reduce_every > 1):
+            # (batched logging reduction, reduce_every > 1: this closes the open batch — its newest row is folded explicitly —
+            # before the recorded step goes away: a collective, like everything that invalidates a recorded step on one rank must
+            # happen on all of them)
+            last = st.end_recording()
             rm = getattr(self, "managers", {}).get("reward") if hasattr(self, "managers") else None
             if rm is not None:
                 rm._apply_reset_stats(last)
-        if self._trace is not None and self._stats is not None and self._stats.group is not None and self._stats.reduce_every > 1:
-            # batched logging reduction: close the open batch (its newest row is folded explicitly) before the recorded step goes
-            # away — a collective, like everything that invalidates a recorded step on one rank must happen on all of them
-            self._stats.flush_reduce()
         self._trace = None
         self._trace_epoch += 1
         self._last_signature = None

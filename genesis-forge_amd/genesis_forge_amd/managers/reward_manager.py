@@ -15,7 +15,7 @@ import torch
 
 from .. import _native as nat
 from .. import gs
-from .._stats import RingSnapshot
+from .._stats import GroupRingSnapshot, RingSnapshot
 from ._program import RewardProgram, spec_of
 from .base import BaseManager, LiveAttr
 from .config import RewardConfigItem
@@ -174,8 +174,8 @@ class RewardManager(BaseManager):
     def _note_snapshot(self, snap):
         """Called by the env after the step's snapshot exists, so curricula can read means later."""
         names = self._pending_names
-        if type(snap) is RingSnapshot:
-            self._pending_names = None  # single-process recorded step: the device keeps the last reset statistics
+        if type(snap) is RingSnapshot or type(snap) is GroupRingSnapshot:
+            self._pending_names = None  # recorded step (single process / batched group ring): the device keeps the last reset statistics
             return
         if names:
             self._pending.append((snap, names, self.env.num_envs))

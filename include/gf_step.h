@@ -700,6 +700,12 @@ typedef struct GfStatsPackArgs {
 } GfStatsPackArgs;
 int gf_stats_pack(const GfStatsPackArgs* a, void* stream);
 
+/* rows: [num_rows <= 64][GF_STATS_VECTOR_LEN] consecutive packed (and, with a process group, all-reduced) statistics rows, oldest
+ * first.  Copies the NEWEST row whose reset_count entry is > 0 to dst; leaves dst alone when no row reset anything.  This keeps
+ * "the episode means of the last reset" (reward_manager.py:138-153, :197-222 — the reference refreshes them inside every reset())
+ * on the device when ring rows are recycled unread, so the host never has to read a row just to carry that value forward. */
+int gf_stats_last_reset(const double* rows, int num_rows, double* dst, void* stream);
+
 typedef struct GfStatsCopyArgs {
     const GfStepStats* src;   /* device, GF_STATS_SHARDS blocks */
     void* dst;                /* pinned host, GF_STATS_SHARDS * sizeof(GfStepStats) */

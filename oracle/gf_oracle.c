@@ -1145,6 +1145,17 @@ GFO_EXPORT int gfo_stats_pack(const GfStatsPackArgs* a) {
     return GF_OK;
 }
 
+GFO_EXPORT int gfo_stats_last_reset(const double* rows, int num_rows, double* dst) {
+    if (!rows || !dst) return GF_E_NULL;
+    if (num_rows < 0 || num_rows > 64) return GF_E_RANGE;
+    for (int r = num_rows - 1; r >= 0; --r)
+        if (rows[(size_t)r * GF_STATS_VECTOR_LEN + GF_MAX_TERM_TERMS] > 0.0) {
+            memcpy(dst, rows + (size_t)r * GF_STATS_VECTOR_LEN, sizeof(double) * GF_STATS_VECTOR_LEN);
+            break;
+        }
+    return GF_OK;
+}
+
 /* host twin of gf_run_ops (the recorded-step replay), so the trace/replay host logic is testable on CPU */
 GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
     if (!ops || num_ops < 0) return GF_E_NULL;

@@ -61,3 +61,40 @@ def run_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every=1
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_probe_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every, probes):
+    """Nobody reads a log except at the ``probes`` steps, where every rank reads that step's log and the reward manager's
+    last-episode means (a curriculum's read).  Resets are rare in this config, so some probes find their answer in a ring row,
+    others in the row that was carried into ``last_reset`` on the device when its batch was recycled."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from genesis_forge_amd import _native as nat
+    from genesis_forge_amd import distributed as gfd
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+    from envs import Go2CommandDirectionEnv
+
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(os.path.join(ROOT, "oracle", "libgf_oracle.so")))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    start, count = sum(sizes[:rank]), sizes[rank]
+    env = Go2CommandDirectionEnv(num_envs=count, max_episode_length_s=2, cmd_resample_s=0.3, contacts=False, history=2, obs_noise=True,
+                                 scene_kwargs=dict(ang_noise=0.0, seed=3))
+    env.build()
+    env.seed(5)
+    gfd.attach(env, reduce_every=reduce_every)
+    env.reset()
+    g = torch.Generator().manual_seed(0)
+    out, resets = {}, []
+    for t in range(steps):
+        act = torch.randn(n_global, 12, generator=g)[start:start + count].contiguous()
+        o, r, te, tr, ex = env.step(act)
+        resets.append(int((te | tr).sum()))
+        if t in probes:
+            rm = env.reward_manager
+            out[t] = ({k: float(v) for k, v in ex["episode"].items()}, {name: rm.last_episode_mean_reward(name) for name in rm.cfg})
+    torch.save({"probes": out, "resets": resets, "traced": env._trace is not None}, os.path.join(out_dir, f"rank{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()

@@ -48,6 +48,12 @@ class OracleBackend(nat.Backend):
         if rc != 0:
             raise nat.GfError(f"gfo_stats_pack failed: {rc}")
 
+    def stats_last_reset(self, rows_ptr, num_rows, dst_ptr):
+        self.lib.gfo_stats_last_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        rc = self.lib.gfo_stats_last_reset(rows_ptr, num_rows, dst_ptr)
+        if rc != 0:
+            raise nat.GfError(f"gfo_stats_last_reset failed: {rc}")
+
     def post_check(self, refs):
         return self.lib.gfo_post_physics_check(C.byref(refs)) == 0
 

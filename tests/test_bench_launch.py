@@ -20,7 +20,7 @@ def _bench(*argv, timeout=240):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=timeout)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]   # gloo's C++ side greets on stdout
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]   # exactly one line: libraries that greet on stdout (gloo, RCCL) are sent to stderr
     assert len(lines) == 1, f"exactly one JSON line expected, got {len(lines)}: {p.stdout[-500:]}"
     return json.loads(lines[0])
 

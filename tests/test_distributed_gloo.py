@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from _dist_worker import run_shard
+from _dist_worker import run_probe_shard, run_shard
 
 
 def _free_port():
@@ -56,6 +56,46 @@ def test_sharded_run_equals_unsharded(oracle_lib_path, reduce_every, read_lag, m
         for key, want in ref[4].items():
             for lg in logs:
                 assert abs(lg[key] - want) <= 1e-6 + 1e-6 * abs(want), (t, key, lg[key], want)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("reduce_every", [8, 32])
+def test_last_episode_means_survive_ring_recycling(oracle_lib_path, reduce_every):
+    """Batched group ring, logs unread: rows are recycled without a host copy, and the last-episode means a curriculum reads come
+    from the newest ring row that reset something — or, when that row is more than a ring ago, from the device row
+    gf_stats_last_reset carried it into.  Same values as the unsharded run (whose single-process ring folds ``last_reset`` in
+    the action kernel)."""
+    n_global, steps, sizes = 70, 190, [33, 37]
+    probes = (60, 183, 189)   # (no probe between the resets of steps 90-110 and step 183: a read would cache the means on the host)
+    with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
+        ctx = mp.get_context("spawn")
+        p = ctx.Process(target=run_probe_shard, args=(0, 1, _free_port(), d1, n_global, steps, [n_global], 1, probes))
+        p.start(); p.join(240)
+        assert p.exitcode == 0
+        port = _free_port()
+        procs = [ctx.Process(target=run_probe_shard, args=(r, 2, port, d2, n_global, steps, sizes, reduce_every, probes)) for r in range(2)]
+        for q in procs:
+            q.start()
+        for q in procs:
+            q.join(240)
+            assert q.exitcode == 0
+        full = torch.load(os.path.join(d1, "rank0.pt"))
+        shards = [torch.load(os.path.join(d2, f"rank{r}.pt")) for r in range(2)]
+    assert all(s["traced"] for s in shards)
+    total = [a + b for a, b in zip(shards[0]["resets"], shards[1]["resets"])]
+    assert total == full["resets"]
+    last = max(t for t in range(183) if total[t])
+    assert 183 - last > 64, "the config should leave the newest reset row more than a ring behind probe 183"
+    assert any(v == v and v != 0.0 for v in full["probes"][183][1].values())
+    for t in probes:
+        want_log, want_means = full["probes"][t]
+        for s in shards:
+            log, means = s["probes"][t]
+            assert log.keys() == want_log.keys()
+            for k, v in want_log.items():
+                assert abs(log[k] - v) <= 1e-6 + 1e-6 * abs(v), (t, k, log[k], v)
+            for k, v in want_means.items():
+                assert (means[k] != means[k] and v != v) or abs(means[k] - v) <= 1e-6 + 1e-6 * abs(v), (t, k, means[k], v)   # (nan: a zero-weight term, as in the reference)
 
 
 def test_shard_partition():

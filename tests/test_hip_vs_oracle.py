@@ -155,3 +155,36 @@ def test_maximum_table_sizes_hip_equals_oracle(hip_backend, oracle_lib_path):
 def test_maximum_table_sizes_run_on_the_oracle(oracle_backend):
     out, env = _run_max_tables("cpu", n=40, steps=12)
     assert torch.isfinite(out[-1][0][1]).all()
+
+
+@pytest.mark.gpu
+def test_stats_last_reset_pick_hip_equals_oracle(hip_backend, oracle_lib_path):
+    """gf_stats_last_reset: the newest row (highest index) whose reset_count entry is > 0 is copied, dst untouched when none is;
+    row counts 1 … 64 (the whole ring), error codes for bad arguments."""
+    import ctypes as C
+    from genesis_forge_amd import _native as nat
+    from genesis_forge_amd._stats import STATS_VECTOR_LEN as L
+
+    NT = nat.GF_MAX_TERM_TERMS
+    orc = C.CDLL(oracle_lib_path)
+    orc.gfo_stats_last_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(11)
+    for n_rows, hot in [(1, []), (1, [0]), (8, [2, 5]), (32, [31]), (32, [0]), (64, [7, 63]), (64, []), (33, [32, 1])]:
+        rows = rng.standard_normal((n_rows, L))
+        rows[:, NT] = 0.0
+        for r in hot:
+            rows[r, NT] = float(r + 1)
+        dst0 = rng.standard_normal(L)
+        want = dst0.copy()
+        assert orc.gfo_stats_last_reset(rows.ctypes.data, n_rows, want.ctypes.data) == 0
+        if hot:
+            assert np.array_equal(want, rows[max(hot)])
+        else:
+            assert np.array_equal(want, dst0)
+        d_rows, d_dst = torch.from_numpy(rows).cuda(), torch.from_numpy(dst0.copy()).cuda()
+        hip_backend.stats_last_reset(d_rows.data_ptr(), n_rows, d_dst.data_ptr())
+        assert np.array_equal(d_dst.cpu().numpy(), want), (n_rows, hot)
+    lib = hip_backend.lib
+    assert lib.gf_stats_last_reset(None, 1, d_dst.data_ptr(), None) == -1   # GF_E_NULL
+    assert lib.gf_stats_last_reset(d_rows.data_ptr(), 65, d_dst.data_ptr(), None) == -2   # GF_E_RANGE
+    assert lib.gf_stats_last_reset(d_rows.data_ptr(), 0, d_dst.data_ptr(), None) == 0

@@ -17,7 +17,14 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "go2_cmd"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 gs.set_device("cuda:0")
 env = tasks.BASELINE_CONFIGS[cfg][1](n)
-env.build(); env.seed(1); env.reset()
+env.build()
+if os.environ.get("GF_DIST_FORCE") == "1":   # the process-group path with one rank (RCCL), reduce_every from GF_REDUCE_EVERY (32)
+    import torch.distributed as dist
+    from genesis_forge_amd import distributed as gfd
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29632")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    gfd.attach(env, reduce_every=int(os.environ.get("GF_REDUCE_EVERY", "32")), force=True)
+env.seed(1); env.reset()
 d = env.action_space.shape[0]
 acts = [torch.randn(n, d, device=gs.device) for _ in range(8)]
 for i in range(50):
