@@ -61,6 +61,7 @@ GF_EXPORT int gf_sizeof(int which) {
         case 16: return (int)sizeof(GfCommandView);
         case 17: return (int)sizeof(GfPostRefs);
         case 18: return (int)sizeof(GfRolloutArgs);
+        case 19: return (int)sizeof(GfHistoryUnrollArgs);
         default: return -1;
     }
 }
@@ -215,6 +216,7 @@ static int replay_patch(const GfReplay* r, const void* actions, const void* cons
                 GfRingClock* c = (GfRingClock*)p->aux;
                 if (!p->target || !c || c->length < 1) return GF_E_RANGE;
                 *(int32_t*)p->target = (c->length - c->calls % c->length) % c->length + 1;
+                if (p->target2) *(int32_t*)p->target2 = *(int32_t*)p->target;
                 ++c->calls;
             } break;
             default: return GF_E_OPCODE;
@@ -274,6 +276,7 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
             case GF_PHASE_SCENE: rc = gf_synth_scene_step((const GfSynthSceneArgs*)a, stream); break;
             case GF_PHASE_TERRAIN: rc = gf_terrain_height((const GfTerrainHeightArgs*)a, stream); break;
             case GF_PHASE_ROLLOUT: rc = gf_rollout_write((const GfRolloutArgs*)a, stream); break;
+            case GF_PHASE_UNROLL: rc = gf_history_unroll((const GfHistoryUnrollArgs*)a, stream); break;
             case GF_PHASE_GAIT: {
                 const GfGaitArgs* g = (const GfGaitArgs*)a;
                 const bool all = g && g->mode != GF_CMD_STEP && deferred.has(g->state);

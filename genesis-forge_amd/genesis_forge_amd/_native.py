@@ -13,7 +13,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-GF_ABI_VERSION = 3
+GF_ABI_VERSION = 4
 GF_MAX_TERMS = 24
 GF_MAX_TERM_TERMS = 16
 GF_MAX_OBS_ITEMS = 24
@@ -82,8 +82,8 @@ GF_O_BASE_QUAT = 13
 GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
 
 (GF_PHASE_ACTION, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
- GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_ROLLOUT,
- GF_PHASE_COUNT) = range(14)
+ GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_ROLLOUT, GF_PHASE_UNROLL,
+ GF_PHASE_COUNT) = range(15)
 
 GF_OPT_PROFILE_STRIDE = 1  # gf_set_option: stamp every k-th launch of the profiled phase
 GF_OPT_CHAIN = 3           # gf_set_option: 1 (default) = fold runs of per-env phases of a recorded step into phase-chain launches
@@ -274,6 +274,11 @@ class GfRolloutArgs(C.Structure):
                 ("obs_out", P), ("reward_out", P), ("done_out", P)]
 
 
+class GfHistoryUnrollArgs(C.Structure):
+    _fields_ = [("ring", P), ("out", P), ("out2", P), ("num_envs", C.c_int64), ("frame_width", C.c_int32), ("history_len", C.c_int32),
+                ("ring_slot", C.c_int32), ("_pad", C.c_int32)]
+
+
 class GfPostRefs(C.Structure):
     _fields_ = [("termination", P), ("reward", P), ("reset", P), ("num_command", C.c_int32), ("num_observe", C.c_int32),
                 ("command_step", P * GF_POST_MAX_CMD), ("command_reset", P * GF_POST_MAX_CMD), ("observe", P * GF_POST_MAX_OBS),
@@ -282,7 +287,7 @@ class GfPostRefs(C.Structure):
 
 ABI_STRUCTS = [GfStepStats, GfActionArgs, GfContactArgs, GfTerminationArgs, GfRewardArgs, GfCommandArgs,
                GfResetArgs, GfObservationArgs, GfRotateArgs, GfSynthSceneArgs, GfTerm, GfObsItem, GfTerrainView, GfTerrainHeightArgs, GfGaitArgs, GfContactView, GfCommandView,
-               GfPostRefs, GfRolloutArgs]
+               GfPostRefs, GfRolloutArgs, GfHistoryUnrollArgs]
 
 PHASE_FUNCS = {
     "action_step": GfActionArgs,
@@ -297,6 +302,7 @@ PHASE_FUNCS = {
     "terrain_height": GfTerrainHeightArgs,
     "gait_step": GfGaitArgs,
     "rollout_write": GfRolloutArgs,
+    "history_unroll": GfHistoryUnrollArgs,
 }
 
 
@@ -305,6 +311,7 @@ PHASE_OF_FN = {
     "reward_step": GF_PHASE_REWARD, "command_step": GF_PHASE_COMMAND, "masked_reset": GF_PHASE_RESET,
     "observe": GF_PHASE_OBSERVE, "entity_rotate": GF_PHASE_ROTATE, "synth_scene_step": GF_PHASE_SCENE,
     "terrain_height": GF_PHASE_TERRAIN, "gait_step": GF_PHASE_GAIT, "rollout_write": GF_PHASE_ROLLOUT,
+    "history_unroll": GF_PHASE_UNROLL,
 }
 
 

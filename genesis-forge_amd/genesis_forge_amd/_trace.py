@@ -88,6 +88,10 @@ class StepTrace:
                 self.ops[k].phase = nat.GF_OP_POST_PHYSICS
                 self.ops[k].args = C.addressof(self.post_refs)
                 k += 1
+            elif fn == "history_unroll":   # the gather of a ring-kept history follows the fused launch as an op of its own
+                self.ops[k].phase = nat.GF_PHASE_UNROLL
+                self.ops[k].args = C.addressof(args)
+                k += 1
             self._cur_op = k - 2  # index of this call's op once the leading STATS_CLEAR op is dropped (below)
             self._hooks(fn, args, owner)
             pre = owner._trace_pre(args) if hasattr(owner, "_trace_pre") else None
@@ -204,11 +208,15 @@ class StepTrace:
             (resets if fns[j] == "command_step" else gresets).append(tail[j])
             j += 1
         obs = []
-        while j < len(fns) and fns[j] == "observe":
-            obs.append(tail[j])
+        while j < len(fns) and fns[j] in ("observe", "history_unroll"):   # (a manager that keeps its history as a ring: frame, then gather)
+            if fns[j] == "observe":
+                obs.append(tail[j])
             j += 1
         if j < len(fns) and fns[j] == "rollout_write":   # learner.RolloutStorage: its rows are stored by the same launch
             refs.rollout = C.addressof(tail[j][1])
+            pol = next((m for m in self.env.managers["observation"] if m.name == tail[j][2].obs_name), None)
+            if pol is not None and pol._unrolled:
+                tail[j][1].obs_out = None   # … except the observation row of a ring-kept history: its gather writes it (learner.py)
             j += 1
         if j != len(fns) or len(steps) != len(resets) or len(steps) > nat.GF_POST_MAX_CMD or len(obs) > nat.GF_POST_MAX_OBS:
             return None
@@ -270,13 +278,21 @@ class StepTrace:
             self.afters.append((self._cur_op, env._after_masked_reset_traced))
         elif fn == "observe":
             self.native.extend(owner._trace_native(args))
+            if not owner._unrolled:
+                self.afters.append((self._cur_op, owner._trace_after))
+        elif fn == "history_unroll":
+            patch, native = owner._trace_unroll(args)
+            if patch is not None:
+                self.patches.append(patch)
+            self.native.extend(native)
             self.afters.append((self._cur_op, owner._trace_after))
         elif fn == "contact_step":
             pass
         elif fn == "rollout_write":
             pol = next(m for m in env.managers["observation"] if m.name == owner.obs_name)
-            self.patches.append(owner._trace_patch(args))
-            self.native.extend(owner._trace_native(args, pol._args))
+            fused = self.post_refs is not None and bool(self.post_refs.rollout)
+            self.patches.append(owner._trace_patch(args, pol if fused and pol._unrolled else None))
+            self.native.extend(owner._trace_native(args, pol, fused))
         else:
             raise RuntimeError(f"untraceable phase {fn}")
 

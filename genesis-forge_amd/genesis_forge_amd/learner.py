@@ -87,15 +87,24 @@ class RolloutStorage:
         self._keep = (obs, reward, terminated, truncated)
         self.env.backend.call("rollout_write", a, owner=self)
 
-    def _trace_patch(self, args):
-        def patch(_actions, a=args, self=self):
+    def _trace_patch(self, args, via_unroll=None):
+        """Recorded step: advance the rows.  ``via_unroll`` = the policy ObservationManager when it keeps its history as a ring and
+        the step is fused: the fused launch only holds the new frame, so the observation row is written by the manager's gather
+        (second destination of gf_history_unroll) and the fused launch gets no observation row."""
+        def patch(_actions, a=args, self=self, om=via_unroll):
             self._next_rows(a)
+            if om is not None:
+                om._unroll_args.out2, a.obs_out = a.obs_out, None
 
         return patch
 
-    def _trace_native(self, args, obs_args) -> list:
-        """`obs` follows the slot the observation kernel writes this step (that manager's rotation comes earlier in the table)."""
-        return [nat.GfReplayPatch(nat.GF_PATCH_COPY, 0, nat.field_addr(args, "obs"), None, nat.field_addr(obs_args, "obs"))]
+    def _trace_native(self, args, pol, fused: bool) -> list:
+        """`obs` follows the tensor the observation launch (or the gather of a ring-kept history) writes this step — that
+        manager's rotation comes earlier in the table."""
+        P = nat.GfReplayPatch
+        if getattr(pol, "_unrolled", False):
+            return [] if fused else [P(nat.GF_PATCH_COPY, 0, nat.field_addr(args, "obs"), None, nat.field_addr(pol._unroll_args, "out"))]
+        return [P(nat.GF_PATCH_COPY, 0, nat.field_addr(args, "obs"), None, nat.field_addr(pol._args, "obs"))]
 
 
 class ActorCriticMLP(torch.nn.Module):

@@ -19,6 +19,14 @@ keeps exactly that contract: the kernel writes into buffers only this manager se
 IS one of ``static_slots`` (3) persistent buffers the kernel writes in rotation — valid until this manager has been asked for
 ``static_slots - 1`` further observations, read-only for the caller when ``history_len > 1`` (the next call reads its history
 frames from it).  No copy, no allocation, nothing that changes from step to step in a recorded step.
+With ``history_len > 1`` both modes have two ways to produce the ``[N, H*O]`` tensor (``history=``, default ``"auto"``): ``"shift"`` —
+the observation launch copies the first ``H-1`` frames of its previous output behind the new frame (one launch, ``(2H-1)*O`` floats
+per env moved inside the step's kernel) — or ``"unroll"``: the manager keeps the history as an in-place ring, the step's kernel
+writes only the new frame, and ``gf_history_unroll`` gathers the ring into the newest-first tensor as a streaming launch of its
+own (``csrc/gf_unroll.hip``).  In ``"fresh"`` mode the gather writes straight into the caller's new tensor, so it REPLACES the
+clone (gait task, 65 536 envs: 194 → 157 µs per step); ``"auto"`` = unroll for ``"fresh"``, shift for ``"static"`` (there the gather
+is an extra launch with the same traffic as the in-kernel shift and measures the same or slower: 145 vs 141 µs, 47.6 vs 42.2 µs
+at 8 192 envs).
 ``output="ring"`` (``history_len > 1`` only) is the in-place history ring: ONE persistent ``[N, H, O]`` buffer is the history,
 a call writes only the new frame into frame slot ``history_head`` and returns the buffer as ``[N, H*O]`` — ``O`` floats of
 traffic per env instead of the ``(2H-1)*O`` a newest-first concatenation costs (gait task: 20 MB instead of 182 MB per step at
@@ -64,17 +72,25 @@ class ObservationManager(BaseManager):
     #: what get_observations() returns when the constructor is not told: "fresh" (reference contract) or "static" (see module
     #: docstring).  GF_OBS_OUTPUT overrides the default for a whole process (unchanged task configs on the fast path).
     default_output = os.environ.get("GF_OBS_OUTPUT", "fresh")
+    #: how a history of H > 1 frames becomes the [N, H*O] tensor in the "fresh" / "static" modes: "shift", "unroll" or "auto"
+    default_history = os.environ.get("GF_OBS_HISTORY", "auto")
     static_slots = _OBS_RING
 
     """Generates an observation tensor from a dict of items (ctor as observation_manager.py:134-156)."""
 
     def __init__(self, env, cfg: dict[str, ObservationConfig], name: str = "policy", history_len: int | None = None,
-                 noise: float | None = None, fused: bool = True, output: str | None = None):
+                 noise: float | None = None, fused: bool = True, output: str | None = None, history: str | None = None):
         super().__init__(env, "observation")
         self._name = name
         self._output = output if output is not None else type(self).default_output
         if self._output not in ("fresh", "static", "ring"):
             raise ValueError("output must be 'fresh', 'static' or 'ring'")
+        self._history_mode = history if history is not None else type(self).default_history
+        if self._history_mode not in ("auto", "shift", "unroll"):
+            raise ValueError("history must be 'auto', 'shift' or 'unroll'")
+        self._unroll_args = nat.GfHistoryUnrollArgs()
+        self._unroll_out: Optional[torch.Tensor] = None
+        self._ring: Optional[torch.Tensor] = None   # the [N, H, O] history of the "unroll" strategy
 
         self.noise = noise
         self._observation_size = 1
@@ -136,7 +152,22 @@ class ObservationManager(BaseManager):
         for i, b in enumerate(self._bufs):
             self._rotor.slot[i] = b.data_ptr()
         self._ring_clock.calls, self._ring_clock.length = 0, self._history_len
+        self._ring = None
         self._dirty = True
+
+    @property
+    def _unrolled(self) -> bool:
+        """History kept as a ring + gather launch (module docstring: ``history=``)."""
+        if self._history_len <= 1 or self._output == "ring" or not self._bufs:
+            return False
+        on = self._history_mode == "unroll" or (self._history_mode == "auto" and self._output == "fresh")
+        if on and self._ring is None:
+            self._ring = torch.zeros_like(self._bufs[0])   # [N, H, O], zero history like the reference's initial frame list
+            u = self._unroll_args
+            u.ring, u.out2, u.num_envs = self._ring.data_ptr(), None, self.env.num_envs
+            u.frame_width, u.history_len, u.ring_slot = self._frame, self._history_len, 1
+            self._unroll_out = self._bufs[0]
+        return on
 
     def _call_item(self, name, cfg) -> torch.Tensor:
         try:
@@ -242,12 +273,29 @@ class ObservationManager(BaseManager):
         out = self._rotate_ring(a)
         env.backend.call("observe", a, owner=self)
         self._keep = keep
+        if self._unrolled:   # the launch wrote the new frame into the ring: gather the ring into this call's tensor
+            u = self._unroll_args
+            u.ring_slot, u.out2 = a.history_ring, None
+            out = self._next_unroll_out()
+            env.backend.call("history_unroll", u, owner=self)
         self._last_out = out    # the buffer the kernel wrote (what a rollout storage copies from)
         return self._hand_out(out)
 
     def _hand_out(self, out: torch.Tensor) -> torch.Tensor:
         """The caller's tensor: a copy nobody else holds (reference contract), or the persistent slot itself (static)."""
-        return out.clone() if self._output == "fresh" else out
+        return out.clone() if self._output == "fresh" and not self._unrolled else out
+
+    def _next_unroll_out(self) -> torch.Tensor:
+        """Destination of this call's gather: a new tensor the caller will own ("fresh"), or the next static slot."""
+        if self._output == "fresh":
+            out = torch.empty_like(self._ring)
+        else:
+            ro = self._rotor
+            ro.cur = (ro.cur + 1) % _OBS_RING
+            out = self._bufs[ro.cur]
+        self._unroll_args.out = out.data_ptr()
+        self._unroll_out = out
+        return out
 
     # -- in-place history ring (output="ring") ------------------------------------------------------------------
     @property
@@ -274,13 +322,14 @@ class ObservationManager(BaseManager):
         return obs.view(n, H, O)[:, self.history_order(), :].reshape(n, H * O)
 
     def _rotate_ring(self, a) -> torch.Tensor:
-        if self._in_place:
+        if self._in_place or self._unrolled:
             H, ck = self._history_len, self._ring_clock
             a.history_ring = (H - ck.calls % H) % H + 1
             ck.calls += 1
             a.prev_obs = None
-            a.obs = self._bufs[0].data_ptr()
-            return self._bufs[0]
+            ring = self._ring if self._unrolled else self._bufs[0]
+            a.obs = ring.data_ptr()
+            return ring
         a.history_ring = 0
         ro = self._rotor
         prev = self._bufs[ro.cur]
@@ -291,6 +340,8 @@ class ObservationManager(BaseManager):
         return out
 
     def _current_out(self) -> torch.Tensor:
+        if self._unrolled:
+            return self._unroll_out
         return self._bufs[0] if self._in_place else self._bufs[self._rotor.cur]
 
     def _bind_exts(self, a, keep: list) -> None:
@@ -308,7 +359,7 @@ class ObservationManager(BaseManager):
 
     def _trace_pre(self, args):
         """Recorded step: Python-level items are evaluated right before this manager's op, where the ordinary path calls them."""
-        if not self._slots.exts:
+        if not self._slots.exts or args is self._unroll_args:   # (the gather op of a ring-kept history has no items)
             return None
 
         def pre(self=self, a=args):
@@ -323,7 +374,11 @@ class ObservationManager(BaseManager):
         the output slot rotation / ring slot, exactly what the ordinary path does in get_observations()."""
         P = nat.GfReplayPatch
         out = [P(nat.GF_PATCH_STREAM, 0, nat.field_addr(args, "stream"), None, None)]
-        if self._in_place:
+        if self._unrolled:   # the frame goes into the ring; the gather op that follows learns the slot from the same patch
+            args.prev_obs, args.obs = None, self._ring.data_ptr()
+            out.append(P(nat.GF_PATCH_RING_SLOT, 0, nat.field_addr(args, "history_ring"), nat.field_addr(self._unroll_args, "ring_slot"),
+                         C.addressof(self._ring_clock)))
+        elif self._in_place:
             args.prev_obs, args.obs = None, self._bufs[0].data_ptr()
             out.append(P(nat.GF_PATCH_RING_SLOT, 0, nat.field_addr(args, "history_ring"), None, C.addressof(self._ring_clock)))
         else:
@@ -332,8 +387,19 @@ class ObservationManager(BaseManager):
                          nat.field_addr(args, "obs"), C.addressof(self._rotor)))
         return out
 
+    def _trace_unroll(self, args):
+        """Recorded step, the gather op: (Python patch or None, native patches) that give it this step's destination."""
+        assert args is self._unroll_args
+        if self._output == "fresh":
+            def patch(_actions, self=self):
+                self._next_unroll_out()
+
+            return patch, []
+        return None, [nat.GfReplayPatch(nat.GF_PATCH_ROTATE, 0, None, nat.field_addr(args, "out"), C.addressof(self._rotor))]
+
     def _trace_after(self) -> None:
         """Recorded step, after the launches have been enqueued: publish this step's observation (a fresh copy by default)."""
-        out = self._current_out()
+        out = self._bufs[self._rotor.cur] if self._unrolled and self._output == "static" else self._current_out()
+        self._unroll_out = out if self._unrolled else self._unroll_out
         self._last_out = out
         self.env._extras["observations"][self._name] = self._hand_out(out)

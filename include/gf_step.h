@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 3
+#define GF_ABI_VERSION 4
 
 #define GF_MAX_TERMS 24          /* reward terms per manager          */
 #define GF_MAX_TERM_TERMS 16     /* termination terms per manager     */
@@ -591,6 +591,26 @@ typedef struct GfRolloutArgs {
 } GfRolloutArgs;
 
 /* ------------------------------------------------------------------------------------------
+ * History ring -> the reference's observation layout.  The reference keeps a list of H frames, pops the oldest, inserts the new
+ * one in front and returns `torch.cat(self._history, dim=-1)` (observation_manager.py:219-226): every call writes a NEW
+ * [N, H*O] tensor, newest frame first.  With the history kept as an in-place ring (GfObservationArgs.history_ring: the step
+ * writes O floats per env) that returned tensor is one streaming gather: out[n, j*O + c] = ring[n, (k + j) mod H, c] with k the
+ * slot of the newest frame.  Unlike shifting the previous output inside the step's kernel, the copy has no dependency on the
+ * step's arithmetic and runs as thousands of short workgroups at the copy rate of the memory system; it is also the caller's
+ * private tensor, so the default output mode needs no clone on top.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct GfHistoryUnrollArgs {
+    const float* ring;        /* [N, H, O]: the `obs` of launches with history_ring != 0 */
+    float* out;               /* [N, H*O], 16-byte aligned */
+    float* out2;              /* optional second destination with the same layout (a rollout-storage row), or NULL */
+    int64_t num_envs;
+    int32_t frame_width;      /* O >= 1 */
+    int32_t history_len;      /* H >= 1 */
+    int32_t ring_slot;        /* the history_ring value of the launch that wrote the newest frame: k + 1 */
+    int32_t _pad;
+} GfHistoryUnrollArgs;
+
+/* ------------------------------------------------------------------------------------------
  * Entry points.  `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream).
  * ---------------------------------------------------------------------------------------- */
 int gf_abi_version(void);
@@ -608,7 +628,7 @@ int gf_abi_version(void);
  * chains — termination → reward → command.step…, and reset → command.reset… → observe… — one launch each (csrc/gf_chain.hip). */
 enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_GRAPH = 2, GF_OPT_CHAIN = 3, GF_OPT_COUNT = 4 };
 int gf_set_option(int option, int value);
-int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView, 17 GfPostRefs, 18 GfRolloutArgs): binding self-check */
+int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView, 17 GfPostRefs, 18 GfRolloutArgs, 19 GfHistoryUnrollArgs): binding self-check */
 const char* gf_build_info(void);
 const char* gf_error_string(int code);
 
@@ -626,6 +646,7 @@ int gf_entity_rotate(const GfRotateArgs* a, void* stream);        /* replaces en
 int gf_terrain_height(const GfTerrainHeightArgs* a, void* stream);/* replaces terrain_manager.py:100-166 */
 int gf_synth_scene_step(const GfSynthSceneArgs* a, void* stream); /* stands in for scene.step() (managed_env.py:292) */
 int gf_rollout_write(const GfRolloutArgs* a, void* stream);       /* replaces the RolloutStorage copy_ launches of the RL library (examples/simple/train.py:125-129) */
+int gf_history_unroll(const GfHistoryUnrollArgs* a, void* stream);/* replaces the torch.cat of observation_manager.py:226 */
 
 /* ------------------------------------------------------------------------------------------
  * Fused post-physics step: everything ManagedEnvironment.step() does after scene.step() and the
@@ -727,8 +748,9 @@ enum {
                                 if target2: *(void**)target2 = r->slot[r->cur]                     (output slots, ping-pong buffers) */
     GF_PATCH_PARAM = 5,      /* *(const void**)target = params[index]                              (statistics ring slots) */
     GF_PATCH_COPY = 6,       /* *(uint64_t*)target = *(const uint64_t*)aux                         (a field that follows another) */
-    GF_PATCH_RING_SLOT = 7   /* c = (GfRingClock*)aux: *(int32_t*)target = (c->length - c->calls % c->length) % c->length + 1; ++c->calls
-                                                                                                   (GfObservationArgs.history_ring) */
+    GF_PATCH_RING_SLOT = 7   /* c = (GfRingClock*)aux: *(int32_t*)target = (c->length - c->calls % c->length) % c->length + 1; ++c->calls;
+                                if target2: *(int32_t*)target2 = the same value
+                                                              (GfObservationArgs.history_ring, GfHistoryUnrollArgs.ring_slot) */
 };
 typedef struct GfRotor {
     int32_t cur;
@@ -769,7 +791,7 @@ int gf_event_synchronize(void* event);   /* blocks the host until the event has 
  * immediately around the kernel launch of the selected phase). */
 enum { GF_PHASE_ACTION = 0, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
        GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_ROLLOUT,
-       GF_PHASE_COUNT };
+       GF_PHASE_UNROLL, GF_PHASE_COUNT };
 int gf_profile_begin(int phase, int max_samples);     /* start recording event pairs for `phase` */
 int gf_profile_end(double* total_ms, int* samples);    /* sync events, return Σ elapsed + count, free them */
 

@@ -1145,6 +1145,25 @@ GFO_EXPORT int gfo_stats_pack(const GfStatsPackArgs* a) {
     return GF_OK;
 }
 
+/* observation_manager.py:219-226: the returned tensor is cat(history), newest frame first; with the history kept as a ring
+ * (slot k = newest, then upwards, wrapping) that is a gather */
+GFO_EXPORT int gfo_history_unroll(const GfHistoryUnrollArgs* a) {
+    if (!a) return GF_E_NULL;
+    if (a->num_envs < 0 || a->frame_width < 1 || a->history_len < 1 || a->ring_slot < 1 || a->ring_slot > a->history_len) return GF_E_RANGE;
+    if ((int64_t)a->frame_width * a->history_len >= (1 << 17)) return GF_E_RANGE;
+    if (a->num_envs == 0) return GF_OK;
+    if (!a->ring || !a->out) return GF_E_NULL;
+    if (((uintptr_t)a->out & 15u) || ((uintptr_t)a->out2 & 15u) || ((uintptr_t)a->ring & 3u)) return GF_E_UNSUPPORTED;
+    const int O = a->frame_width, H = a->history_len, k = a->ring_slot - 1;
+    for (int64_t n = 0; n < a->num_envs; ++n)
+        for (int j = 0; j < H; ++j) {
+            const float* src = a->ring + ((size_t)n * H + (size_t)((k + j) % H)) * O;
+            memcpy(a->out + ((size_t)n * H + j) * O, src, sizeof(float) * (size_t)O);
+            if (a->out2) memcpy(a->out2 + ((size_t)n * H + j) * O, src, sizeof(float) * (size_t)O);
+        }
+    return GF_OK;
+}
+
 GFO_EXPORT int gfo_stats_last_reset(const double* rows, int num_rows, double* dst) {
     if (!rows || !dst) return GF_E_NULL;
     if (num_rows < 0 || num_rows > 64) return GF_E_RANGE;
@@ -1177,6 +1196,7 @@ GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
             case GF_OP_STATS_CLEAR: rc = gfo_stats_clear((GfStepStats*)a); break;
             case GF_OP_POST_PHYSICS: rc = gfo_post_physics_step((const GfPostRefs*)a); break;
             case GF_PHASE_ROLLOUT: rc = gfo_rollout_write((const GfRolloutArgs*)a); break;
+            case GF_PHASE_UNROLL: rc = gfo_history_unroll((const GfHistoryUnrollArgs*)a); break;
             case GF_OP_STATS_PACK: rc = gfo_stats_pack((const GfStatsPackArgs*)a); break;
             case GF_OP_STATS_COPY: {
                 const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
@@ -1232,6 +1252,7 @@ static int replay_patch(const GfReplay* r, const void* actions, const void* cons
                 GfRingClock* c = (GfRingClock*)p->aux;
                 if (!p->target || !c || c->length < 1) return GF_E_RANGE;
                 *(int32_t*)p->target = (c->length - c->calls % c->length) % c->length + 1;
+                if (p->target2) *(int32_t*)p->target2 = *(int32_t*)p->target;
                 ++c->calls;
             } break;
             default: return GF_E_OPCODE;
@@ -1269,6 +1290,7 @@ GFO_EXPORT int gfo_sizeof(int which) {
         case 16: return (int)sizeof(GfCommandView);
         case 17: return (int)sizeof(GfPostRefs);
         case 18: return (int)sizeof(GfRolloutArgs);
+        case 19: return (int)sizeof(GfHistoryUnrollArgs);
         default: return -1;
     }
 }

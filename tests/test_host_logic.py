@@ -353,3 +353,40 @@ def test_in_place_history_ring_holds_the_reference_frames(oracle_backend, trace)
     assert len(ptrs) == 1, "the ring IS the returned tensor"
     for t, (a, b) in enumerate(zip(want, got)):
         assert torch.equal(a, b), f"frames differ at observation {t}"
+
+
+@pytest.mark.parametrize("trace,output", [(False, "fresh"), (True, "fresh"), (True, "static")])
+def test_history_unroll_equals_history_shift(oracle_backend, trace, output):
+    """history="unroll" (ring + gf_history_unroll, the default for output="fresh") returns exactly the tensors history="shift"
+    returns (observation_manager.py:218-226), ordinary and recorded steps alike, and the "fresh" tensors are the caller's own."""
+    from genesis_forge_amd.managers import ObservationManager
+
+    def run(history):
+        old = (ObservationManager.default_output, ObservationManager.default_history)
+        ObservationManager.default_output, ObservationManager.default_history = output, history
+        try:
+            env = Go2CommandDirectionEnv(num_envs=70, max_episode_length_s=0.4, cmd_resample_s=0.2, history=3, contacts=True,
+                                         scene_kwargs=dict(ang_noise=0.3, seed=3))
+            env.trace_enabled = trace
+            env.build()
+        finally:
+            ObservationManager.default_output, ObservationManager.default_history = old
+        om = env.observation_manager
+        assert om._unrolled == (history == "unroll")
+        env.seed(9)
+        obs0, _ = env.reset()
+        g = torch.Generator().manual_seed(1)
+        held = [obs0]
+        outs = [obs0.clone()]
+        for _ in range(11):
+            held.append(env.step(torch.randn(70, 12, generator=g))[0])
+            outs.append(held[-1].clone())
+        assert (env._trace is not None) == trace
+        if output == "fresh":   # nobody overwrote a tensor the caller kept
+            assert all(torch.equal(h, o) for h, o in zip(held, outs)) and len({h.data_ptr() for h in held}) == len(held)
+        return outs, (env._trace.n_ops if trace else 0)
+
+    (want, ops_shift), (got, ops_unroll) = run("shift"), run("unroll")
+    assert ops_unroll == ops_shift + (1 if trace else 0), "a recorded step carries the gather as one more op behind the fused launch"
+    for t, (a, b) in enumerate(zip(want, got)):
+        assert torch.equal(a, b), f"observation {t} differs"

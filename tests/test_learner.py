@@ -30,13 +30,21 @@ def _make(kind, n):
     raise KeyError(kind)
 
 
-def _check_rollout(dev, kind, n, trace, horizon=5, steps=17, fuse=True):
+def _check_rollout(dev, kind, n, trace, horizon=5, steps=17, fuse=True, output="fresh"):
+    """``output``: "fresh" keeps a history of H > 1 frames as a ring and gathers it (the gather stores the storage row as its second
+    destination when the step is fused), "static" shifts it inside the observation launch (the fused launch stores the row)."""
     from genesis_forge_amd.learner import RolloutStorage
+    from genesis_forge_amd.managers import ObservationManager
 
-    env = _make(kind, n)
-    env.trace_enabled = trace
-    env.fuse_post_physics = fuse
-    env.build()
+    old, ObservationManager.default_output = ObservationManager.default_output, output
+    try:   # (the managers are created by env.config(), i.e. inside build())
+        env = _make(kind, n)
+        env.trace_enabled = trace
+        env.fuse_post_physics = fuse
+        env.build()
+    finally:
+        ObservationManager.default_output = old
+    assert all(m._output == output for m in env.managers["observation"])
     env.seed(7)
     obs, _ = env.reset()
     store = RolloutStorage(env, horizon).attach()
@@ -67,17 +75,23 @@ def _check_rollout(dev, kind, n, trace, horizon=5, steps=17, fuse=True):
     return env
 
 
-@pytest.mark.parametrize("kind,trace", [("go2", False), ("go2", True), ("go2_hist", True), ("gait", True), ("gait_curriculum", True)])
-def test_rollout_storage_rows_cpu(oracle_backend, kind, trace):
-    env = _check_rollout("cpu", kind, 70, trace)
+@pytest.mark.parametrize("kind,trace,output", [("go2", False, "fresh"), ("go2", True, "fresh"), ("go2_hist", True, "fresh"), ("gait", True, "fresh"),
+                                               ("gait_curriculum", True, "fresh"), ("go2_hist", True, "static"), ("go2_hist", False, "static"),
+                                               ("gait", True, "static")])
+def test_rollout_storage_rows_cpu(oracle_backend, kind, trace, output):
+    env = _check_rollout("cpu", kind, 70, trace, output=output)
     assert (env._trace is not None) == trace
+    if kind in ("go2_hist", "gait"):
+        assert all(m._unrolled == (output == "fresh") for m in env.managers["observation"] if m._history_len > 1)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,trace,fuse", [("go2", False, True), ("go2", True, True), ("go2", True, False), ("go2_hist", True, True), ("gait", True, True),
-                                             ("gait", True, False), ("gait_curriculum", True, True)])
-def test_rollout_storage_rows_hip(hip_backend, kind, trace, fuse):
-    env = _check_rollout("cuda", kind, 1000, trace, fuse=fuse)
+@pytest.mark.parametrize("kind,trace,fuse,output", [("go2", False, True, "fresh"), ("go2", True, True, "fresh"), ("go2", True, False, "fresh"),
+                                                    ("go2_hist", True, True, "fresh"), ("gait", True, True, "fresh"), ("gait", True, False, "fresh"),
+                                                    ("gait_curriculum", True, True, "fresh"), ("go2_hist", True, True, "static"),
+                                                    ("gait", True, True, "static"), ("gait", True, False, "static")])
+def test_rollout_storage_rows_hip(hip_backend, kind, trace, fuse, output):
+    env = _check_rollout("cuda", kind, 1000, trace, fuse=fuse, output=output)
     tr = env._trace
     assert (tr is not None) == trace
     if trace and kind != "gait_curriculum":
