@@ -42,7 +42,9 @@ PRIMING_STEPS = 8      # setup, not warm-up: an env records its step over its fi
 HBM_POINT_ENVS = 1 << 20
 GRID_N = (64, 4096, 16384, 65536)
 GRID_D = (12, 28)
-OBS_OUTPUT = os.environ.get("GF_OBS_OUTPUT", "static")
+# the package's default output contract (the reference's: every step returns a tensor of the caller's own — the fused launch writes
+# straight into it); GF_OBS_OUTPUT=static selects the persistent output slots instead (same step time within the box-to-box noise)
+OBS_OUTPUT = os.environ.get("GF_OBS_OUTPUT", "fresh")
 
 
 def reward_bytes_per_env(D: int, T: int, cmd_width: int) -> int:

@@ -278,6 +278,9 @@ class StepTrace:
             self.afters.append((self._cur_op, env._after_masked_reset_traced))
         elif fn == "observe":
             self.native.extend(owner._trace_native(args))
+            fresh = owner._trace_fresh_patch(args)
+            if fresh is not None:
+                self.patches.append(fresh)
             if not owner._unrolled:
                 self.afters.append((self._cur_op, owner._trace_after))
         elif fn == "history_unroll":

@@ -121,6 +121,20 @@ class ObservationManager(BaseManager):
         return self._name
 
     @property
+    def output(self) -> str:
+        """"fresh", "static" or "ring" (module docstring).  Assigning it drops a recorded step: the step's patch table is per mode."""
+        return self._output
+
+    @output.setter
+    def output(self, value: str) -> None:
+        if value not in ("fresh", "static", "ring"):
+            raise ValueError("output must be 'fresh', 'static' or 'ring'")
+        if value != self._output:
+            self._output = value
+            if hasattr(self.env, "invalidate_trace"):
+                self.env.invalidate_trace()
+
+    @property
     def observation_space(self):
         return self._observation_space
 
@@ -282,8 +296,20 @@ class ObservationManager(BaseManager):
         return self._hand_out(out)
 
     def _hand_out(self, out: torch.Tensor) -> torch.Tensor:
-        """The caller's tensor: a copy nobody else holds (reference contract), or the persistent slot itself (static)."""
-        return out.clone() if self._output == "fresh" and not self._unrolled else out
+        """The caller's tensor: one nobody else holds (reference contract) — the launch wrote it directly (no history: a new tensor
+        per call; history kept as a ring: the gather's destination), or it is a copy — or the persistent slot itself (static)."""
+        return out.clone() if self._output == "fresh" and not self._unrolled and not self._direct_fresh else out
+
+    @property
+    def _direct_fresh(self) -> bool:
+        """output="fresh" without history: the launch reads no previous output, so it writes straight into the caller's new tensor."""
+        return self._output == "fresh" and self._history_len == 1 and bool(self._bufs)
+
+    def _next_fresh_out(self, a) -> torch.Tensor:
+        out = torch.empty_like(self._bufs[0])
+        a.obs = out.data_ptr()
+        self._unroll_out = out
+        return out
 
     def _next_unroll_out(self) -> torch.Tensor:
         """Destination of this call's gather: a new tensor the caller will own ("fresh"), or the next static slot."""
@@ -331,6 +357,9 @@ class ObservationManager(BaseManager):
             a.obs = ring.data_ptr()
             return ring
         a.history_ring = 0
+        if self._direct_fresh:
+            a.prev_obs = None
+            return self._next_fresh_out(a)
         ro = self._rotor
         prev = self._bufs[ro.cur]
         ro.cur = (ro.cur + 1) % _OBS_RING
@@ -340,7 +369,7 @@ class ObservationManager(BaseManager):
         return out
 
     def _current_out(self) -> torch.Tensor:
-        if self._unrolled:
+        if self._unrolled or self._direct_fresh:
             return self._unroll_out
         return self._bufs[0] if self._in_place else self._bufs[self._rotor.cur]
 
@@ -381,11 +410,23 @@ class ObservationManager(BaseManager):
         elif self._in_place:
             args.prev_obs, args.obs = None, self._bufs[0].data_ptr()
             out.append(P(nat.GF_PATCH_RING_SLOT, 0, nat.field_addr(args, "history_ring"), None, C.addressof(self._ring_clock)))
+        elif self._direct_fresh:
+            args.history_ring, args.prev_obs = 0, None   # `obs` = this step's new tensor (_trace_fresh_patch)
         else:
             args.history_ring = 0
             out.append(P(nat.GF_PATCH_ROTATE, 0, nat.field_addr(args, "prev_obs") if self._history_len > 1 else None,
                          nat.field_addr(args, "obs"), C.addressof(self._rotor)))
         return out
+
+    def _trace_fresh_patch(self, args):
+        """Recorded step, output="fresh" without history: a Python patch that points the launch at this step's new tensor."""
+        if not self._direct_fresh:
+            return None
+
+        def patch(_actions, self=self, a=args):
+            self._next_fresh_out(a)
+
+        return patch
 
     def _trace_unroll(self, args):
         """Recorded step, the gather op: (Python patch or None, native patches) that give it this step's destination."""
@@ -400,6 +441,6 @@ class ObservationManager(BaseManager):
     def _trace_after(self) -> None:
         """Recorded step, after the launches have been enqueued: publish this step's observation (a fresh copy by default)."""
         out = self._bufs[self._rotor.cur] if self._unrolled and self._output == "static" else self._current_out()
-        self._unroll_out = out if self._unrolled else self._unroll_out
+        self._unroll_out = out if self._unrolled or self._direct_fresh else self._unroll_out
         self._last_out = out
         self.env._extras["observations"][self._name] = self._hand_out(out)

@@ -316,11 +316,11 @@ def test_static_observation_output_is_opt_in(oracle_backend):
     assert ObservationManager.default_output == "fresh"
     env = Go2CommandDirectionEnv(num_envs=16, scene_kwargs=dict(seed=3))
     env.build()
-    env.observation_manager._output = "static"
+    env.observation_manager.output = "static"
     env.reset()
     ptrs = [env.step(torch.zeros(16, 12))[0].data_ptr() for _ in range(7)]
     assert len(set(ptrs)) == ObservationManager.static_slots and ptrs[0] == ptrs[3] == ptrs[6]
-    env.observation_manager._output = "fresh"
+    env.observation_manager.output = "fresh"
     ptrs = {env.step(torch.zeros(16, 12))[0].data_ptr() for _ in range(3)} & set(ptrs)
     assert not ptrs, "fresh outputs never alias the persistent slots"
 
@@ -335,7 +335,7 @@ def test_in_place_history_ring_holds_the_reference_frames(oracle_backend, trace)
         env.trace_enabled = trace
         env.build()
         om = env.observation_manager
-        om._output = output
+        om.output = output
         env.seed(9)
         obs0, _ = env.reset()
         g = torch.Generator().manual_seed(1)

@@ -32,7 +32,7 @@ def main():
     from genesis_forge_amd import gs
     from genesis_forge_amd.managers import ObservationManager
 
-    ObservationManager.default_output = os.environ.get("GF_OBS_OUTPUT", "static")   # as bench.py: persistent output slots
+    ObservationManager.default_output = os.environ.get("GF_OBS_OUTPUT", "fresh")   # as bench.py: the default output contract
 
     if not torch.cuda.is_available():
         raise SystemExit("needs a ROCm GPU")

@@ -12,7 +12,7 @@ import torch
 from genesis_forge_amd import gs, tasks
 from genesis_forge_amd.managers import ObservationManager
 
-ObservationManager.default_output = os.environ.get("GF_OBS_OUTPUT", "static")
+ObservationManager.default_output = os.environ.get("GF_OBS_OUTPUT", "fresh")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "go2_cmd"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 gs.set_device("cuda:0")
