@@ -13,6 +13,7 @@ int contact_launch(const GfContactArgs* const* mgrs, int num, hipStream_t s);
 int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc, DeferredFlags* deferred);   // gf_chain.hip
 int chain_b_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc, DeferredFlags* deferred);
 int gait_launch(const GfGaitArgs* a, hipStream_t s, bool flags_all);                                      // gf_gait.hip
+int unroll_pair(const GfHistoryUnrollArgs* a, const GfHistoryUnrollArgs* b, hipStream_t s, int* fused);   // gf_unroll.hip
 }
 
 #define GF_EXPORT __attribute__((visibility("default")))
@@ -276,7 +277,13 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
             case GF_PHASE_SCENE: rc = gf_synth_scene_step((const GfSynthSceneArgs*)a, stream); break;
             case GF_PHASE_TERRAIN: rc = gf_terrain_height((const GfTerrainHeightArgs*)a, stream); break;
             case GF_PHASE_ROLLOUT: rc = gf_rollout_write((const GfRolloutArgs*)a, stream); break;
-            case GF_PHASE_UNROLL: rc = gf_history_unroll((const GfHistoryUnrollArgs*)a, stream); break;
+            case GF_PHASE_UNROLL: {   // the gathers of two managers (policy + critic) share a launch
+                int fused = 0;
+                if (a && i + 1 < num_ops && ops[i + 1].phase == GF_PHASE_UNROLL && ops[i + 1].args)
+                    rc = gf::unroll_pair((const GfHistoryUnrollArgs*)a, (const GfHistoryUnrollArgs*)ops[i + 1].args, s, &fused);
+                if (fused) { if (rc == GF_OK) i += 1; break; }
+                if (rc == GF_OK) rc = gf_history_unroll((const GfHistoryUnrollArgs*)a, stream);
+            } break;
             case GF_PHASE_GAIT: {
                 const GfGaitArgs* g = (const GfGaitArgs*)a;
                 const bool all = g && g->mode != GF_CMD_STEP && deferred.has(g->state);

@@ -51,10 +51,10 @@ __device__ __forceinline__ int64_t rows_before(int64_t e, const UnrollConsts& c)
 // (whole units and edge halves) is issued before the one wait; a first version composed edge units from element loads AFTER the
 // stores, and since every wave meets an edge that put four more serialised round trips on every wave: 48 us instead of 25 for the
 // gait policy history at 65 536 envs (profiles/r02_m_unroll_edges.txt).
-__global__ __launch_bounds__(kUnrollBlock) void history_unroll_kernel(const GfHistoryUnrollArgs a, const UnrollConsts uc) {
+__device__ __forceinline__ void unroll_chunk(const GfHistoryUnrollArgs& a, const UnrollConsts& uc, const unsigned block) {
     const UnrollMap map(uc, a.frame_width, a.history_len, a.ring_slot - 1);
     const int64_t total = a.num_envs * (int64_t)map.OH, units = total >> 2;
-    const int64_t e0 = (int64_t)blockIdx.x * kUnrollChunk;
+    const int64_t e0 = (int64_t)block * kUnrollChunk;
     const int64_t n0 = rows_before(e0, uc);   // workgroup-uniform
     const int c0 = (int)(e0 - n0 * map.OH);
     const GF_GLOBAL float* ring = G(a.ring) + n0 * map.OH;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kUnrollBlock) void history_unroll_kernel(const GfHi
     }
     // the array's last total mod 4 floats (they belong to the last row)
     const int tail = (int)(total & 3);
-    if (blockIdx.x == 0 && tid < tail) {
+    if (block == 0 && tid < tail) {
         const int64_t e = (units << 2) + tid, n = rows_before(e, uc);
         int cc;
         const int so = map.src((int)(e - n * map.OH), cc);
@@ -122,6 +122,15 @@ __global__ __launch_bounds__(kUnrollBlock) void history_unroll_kernel(const GfHi
         G(a.out)[e] = r;
         if (a.out2) G(a.out2)[e] = r;
     }
+}
+
+__global__ __launch_bounds__(kUnrollBlock) void history_unroll_kernel(const GfHistoryUnrollArgs a, const UnrollConsts uc) { unroll_chunk(a, uc, blockIdx.x); }
+
+// two managers (policy + critic of one env), one launch: workgroups [0, split) gather the first, the rest the second
+__global__ __launch_bounds__(kUnrollBlock) void history_unroll2_kernel(const GfHistoryUnrollArgs a, const UnrollConsts ua, const GfHistoryUnrollArgs b,
+                                                                        const UnrollConsts ub, const unsigned split) {
+    if (blockIdx.x < split) unroll_chunk(a, ua, blockIdx.x);
+    else unroll_chunk(b, ub, blockIdx.x - split);
 }
 
 int unroll_prep(const GfHistoryUnrollArgs* a) {
@@ -134,22 +143,44 @@ int unroll_prep(const GfHistoryUnrollArgs* a) {
     return GF_OK;
 }
 
+
+
+static UnrollConsts unroll_consts(const GfHistoryUnrollArgs* a) {
+    const uint64_t oh = (uint64_t)a->frame_width * (uint64_t)a->history_len, o = (uint64_t)a->frame_width;
+    UnrollConsts uc;
+    uc.m_oh = (((uint64_t)1 << 40) + oh - 1) / oh;
+    uc.m_o = (((uint64_t)1 << 40) + o - 1) / o;
+    uc.big_oh = oh > 1 ? ~(uint64_t)0 / oh + 1 : 0;   // ceil(2^64 / oh) for oh >= 2 (2^64 is a multiple of oh only for powers of two, where this is exact too)
+    return uc;
+}
+static int64_t unroll_blocks(const GfHistoryUnrollArgs* a) {
+    const int64_t total = a->num_envs * (int64_t)a->frame_width * a->history_len;
+    return (total + kUnrollChunk - 1) / kUnrollChunk;
+}
+
+// gf_run_ops: two consecutive gather ops share a launch.  Returns GF_OK or an error; *fused = 1 when both were launched.
+int unroll_pair(const GfHistoryUnrollArgs* a, const GfHistoryUnrollArgs* b, hipStream_t s, int* fused) {
+    *fused = 0;
+    int rc = unroll_prep(a);
+    if (rc) return rc;
+    if (unroll_prep(b) != GF_OK || a->num_envs == 0 || b->num_envs == 0 || g_prof.phase == GF_PHASE_UNROLL) return GF_OK;   // caller launches them one by one
+    const int64_t na = unroll_blocks(a), nb = unroll_blocks(b);
+    if (na + nb >= (int64_t)1 << 31) return GF_OK;
+    klaunch(history_unroll2_kernel, dim3((unsigned)(na + nb)), dim3(kUnrollBlock), 0, s, *a, unroll_consts(a), *b, unroll_consts(b), (unsigned)na);
+    *fused = 1;
+    return launch_status();
+}
+
 }  // namespace gf
 
 extern "C" __attribute__((visibility("default"))) int gf_history_unroll(const GfHistoryUnrollArgs* a, void* stream) {
     const int rc = gf::unroll_prep(a);
     if (rc) return rc;
     if (a->num_envs == 0) return GF_OK;
-    const int64_t total = a->num_envs * (int64_t)a->frame_width * a->history_len;
-    const int64_t blocks = (total + gf::kUnrollChunk - 1) / gf::kUnrollChunk;
+    const int64_t blocks = gf::unroll_blocks(a);
     if (blocks >= (int64_t)1 << 31) return GF_E_RANGE;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_UNROLL, s);
-    const uint64_t oh = (uint64_t)a->frame_width * (uint64_t)a->history_len, o = (uint64_t)a->frame_width;
-    gf::UnrollConsts uc;
-    uc.m_oh = (((uint64_t)1 << 40) + oh - 1) / oh;
-    uc.m_o = (((uint64_t)1 << 40) + o - 1) / o;
-    uc.big_oh = oh > 1 ? ~(uint64_t)0 / oh + 1 : 0;   // ceil(2^64 / oh) (oh >= 2: 2^64 - 1 is never a multiple short of 2^64 by more than oh - 1)
-    GF_LAUNCH(scope, gf::history_unroll_kernel, (unsigned)blocks, gf::kUnrollBlock, 0, s, *a, uc);
+    GF_LAUNCH(scope, gf::history_unroll_kernel, (unsigned)blocks, gf::kUnrollBlock, 0, s, *a, gf::unroll_consts(a));
     return gf::launch_status();
 }
