@@ -91,6 +91,7 @@ class ObservationManager(BaseManager):
         self._unroll_args = nat.GfHistoryUnrollArgs()
         self._unroll_out: Optional[torch.Tensor] = None
         self._ring: Optional[torch.Tensor] = None   # the [N, H, O] history of the "unroll" strategy
+        self._fresh_pool: list = []                 # output="fresh": rows of the current block not handed out yet
 
         self.noise = noise
         self._observation_size = 1
@@ -167,6 +168,7 @@ class ObservationManager(BaseManager):
             self._rotor.slot[i] = b.data_ptr()
         self._ring_clock.calls, self._ring_clock.length = 0, self._history_len
         self._ring = None
+        self._fresh_pool = []
         self._dirty = True
 
     @property
@@ -305,8 +307,24 @@ class ObservationManager(BaseManager):
         """output="fresh" without history: the launch reads no previous output, so it writes straight into the caller's new tensor."""
         return self._output == "fresh" and self._history_len == 1 and bool(self._bufs)
 
+    def _take_fresh(self) -> torch.Tensor:
+        """A tensor nobody else holds.  Observations come out of blocks of 3 … 32 rows (about 4 MB; one ``torch.empty`` per block: the
+        allocator call costs the host ~2.5 µs — 20.9 instead of 16.3 µs per step at 4 096 envs when paid every step); each row is a
+        separate tensor, never handed out twice, and a block's memory goes back to the allocator when the last of its rows has been
+        dropped.  From 64 MB per observation on, one allocation per call."""
+        pool = self._fresh_pool
+        if not pool:
+            ref = self._bufs[0]
+            n = ref.numel()
+            pitch = (n + 63) & ~63   # rows start 256-byte aligned whatever the frame width (the kernels store 16-byte units)
+            nbytes = pitch * ref.element_size()
+            k = 1 if nbytes >= (64 << 20) else max(3, min(32, (4 << 20) // nbytes))
+            block = torch.empty(k * pitch, dtype=ref.dtype, device=ref.device)
+            pool = self._fresh_pool = [block[i * pitch:i * pitch + n].view(ref.shape) for i in range(k)]
+        return pool.pop()
+
     def _next_fresh_out(self, a) -> torch.Tensor:
-        out = torch.empty_like(self._bufs[0])
+        out = self._take_fresh()
         a.obs = out.data_ptr()
         self._unroll_out = out
         return out
@@ -314,7 +332,7 @@ class ObservationManager(BaseManager):
     def _next_unroll_out(self) -> torch.Tensor:
         """Destination of this call's gather: a new tensor the caller will own ("fresh"), or the next static slot."""
         if self._output == "fresh":
-            out = torch.empty_like(self._ring)
+            out = self._take_fresh()
         else:
             ro = self._rotor
             ro.cur = (ro.cur + 1) % _OBS_RING
