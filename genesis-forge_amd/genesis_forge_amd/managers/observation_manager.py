@@ -93,6 +93,8 @@ class ObservationManager(BaseManager):
         self._ring: Optional[torch.Tensor] = None   # the [N, H, O] history of the "unroll" strategy
         self._fresh_pool: list = []                 # output="fresh": (tensor, address) rows of the current block not handed out yet
         self._fresh_ptr = 0
+        self._unrolled = False       # history kept as a ring + gather launch (module docstring: ``history=``); set by _refresh_modes()
+        self._direct_fresh = False   # output="fresh" without history: the launch writes straight into the caller's new tensor
 
         self.noise = noise
         self._observation_size = 1
@@ -133,6 +135,7 @@ class ObservationManager(BaseManager):
             raise ValueError("output must be 'fresh', 'static' or 'ring'")
         if value != self._output:
             self._output = value
+            self._refresh_modes()
             if hasattr(self.env, "invalidate_trace"):
                 self.env.invalidate_trace()
 
@@ -171,20 +174,22 @@ class ObservationManager(BaseManager):
         self._ring = None
         self._fresh_pool = []
         self._dirty = True
+        self._refresh_modes()
 
-    @property
-    def _unrolled(self) -> bool:
-        """History kept as a ring + gather launch (module docstring: ``history=``)."""
-        if self._history_len <= 1 or self._output == "ring" or not self._bufs:
-            return False
-        on = self._history_mode == "unroll" or (self._history_mode == "auto" and self._output == "fresh")
+    def _refresh_modes(self) -> None:
+        """The two per-mode flags the step's hot path reads (plain attributes: a property costs the host ~0.25 µs per read and a
+        recorded step reads them seven times)."""
+        built = bool(self._bufs)
+        self._direct_fresh = built and self._output == "fresh" and self._history_len == 1
+        on = built and self._history_len > 1 and self._output != "ring" and (
+            self._history_mode == "unroll" or (self._history_mode == "auto" and self._output == "fresh"))
+        self._unrolled = on
         if on and self._ring is None:
             self._ring = torch.zeros_like(self._bufs[0])   # [N, H, O], zero history like the reference's initial frame list
             u = self._unroll_args
             u.ring, u.out2, u.num_envs = self._ring.data_ptr(), None, self.env.num_envs
             u.frame_width, u.history_len, u.ring_slot = self._frame, self._history_len, 1
             self._unroll_out = self._bufs[0]
-        return on
 
     def _call_item(self, name, cfg) -> torch.Tensor:
         try:
@@ -302,11 +307,6 @@ class ObservationManager(BaseManager):
         """The caller's tensor: one nobody else holds (reference contract) — the launch wrote it directly (no history: a new tensor
         per call; history kept as a ring: the gather's destination), or it is a copy — or the persistent slot itself (static)."""
         return out.clone() if self._output == "fresh" and not self._unrolled and not self._direct_fresh else out
-
-    @property
-    def _direct_fresh(self) -> bool:
-        """output="fresh" without history: the launch reads no previous output, so it writes straight into the caller's new tensor."""
-        return self._output == "fresh" and self._history_len == 1 and bool(self._bufs)
 
     def _take_fresh(self) -> torch.Tensor:
         """A tensor nobody else holds.  Observations come out of blocks of 3 … 32 rows (≈ 16 MB; from 64 MB per observation on:

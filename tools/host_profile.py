@@ -44,4 +44,4 @@ for i in range(2000):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(14)
+st.sort_stats("tottime").print_stats(int(os.environ.get("GF_PROFILE_ROWS", "14")))
