@@ -128,19 +128,49 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     };
 
     // ---- state that lives across the barrier, per role -------------------------------------------------------------
-    float4 q = make_float4(1.f, 0.f, 0.f, 0.f);       // wave 0
+    // The roles are branches of ONE function, so to the register allocator a value that wave 0 carries across the barrier and a value
+    // that wave 2 carries across it are both live at the barrier: role state ADDS UP.  The control wave's quaternion / counters / gait
+    // row (25 words) and the three DOF rows the other waves hold (36 words at 12 DOF) therefore share storage — a union; every execution
+    // path touches one member only and the compiler merges the two views word by word into the same registers.  VGPRs: 12-DOF
+    // interpreter 148 → 124 (three → four workgroups per CU: 15.5 → 11.0 µs at 65 536 envs, 171 → 151 µs at 1 M), gait program 104 → 86,
+    // the other static programs 84–86 → 78–80, 28-DOF interpreter 197 → 173.  What is indexed at run time by the interpreter (`cmd`,
+    // `cmd_dirty`) stays outside: inside the union such an access becomes an address computation and the member goes to scratch.
     V3 pos{0, 0, 0};                                    // waves 0, 1
-    int ep_len = 0, term = 0, trunc = 0;                // wave 0
-    float cmd[GF_POST_MAX_CMD][kPostMaxRanges] = {};    // wave 0
-    bool cmd_dirty[GF_POST_MAX_CMD] = {false, false};   // wave 0
-    float grow[GF_GAIT_ROW] = {};                       // wave 0: the gait manager's state row, stored after the last barrier
-    int gait_sel = 0;                                   // wave 0
-    bool gait_resampled = false;                        // wave 0
     float dof_dev = 0.f, act_rate = 0.f, secs_in = 0.f; // wave 1
     float cmd0[3] = {0.f, 0.f, 0.f};                    // wave 1
-    float4 r_a[R], r_b[R], r_c[R];                      // wave 1: dof_pos/actions/last; wave 2: dof_pos/dof_vel/default; wave 3: targets/actions
+    struct CtlState {                                   // wave 0
+        __device__ CtlState() {}
+        float4 q;
+        int ep_len, term, trunc;
+        float grow[GF_GAIT_ROW];                        // the gait manager's state row, stored after the last barrier
+        int gait_sel, gait_resampled;
+    };
+    struct RowState { float4 r_a[R], r_b[R], r_c[R]; __device__ RowState() {} }; // wave 1: dof_pos/actions/last; wave 2: dof_pos/dof_vel/default; wave 3: targets/actions
+    union Persist {
+        CtlState ctl;
+        RowState rows;
+        __device__ Persist() {}
+    } persist;
+    float4 (&r_a)[R] = persist.rows.r_a;
+    float4 (&r_b)[R] = persist.rows.r_b;
+    float4 (&r_c)[R] = persist.rows.r_c;
+    CtlState& ctl = persist.ctl;
+    float4& q = ctl.q;
+    int& ep_len = ctl.ep_len; int& term = ctl.term; int& trunc = ctl.trunc;
+    float cmd[GF_POST_MAX_CMD][kPostMaxRanges] = {};    // wave 0 (outside the union: indexed at run time by the interpreter)
+    bool cmd_dirty[GF_POST_MAX_CMD] = {false, false};   // wave 0 (outside the union: a run-time index into a two-entry array)
+    float (&grow)[GF_GAIT_ROW] = ctl.grow;
+    int& gait_sel = ctl.gait_sel; int& gait_resampled = ctl.gait_resampled;
+    if (wave == 0) {
+        q = make_float4(1.f, 0.f, 0.f, 0.f);
+        ep_len = 0; term = 0; trunc = 0;
 #pragma unroll
-    for (int c = 0; c < DV; ++c) { r_a[c] = z4; r_b[c] = z4; r_c[c] = z4; }
+        for (int j = 0; j < GF_GAIT_ROW; ++j) grow[j] = 0.f;
+        gait_sel = 0; gait_resampled = 0;
+    } else {
+#pragma unroll
+        for (int c = 0; c < DV; ++c) { r_a[c] = z4; r_b[c] = z4; r_c[c] = z4; }
+    }
 
     if (wave == 0) {
         // ---- control: loads -------------------------------------------------------------------------------------------
@@ -176,7 +206,9 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         auto term_body = [&](int k, const GfTerm& t) GF_INLINE_LAMBDA {
             int v = eval_termination_term(t, a, tr, (uint32_t)has_maxlen);
             v = live ? v : 0;
-            if (t.flags & GF_TERM_FLAG_TIME_OUT) trunc |= v; else term |= v;
+            const int is_to = (t.flags & GF_TERM_FLAG_TIME_OUT) ? 1 : 0;   // (selects on values: an `if … trunc |= v; else term |= v;` makes the
+            trunc |= is_to ? v : 0;                                        //  compiler pick an ADDRESS inside the union below → scratch)
+            term |= is_to ? 0 : v;
             if (shard) {
                 const unsigned long long hit = __ballot(v);
                 if (hit && lane == 0) atomicAdd(&shard->term_fired[k], popc64(hit));
@@ -246,7 +278,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 }
                 grow[GF_GAIT_HEIGHT] = ((fixed_mask >> g) & 1) ? gg.clearance_lo : uniform_range(u.y, gg.clearance_lo, gg.clearance_hi);
                 grow[GF_GAIT_PERIOD] = uniform_range(u.z, gg.period_lo, gg.period_hi);
-                gait_resampled = true;
+                gait_resampled = 1;
             };
             if (live && (ep_len % UNI(gg.resample_steps)) == 0) resample(gg.stream_step);
             if (shard) {   // _log_metrics (:430-441): envs per gait, after this step's resample
