@@ -131,13 +131,12 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     // The roles are branches of ONE function, so to the register allocator a value that wave 0 carries across the barrier and a value
     // that wave 2 carries across it are both live at the barrier: role state ADDS UP.  The control wave's quaternion / counters / gait
     // row (25 words) and the three DOF rows the other waves hold (36 words at 12 DOF) therefore share storage — a union; every execution
-    // path touches one member only and the compiler merges the two views word by word into the same registers.  VGPRs: 12-DOF
-    // interpreter 148 → 124 (three → four workgroups per CU: 15.5 → 11.0 µs at 65 536 envs, 171 → 151 µs at 1 M), gait program 104 → 86,
-    // the other static programs 84–86 → 78–80, 28-DOF interpreter 197 → 173.  What is indexed at run time by the interpreter (`cmd`,
-    // `cmd_dirty`) stays outside: inside the union such an access becomes an address computation and the member goes to scratch.
-    V3 pos{0, 0, 0};                                    // waves 0, 1
-    float dof_dev = 0.f, act_rate = 0.f, secs_in = 0.f; // wave 1
-    float cmd0[3] = {0.f, 0.f, 0.f};                    // wave 1
+    // path touches one member only and the compiler merges the two views word by word into the same registers.  The reward wave's rows
+    // are dead once they are reduced, so what is left of them (position, two sums, seconds, three command columns) takes their place too,
+    // written at the end of its pre-barrier block.  VGPRs: 12-DOF interpreter 148 → 116 (three → four workgroups per CU: 15.5 → 10.9 µs
+    // at 65 536 envs, 171 → 145 µs at 1 M), 28-DOF interpreter 197 → 166 (two → three), gait program 104 → 86, the other static programs
+    // 84–86 → 72.  What is indexed at run time by the interpreter (`cmd`, `cmd_dirty`) stays outside: inside the union such an access
+    // becomes an address computation and the member goes to scratch.
     struct CtlState {                                   // wave 0
         __device__ CtlState() {}
         float4 q;
@@ -146,11 +145,18 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         int gait_sel, gait_resampled;
     };
     struct RowState { float4 r_a[R], r_b[R], r_c[R]; __device__ RowState() {} }; // wave 1: dof_pos/actions/last; wave 2: dof_pos/dof_vel/default; wave 3: targets/actions
+    struct RewState {                                   // wave 1: what is left of its rows once they are reduced (written at the END of
+        __device__ RewState() {}                        // its pre-barrier block, when it has read the rows for the last time)
+        V3 pos;
+        float dof_dev, act_rate, secs_in, cmd0[3];
+    };
     union Persist {
         CtlState ctl;
         RowState rows;
+        RewState rew;
         __device__ Persist() {}
     } persist;
+    RewState& rew = persist.rew;
     float4 (&r_a)[R] = persist.rows.r_a;
     float4 (&r_b)[R] = persist.rows.r_b;
     float4 (&r_c)[R] = persist.rows.r_c;
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         const GF_GLOBAL float* pp = gsel((needs & PN_POS) != 0, UNI(a.pos), 3u * e);
         const GF_GLOBAL float* lp = gsel((needs & PN_LIN) != 0, UNI(a.lin_vel), 3u * e);
         const GF_GLOBAL float* ap = gsel((needs & PN_ANG) != 0, UNI(a.ang_vel), 3u * e);
-        pos = V3{pp[0], pp[1], pp[2]};
+        const V3 pos{pp[0], pp[1], pp[2]};
         const V3 lin{lp[0], lp[1], lp[2]}, ang{ap[0], ap[1], ap[2]};
         ep_len = *gsel((needs & PN_EPLEN) != 0, UNI(a.episode_length), e);
         const int max_len = *gsel((needs & PN_MAXLEN) != 0, UNI(a.max_episode_length), e);
@@ -355,9 +361,10 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
 #pragma unroll
         for (int c = 0; c < DV; ++c) { r_a[c] = ldg4(p0 + 4 * c); r_b[c] = ldg4(p1 + 4 * c); r_c[c] = ldg4(p2 + 4 * c); r_def[c] = ldg4(p3 + 4 * c); }
         const GF_GLOBAL float* pp = gsel((needs & PN_POS) != 0, UNI(a.pos), 3u * e);
-        pos = V3{pp[0], pp[1], pp[2]};
+        const V3 pos{pp[0], pp[1], pp[2]};
         const float* k_secs = UNI(a.episode_seconds);
-        secs_in = *gsel(has_reward && k_secs != nullptr, k_secs, e);
+        const float secs_in = *gsel(has_reward && k_secs != nullptr, k_secs, e);
+        float dof_dev = 0.f, act_rate = 0.f, cmd0[3];
         {   // command view 0 as it is BEFORE this step's resample (its new values are stored only after the second barrier)
             const float* v0 = UNI(a.command[0].command);
             const bool nv = v0 != nullptr;
@@ -381,6 +388,10 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             d = r_c[c].z - r_b[c].z; act_rate += d * d;
             d = r_c[c].w - r_b[c].w; act_rate += d * d;
         }
+        // the rows have been read for the last time: what is left of them takes their place in the union
+        rew.pos = pos;
+        rew.dof_dev = dof_dev; rew.act_rate = act_rate; rew.secs_in = secs_in;
+        rew.cmd0[0] = cmd0[0]; rew.cmd0[1] = cmd0[1]; rew.cmd0[2] = cmd0[2];
     } else if (wave == 2) {
         const GF_GLOBAL float* p0 = gsel((needs & PN_DOFPOS) != 0, UNI(a.dof_pos), ro);
         const GF_GLOBAL float* p1 = gsel((needs & PN_DOFVEL) != 0, UNI(a.dof_vel), ro);
@@ -455,16 +466,16 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         // ---- reward: the term fold (reward_manager.py:166-195) + the manager's reset folded into the sum update -----------------
         if (has_reward) {
             RewardRegs rr;
-            rr.pos = pos;
+            rr.pos = rew.pos;
             rr.blin = V3{xch[(X_BLIN + 0) * kEnvBlock + lane], xch[(X_BLIN + 1) * kEnvBlock + lane], xch[(X_BLIN + 2) * kEnvBlock + lane]};
             rr.bang = V3{xch[(X_BANG + 0) * kEnvBlock + lane], xch[(X_BANG + 1) * kEnvBlock + lane], xch[(X_BANG + 2) * kEnvBlock + lane]};
             rr.grav = V3{xch[(X_GRAV + 0) * kEnvBlock + lane], xch[(X_GRAV + 1) * kEnvBlock + lane], xch[(X_GRAV + 2) * kEnvBlock + lane]};
-            rr.dof_dev = dof_dev; rr.act_rate = act_rate; rr.terminated = xch[X_TERM * kEnvBlock + lane] != 0.f ? 1 : 0;
-            rr.cmd0[0] = cmd0[0]; rr.cmd0[1] = cmd0[1]; rr.cmd0[2] = cmd0[2];
+            rr.dof_dev = rew.dof_dev; rr.act_rate = rew.act_rate; rr.terminated = xch[X_TERM * kEnvBlock + lane] != 0.f ? 1 : 0;
+            rr.cmd0[0] = rew.cmd0[0]; rr.cmd0[1] = rew.cmd0[1]; rr.cmd0[2] = rew.cmd0[2];
             rr.n = n; rr.live = live;
             const float dt = UNI(a.dt);
             const uint32_t log_mask = UNI(a.reward_log_mask);
-            const float secs_new = secs_in + dt;
+            const float secs_new = rew.secs_in + dt;
             float buf = 0.f;
             const bool log_reset = logging && done_mask != 0;
             auto reward_body = [&](int k, const GfTerm& t) GF_INLINE_LAMBDA {
