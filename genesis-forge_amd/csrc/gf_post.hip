@@ -912,8 +912,9 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_check(cons
     return gf::pack(r, pk);
 }
 
+template <class P>
 static size_t lds_ws_floats(int omax, int n_gait) {
-    return (size_t)(gf::x_fields(n_gait) + gf::kPostMaxReward + gf::kPostAuxRows) * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock;
+    return (size_t)(gf::x_fields(n_gait) + gf::ws_sum_rows<P>() + gf::ws_aux_rows<P>()) * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock;
 }
 
 // Static programs in registration order; program id = 1 + index (0 = table interpreter).
@@ -968,15 +969,13 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
         if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid, gf::kEnvBlock, lds, s, a);
         else GF_LAUNCH(scope, gf::post_kernel<3>, grid, gf::kEnvBlock, lds, s, a);
     } else if (const int prog = select_program(a)) {
-        const size_t lds_st = lds_ws_floats(omax, a.n_gait) * sizeof(float);
 #define GF_RUN(id, P) \
-        if (prog == id) GF_LAUNCH(scope, gf::post_ws_kernel<P>, grid, gf::kWsBlock, lds_st, s, a);
+        if (prog == id) GF_LAUNCH(scope, gf::post_ws_kernel<P>, grid, gf::kWsBlock, lds_ws_floats<P>(omax, a.n_gait) * sizeof(float), s, a);
         GF_POST_PROGRAMS(GF_RUN)
 #undef GF_RUN
     } else {
-        const size_t lds_ws = sizeof(gf::GfPostArgs) + lds_ws_floats(omax, a.n_gait) * sizeof(float);
-        if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<7>>, grid, gf::kWsBlock, lds_ws, s, a);
-        else GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<3>>, grid, gf::kWsBlock, lds_ws, s, a);
+        if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<7>>, grid, gf::kWsBlock, sizeof(gf::GfPostArgs) + lds_ws_floats<gf::Interp<7>>(omax, a.n_gait) * sizeof(float), s, a);
+        else GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<3>>, grid, gf::kWsBlock, sizeof(gf::GfPostArgs) + lds_ws_floats<gf::Interp<3>>(omax, a.n_gait) * sizeof(float), s, a);
     }
     return gf::launch_status();
 }

@@ -72,6 +72,15 @@ __device__ __forceinline__ T uni_p(const T& v) {
 #define GF_INLINE_LAMBDA __attribute__((always_inline))
 
 template <class P>
+__host__ __device__ constexpr int ws_sum_rows() {
+    if constexpr (P::kStatic) return P::n_rew;
+    else return kPostMaxReward;
+}
+template <class P>
+__host__ __device__ constexpr int ws_aux_rows() { return 4 * P::DV; }
+static_assert(kPostAuxRows >= 4 * 7, "aux rows cover 28 DOF");
+
+template <class P>
 __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg) {
     constexpr int DV = P::DV;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -88,9 +97,12 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     if constexpr (P::kStatic) has_gait = P::n_gait > 0;
     else has_gait = UNI(a.n_gait) > 0;
     float* xch = lds + kArgVec * 4;                          // [x_fields][64]
-    float* lds_sums = xch + x_fields(has_gait ? 1 : 0) * kEnvBlock;   // [kPostMaxReward][64]
-    float* lds_aux = lds_sums + kPostMaxReward * kEnvBlock;  // [kPostAuxRows][64]
-    float* tile = lds_aux + kPostAuxRows * kEnvBlock;        // [64][O+1]
+    // a static program knows how many reward rows it has and every variant knows its DOF chunks: the LDS a workgroup asks for decides
+    // how many of them a CU holds (Go2 programs: 30 KB → 22.5 KB, five → seven workgroups per CU, what their 72 VGPRs allow)
+    constexpr int kSumRows = ws_sum_rows<P>(), kAuxRows = ws_aux_rows<P>();
+    float* lds_sums = xch + x_fields(has_gait ? 1 : 0) * kEnvBlock;   // [kSumRows][64]
+    float* lds_aux = lds_sums + kSumRows * kEnvBlock;        // [kAuxRows][64]: 4 per float4 chunk of a DOF row
+    float* tile = lds_aux + kAuxRows * kEnvBlock;            // [64][O+1]
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (GF_WAVE - 1);
