@@ -624,9 +624,10 @@ static int pack(const GfPostRefs* r, Packer& pk) {
         needs |= PN_EPLEN;
     }
 
-    // termination terms
-    a.num_term = T.num_terms;
-    for (int k = 0; k < T.num_terms; ++k) {
+    // termination terms (not evaluated when the phase has already run as a launch of its own: the masks are inputs then)
+    a.term_done = (r->flags & GF_POST_TERMINATION_DONE) ? 1 : 0;
+    a.num_term = a.term_done ? 0 : T.num_terms;
+    for (int k = 0; k < a.num_term; ++k) {
         GfTerm t = T.terms[k];
         switch (t.op) {
             case GF_T_TIMEOUT: if (T.max_episode_length) needs |= PN_EPLEN | PN_MAXLEN; break;
@@ -706,6 +707,10 @@ static int pack(const GfPostRefs* r, Packer& pk) {
                         a.gait_wave_flags = RW->gait_wave_flags;
                     }
                 } break;
+                case GF_R_EXTERNAL:   // a column the host evaluated after the termination phase: only behind GF_POST_TERMINATION_DONE
+                    UNSUP(!a.term_done || t.i[0] < 0 || t.i[0] >= GF_MAX_EXT || !RW->ext[t.i[0]]);
+                    a.ext[t.i[0]] = RW->ext[t.i[0]];
+                    break;
                 default: return GF_E_UNSUPPORTED;
             }
             if (t.op == GF_R_BASE_HEIGHT && (t.flags & GF_RW_FLAG_CMD)) {
@@ -964,7 +969,7 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     gf::PhaseScope scope(GF_PHASE_POST, s);
     bool any_ring = false;
     for (int m = 0; m < a.n_obs; ++m) any_ring = any_ring || a.obs[m].ring != 0;
-    const bool ws_only = a.n_gait || a.roll_obs || a.roll_reward || a.roll_done || any_ring;   // the one-wave variant has neither a gait manager nor rollout stores
+    const bool ws_only = a.n_gait || a.roll_obs || a.roll_reward || a.roll_done || any_ring || a.term_done;   // the one-wave variant has neither a gait manager nor rollout stores
     if (gf::g_options[GF_OPT_POST_VARIANT] == 0 && !ws_only) {
         if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid, gf::kEnvBlock, lds, s, a);
         else GF_LAUNCH(scope, gf::post_kernel<3>, grid, gf::kEnvBlock, lds, s, a);

@@ -99,7 +99,7 @@ struct alignas(16) GfPostArgs {
     GfContactView contact[GF_MAX_CONTACT_VIEWS];
     GfCommandView command[GF_MAX_COMMAND_VIEWS];
     int32_t cmd_of_view[GF_MAX_COMMAND_VIEWS];   // index into cmds[] of the manager that owns the view's buffer, or -1
-    const float* ext[1];
+    const float* ext[GF_MAX_EXT];   // host-evaluated reward columns (GF_R_EXTERNAL)
     float* state[4];
     // reset
     int32_t scene_reset, set_quat, zero_velocity, reset_env /* bit0: actions rows, bit1: episode_length */, reset_dofs;
@@ -123,7 +123,7 @@ struct alignas(16) GfPostArgs {
     float* roll_reward;
     uint8_t* roll_done;
     int32_t roll_obs_index;
-    int32_t _pad1;
+    int32_t term_done;   // GF_POST_TERMINATION_DONE: the masks are inputs, the termination table is not evaluated
     const uint8_t* gait_wave_flags;   // == gait.flags_in when the reward terms reproduce the env-0 quirk (GF_R_GAIT_PHASE)
     PostGait gait;
     GfTerm tterms[kPostMaxTerm];

@@ -267,6 +267,7 @@ class GfStatsPackArgs(C.Structure):
     _fields_ = [("src", P), ("dst", P)]
 
 GF_POST_MAX_CMD, GF_POST_MAX_OBS, GF_POST_MAX_GAIT = 2, 2, 1
+GF_POST_TERMINATION_DONE = 1   # GfPostRefs.flags
 
 
 class GfRolloutArgs(C.Structure):
@@ -282,7 +283,7 @@ class GfHistoryUnrollArgs(C.Structure):
 class GfPostRefs(C.Structure):
     _fields_ = [("termination", P), ("reward", P), ("reset", P), ("num_command", C.c_int32), ("num_observe", C.c_int32),
                 ("command_step", P * GF_POST_MAX_CMD), ("command_reset", P * GF_POST_MAX_CMD), ("observe", P * GF_POST_MAX_OBS),
-                ("num_gait", C.c_int32), ("_pad", C.c_int32), ("gait_step", P * GF_POST_MAX_GAIT), ("gait_reset", P * GF_POST_MAX_GAIT),
+                ("num_gait", C.c_int32), ("flags", C.c_int32), ("gait_step", P * GF_POST_MAX_GAIT), ("gait_reset", P * GF_POST_MAX_GAIT),
                 ("gait_flags_next", P * GF_POST_MAX_GAIT), ("rollout", P)]
 
 ABI_STRUCTS = [GfStepStats, GfActionArgs, GfContactArgs, GfTerminationArgs, GfRewardArgs, GfCommandArgs,

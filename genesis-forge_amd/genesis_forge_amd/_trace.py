@@ -79,12 +79,17 @@ class StepTrace:
         if self.post_refs is None:
             self._gait_swaps = []
         first_post = self._post_start(calls) if self.post_refs is not None else len(calls)
+        self.post_split = self.post_refs is not None and bool(self.post_refs.flags & nat.GF_POST_TERMINATION_DONE)
         for idx, (fn, args, owner) in enumerate(calls):
             if idx < first_post:
                 self.ops[k].phase = nat.PHASE_OF_FN[fn]
                 self.ops[k].args = C.addressof(args)
                 k += 1
-            elif idx == first_post:
+            elif idx == first_post and self.post_split:   # termination as a launch of its own, the fused launch behind it (Python between)
+                self.ops[k].phase = nat.PHASE_OF_FN[fn]
+                self.ops[k].args = C.addressof(args)
+                k += 1
+            elif idx == first_post + (1 if self.post_split else 0):
                 self.ops[k].phase = nat.GF_OP_POST_PHYSICS
                 self.ops[k].args = C.addressof(self.post_refs)
                 k += 1
@@ -96,7 +101,7 @@ class StepTrace:
             self._hooks(fn, args, owner)
             pre = owner._trace_pre(args) if hasattr(owner, "_trace_pre") else None
             if pre is not None:
-                assert idx < first_post, "a phase with Python-level terms cannot be part of the fused launch"
+                assert idx < first_post + (2 if self.post_split else 0), "a phase with Python-level terms cannot be part of the fused launch"
                 self.splits.append((self._cur_op, pre))
         self.native.extend(self._gait_swaps)   # after the gait managers' own patches (those refill the descriptors)
         # single process: statistics go to a device ring slot per step (no memset, no copy); with a process group the
@@ -186,9 +191,17 @@ class StepTrace:
         fns = [c[0] for c in tail]
         if not fns or fns[0] != "termination_step":
             return None
-        if any(hasattr(c[2], "_trace_pre") and c[2]._trace_pre(c[1]) is not None for c in tail):
-            return None  # Python runs between these phases: they stay separate ops
         refs = nat.GfPostRefs()
+        py = [i for i, c in enumerate(tail) if hasattr(c[2], "_trace_pre") and c[2]._trace_pre(c[1]) is not None]
+        if py:
+            # Python runs between these phases.  Callables of the termination and reward phases (the common customisation: a lambda as
+            # a reward term) still leave everything behind the termination phase fusable: termination runs as a launch of its own,
+            # the callables run where the reference calls them (before their phase, after the earlier ones: a reward callable may
+            # read this step's termination buffers), and ONE launch does reward … observation with the termination masks as inputs
+            # (GF_POST_TERMINATION_DONE).  A callable of a later phase (an observation item) sees the post-reset state: no fusion.
+            if any(fns[i] not in ("termination_step", "reward_step") for i in py) or len(fns) < 2:
+                return None
+            refs.flags = nat.GF_POST_TERMINATION_DONE
         refs.termination = C.addressof(tail[0][1])
         j = 1
         if j < len(fns) and fns[j] == "reward_step":

@@ -664,6 +664,14 @@ int gf_history_unroll(const GfHistoryUnrollArgs* a, void* stream);/* replaces th
 #define GF_POST_MAX_OBS 2
 #define GF_POST_MAX_GAIT 1
 
+/* GfPostRefs.flags.  GF_POST_TERMINATION_DONE: the termination phase of this step has ALREADY run as a launch of its own
+ * (gf_termination_step on `termination`: masks and statistics are final) — the fused launch reads `terminated` / `truncated`
+ * instead of evaluating the terms.  This is how a step whose task config carries Python-level terms still fuses everything behind
+ * them: a host-evaluated reward column (GF_R_EXTERNAL) has to be computed after the termination phase and before the reward
+ * phase (managed_env.py:303-319: the callable may read this step's termination buffers), so the step is
+ * termination launch -> the callables -> ONE launch for reward ... observation.  Any termination table is then acceptable,
+ * including GF_T_EXTERNAL terms. */
+enum { GF_POST_TERMINATION_DONE = 1 };
 typedef struct GfPostRefs {
     const GfTerminationArgs* termination;                 /* required */
     const GfRewardArgs* reward;                           /* may be NULL */
@@ -680,7 +688,7 @@ typedef struct GfPostRefs {
      * the caller makes the current buffer afterwards (ping-pong).  Sequentially the result is the same: gait.step rewrites every
      * block's byte, gait.reset the blocks with a reset env, both from the rows they hold. */
     int32_t num_gait;
-    int32_t _pad;
+    int32_t flags;                                    /* GF_POST_* bits */
     const GfGaitArgs* gait_step[GF_POST_MAX_GAIT];    /* mode GF_CMD_STEP */
     const GfGaitArgs* gait_reset[GF_POST_MAX_GAIT];   /* mode GF_CMD_MASKED on the termination masks, same state */
     uint8_t* gait_flags_next[GF_POST_MAX_GAIT];       /* same size as wave_flags; may be NULL when wave_flags is NULL */

@@ -1097,8 +1097,10 @@ GFO_EXPORT int gfo_post_physics_check(const GfPostRefs* r) { return (r && r->ter
 
 GFO_EXPORT int gfo_post_physics_step(const GfPostRefs* r) {
     if (!r || !r->termination || !r->reset) return GF_E_NULL;
-    int rc = gfo_termination_step(r->termination);
-    if (rc) return rc;
+    int rc = GF_OK;
+    /* GF_POST_TERMINATION_DONE: the termination phase already ran as a call of its own (Python-level terms between it and the
+     * reward phase, managed_env.py:303-319) */
+    if (!(r->flags & GF_POST_TERMINATION_DONE) && (rc = gfo_termination_step(r->termination))) return rc;
     if (r->reward && (rc = gfo_reward_step(r->reward))) return rc;
     for (int c = 0; c < r->num_command; ++c)
         if ((rc = gfo_command_step(r->command_step[c]))) return rc;

@@ -88,6 +88,7 @@ def make_fuzz_env(seed: int):
                 item["weight"] = 0.0 if pick(0.08) else rnd.choice([-1, 1]) * uni(0.01, 3.0)
                 rcfg[name] = item
             self.has_user_term = pick(0.3)
+            self.has_user_obs = False   # a Python-level OBSERVATION item (sees the post-reset state: nothing behind it can be fused)
             if self.has_user_term:  # a user-level Python term: evaluated in torch on both sides, in the middle of the recorded step
                 rcfg["user_height"] = {"weight": 0.3, "fn": lambda env: torch.tanh(env.robot.get_pos()[:, 2])}
             self.reward_manager = RewardManager(self, logging_enabled=pick(0.85), cfg=rcfg)
@@ -131,6 +132,7 @@ def make_fuzz_env(seed: int):
                 cfg = {}
                 if pick(0.15):  # a user-level observation item (evaluated in front of this manager's op)
                     self.has_user_term = True
+                    self.has_user_obs = True
                     cfg["user_xy"] = {"fn": lambda env: env.robot.get_pos()[:, :2] * 2.0}
                 for name in chosen:
                     it = items[name]()
@@ -181,7 +183,7 @@ def _run(seed, dev, steps=STEPS):
             state[f"contacts_{len([k for k in state if k.startswith('contacts_')])}"] = cm.contacts
         out.append(({k: f(v) for k, v in state.items()}, {k: float(v) for k, v in extras["episode"].items()}))
     info = {"n": n, "recorded": env._trace is not None, "fused": bool(env._trace is not None and env._trace.post_refs is not None),
-            "user_term": env.has_user_term, "third_obs": env.third_obs, "overrides_reset": env.overrides_reset}
+            "user_term": env.has_user_term, "user_obs": env.has_user_obs, "third_obs": env.third_obs, "overrides_reset": env.overrides_reset}
     return out, info
 
 
@@ -228,7 +230,9 @@ def test_random_config_hip_equals_oracle(hip_backend, oracle_lib_path, seed):
     # every config is recorded; a user-level Python term or a third ObservationManager keeps it off the fused kernel
     assert info["recorded"], info
     if os.environ.get("GF_NO_FUSE", "0") != "1":  # (the whole suite is also run with every config forced onto the phase chains)
-        assert info["fused"] == (not info["user_term"] and not info["third_obs"] and not info["overrides_reset"]), info
+        # Python-level reward / termination terms leave everything behind the termination phase fused (termination runs as a launch of
+        # its own, GF_POST_TERMINATION_DONE); a Python-level observation item, a third ObservationManager or a reset() override do not
+        assert info["fused"] == (not info["user_obs"] and not info["third_obs"] and not info["overrides_reset"]), info
 
 
 @pytest.mark.gpu
