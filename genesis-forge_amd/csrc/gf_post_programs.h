@@ -188,7 +188,7 @@ struct ProgGo2GaitTrainer {
 // ---- matching -------------------------------------------------------------------------------------------------------------------
 template <class P>
 bool program_matches(const GfPostArgs& a) {
-    if (a.num_dofs != 4 * P::DV || a.num_term != P::n_term || a.num_rew != P::n_rew || a.n_cmd != P::n_cmd || a.n_obs != P::n_obs || a.n_air != P::n_air ||
+    if (a.term_done || a.num_dofs != 4 * P::DV || a.num_term != P::n_term || a.num_rew != P::n_rew || a.n_cmd != P::n_cmd || a.n_obs != P::n_obs || a.n_air != P::n_air ||
         a.n_gait != P::n_gait)
         return false;
     for (int k = 0; k < P::n_term; ++k)

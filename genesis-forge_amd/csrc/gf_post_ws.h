@@ -217,9 +217,11 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         }
         // ---- body-frame vectors, termination -----------------------------------------------------------------------------
         const V3 blin = rot_inv(q, lin), bang = rot_inv(q, ang), grav = rot_inv(q, V3{0.f, 0.f, -1.f});
-        if (UNI(a.term_done)) {   // the termination phase ran as a launch of its own (Python-level terms in the step): its masks are inputs
-            term = live ? (int)G(UNI(a.terminated))[n] : 0;
-            trunc = live ? (int)G(UNI(a.truncated))[n] : 0;
+        if constexpr (!P::kStatic) {   // (a static program has its termination table: a launch with none never selects one)
+            if (UNI(a.term_done)) {    // the termination phase ran as a launch of its own (Python-level terms in the step): its masks are inputs
+                term = live ? (int)G(UNI(a.terminated))[n] : 0;
+                trunc = live ? (int)G(UNI(a.truncated))[n] : 0;
+            }
         }
         TermRegs tr;
         const int has_maxlen = UNI(a.has_maxlen);
