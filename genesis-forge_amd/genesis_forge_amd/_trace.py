@@ -392,8 +392,9 @@ def traceable(env, tail_python: bool = False) -> bool:
     from .managed_env import ManagedEnvironment, _most_derived_is_ours
     from .managers.action import PositionActionManager
 
-    if type(env).step is not ManagedEnvironment.step:
-        return False
+    # (a step() override is user code AROUND the step — `…; return super().step(actions)` — i.e. code of the training loop: what is
+    # recorded is ManagedEnvironment.step itself, and a manager call the override makes between steps goes through the same
+    # watched-descriptor check as one the training script makes, StepTrace.fresh)
     if (type(env).reset is not ManagedEnvironment.reset) != tail_python:
         return False
     if tail_python and env.stats.group is not None:

@@ -105,23 +105,44 @@ def test_parity_draws_disable_trace(oracle_backend):
 
 def test_user_overrides_limit_what_is_recorded(oracle_backend):
     """A reset() override is honoured by index list: the step is recorded only up to the reset (the rest stays Python).
-    A step() override is user code around the whole step: never recorded."""
+    A step() override that wraps `super().step()` is code around the step, like the training loop's: the step inside is recorded and
+    fused all the same, and a manager call the override makes between steps drops the recording like one the script makes.
+    A get_observations() override is code INSIDE the step: never recorded."""
     class ResetEnv(Go2CommandDirectionEnv):
         def reset(self, env_ids=None):
             return super().reset(env_ids)
 
     class StepEnv(Go2CommandDirectionEnv):
-        def step(self, actions):
-            return super().step(actions)
+        seen = 0
 
-    for cls, recorded in ((ResetEnv, True), (StepEnv, False)):
-        env = cls(num_envs=8)
+        def step(self, actions):
+            self.seen += 1   # (the reference's gait example renders a camera here)
+            return super().step(actions * 1.0)
+
+    class ObsEnv(Go2CommandDirectionEnv):
+        def get_observations(self):
+            return super().get_observations()
+
+    ref = Go2CommandDirectionEnv(num_envs=8, scene_kwargs=dict(seed=3))
+    ref.trace_enabled = False
+    ref.build()
+    ref.seed(5)
+    ref.reset()
+    g = torch.Generator().manual_seed(0)
+    acts = [torch.randn(8, 12, generator=g) for _ in range(6)]
+    want = [ref.step(a)[0].clone() for a in acts]
+    for cls, how in ((ResetEnv, "tail"), (StepEnv, "fused"), (ObsEnv, None)):
+        env = cls(num_envs=8, scene_kwargs=dict(seed=3))
         env.build()
+        env.seed(5)
         env.reset()
-        for _ in range(5):
-            env.step(torch.zeros(8, 12))
-        if recorded:
+        got = [env.step(a)[0].clone() for a in acts]
+        for t, (x, y) in enumerate(zip(want, got)):
+            assert torch.equal(x, y), f"{cls.__name__}: observation {t} differs from the plain env"
+        if how == "tail":
             assert env._trace is not None and env._trace.tail_python and env._trace.post_refs is None
+        elif how == "fused":
+            assert env._trace is not None and not env._trace.tail_python and env._trace.post_refs is not None and env.seen == 6
         else:
             assert env._trace is None
 
