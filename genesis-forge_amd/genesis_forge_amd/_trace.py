@@ -42,10 +42,16 @@ class Recorder:
     def __init__(self):
         self.calls: list = []
         self.tail_python = False
+        #: launches of the Python tail, by part ("reset": inside the user's reset() → ManagedEnvironment.reset of the done envs;
+        #: "obs": get_observations()) — a recorded step replays each part with one native call when it was seen (StepTrace.tail_seg)
+        self.tail: dict = {}
+        self.part = None
 
     def record(self, fn, args, owner):
         if not self.tail_python:
             self.calls.append((fn, args, owner))
+        elif self.part is not None:
+            self.tail.setdefault(self.part, []).append((fn, args, owner))
 
     def cut_tail(self):
         """Everything the step does from here on stays Python in the recorded step (an env that overrides ``reset()``: the
@@ -57,9 +63,10 @@ class Recorder:
 
 
 class StepTrace:
-    def __init__(self, env, calls: list, tail_python: bool = False):
+    def __init__(self, env, calls: list, tail_python: bool = False, tail_calls: Optional[dict] = None):
         self.env = env
         self.tail_python = tail_python
+        self.tail_seg: dict = {}   # "reset" / "obs" → native segment of the Python tail (see _build_tail_segment)
         self.backend = env.backend
         self.epoch = env._trace_epoch
         self.patches: list[Callable] = []   # Python-side per-step work that has Python semantics (live ranges, log registration)
@@ -142,6 +149,14 @@ class StepTrace:
         #: the descriptors this recording froze: a phase call that goes through one of them from now on (a manager method the
         #: training script calls between steps) makes the recording stale (Backend._note_call, fresh())
         self.arg_set = {C.addressof(c[1]) for c in calls}
+        # (both parts or none: the observation descriptors of a step WITH a reset carry the stale-quaternion stash and the termination
+        # masks — with all-false masks they also describe a step without one; the descriptors of a step without a reset do not)
+        if tail_python and tail_calls and tail_calls.get("reset") and tail_calls.get("obs"):
+            for part in ("reset", "obs"):
+                seg = self._build_tail_segment(tail_calls.get(part) or [])
+                if seg is not None:
+                    self.tail_seg[part] = seg
+                    self.arg_set.update(C.addressof(c[1]) for c in tail_calls[part])
         b = self.backend
         b.__dict__.setdefault("dirty", set()).difference_update(self.arg_set)
         b.__dict__.setdefault("watched", set()).update(self.arg_set)
@@ -174,6 +189,48 @@ class StepTrace:
                 self.backend.graph_destroy(g)
             except Exception:
                 pass
+
+    # -- the Python tail of an env that overrides reset(), part by part ----------------------------------------------------
+    def _build_tail_segment(self, calls):
+        """The launches one part of the Python tail made in the ordinary step (the in-step reset of the done envs by the
+        termination masks; the observations) as a patch table + op list of their own.  The user's reset() still runs — its code
+        before and after ``super().reset(ids)`` sees exactly what it sees in an ordinary step — but what ``super().reset(ids)`` and
+        ``get_observations()`` do is one native call each instead of a Python walk over every manager."""
+        if not calls or any(hasattr(o, "_trace_pre") and o._trace_pre(a) is not None for _, a, o in calls):
+            return None   # (a Python-level observation item: that part stays phase by phase)
+        if any(fn not in nat.PHASE_OF_FN for fn, _, _ in calls):
+            return None
+        # gathers behind all observation launches: two of them then share a launch (gf_run_ops)
+        calls = [c for c in calls if c[0] != "history_unroll"] + [c for c in calls if c[0] == "history_unroll"]
+        saved = (self.native, self.patches, self.afters, self._cur_op)
+        self.native, self.patches, self.afters = [], [], []
+        try:
+            ops = (nat.GfOp * len(calls))()
+            P = nat.GfReplayPatch
+            for k, (fn, args, owner) in enumerate(calls):
+                ops[k].phase, ops[k].args = nat.PHASE_OF_FN[fn], C.addressof(args)
+                self._cur_op = k
+                self._hooks(fn, args, owner)
+                if hasattr(args, "stats") and args.stats:
+                    self.native.append(P(nat.GF_PATCH_PARAM, 0, nat.field_addr(args, "stats"), None, None))
+            table = (nat.GfReplayPatch * max(1, len(self.native)))(*self.native)
+            desc = nat.GfReplay(C.addressof(ops), len(calls), len(self.native), C.addressof(table), C.addressof(self.env._rng_c))
+            return {"ops": ops, "table": table, "desc": desc, "patches": self.patches, "afters": [f for _, f in self.afters],
+                    "keep": [c[1] for c in calls]}
+        finally:
+            self.native, self.patches, self.afters, self._cur_op = saved
+
+    def run_tail_segment(self, part: str) -> bool:
+        """Replay one part of the Python tail natively; False when that part was not recorded (the caller walks the managers)."""
+        seg = self.tail_seg.get(part)
+        if seg is None:
+            return False
+        for p in seg["patches"]:
+            p(None)
+        self.backend.replay_step(seg["desc"], None, self.params, 5)
+        for f in seg["afters"]:
+            f()
+        return True
 
     # -- fused post-physics launch -----------------------------------------------------------------------
     @staticmethod
@@ -370,7 +427,7 @@ class StepTrace:
         if self.tail_python:
             # reset (the user's override, by index list, behind the same nonzero() sync the reference pays) and observations,
             # phase by phase; their launches write their statistics into this step's ring slot
-            env.stats.ptr_override, env._in_step = cur, True
+            env.stats.ptr_override, env._in_step, env._tail_trace = cur, True, self
             try:
                 env._reset_done(tm._terminated_buf, tm._truncated_buf)
                 obs_tail = env.get_observations()
@@ -380,7 +437,7 @@ class StepTrace:
                     ro.write(pol._last_out if pol is not None else obs_tail, rm._reward_buf if rm is not None else env._reward_buf,
                              tm._terminated_buf, tm._truncated_buf)
             finally:
-                env.stats.ptr_override, env._in_step = None, False
+                env.stats.ptr_override, env._in_step, env._tail_trace = None, False, None
         env._finish_step_light(snap)
         extras = env._extras
         obs = extras["observations"].get("policy") if len(env.managers["observation"]) > 0 else obs_tail

@@ -180,7 +180,7 @@ class ManagedEnvironment(GenesisEnv):
         if epoch == self._trace_epoch:  # nothing was invalidated while the step ran
             sig = rec.signature()
             if sig == self._last_signature and _trace.traceable(self, rec.tail_python):
-                self._trace = _trace.StepTrace(self, rec.calls, rec.tail_python)
+                self._trace = _trace.StepTrace(self, rec.calls, rec.tail_python, rec.tail)
             self._last_signature = sig
         return out
 
@@ -261,7 +261,11 @@ class ManagedEnvironment(GenesisEnv):
             # a user subclass overrides reset(): honour it exactly like the reference does
             ids = (terminated | truncated).nonzero(as_tuple=False).reshape((-1,)).detach()
             if ids.numel() > 0:
-                self.reset(ids)
+                self._done_ids = ids   # (reset() recognises THIS index list: the done envs, i.e. the termination masks)
+                try:
+                    self.reset(ids)
+                finally:
+                    self._done_ids = None
             return
         self._reset_with_mask(terminated, truncated, ids=None)
 
@@ -300,6 +304,21 @@ class ManagedEnvironment(GenesisEnv):
     def reset(self, env_ids: list[int] | None = None):
         """Reset one or more environments and every registered manager (managed_env.py:336-371)."""
         outside = not self._in_step
+        if not outside and env_ids is not None and env_ids is getattr(self, "_done_ids", None):
+            # the in-step reset of the done envs, reached through a user override of reset(): the index list IS the termination masks,
+            # so the launches are the mask path's (persistent descriptors: a recorded step replays them with one native call)
+            tr = getattr(self, "_tail_trace", None)
+            if tr is None or not tr.run_tail_segment("reset"):
+                tm = self.managers["termination"]
+                rec = self.backend.tracer
+                if rec is not None:
+                    rec.part = "reset"
+                try:
+                    self._reset_with_mask(tm._terminated_buf, tm._truncated_buf, ids=env_ids)
+                finally:
+                    if rec is not None:
+                        rec.part = None
+            return None, self.extras
         if outside:
             # a reset the training script calls between steps refills the persistent reset / masked-resample descriptors with
             # ITS masks — the ones a recorded step replays in place: drop the recording (two ordinary steps, then recorded again)
@@ -327,11 +346,24 @@ class ManagedEnvironment(GenesisEnv):
                 return self.extras["observations"]["policy"]
             if "observations" not in self.extras:
                 self.extras["observations"] = _obs_dict()
-            policy_obs = None
-            for m in self.managers["observation"]:
-                obs = m.get_observations()
-                self.extras["observations"][m.name] = obs
-                if m.name == "policy":
-                    policy_obs = obs
-            return policy_obs
+            tr = getattr(self, "_tail_trace", None)
+            if tr is not None and tr.run_tail_segment("obs"):   # the Python tail of a recorded step: one native call
+                return self.extras["observations"].get("policy")
+            rec = self.backend.tracer if self._in_step else None
+            if rec is not None:
+                rec.part = "obs"
+            try:
+                return self._observe_all()
+            finally:
+                if rec is not None:
+                    rec.part = None
         return super().get_observations()
+
+    def _observe_all(self):
+        policy_obs = None
+        for m in self.managers["observation"]:
+            obs = m.get_observations()
+            self.extras["observations"][m.name] = obs
+            if m.name == "policy":
+                policy_obs = obs
+        return policy_obs
