@@ -20,11 +20,15 @@ Python-level terms (a lambda as a reward / termination term, an observation item
 stop a step from being recorded: the op list is cut in front of the op that consumes them, and the replay
 runs ``gf_run_ops`` on the ops before the cut, then evaluates the callables — at exactly the point of the
 step where the ordinary path (and the reference) calls them, on the same stream, no host sync — hands the
-fresh columns to the descriptor, and continues with the next run of ops.
+fresh columns to the descriptor, and continues with the next run of ops.  Callables of the termination and reward phases keep
+the step on the fused post-physics launch: termination runs as a launch of its own, the callables run, one launch does
+reward … observation with the termination masks as inputs (``GF_POST_TERMINATION_DONE``, ``_fuse_post``).
 
-An env that overrides ``reset()`` is recorded up to the reset (``tail_python``): the reset — user code, by index list, behind
-the ``nonzero()`` sync the reference pays too — and the observations that follow run phase by phase, with their launches
-pointed at the step's statistics slot.  A recording also watches its descriptors: a phase call outside the replay that goes
+An env that overrides ``reset()`` is recorded up to the reset (``tail_python``): the user's ``reset()`` runs — by index list,
+behind the ``nonzero()`` sync the reference pays too — and what ``super().reset(ids)`` and ``get_observations()`` launch is
+replayed natively, one segment each, where the user's code reaches it (``tail_seg``; recorded from an ordinary step that had a
+done env, walked phase by phase until then), with the launches pointed at the step's statistics slot.  A ``step()`` override
+around ``super().step()`` is code of the training loop: the step inside is recorded as without it.  A recording also watches its descriptors: a phase call outside the replay that goes
 through one of them (``reset([…])`` or ``resample_command([…])`` called by the training script between steps) drops it.
 """
 from __future__ import annotations
