@@ -86,9 +86,11 @@ class StepTrace:
         self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_CLEAR, stats.ptr
         k += 1
         self._gait_swaps: list = []
+        self._late: set = set()
         self.post_refs = self._fuse_post(calls) if env.fuse_post_physics else None
         if self.post_refs is None:
             self._gait_swaps = []
+            self._late = set()
         first_post = self._post_start(calls) if self.post_refs is not None else len(calls)
         self.post_split = self.post_refs is not None and bool(self.post_refs.flags & nat.GF_POST_TERMINATION_DONE)
         for idx, (fn, args, owner) in enumerate(calls):
@@ -104,15 +106,15 @@ class StepTrace:
                 self.ops[k].phase = nat.GF_OP_POST_PHYSICS
                 self.ops[k].args = C.addressof(self.post_refs)
                 k += 1
-            elif fn == "history_unroll":   # the gather of a ring-kept history follows the fused launch as an op of its own
-                self.ops[k].phase = nat.GF_PHASE_UNROLL
+            elif fn == "history_unroll" or idx in self._late:   # the gather of a ring-kept history — and an observation manager with a
+                self.ops[k].phase = nat.PHASE_OF_FN[fn]         # Python-level item — follow the fused launch as ops of their own
                 self.ops[k].args = C.addressof(args)
                 k += 1
             self._cur_op = k - 2  # index of this call's op once the leading STATS_CLEAR op is dropped (below)
             self._hooks(fn, args, owner)
             pre = owner._trace_pre(args) if hasattr(owner, "_trace_pre") else None
             if pre is not None:
-                assert idx < first_post + (2 if self.post_split else 0), "a phase with Python-level terms cannot be part of the fused launch"
+                assert idx < first_post + (2 if self.post_split else 0) or idx in self._late, "a phase with Python-level terms cannot be part of the fused launch"
                 self.splits.append((self._cur_op, pre))
         self.native.extend(self._gait_swaps)   # after the gait managers' own patches (those refill the descriptors)
         # single process: statistics go to a device ring slot per step (no memset, no copy); with a process group the
@@ -259,10 +261,14 @@ class StepTrace:
             # a reward term) still leave everything behind the termination phase fusable: termination runs as a launch of its own,
             # the callables run where the reference calls them (before their phase, after the earlier ones: a reward callable may
             # read this step's termination buffers), and ONE launch does reward … observation with the termination masks as inputs
-            # (GF_POST_TERMINATION_DONE).  A callable of a later phase (an observation item) sees the post-reset state: no fusion.
-            if any(fns[i] not in ("termination_step", "reward_step") for i in py) or len(fns) < 2:
+            # (GF_POST_TERMINATION_DONE).  A Python-level OBSERVATION item sees the post-reset state: the manager that owns it is left
+            # out of the fused launch and observes behind it, after its callables, as a launch of its own (self._late).
+            if any(fns[i] not in ("termination_step", "reward_step", "observe") for i in py) or len(fns) < 2:
                 return None
-            refs.flags = nat.GF_POST_TERMINATION_DONE
+            if any(fns[i] in ("termination_step", "reward_step") for i in py):
+                refs.flags = nat.GF_POST_TERMINATION_DONE
+        late_obs = {k for k in py if fns[k] == "observe"}
+        self._late = set()
         refs.termination = C.addressof(tail[0][1])
         j = 1
         if j < len(fns) and fns[j] == "reward_step":
@@ -284,8 +290,15 @@ class StepTrace:
         obs = []
         while j < len(fns) and fns[j] in ("observe", "history_unroll"):   # (a manager that keeps its history as a ring: frame, then gather)
             if fns[j] == "observe":
-                obs.append(tail[j])
+                if j in late_obs:
+                    self._late.add(i + j)     # (indices into `calls`) this manager's launch, and its gather, stay ops of their own
+                else:
+                    obs.append(tail[j])
+            elif any(tail[k][2] is tail[j][2] for k in late_obs):
+                self._late.add(i + j)
             j += 1
+        if late_obs and j < len(fns) and fns[j] == "rollout_write":
+            return None   # (a rollout row out of an observation that is not part of the fused launch: keep the chains)
         if j < len(fns) and fns[j] == "rollout_write":   # learner.RolloutStorage: its rows are stored by the same launch
             refs.rollout = C.addressof(tail[j][1])
             pol = next((m for m in self.env.managers["observation"] if m.name == tail[j][2].obs_name), None)

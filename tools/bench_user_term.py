@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Step time of a config with one user-level (Python) reward term: recorded step (cut around the call) vs phase by phase.
-    python tools/bench_user_term.py [num_envs]"""
+"""Step time of a config with one user-level (Python) term — a reward lambda (default) or an observation item (`obs`): recorded step
+(cut around the call) vs phase by phase.      python tools/bench_user_term.py [num_envs] [reward|obs]"""
 import os
 import sys
 import time
@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from genesis_forge_amd import gs
 from genesis_forge_amd.tasks import Go2CommandDirectionEnv
+
+
+KIND = sys.argv[2] if len(sys.argv) > 2 else "reward"
 
 
 def run(n, trace, steps=400):
@@ -27,9 +30,17 @@ def run(n, trace, steps=400):
         orig()
         from genesis_forge_amd.managers import RewardManager
         rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in env.reward_manager.cfg.items()}
-        rc.update(cfg_add)
+        if KIND == "reward":
+            rc.update(cfg_add)
         env.managers["reward"] = None
         env.reward_manager = RewardManager(env, logging_enabled=True, cfg=rc)
+        if KIND == "obs":   # a Python-level observation item: the manager observes behind the fused launch, after the callable
+            from genesis_forge_amd.managers import ObservationManager
+            om = env.observation_manager
+            oc = {k: {"fn": v.fn, "params": dict(v.params), "scale": v.scale, "noise": v.noise} for k, v in om.cfg.items()}
+            oc["user_xy"] = {"fn": lambda env: env.robot.get_pos()[:, :2] * 2.0}
+            env.managers["observation"].remove(om)
+            env.observation_manager = ObservationManager(env, cfg=oc)
 
     env.config = config
     env.build()
@@ -50,7 +61,7 @@ def run(n, trace, steps=400):
 
 if __name__ == "__main__":
     gs.set_device("cuda:0")
-    for n in ([int(sys.argv[1])] if len(sys.argv) > 1 else [4096, 65536]):
+    for n in ([int(sys.argv[1])] if len(sys.argv) > 1 and sys.argv[1].isdigit() else [4096, 65536]):
         for trace in (True, False):
             dt, rec, splits, ops = run(n, trace)
-            print(f"N={n:6d} recorded={rec!s:5s} cuts={splits} ops={ops}  {dt:8.1f} us/step  {n / dt:8.1f} M env-steps/s", flush=True)
+            print(f"{KIND:6s} N={n:6d} recorded={rec!s:5s} cuts={splits} ops={ops}  {dt:8.1f} us/step  {n / dt:8.1f} M env-steps/s", flush=True)
