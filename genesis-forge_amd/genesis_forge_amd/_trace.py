@@ -290,6 +290,8 @@ class StepTrace:
         obs = []
         while j < len(fns) and fns[j] in ("observe", "history_unroll"):   # (a manager that keeps its history as a ring: frame, then gather)
             if fns[j] == "observe":
+                if j not in late_obs and len(obs) >= nat.GF_POST_MAX_OBS:
+                    late_obs.add(j)           # more managers than the fused launch holds: the further ones observe behind it
                 if j in late_obs:
                     self._late.add(i + j)     # (indices into `calls`) this manager's launch, and its gather, stay ops of their own
                 else:
