@@ -896,8 +896,10 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     UNSUP((needs & PN_LIN) && !a.lin_vel);
     UNSUP((needs & PN_ANG) && !a.ang_vel);
     UNSUP((needs & PN_EPLEN) && !a.episode_length);
-    UNSUP((needs & (PN_DOFPOS | PN_DOFVEL | PN_TARGETS | PN_ACTIONS | PN_LAST)) && (D != 12 && D != 28));
-    UNSUP((a.reset_dofs || (a.reset_env & 1)) && (D != 12 && D != 28));
+    // DOF rows are float4 chunks: 12 and 28 DOF have static programs / both kernel variants, 8 / 16 / 20 / 24 the four-wave interpreter
+    const bool dofs_ok = D == 8 || D == 12 || D == 16 || D == 20 || D == 24 || D == 28;
+    UNSUP((needs & (PN_DOFPOS | PN_DOFVEL | PN_TARGETS | PN_ACTIONS | PN_LAST)) && !dofs_ok);
+    UNSUP((a.reset_dofs || (a.reset_env & 1)) && !dofs_ok);
     UNSUP((needs & PN_DOFPOS) && !a.dof_pos);
     UNSUP((needs & PN_DOFVEL) && !a.dof_vel);
     UNSUP((needs & PN_TARGETS) && !a.targets);
@@ -969,7 +971,7 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     gf::PhaseScope scope(GF_PHASE_POST, s);
     bool any_ring = false;
     for (int m = 0; m < a.n_obs; ++m) any_ring = any_ring || a.obs[m].ring != 0;
-    const bool ws_only = a.n_gait || a.roll_obs || a.roll_reward || a.roll_done || any_ring || a.term_done;   // the one-wave variant has neither a gait manager nor rollout stores
+    const bool ws_only = a.n_gait || a.roll_obs || a.roll_reward || a.roll_done || any_ring || a.term_done || (a.num_dofs != 12 && a.num_dofs != 28);   // the one-wave variant has neither a gait manager nor rollout stores
     if (gf::g_options[GF_OPT_POST_VARIANT] == 0 && !ws_only) {
         if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid, gf::kEnvBlock, lds, s, a);
         else GF_LAUNCH(scope, gf::post_kernel<3>, grid, gf::kEnvBlock, lds, s, a);
@@ -979,8 +981,17 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
         GF_POST_PROGRAMS(GF_RUN)
 #undef GF_RUN
     } else {
-        if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<7>>, grid, gf::kWsBlock, sizeof(gf::GfPostArgs) + lds_ws_floats<gf::Interp<7>>(omax, a.n_gait) * sizeof(float), s, a);
-        else GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<3>>, grid, gf::kWsBlock, sizeof(gf::GfPostArgs) + lds_ws_floats<gf::Interp<3>>(omax, a.n_gait) * sizeof(float), s, a);
+#define GF_RUN_INTERP(DV_) \
+        GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<DV_>>, grid, gf::kWsBlock, sizeof(gf::GfPostArgs) + lds_ws_floats<gf::Interp<DV_>>(omax, a.n_gait) * sizeof(float), s, a)
+        switch (a.num_dofs) {
+            case 8: GF_RUN_INTERP(2); break;
+            case 16: GF_RUN_INTERP(4); break;
+            case 20: GF_RUN_INTERP(5); break;
+            case 24: GF_RUN_INTERP(6); break;
+            case 28: GF_RUN_INTERP(7); break;
+            default: GF_RUN_INTERP(3); break;   // 12 DOF; configs without DOF rows (pack() let nothing else through)
+        }
+#undef GF_RUN_INTERP
     }
     return gf::launch_status();
 }

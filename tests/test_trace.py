@@ -423,7 +423,8 @@ def test_recorded_step_follows_live_manager_attributes(oracle_backend):
 
 @pytest.mark.parametrize("dofs", [7, 16])
 def test_other_dof_counts_use_phase_chains_cpu(oracle_backend, dofs):
-    """A DOF count without a fused variant (neither 12 nor 28): the step is still recorded; on the GPU its phases run as chains."""
+    """Other DOF counts: the step is still recorded; on the GPU a multiple of four up to 28 runs the fused launch (float4 row chunks),
+    anything else the phase chains."""
     a, _ = _run_humanoid("cpu", "ordinary", 50, dofs)
     b, env = _run_humanoid("cpu", "fused", 50, dofs)
     assert env._trace is not None
@@ -431,17 +432,18 @@ def test_other_dof_counts_use_phase_chains_cpu(oracle_backend, dofs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dofs,n", [(7, 300), (10, 65), (16, 1000), (20, 129)])
+@pytest.mark.parametrize("dofs,n", [(7, 300), (10, 65), (16, 1000), (20, 129), (8, 257), (24, 1000)])
 def test_other_dof_counts_hip(hip_backend, oracle_lib_path, dofs, n):
-    """Scalar-row (D % 4 != 0) and other vector-row variants of the reward / action / scene kernels, through the phase chains:
-    recorded == ordinary on HIP, and HIP == oracle."""
+    """Scalar-row (D % 4 != 0) variants of the reward / action / scene kernels through the phase chains, and the 8 / 16 / 20 / 24-DOF
+    variants of the fused launch's interpreter: recorded == ordinary on HIP, and HIP == oracle."""
     from genesis_forge_amd import _native as nat
     from genesis_forge_amd import gs
     from oracle_backend import OracleBackend
 
     a, _ = _run_humanoid("cuda", "ordinary", n, dofs)
     b, env = _run_humanoid("cuda", "fused", n, dofs)
-    assert env._trace is not None and env._trace.post_refs is None, "no fused variant for this DOF count: phase chains"
+    assert env._trace is not None
+    assert (env._trace.post_refs is not None) == (dofs % 4 == 0), "float4 row chunks: multiples of four run the fused launch, the rest the phase chains"
     _same_h(a, b)
     torch.cuda.synchronize()
     gs.set_device("cpu")
