@@ -637,7 +637,7 @@ static int pack(const GfPostRefs* r, Packer& pk) {
             case GF_T_CONTACT_FORCE_GRACE: needs |= PN_EPLEN;  // fallthrough
             case GF_T_HAS_CONTACT:
             case GF_T_CONTACT_FORCE: break;
-            default: return GF_E_UNSUPPORTED;  // EXTERNAL columns cannot be fused
+            default: return GF_E_UNSUPPORTED;  // GF_T_EXTERNAL: a host-evaluated column needs GF_POST_TERMINATION_DONE (the table is then not evaluated here)
         }
         if (term_op_has_contact(t.op)) {
             UNSUP(t.i[0] < 0 || t.i[0] >= GF_MAX_CONTACT_VIEWS || !T.contact[t.i[0]].contacts);
