@@ -808,6 +808,10 @@ static int pack(const GfPostRefs* r, Packer& pk) {
         UNSUP(RS.zero_velocity && (!RS.scene_lin_vel || !RS.scene_ang_vel));
         merge_entity(a, ev);
         a.set_quat = RS.set_quat; a.zero_velocity = RS.zero_velocity; a.quat_stash = RS.quat_stash;
+        // the stash takes the PRE-reset quaternion out of the control wave's registers: it has to be loaded even when no term or
+        // observation item of THIS launch reads it (termination done by a launch of its own, the body-frame items in an observation
+        // manager that runs behind this launch, a getter the training script calls between steps) — found by the fuzz soak, seeds 123 / 140
+        if (RS.quat_stash && (RS.set_quat || (RS.spawn_mode && RS.spawn_set_quat))) needs |= PN_QUAT;
         for (int j = 0; j < 3; ++j) a.reset_pos[j] = RS.reset_pos[j];
         for (int j = 0; j < 4; ++j) a.reset_quat[j] = RS.reset_quat[j];
         if (RS.zero_velocity && RS.scene_dof_vel) {

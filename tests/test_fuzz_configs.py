@@ -16,7 +16,10 @@ import torch
 
 from helpers import FLOAT_TOL
 
-SEEDS = list(range(28))
+# GF_FUZZ_SEEDS="first:last" runs another range (a soak run hunts with hundreds; the committed default is what CI affords)
+# 123 / 140: found by such a run — the control wave's pre-reset quaternion was not loaded when only the stale-quaternion stash needed it
+# (termination done by a launch of its own; the body-frame items in a manager that observes behind the fused launch)
+SEEDS = list(range(*map(int, os.environ["GF_FUZZ_SEEDS"].split(":")))) if os.environ.get("GF_FUZZ_SEEDS") else list(range(28)) + [123, 140]
 STEPS = 48
 
 
