@@ -23,6 +23,28 @@ def _make(kind, n):
     if kind == "go2_hist":
         return tasks.Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=0.4, cmd_resample_s=0.2, history=3, contacts=True, obs_noise=True,
                                             scene_kwargs=dict(ang_noise=0.3, seed=3))
+    if kind in ("go2_user_reward", "go2_user_obs"):   # a Python-level term in the step: termination launch → callable → fused launch (rows
+        env = tasks.Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=0.4, cmd_resample_s=0.2, history=2, contacts=True,   # included); an
+                                           scene_kwargs=dict(ang_noise=0.3, seed=3))                                          # observation callable: chains
+        base = env.config
+
+        def config():
+            base()
+            from genesis_forge_amd.managers import ObservationManager, RewardManager
+            if kind == "go2_user_reward":
+                rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in env.reward_manager.cfg.items()}
+                rc["user_height"] = {"weight": 0.3, "fn": lambda e: torch.tanh(e.robot.get_pos()[:, 2])}
+                env.managers["reward"] = None
+                env.reward_manager = RewardManager(env, logging_enabled=True, cfg=rc)
+            else:
+                om = env.observation_manager
+                oc = {k: {"fn": v.fn, "params": dict(v.params), "scale": v.scale, "noise": v.noise} for k, v in om.cfg.items()}
+                oc["user_xy"] = {"fn": lambda env: env.robot.get_pos()[:, :2] * 2.0}
+                env.managers["observation"].remove(om)
+                env.observation_manager = ObservationManager(env, cfg=oc, history_len=2)
+
+        env.config = config
+        return env
     if kind == "gait":
         return tasks.Go2GaitTrainingEnv(num_envs=n, max_episode_length_s=0.4, scene_kwargs=dict(ang_noise=0.3, seed=3, contact_prob=0.05))
     if kind == "gait_curriculum":   # reset() override: recorded up to the reset, the tail (and the rollout write) runs phase by phase
@@ -77,7 +99,8 @@ def _check_rollout(dev, kind, n, trace, horizon=5, steps=17, fuse=True, output="
 
 @pytest.mark.parametrize("kind,trace,output", [("go2", False, "fresh"), ("go2", True, "fresh"), ("go2_hist", True, "fresh"), ("gait", True, "fresh"),
                                                ("gait_curriculum", True, "fresh"), ("go2_hist", True, "static"), ("go2_hist", False, "static"),
-                                               ("gait", True, "static")])
+                                               ("gait", True, "static"), ("go2_user_reward", True, "fresh"), ("go2_user_obs", True, "fresh"),
+                                               ("go2_user_reward", True, "static")])
 def test_rollout_storage_rows_cpu(oracle_backend, kind, trace, output):
     env = _check_rollout("cpu", kind, 70, trace, output=output)
     assert (env._trace is not None) == trace
@@ -89,15 +112,19 @@ def test_rollout_storage_rows_cpu(oracle_backend, kind, trace, output):
 @pytest.mark.parametrize("kind,trace,fuse,output", [("go2", False, True, "fresh"), ("go2", True, True, "fresh"), ("go2", True, False, "fresh"),
                                                     ("go2_hist", True, True, "fresh"), ("gait", True, True, "fresh"), ("gait", True, False, "fresh"),
                                                     ("gait_curriculum", True, True, "fresh"), ("go2_hist", True, True, "static"),
-                                                    ("gait", True, True, "static"), ("gait", True, False, "static")])
+                                                    ("gait", True, True, "static"), ("gait", True, False, "static"),
+                                                    ("go2_user_reward", True, True, "fresh"), ("go2_user_reward", True, True, "static"),
+                                                    ("go2_user_obs", True, True, "fresh")])
 def test_rollout_storage_rows_hip(hip_backend, kind, trace, fuse, output):
     env = _check_rollout("cuda", kind, 1000, trace, fuse=fuse, output=output)
     tr = env._trace
     assert (tr is not None) == trace
     if trace and kind != "gait_curriculum":
-        assert (tr.post_refs is not None) == fuse
-        if fuse:
+        fused = fuse and kind != "go2_user_obs"   # (a rollout row out of a manager that observes behind the fused launch: phase chains)
+        assert (tr.post_refs is not None) == fused
+        if fused:
             assert tr.post_refs.rollout, "the fused post-physics launch stores the rollout rows itself"
+            assert bool(tr.post_refs.flags & 1) == (kind == "go2_user_reward"), "a Python-level reward term: termination as a launch of its own"
 
 
 def test_rollout_write_abi_validation(oracle_backend):
