@@ -13,9 +13,21 @@ from envs import Go2GaitTrainingEnv
 SCENE = dict(ang_noise=0.4, seed=9, contact_prob=0.04, contact_force=4.0, max_collision_pairs=14)
 
 
-def _run(dev, n, steps, trace, events=None):
+def _run(dev, n, steps, trace, events=None, user_term=False):
     env = Go2GaitTrainingEnv(num_envs=n, max_episode_length_s=1, scene_kwargs=dict(SCENE))
     env.trace_enabled = trace
+    if user_term:   # a Python-level reward term: termination launch → callable → the fused launch with the gait manager inside
+        base = env.config
+
+        def config():
+            base()
+            from genesis_forge_amd.managers import RewardManager
+            rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in env.reward_manager.cfg.items()}
+            rc["user_height"] = {"weight": 0.3, "fn": lambda e: torch.tanh(e.robot.get_pos()[:, 2])}
+            env.managers["reward"] = None
+            env.reward_manager = RewardManager(env, logging_enabled=True, cfg=rc)
+
+        env.config = config
     env.build()
     env.seed(11)
     env.velocity_command.resample_time_sec = 0.3
@@ -101,6 +113,13 @@ def test_gait_recorded_step_equals_ordinary_cpu(oracle_backend):
     _same(a, b, exact_floats=True)
 
 
+def test_gait_with_python_reward_term_recorded_equals_ordinary_cpu(oracle_backend):
+    a, _ = _run("cpu", 70, 50, trace=False, events=EVENTS, user_term=True)
+    b, env = _run("cpu", 70, 50, trace=True, events=EVENTS, user_term=True)
+    assert env._trace is not None and len(env._trace.splits) == 1
+    _same(a, b, exact_floats=True)
+
+
 def test_reward_methods_callable_like_the_reference(oracle_backend):
     """`gait.gait_phase_reward(env, contact_manager=…)` / `foot_height_reward(env)` as direct calls: kernel path == torch path."""
     _, env = _run("cpu", 64, 8, trace=False)
@@ -130,6 +149,29 @@ def test_gait_pipeline_hip_equals_oracle(hip_backend, oracle_lib_path, n, trace)
     nat.set_backend(OracleBackend(oracle_lib_path))
     try:
         ref, _ = _run("cpu", n, 60, trace=False, events=EVENTS)
+    finally:
+        nat.set_backend(None)
+        gs.set_device("cuda:0")
+    _same(hip, ref, exact_floats=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [65, 1000])
+def test_gait_with_python_reward_term_hip_equals_oracle(hip_backend, oracle_lib_path, n):
+    """Gait task + a lambda as reward term: the recorded step is termination launch → callable → ONE launch for reward … observation
+    with the gait manager inside (GF_POST_TERMINATION_DONE); HIP == oracle and the step stays fused."""
+    from genesis_forge_amd import _native as nat
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+
+    hip, env = _run("cuda", n, 60, trace=True, events=EVENTS, user_term=True)
+    torch.cuda.synchronize()
+    tr = env._trace
+    assert tr is not None and tr.post_refs is not None and tr.post_refs.flags & 1 and tr.post_refs.num_gait == 1
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(oracle_lib_path))
+    try:
+        ref, _ = _run("cpu", n, 60, trace=False, events=EVENTS, user_term=True)
     finally:
         nat.set_backend(None)
         gs.set_device("cuda:0")
