@@ -32,6 +32,14 @@ def make_fuzz_env(seed: int):
     from envs import GO2_DEFAULT_POS, GO2_JOINTS
 
     rnd = random.Random(1000 + seed)
+    rnd_out = random.Random(77000 + seed)   # output / history modes of the observation managers (a stream of its own: the configs of the
+    #                                         seeds above are what they were before the modes were drawn)
+
+    def out_mode(history):
+        if not history or history < 2:
+            return dict(output=rnd_out.choice(["fresh", "fresh", "static"]))
+        return dict(output=rnd_out.choice(["fresh", "fresh", "static", "static", "ring"]), history=rnd_out.choice(["auto", "auto", "shift", "unroll"]))
+
     n = rnd.choice([1, 63, 64, 65, 130, 257, 1000])
     pick = lambda p: rnd.random() < p
     uni = lambda lo, hi: round(rnd.uniform(lo, hi), 3)
@@ -146,14 +154,17 @@ def make_fuzz_env(seed: int):
                     cfg[name] = it
                 return cfg
 
-            self.observation_manager = ObservationManager(self, name="policy", cfg=obs_cfg(2), history_len=rnd.choice([None, None, 2, 3, 5]),
-                                                          noise=0.02 if pick(0.15) else None)
+            h = rnd.choice([None, None, 2, 3, 5])
+            self.observation_manager = ObservationManager(self, name="policy", cfg=obs_cfg(2), history_len=h, noise=0.02 if pick(0.15) else None,
+                                                          **out_mode(h))
             self.third_obs = False
             if pick(0.35):
-                ObservationManager(self, name="critic", cfg=obs_cfg(1), history_len=rnd.choice([None, 4]))
+                h = rnd.choice([None, 4])
+                ObservationManager(self, name="critic", cfg=obs_cfg(1), history_len=h, **out_mode(h))
                 self.third_obs = pick(0.4)
-                if self.third_obs:  # more observation managers than the fused kernel takes: the recorded step runs as phase chains
-                    ObservationManager(self, name="extra", cfg=obs_cfg(1), history_len=rnd.choice([None, 2]))
+                if self.third_obs:  # more observation managers than the fused kernel takes: the third observes behind the fused launch
+                    h = rnd.choice([None, 2])
+                    ObservationManager(self, name="extra", cfg=obs_cfg(1), history_len=h, **out_mode(h))
 
     FuzzEnv.overrides_reset = pick(0.2)
     if FuzzEnv.overrides_reset:  # a user reset(): honoured by index list; the step is recorded up to the reset only
