@@ -490,6 +490,9 @@ BASELINE_CONFIGS = {
     "rough_terrain": (16384, lambda n, **kw: Go2RoughTerrainEnv(num_envs=n, height_reward=False,
                                                                scene_kwargs=dict(_CON, max_collision_pairs=30), **kw)),
     "humanoid": (8192, lambda n, **kw: BerkeleyHumanoidEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.002, max_collision_pairs=30), **kw)),
+    # BASELINE config 4 as stated ("~28-DOF"): the same kind of manager stack over a synthetic 28-joint humanoid (the reference's
+    # berkeley_humanoid example, "humanoid" above, has 12 actuated joints)
+    "humanoid28": (8192, lambda n, **kw: HumanoidGaitLikeEnv(num_envs=n, dofs=28, **kw)),
     "gait": (65536, lambda n, **kw: Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.001), **kw)),
     "gait_8192": (8192, lambda n, **kw: Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.001), **kw)),
 }
