@@ -75,6 +75,8 @@ class ManagedEnvironment(GenesisEnv):
         self._terminated_buf = torch.zeros((self.num_envs,), device=gs.device, dtype=gs.tc_bool)
         self._truncated_buf = torch.zeros((self.num_envs,), device=gs.device, dtype=gs.tc_bool)
         self._reset_args = nat.GfResetArgs()
+        self._done_ids = None     # the index list of this step's done envs while a user reset() override holds it (reset() recognises it)
+        self._tail_trace = None   # the recorded step whose Python tail is running (its reset / observation segments replay natively)
         #: record the step and replay it through gf_run_ops when possible (see _trace.py); GF_NO_TRACE=1 disables
         self.trace_enabled = os.environ.get("GF_NO_TRACE", "0") != "1"
         #: replace the recorded post-physics phases by the fused gf_post_physics_step launch; GF_NO_FUSE=1 disables
@@ -304,10 +306,10 @@ class ManagedEnvironment(GenesisEnv):
     def reset(self, env_ids: list[int] | None = None):
         """Reset one or more environments and every registered manager (managed_env.py:336-371)."""
         outside = not self._in_step
-        if not outside and env_ids is not None and env_ids is getattr(self, "_done_ids", None):
+        if not outside and env_ids is not None and env_ids is self._done_ids:
             # the in-step reset of the done envs, reached through a user override of reset(): the index list IS the termination masks,
             # so the launches are the mask path's (persistent descriptors: a recorded step replays them with one native call)
-            tr = getattr(self, "_tail_trace", None)
+            tr = self._tail_trace
             if tr is None or not tr.run_tail_segment("reset"):
                 tm = self.managers["termination"]
                 rec = self.backend.tracer
@@ -346,7 +348,7 @@ class ManagedEnvironment(GenesisEnv):
                 return self.extras["observations"]["policy"]
             if "observations" not in self.extras:
                 self.extras["observations"] = _obs_dict()
-            tr = getattr(self, "_tail_trace", None)
+            tr = self._tail_trace
             if tr is not None and tr.run_tail_segment("obs"):   # the Python tail of a recorded step: one native call
                 return self.extras["observations"].get("policy")
             rec = self.backend.tracer if self._in_step else None
