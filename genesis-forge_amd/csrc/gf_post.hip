@@ -931,7 +931,8 @@ static size_t lds_ws_floats(int omax, int n_gait) {
 // Static programs in registration order; program id = 1 + index (0 = table interpreter).
 #define GF_POST_PROGRAMS(X)                                                                                                \
     X(1, gf::ProgGo2CommandDirection) X(2, gf::ProgGo2Simple) X(3, gf::ProgGo2Contacts) X(4, gf::ProgGo2RoughTerrain) \
-    X(5, gf::ProgBerkeleyHumanoid) X(6, gf::ProgGo2GaitTrainer)
+    X(5, gf::ProgBerkeleyHumanoid) X(6, gf::ProgGo2GaitTrainer) \
+    X(7, gf::ProgHumanoid28Stress)
 
 static int select_program(const gf::GfPostArgs& a) {
     if (gf::g_options[GF_OPT_POST_VARIANT] < 2) return 0;

@@ -186,6 +186,28 @@ struct ProgGo2GaitTrainer {
 };
 
 // ---- matching -------------------------------------------------------------------------------------------------------------------
+// a recorded signature (registered with tools/register_program.py)
+struct ProgHumanoid28Stress {
+    static constexpr bool kStatic = true;
+    static constexpr const char* name = "humanoid28_stress";
+    static constexpr int DV = 7;
+    static constexpr int n_term = 4;
+    static constexpr TermSig term[4] = {{1, 1}, {2, 0}, {6, 0}, {3, 0}};
+    static constexpr int n_rew = 12;
+    static constexpr RewSig rew[12] = {{10, 0, 0, 0}, {11, 0, 0, 2}, {8, 0, 0, 0}, {9, 0, 0, 0}, {4, 0, 0, 0}, {12, 0, 0, 0}, {15, 4, 1, 0}, {14, 0, 2, 0}, {16, 0, 1, 0}, {1, 0, 0, 0}, {7, 0, 0, 0}, {3, 0, 0, 0}};
+    static constexpr int n_cmd = 2;
+    static constexpr int cmd_width[GF_POST_MAX_CMD] = {3, 1};
+    static constexpr int n_obs = 2;
+    static constexpr int obs_width[GF_POST_MAX_OBS] = {94, 61};
+    static constexpr int obs_history[GF_POST_MAX_OBS] = {3, 1};
+    static constexpr int obs_items[GF_POST_MAX_OBS] = {7, 4};
+    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {
+        {{1, 1, 1, false, true}, {1, 3, 0, false, true}, {2, 3, 0, true, true}, {4, 3, 0, false, true}, {5, 28, 0, false, true}, {6, 28, 0, true, true}, {8, 28, 0, false, true}},
+        {{10, 2, 1, true, false}, {3, 3, 0, false, false}, {7, 28, 0, false, false}, {9, 28, 0, false, false}}};
+    static constexpr int n_air = 2;
+    static constexpr int n_gait = 0;
+};
+
 template <class P>
 bool program_matches(const GfPostArgs& a) {
     if (a.term_done || a.num_dofs != 4 * P::DV || a.num_term != P::n_term || a.num_rew != P::n_rew || a.n_cmd != P::n_cmd || a.n_obs != P::n_obs || a.n_air != P::n_air ||

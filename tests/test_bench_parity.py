@@ -44,7 +44,9 @@ CASES = [
     ("humanoid", 8192, "short", 24, "berkeley_humanoid"),
     ("gait", 8192, "bench", 20, None),
     ("gait", 65536, "short", 20, None),
-    ("humanoid28", 8192, "short", 24, "interpreter"),   # BASELINE config 4 as stated ("~28-DOF"): synthetic 28-DOF humanoid, D = 28 fused variant
+    ("humanoid28", 8192, "short", 24, "humanoid28_stress"),   # BASELINE config 4 as stated ("~28-DOF"): synthetic 28-DOF humanoid, static program 7
+    ("humanoid28", 8192, "interp", 24, "interpreter"),        # … and the 28-DOF table interpreter every other 28-DOF config runs (GF_OPT_POST_VARIANT = 1)
+    ("go2_cmd", 65536, "interp", 18, "interpreter"),          # … and the 12-DOF interpreter at the benchmark size
 ]
 
 
@@ -53,7 +55,7 @@ def _make(name, n, variant):
 
     if name == "humanoid28":
         return tasks.HumanoidGaitLikeEnv(num_envs=n, dofs=28)
-    kw = {} if variant == "bench" else {"max_episode_length_s": 0.3}
+    kw = {} if variant == "bench" else {"max_episode_length_s": 0.3}   # ("short" / "interp": 0.3 s episodes)
     env = tasks.BASELINE_CONFIGS[name][1](n, **kw)
     return env
 
@@ -110,6 +112,17 @@ def test_timed_workload_hip_equals_oracle(hip_backend, oracle_lib_path, name, n,
     from oracle_backend import OracleBackend
 
     hip, cpu = _Side("cuda:0", hip_backend), _Side("cpu", OracleBackend(oracle_lib_path))
+    if variant == "interp":   # keep the config off its static program: the table interpreter of the fused launch at this size
+        hip_backend.set_option(nat.GF_OPT_POST_VARIANT, 1)
+        try:
+            _timed_workload(hip_backend, hip, cpu, name, n, "short", steps, program)
+        finally:
+            hip_backend.set_option(nat.GF_OPT_POST_VARIANT, 2)
+        return
+    _timed_workload(hip_backend, hip, cpu, name, n, variant, steps, program)
+
+
+def _timed_workload(hip_backend, hip, cpu, name, n, variant, steps, program):
     envs = {}
     for key, side in (("hip", hip), ("cpu", cpu)):
         with side:
