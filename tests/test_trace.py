@@ -632,3 +632,58 @@ def test_in_place_history_ring_stand_alone_kernel_hip(hip_backend, monkeypatch):
     for t, (a, b) in enumerate(zip(want, got)):
         for k, (x, y) in enumerate(zip(a, b)):
             assert torch.equal(x, y), f"output {k} differs at step {t}"
+
+
+def _run_dof_variant(dev, seed, trace):
+    """The Go2 command stack over a synthetic D-joint robot with drawn D, env count, history, noise and episode / resample periods."""
+    import random
+
+    rnd = random.Random(9000 + seed)
+    dofs = rnd.choice([7, 8, 10, 16, 19, 20, 24, 28])
+    n = rnd.choice([63, 64, 65, 257, 1000])
+    env = Go2CommandDirectionEnv(num_envs=n, dofs=dofs, max_episode_length_s=rnd.choice([0.3, 0.5]), cmd_resample_s=rnd.choice([0.1, 0.3]),
+                                 history=rnd.choice([None, 2, 3]), obs_noise=rnd.random() < 0.5,
+                                 scene_kwargs=dict(ang_noise=rnd.choice([0.1, 0.3]), seed=seed))
+    env.trace_enabled = trace
+    env.build()
+    env.seed(100 + seed)
+    env.reset()
+    g = torch.Generator().manual_seed(seed)
+    outs = []
+    for _ in range(36):
+        o, r, te, tr, ex = env.step(torch.randn(n, dofs, generator=g).to(dev))
+        outs.append((o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone(), {k: float(v) for k, v in ex["episode"].items()},
+                     env.velocity_command._command.cpu().clone(), env.action_manager.get_dofs_position().cpu().clone()))
+    return outs, env, dofs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_random_dof_variant_hip_equals_oracle(hip_backend, oracle_lib_path, seed):
+    """8 / 16 / 20 / 24 / 28 DOF: the interpreter variants of the fused launch; 7 / 10 / 19: the phase chains with scalar rows —
+    recorded on HIP == phase by phase on the oracle, and every variant resets envs."""
+    from genesis_forge_amd import _native as nat
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+
+    hip, env, dofs = _run_dof_variant("cuda", seed, True)
+    torch.cuda.synchronize()
+    assert env._trace is not None and (env._trace.post_refs is not None) == (dofs % 4 == 0)
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(oracle_lib_path))
+    try:
+        ref, _, _ = _run_dof_variant("cpu", seed, False)
+    finally:
+        nat.set_backend(None)
+        gs.set_device("cuda:0")
+    resets = 0
+    for t, (x, y) in enumerate(zip(hip, ref)):
+        for k in (2, 3):
+            assert torch.equal(x[k], y[k]), f"mask {k} differs at step {t} (D = {dofs})"
+        for k in (0, 1, 5, 6):
+            assert torch.allclose(x[k], y[k], atol=1e-5, rtol=0), f"output {k} differs at step {t} (D = {dofs}): {(x[k] - y[k]).abs().max()}"
+        assert set(x[4]) == set(y[4]), f"log keys differ at step {t}"
+        for key in x[4]:
+            assert abs(x[4][key] - y[4][key]) <= 1e-5 + 1e-5 * abs(y[4][key]), (t, key)
+        resets += int(y[2].sum() + y[3].sum())
+    assert resets > 0
