@@ -397,10 +397,10 @@ __global__ __launch_bounds__(kEnvBlock) void post_kernel(const GfPostArgs karg) 
                     row[col + 1] = obs_finish(f, v.y, col + 1);
                     row[col + 2] = obs_finish(f, v.z, col + 2);
                 } break;
-                case GF_O_DOF_POS: put_row<DV>(f, r_pos, row, col); break;
-                case GF_O_DOF_VEL: put_row<DV>(f, r_vel, row, col); break;
-                case GF_O_ACTIONS: put_row<DV>(f, r_tgt, row, col); break;
-                case GF_O_RAW_ACTIONS: put_row<DV>(f, o_act, row, col); break;
+                case GF_O_DOF_POS: put_row<DV>(f, r_pos, row, col, 4 * DV); break;
+                case GF_O_DOF_VEL: put_row<DV>(f, r_vel, row, col, 4 * DV); break;
+                case GF_O_ACTIONS: put_row<DV>(f, r_tgt, row, col, 4 * DV); break;
+                case GF_O_RAW_ACTIONS: put_row<DV>(f, o_act, row, col, 4 * DV); break;
                 case GF_O_DOF_FORCE: {
                     const GF_GLOBAL float* r = G(a.dof_force) + n * D;
                     for (int j = 0; j < it.width; ++j) row[col + j] = obs_finish(f, r[j], col + j);
@@ -900,8 +900,9 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     UNSUP((needs & PN_LIN) && !a.lin_vel);
     UNSUP((needs & PN_ANG) && !a.ang_vel);
     UNSUP((needs & PN_EPLEN) && !a.episode_length);
-    // DOF rows are float4 chunks: 12 and 28 DOF have static programs / both kernel variants, 8 / 16 / 20 / 24 the four-wave interpreter
-    const bool dofs_ok = D == 8 || D == 12 || D == 16 || D == 20 || D == 24 || D == 28;
+    // DOF rows are ceil(D / 4) float4 chunks (a last chunk of fewer than four floats is handled element by element, gf_post_args.h):
+    // 12 and 28 DOF have static programs / both kernel variants, every other count up to 28 a four-wave interpreter variant
+    const bool dofs_ok = D >= 1 && D <= 28;
     UNSUP((needs & (PN_DOFPOS | PN_DOFVEL | PN_TARGETS | PN_ACTIONS | PN_LAST)) && !dofs_ok);
     UNSUP((a.reset_dofs || (a.reset_env & 1)) && !dofs_ok);
     UNSUP((needs & PN_DOFPOS) && !a.dof_pos);
@@ -988,13 +989,14 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     } else {
 #define GF_RUN_INTERP(DV_) \
         GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<DV_>>, grid, gf::kWsBlock, sizeof(gf::GfPostArgs) + lds_ws_floats<gf::Interp<DV_>>(omax, a.n_gait) * sizeof(float), s, a)
-        switch (a.num_dofs) {
-            case 8: GF_RUN_INTERP(2); break;
-            case 16: GF_RUN_INTERP(4); break;
-            case 20: GF_RUN_INTERP(5); break;
-            case 24: GF_RUN_INTERP(6); break;
-            case 28: GF_RUN_INTERP(7); break;
-            default: GF_RUN_INTERP(3); break;   // 12 DOF; configs without DOF rows (pack() let nothing else through)
+        switch ((a.num_dofs + 3) / 4) {   // chunks per row
+            case 1: GF_RUN_INTERP(1); break;
+            case 2: GF_RUN_INTERP(2); break;
+            case 4: GF_RUN_INTERP(4); break;
+            case 5: GF_RUN_INTERP(5); break;
+            case 6: GF_RUN_INTERP(6); break;
+            case 7: GF_RUN_INTERP(7); break;
+            default: GF_RUN_INTERP(3); break;   // 9 … 12 DOF; configs without DOF rows (pack() let nothing above 28 through)
         }
 #undef GF_RUN_INTERP
     }

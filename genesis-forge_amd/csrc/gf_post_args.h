@@ -159,15 +159,56 @@ __device__ __noinline__ float4 draw_unit4(uint64_t seed, uint64_t stream, uint32
     return make_float4(u24_to_unit(r.x), u24_to_unit(r.y), u24_to_unit(r.z), u24_to_unit(r.w));
 }
 
+// ---- [N, D] rows as DV = ceil(D / 4) float4 chunks of registers ------------------------------------------------------------------
+// D % 4 == 0 (every static program; D is then a compile-time 4·DV and the tail code folds away): a row is DV aligned 16-byte accesses.
+// Otherwise rows are only dword aligned (the same 16-byte instructions take them) and the LAST chunk holds D - 4·(DV-1) < 4 floats of
+// the row: it is read and written element by element (a 16-byte access would touch the next env's row — or, for the last env, memory
+// behind the array) and its missing floats read as zero, so sums over a row need no mask.
+typedef float f32x4d __attribute__((ext_vector_type(4), aligned(4)));
+template <int DV>
+__device__ __forceinline__ void row_load(float4 (&r)[DV], const GF_GLOBAL float* p, const int D) {
+#pragma unroll
+    for (int c = 0; c < DV - 1; ++c) {
+        const f32x4d v = *reinterpret_cast<const GF_GLOBAL f32x4d*>(p + 4 * c);
+        r[c] = make_float4(v.x, v.y, v.z, v.w);
+    }
+    const GF_GLOBAL float* q = p + 4 * (DV - 1);
+    const int t = D - 4 * (DV - 1);
+    if (t >= 4) {
+        const f32x4d v = *reinterpret_cast<const GF_GLOBAL f32x4d*>(q);
+        r[DV - 1] = make_float4(v.x, v.y, v.z, v.w);
+    } else {   // in-bounds, unconditional element loads (clamped index), then selects
+        const float x = q[0], y = q[t > 1 ? 1 : 0], z = q[t > 2 ? 2 : 0];
+        r[DV - 1] = make_float4(x, t > 1 ? y : 0.f, t > 2 ? z : 0.f, 0.f);
+    }
+}
+template <int DV>
+__device__ __forceinline__ void row_store(GF_GLOBAL float* p, const float4 (&r)[DV], const int D) {
+#pragma unroll
+    for (int c = 0; c < DV - 1; ++c) *reinterpret_cast<GF_GLOBAL f32x4d*>(p + 4 * c) = f32x4d{r[c].x, r[c].y, r[c].z, r[c].w};
+    GF_GLOBAL float* q = p + 4 * (DV - 1);
+    const int t = D - 4 * (DV - 1);
+    const float4 l = r[DV - 1];
+    if (t >= 4) {
+        *reinterpret_cast<GF_GLOBAL f32x4d*>(q) = f32x4d{l.x, l.y, l.z, l.w};
+    } else {
+        q[0] = l.x;
+        if (t > 1) q[1] = l.y;
+        if (t > 2) q[2] = l.z;
+    }
+}
+
 // one [D] row of registers → the lane's observation tile row (separate call per source keeps every index static)
 template <int DV>
-__device__ __forceinline__ void put_row(const ObsFin& f, const float4 (&r)[DV], float* row, int col) {
+__device__ __forceinline__ void put_row(const ObsFin& f, const float4 (&r)[DV], float* row, int col, const int D) {
 #pragma unroll
     for (int c = 0; c < DV; ++c) {
+        const bool last = c == DV - 1;
+        const int t = last ? D - 4 * (DV - 1) : 4;   // floats of this chunk that belong to the row
         row[col + 4 * c + 0] = obs_finish(f, r[c].x, col + 4 * c + 0);
-        row[col + 4 * c + 1] = obs_finish(f, r[c].y, col + 4 * c + 1);
-        row[col + 4 * c + 2] = obs_finish(f, r[c].z, col + 4 * c + 2);
-        row[col + 4 * c + 3] = obs_finish(f, r[c].w, col + 4 * c + 3);
+        if (t > 1) row[col + 4 * c + 1] = obs_finish(f, r[c].y, col + 4 * c + 1);
+        if (t > 2) row[col + 4 * c + 2] = obs_finish(f, r[c].z, col + 4 * c + 2);
+        if (t > 3) row[col + 4 * c + 3] = obs_finish(f, r[c].w, col + 4 * c + 3);
     }
 }
 

@@ -242,7 +242,7 @@ inline int describe_program(const GfPostArgs& a, char* buf, int cap) {
             n += w > 0 ? w : 0;
         }
     };
-    put("DV = %d; n_term = %d; term = {", a.num_dofs / 4, a.num_term);
+    put("DV = %d; n_term = %d; term = {", (a.num_dofs + 3) / 4, a.num_term);
     for (int k = 0; k < a.num_term; ++k) put("{%d, %d}%s", a.tterms[k].op, a.tterms[k].flags, k + 1 < a.num_term ? ", " : "");
     put("}; n_rew = %d; rew = {", a.num_rew);
     for (int k = 0; k < a.num_rew; ++k) put("{%d, %d, %d, %d}%s", a.rterms[k].op, a.rterms[k].flags, a.rterms[k].i[0], a.rterms[k].i[1], k + 1 < a.num_rew ? ", " : "");

@@ -376,8 +376,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         const GF_GLOBAL float* p2 = gsel((needs & PN_ACTRATE) != 0, UNI(a.env_last_actions), ro);
         const GF_GLOBAL float* p3 = gsel((needs & PN_DOFDEV) != 0, UNI(a.default_dof_pos), 0u);
         float4 r_def[R];
-#pragma unroll
-        for (int c = 0; c < DV; ++c) { r_a[c] = ldg4(p0 + 4 * c); r_b[c] = ldg4(p1 + 4 * c); r_c[c] = ldg4(p2 + 4 * c); r_def[c] = ldg4(p3 + 4 * c); }
+        row_load<DV>(r_a, p0, D); row_load<DV>(r_b, p1, D); row_load<DV>(r_c, p2, D); row_load<DV>(r_def, p3, D);
         const GF_GLOBAL float* pp = gsel((needs & PN_POS) != 0, UNI(a.pos), 3u * e);
         const V3 pos{pp[0], pp[1], pp[2]};
         const float* k_secs = UNI(a.episode_seconds);
@@ -415,13 +414,11 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         const GF_GLOBAL float* p1 = gsel((needs & PN_DOFVEL) != 0, UNI(a.dof_vel), ro);
         const float* k_def = UNI(a.default_dof_pos);
         const GF_GLOBAL float* p2 = gsel(k_def != nullptr, k_def, 0u);
-#pragma unroll
-        for (int c = 0; c < DV; ++c) { r_a[c] = ldg4(p0 + 4 * c); r_b[c] = ldg4(p1 + 4 * c); r_c[c] = ldg4(p2 + 4 * c); }
+        row_load<DV>(r_a, p0, D); row_load<DV>(r_b, p1, D); row_load<DV>(r_c, p2, D);
     } else {
         const GF_GLOBAL float* p0 = gsel((needs & PN_TARGETS) != 0, UNI(a.targets), ro);
         const GF_GLOBAL float* p1 = gsel((needs & PN_ACTIONS) != 0, UNI(a.env_actions), ro);
-#pragma unroll
-        for (int c = 0; c < DV; ++c) { r_a[c] = ldg4(p0 + 4 * c); r_b[c] = ldg4(p1 + 4 * c); }
+        row_load<DV>(r_a, p0, D); row_load<DV>(r_b, p1, D);
     }
     GF_WSTAMP(2);
     // every load above has landed (registers / LDS) before any wave starts storing state behind the barrier
@@ -445,10 +442,11 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         if (shard && done_mask && lane == 0) atomicAdd(&shard->reset_count, popc64(done_mask));
         if (done) {
             if ((reset_env & 1) && a.env_actions) {
-                GF_GLOBAL f32x4* ra = reinterpret_cast<GF_GLOBAL f32x4*>(G(a.env_actions) + n * D);
-                GF_GLOBAL f32x4* rl = reinterpret_cast<GF_GLOBAL f32x4*>(G(a.env_last_actions) + n * D);
+                float4 zr[R];
 #pragma unroll
-                for (int c = 0; c < DV; ++c) { ra[c] = f32x4{0.f, 0.f, 0.f, 0.f}; rl[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int c = 0; c < DV; ++c) zr[c] = z4;
+                row_store<DV>(G(a.env_actions) + n * D, zr, D);
+                row_store<DV>(G(a.env_last_actions) + n * D, zr, D);
             }
             if (reset_env & 2) G(a.episode_length)[n] = 0;
             if (a.max_episode_length && a.max_random_scaling > 0.0f) {
@@ -557,8 +555,6 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                         sc[3 * kEnvBlock] = uniform_range(r4.w, -1.0f, 1.0f) * dof_noise;
                     }
                 }
-                GF_GLOBAL f32x4* dp = reinterpret_cast<GF_GLOBAL f32x4*>(G(a.dof_pos) + n * D);
-                GF_GLOBAL f32x4* dv = reinterpret_cast<GF_GLOBAL f32x4*>(G(k_dvel) + n * D);
 #pragma unroll
                 for (int c = 0; c < DV; ++c) {
                     float4 p = r_c[c];
@@ -570,14 +566,15 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                         p.w = p.w + sc[3 * kEnvBlock];
                     }
                     r_a[c] = p;
-                    dp[c] = f32x4{p.x, p.y, p.z, p.w};
-                    if (k_dvel) { dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; r_b[c] = z4; }
+                    if (k_dvel) r_b[c] = z4;
                 }
+                row_store<DV>(G(a.dof_pos) + n * D, r_a, D);   // (a row's last chunk: only its own floats, row_store)
+                if (k_dvel) row_store<DV>(G(k_dvel) + n * D, r_b, D);
             }
             if (scene_reset && zero_velocity && k_dvel) {
-                GF_GLOBAL f32x4* dv = reinterpret_cast<GF_GLOBAL f32x4*>(G(k_dvel) + n * D);
 #pragma unroll
-                for (int c = 0; c < DV; ++c) { dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; r_b[c] = z4; }
+                for (int c = 0; c < DV; ++c) r_b[c] = z4;
+                row_store<DV>(G(k_dvel) + n * D, r_b, D);
             }
         }
     } else {
@@ -638,10 +635,10 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 const bool row_item = op == GF_O_DOF_POS || op == GF_O_DOF_VEL;
                 if (row_item == rows_wave) {
                     switch (op) {
-                        case GF_O_DOF_POS: put_row<DV>(f, r_a, row, col); break;
-                        case GF_O_DOF_VEL: put_row<DV>(f, r_b, row, col); break;
-                        case GF_O_ACTIONS: put_row<DV>(f, r_a, row, col); break;
-                        case GF_O_RAW_ACTIONS: put_row<DV>(f, r_b, row, col); break;
+                        case GF_O_DOF_POS: put_row<DV>(f, r_a, row, col, D); break;
+                        case GF_O_DOF_VEL: put_row<DV>(f, r_b, row, col, D); break;
+                        case GF_O_ACTIONS: put_row<DV>(f, r_a, row, col, D); break;
+                        case GF_O_RAW_ACTIONS: put_row<DV>(f, r_b, row, col, D); break;
                         case GF_O_COMMAND: {
                             const int owner = a.cmd_of_view[it.i0];
                             if (owner == kViewGait) {   // the gait manager's post-step, post-reset row (observation(): columns 0..13)
