@@ -901,8 +901,8 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     UNSUP((needs & PN_ANG) && !a.ang_vel);
     UNSUP((needs & PN_EPLEN) && !a.episode_length);
     // DOF rows are ceil(D / 4) float4 chunks (a last chunk of fewer than four floats is handled element by element, gf_post_args.h):
-    // 12 and 28 DOF have static programs / both kernel variants, every other count up to 28 a four-wave interpreter variant
-    const bool dofs_ok = D >= 1 && D <= 28;
+    // 12 and 28 DOF have static programs / both kernel variants, every other count up to 32 a four-wave interpreter variant
+    const bool dofs_ok = D >= 1 && D <= 32;
     UNSUP((needs & (PN_DOFPOS | PN_DOFVEL | PN_TARGETS | PN_ACTIONS | PN_LAST)) && !dofs_ok);
     UNSUP((a.reset_dofs || (a.reset_env & 1)) && !dofs_ok);
     UNSUP((needs & PN_DOFPOS) && !a.dof_pos);
@@ -996,7 +996,8 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
             case 5: GF_RUN_INTERP(5); break;
             case 6: GF_RUN_INTERP(6); break;
             case 7: GF_RUN_INTERP(7); break;
-            default: GF_RUN_INTERP(3); break;   // 9 … 12 DOF; configs without DOF rows (pack() let nothing above 28 through)
+            case 8: GF_RUN_INTERP(8); break;
+            default: GF_RUN_INTERP(3); break;   // 9 … 12 DOF; configs without DOF rows (pack() let nothing above 32 through)
         }
 #undef GF_RUN_INTERP
     }

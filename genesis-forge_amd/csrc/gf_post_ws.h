@@ -78,7 +78,7 @@ __host__ __device__ constexpr int ws_sum_rows() {
 }
 template <class P>
 __host__ __device__ constexpr int ws_aux_rows() { return 4 * P::DV; }
-static_assert(kPostAuxRows >= 4 * 7, "aux rows cover 28 DOF");
+static_assert(kPostAuxRows >= 4 * 8, "aux rows cover 32 DOF");
 
 template <class P>
 __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg) {

@@ -658,7 +658,7 @@ int gf_history_unroll(const GfHistoryUnrollArgs* a, void* stream);/* replaces th
  * definition those of calling the phases in sequence — which is what the oracle twin does); the call
  * packs them into one kernarg block.  Returns GF_E_UNSUPPORTED when the combination cannot be fused
  * (host-evaluated columns without GF_POST_TERMINATION_DONE — see below —, host-evaluated observation items, parity-mode draws,
- * more than 28 DOF, phases reading different buffers, more than 2 command / 1 gait /
+ * more than 32 DOF, phases reading different buffers, more than 2 command / 1 gait /
  * 2 observation managers …): the caller then runs the phases one by one (or leaves a manager out of the call and runs it behind).
  * ---------------------------------------------------------------------------------------- */
 #define GF_POST_MAX_CMD 2

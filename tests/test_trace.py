@@ -638,7 +638,7 @@ def _run_dof_variant(dev, seed, trace):
     import random
 
     rnd = random.Random(9000 + seed)
-    dofs = rnd.choice([7, 8, 10, 16, 19, 20, 24, 28])
+    dofs = rnd.choice([7, 8, 10, 16, 19, 20, 23, 24, 28, 29, 32])
     n = rnd.choice([63, 64, 65, 257, 1000])
     env = Go2CommandDirectionEnv(num_envs=n, dofs=dofs, max_episode_length_s=rnd.choice([0.3, 0.5]), cmd_resample_s=rnd.choice([0.1, 0.3]),
                                  history=rnd.choice([None, 2, 3]), obs_noise=rnd.random() < 0.5,
@@ -659,7 +659,7 @@ def _run_dof_variant(dev, seed, trace):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("GF_DOF_SEEDS", "16"))))
 def test_random_dof_variant_hip_equals_oracle(hip_backend, oracle_lib_path, seed):
-    """7 … 28 DOF on the interpreter variants of the fused launch (rows as ceil(D / 4) float4 chunks; D % 4 != 0: the last chunk element by
+    """7 … 32 DOF on the interpreter variants of the fused launch (rows as ceil(D / 4) float4 chunks; D % 4 != 0: the last chunk element by
     element, rows only dword aligned) — recorded on HIP == phase by phase on the oracle, and every variant resets envs."""
     from genesis_forge_amd import _native as nat
     from genesis_forge_amd import gs
