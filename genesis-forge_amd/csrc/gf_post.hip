@@ -987,8 +987,14 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
         GF_POST_PROGRAMS(GF_RUN)
 #undef GF_RUN
     } else {
+#define GF_RUN_INTERP_T(DV_, T_)                                                                                              \
+        do {                                                                                                                  \
+            using Var = gf::Interp<DV_, T_>;                                                                                  \
+            const size_t lds_var = sizeof(gf::GfPostArgs) + lds_ws_floats<Var>(omax, a.n_gait) * sizeof(float);               \
+            GF_LAUNCH(scope, gf::post_ws_kernel<Var>, grid, gf::kWsBlock, lds_var, s, a);                                     \
+        } while (0)
 #define GF_RUN_INTERP(DV_) \
-        GF_LAUNCH(scope, gf::post_ws_kernel<gf::Interp<DV_>>, grid, gf::kWsBlock, sizeof(gf::GfPostArgs) + lds_ws_floats<gf::Interp<DV_>>(omax, a.n_gait) * sizeof(float), s, a)
+        do { if (a.num_dofs == 4 * DV_) GF_RUN_INTERP_T(DV_, false); else GF_RUN_INTERP_T(DV_, true); } while (0)
         switch ((a.num_dofs + 3) / 4) {   // chunks per row
             case 1: GF_RUN_INTERP(1); break;
             case 2: GF_RUN_INTERP(2); break;
@@ -997,8 +1003,11 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
             case 6: GF_RUN_INTERP(6); break;
             case 7: GF_RUN_INTERP(7); break;
             case 8: GF_RUN_INTERP(8); break;
-            default: GF_RUN_INTERP(3); break;   // 9 … 12 DOF; configs without DOF rows (pack() let nothing above 32 through)
+            default:   // 9 … 12 DOF; configs without DOF rows (num_dofs of the action manager all the same; pack() let nothing above 32 through)
+                if (a.num_dofs >= 9 && a.num_dofs < 12) GF_RUN_INTERP_T(3, true); else GF_RUN_INTERP_T(3, false);
+                break;
         }
+#undef GF_RUN_INTERP_T
 #undef GF_RUN_INTERP
     }
     return gf::launch_status();

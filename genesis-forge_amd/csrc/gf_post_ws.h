@@ -42,10 +42,13 @@ struct TermSig { int op, flags; };
 struct RewSig { int op, flags, i0, i1; };
 struct ItemSig { int op, width, i0; bool scaled, noisy; };
 
-template <int DV_>
+template <int DV_, bool TAIL_ = false>
 struct Interp {
     static constexpr bool kStatic = false;
     static constexpr int DV = DV_;
+    // kTail: D % 4 != 0 — rows are only dword aligned and the last chunk is short (row_load / row_store); without it D = 4·DV is a
+    // compile-time constant like in the static programs (a run-time test per row load cost the 12-DOF interpreter 8 % at 1 M envs)
+    static constexpr bool kTail = TAIL_;
 };
 
 template <class F, int... I>
@@ -113,7 +116,10 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     const int64_t n = live ? n_raw : N - 1;
     const uint32_t e = (uint32_t)n;
     const uint32_t genv = e + UNI(a.env_offset);
-    const int D = P::kStatic ? 4 * DV : UNI(a.num_dofs);
+    int D = 4 * DV;
+    if constexpr (!P::kStatic) {
+        if constexpr (P::kTail) D = UNI(a.num_dofs);
+    }
     const uint32_t needs = UNI(a.needs);
     int n_term = 0, n_rew = 0, n_cmd = 0, n_obs = 0;
     if constexpr (P::kStatic) {
