@@ -5,8 +5,8 @@ import torch
 from envs import Go2CommandDirectionEnv
 
 
-def _run(dev, trace, n=70, steps=50, mutate_at=None):
-    env = Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, contacts=True, history=2, obs_noise=True,
+def _run(dev, trace, n=70, steps=50, mutate_at=None, cls=None):
+    env = (cls or Go2CommandDirectionEnv)(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, contacts=True, history=2, obs_noise=True,
                                  scene_kwargs=dict(ang_noise=0.3, seed=3))
     env.trace_enabled = trace
     env.build()
@@ -45,6 +45,26 @@ def test_trace_invalidated_by_mutation_cpu(oracle_backend):
     b, env = _run("cpu", True, mutate_at=20)
     _same(a, b)
     assert env._trace is not None, "trace should have been re-recorded after the mutation"
+
+
+def test_reset_override_with_curriculum_mutation_cpu(oracle_backend):
+    """An env that overrides reset() AND is mutated in mid-run (a curriculum): the recording — main segment and the two native tail
+    segments — is dropped and rebuilt, and every step equals the ordinary path's."""
+    class HookEnv(Go2CommandDirectionEnv):
+        hooks = 0
+
+        def reset(self, env_ids=None):
+            out = super().reset(env_ids)
+            if env_ids is not None:
+                self.hooks += 1
+            return out
+
+    a, e0 = _run("cpu", False, mutate_at=20, cls=HookEnv)
+    b, env = _run("cpu", True, mutate_at=20, cls=HookEnv)
+    _same(a, b)
+    tr = env._trace
+    assert tr is not None and tr.tail_python and sorted(tr.tail_seg) == ["obs", "reset"]
+    assert env.hooks == e0.hooks > 0
 
 
 @pytest.mark.parametrize("trace", [False, True])
