@@ -157,12 +157,9 @@ class StepTrace:
         self.arg_set = {C.addressof(c[1]) for c in calls}
         # (both parts or none: the observation descriptors of a step WITH a reset carry the stale-quaternion stash and the termination
         # masks — with all-false masks they also describe a step without one; the descriptors of a step without a reset do not)
-        if tail_python and tail_calls and tail_calls.get("reset") and tail_calls.get("obs"):
-            for part in ("reset", "obs"):
-                seg = self._build_tail_segment(tail_calls.get(part) or [])
-                if seg is not None:
-                    self.tail_seg[part] = seg
-                    self.arg_set.update(C.addressof(c[1]) for c in tail_calls[part])
+        self._tail_tries = 0
+        if tail_python:
+            self._adopt_tail(tail_calls)
         b = self.backend
         b.__dict__.setdefault("dirty", set()).difference_update(self.arg_set)
         b.__dict__.setdefault("watched", set()).update(self.arg_set)
@@ -225,6 +222,20 @@ class StepTrace:
                     "keep": [c[1] for c in calls]}
         finally:
             self.native, self.patches, self.afters, self._cur_op = saved
+
+    def _adopt_tail(self, tail_calls) -> None:
+        if not tail_calls or not tail_calls.get("reset") or not tail_calls.get("obs"):
+            return
+        segs = {part: self._build_tail_segment(tail_calls[part]) for part in ("reset", "obs")}
+        if any(v is None for v in segs.values()):
+            self._tail_tries = 1 << 30   # a part that cannot be replayed natively (a Python-level observation item): stop trying
+            return
+        self.tail_seg = segs
+        mine = {C.addressof(c[1]) for part in ("reset", "obs") for c in tail_calls[part]}
+        self.arg_set.update(mine)
+        b = self.backend
+        b.__dict__.setdefault("dirty", set()).difference_update(mine)
+        b.__dict__.setdefault("watched", set()).update(mine)
 
     def run_tail_segment(self, part: str) -> bool:
         """Replay one part of the Python tail natively; False when that part was not recorded (the caller walks the managers)."""
@@ -447,6 +458,13 @@ class StepTrace:
             # reset (the user's override, by index list, behind the same nonzero() sync the reference pays) and observations,
             # phase by phase; their launches write their statistics into this step's ring slot
             env.stats.ptr_override, env._in_step, env._tail_trace = cur, True, self
+            rec = None
+            if not self.tail_seg and self._tail_tries < 64:
+                # the ordinary steps this recording came from had no done env, so their tail could not be recorded (the observation
+                # descriptors of a step with a reset are the ones that serve every step): record it from this step's Python walk
+                rec = Recorder()
+                rec.tail_python = True
+                self.backend.tracer = rec
             try:
                 env._reset_done(tm._terminated_buf, tm._truncated_buf)
                 obs_tail = env.get_observations()
@@ -457,6 +475,10 @@ class StepTrace:
                              tm._terminated_buf, tm._truncated_buf)
             finally:
                 env.stats.ptr_override, env._in_step, env._tail_trace = None, False, None
+                if rec is not None:
+                    self.backend.tracer = None
+                    self._tail_tries += 1
+                    self._adopt_tail(rec.tail)
         env._finish_step_light(snap)
         extras = env._extras
         obs = extras["observations"].get("policy") if len(env.managers["observation"]) > 0 else obs_tail

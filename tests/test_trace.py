@@ -67,6 +67,38 @@ def test_reset_override_with_curriculum_mutation_cpu(oracle_backend):
     assert env.hooks == e0.hooks > 0
 
 
+def test_reset_override_tail_is_adopted_when_the_first_reset_comes_late_cpu(oracle_backend):
+    """No env is done while the step is being recorded (1 s episodes, no early terminations): the recording starts without native tail
+    segments and adopts them from the Python walk of the first replayed step that resets an env."""
+    class HookEnv(Go2CommandDirectionEnv):
+        def reset(self, env_ids=None):
+            return super().reset(env_ids)
+
+    def run(trace):
+        env = HookEnv(num_envs=70, max_episode_length_s=1, cmd_resample_s=0.3, history=2, scene_kwargs=dict(ang_noise=0.0, seed=3))
+        env.trace_enabled = trace
+        env.build()
+        env.seed(5)
+        env.reset()
+        g = torch.Generator().manual_seed(0)
+        outs, seen = [], []
+        for t in range(75):
+            o, r, te, tr, ex = env.step(torch.randn(70, 12, generator=g))
+            outs.append((o.clone(), r.clone(), te.clone(), tr.clone(), {k: float(v) for k, v in ex["episode"].items()}))
+            seen.append((int((te | tr).sum()), bool(env._trace is not None and env._trace.tail_seg)))
+        return outs, seen
+
+    a, _ = run(False)
+    b, seen = run(True)
+    first = next(t for t, (done, _) in enumerate(seen) if done)
+    assert first > 5, "the config should not reset an env while the step is being recorded"
+    assert not any(seg for _, seg in seen[:first]) and all(seg for _, seg in seen[first:]), "tail segments from the first step with a reset on"
+    for t, (x, y) in enumerate(zip(a, b)):
+        for k in range(4):
+            assert torch.equal(x[k], y[k]), f"output {k} differs at step {t}"
+        assert x[4] == y[4], f"log differs at step {t}"
+
+
 @pytest.mark.parametrize("trace", [False, True])
 def test_params_dict_bulk_mutations_take_effect(oracle_backend, trace):
     """the reference re-reads **params every step, so params.update(...) / pop / setdefault / |= / clear take effect
