@@ -27,7 +27,7 @@ reward … observation with the termination masks as inputs (``GF_POST_TERMINATI
 An env that overrides ``reset()`` is recorded up to the reset (``tail_python``): the user's ``reset()`` runs — by index list,
 behind the ``nonzero()`` sync the reference pays too — and what ``super().reset(ids)`` and ``get_observations()`` launch is
 replayed natively, one segment each, where the user's code reaches it (``tail_seg``; recorded from an ordinary step that had a
-done env, walked phase by phase until then), with the launches pointed at the step's statistics slot.  A ``step()`` override
+done env, or adopted from the first replayed step that resets one — walked phase by phase until then), with the launches pointed at the step's statistics slot.  A ``step()`` override
 around ``super().step()`` is code of the training loop: the step inside is recorded as without it.  A recording also watches its descriptors: a phase call outside the replay that goes
 through one of them (``reset([…])`` or ``resample_command([…])`` called by the training script between steps) drops it.
 """
