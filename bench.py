@@ -224,7 +224,7 @@ def parse_args(argv):
     ap.add_argument("--no-sweep", action="store_true", help="skip the 4096 / 16384-env side measurements")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the 1 048 576-env roofline_hbm measurement")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stamping pass (roofline)")
-    ap.add_argument("--profile-samples", type=int, default=64, help="stamped launches of the dominant kernel in the stamping pass")
+    ap.add_argument("--profile-samples", type=int, default=200, help="stamped launches of the dominant kernel in the stamping pass")
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="the stamping pass stamps every k-th launch: a stamped launch blocks the host for ~12 us and drains the queue, "
                          "so the launches between two stamps let the pipeline refill")
