@@ -67,8 +67,8 @@ def make_env(num_envs: int, config: str = "go2_cmd", dofs: int = 12):
     from genesis_forge_amd import tasks
     from genesis_forge_amd.managers import ObservationManager
 
-    # observations are returned in persistent output slots (hipGraph-style static outputs, ObservationManager(output="static"));
-    # the package default ("fresh": the reference's contract, a private copy per call) costs one extra copy launch per step
+    # the mode the step's observations are returned in: the package default "fresh" — the reference's contract, a new tensor per
+    # call that the step's launch writes directly — unless GF_OBS_OUTPUT asks for "static" (persistent slots) or "ring"
     ObservationManager.default_output = OBS_OUTPUT
 
     if config == "go2_cmd":
@@ -242,11 +242,16 @@ def main():
         return cpu_single()
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # Start one rank per GPU ourselves.  Nothing in this process has touched the GPU (torch is not even imported): the
-        # ranks are fresh interpreters, this one only relays rank 0's line and exits with their status.
-        from genesis_forge_amd.launch import spawn_ranks
+        # Start one rank per GPU ourselves.  Nothing in this process touches the GPU: launch.py is loaded from its FILE (importing
+        # the package would run gs._default_device(), i.e. torch.cuda.is_available(), which opens the runtime) and needs only the
+        # standard library; the ranks are fresh interpreters, this one only relays rank 0's line and exits with their status.
+        import importlib.util
 
-        sys.exit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + argv, args.gpus))
+        spec = importlib.util.spec_from_file_location(
+            "_gf_launch", os.path.join(ROOT, "genesis-forge_amd", "genesis_forge_amd", "launch.py"))
+        launch = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(launch)
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + argv, args.gpus))
     run_rank(args)
 
 

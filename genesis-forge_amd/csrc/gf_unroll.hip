@@ -62,6 +62,7 @@ __device__ __forceinline__ void unroll_chunk(const GfHistoryUnrollArgs& a, const
     GF_GLOBAL float* out2 = a.out2 ? G(a.out2) + n0 * map.OH : nullptr;
     const int tid = (int)threadIdx.x;
     const bool wide = map.O >= 4;   // uniform
+    const GF_GLOBAL float* vbase = wide ? ring : (const GF_GLOBAL float*)g_zero_pad;
     f32x4u v[kUnrollUnits], w[kUnrollUnits];
     int at[kUnrollUnits], lead[kUnrollUnits];   // lead: floats of the unit that belong to the frame its first float is in (>= 4: all)
     uint32_t on_mask = 0u;
@@ -76,7 +77,10 @@ __device__ __forceinline__ void unroll_chunk(const GfHistoryUnrollArgs& a, const
         at[k] = ec;
         lead[k] = on ? la : 4;
         on_mask |= on ? 1u << k : 0u;
-        v[k] = *reinterpret_cast<const GF_GLOBAL f32x4u*>(ring + (!on || !wide ? 0 : (la >= 4 ? so : so + la - 4)));   // unconditional, back to back
+        // unconditional, back to back.  A lane past the array reads `ring + 0` — 16 bytes that exist when a frame is at least a unit
+        // wide; with narrower frames (`!wide`: the element path below does the loading) `ring + 0` may end less than 16 bytes before
+        // the end of the tensor (O*H < 4, last row), so the wave-uniform base is the code object's zero pad then
+        v[k] = *reinterpret_cast<const GF_GLOBAL f32x4u*>(vbase + (!on || !wide ? 0 : (la >= 4 ? so : so + la - 4)));
         w[k] = f32x4u{0.f, 0.f, 0.f, 0.f};   // (not v[k]: a copy would wait for the load)
     }
     if (wide) {

@@ -223,8 +223,25 @@ class StepTrace:
         finally:
             self.native, self.patches, self.afters, self._cur_op = saved
 
+    def _tail_native_ok(self) -> bool:
+        """The native tail replays only what went through ``backend.call``: every manager's reset must be a section of the masked
+        reset (or a no-op) — a manager that needs ``reset(ids)`` (a Python ``on_reset`` entry, a user manager class, a user
+        ``resample_command``) is walked phase by phase — and the observation descriptors must be ones a recording may freeze."""
+        env = self.env
+        _, indexed = env._reset_partition()
+        if indexed:
+            return False
+        if any(not om._traceable() for om in env.managers["observation"]):
+            return False
+        if any(not em.enabled for em in env.managers["entity"]):
+            return False
+        return True
+
     def _adopt_tail(self, tail_calls) -> None:
         if not tail_calls or not tail_calls.get("reset") or not tail_calls.get("obs"):
+            return
+        if not self._tail_native_ok():
+            self._tail_tries = 1 << 30   # the tail stays a Python walk for the life of this recording
             return
         segs = {part: self._build_tail_segment(tail_calls[part]) for part in ("reset", "obs")}
         if any(v is None for v in segs.values()):
@@ -241,6 +258,10 @@ class StepTrace:
         """Replay one part of the Python tail natively; False when that part was not recorded (the caller walks the managers)."""
         seg = self.tail_seg.get(part)
         if seg is None:
+            return False
+        if self.epoch != self.env._trace_epoch or not self.fresh():
+            # something the frozen descriptors depend on was mutated since this step began (the user's reset() override ran a
+            # curriculum): the rest of the tail walks the managers, which read the live values like the ordinary step does
             return False
         for p in seg["patches"]:
             p(None)
@@ -477,8 +498,9 @@ class StepTrace:
                 env.stats.ptr_override, env._in_step, env._tail_trace = None, False, None
                 if rec is not None:
                     self.backend.tracer = None
-                    self._tail_tries += 1
-                    self._adopt_tail(rec.tail)
+                    if rec.tail.get("reset"):      # only a step that reset an env can yield both parts: the others do not count
+                        self._tail_tries += 1
+                        self._adopt_tail(rec.tail)
         env._finish_step_light(snap)
         extras = env._extras
         obs = extras["observations"].get("policy") if len(env.managers["observation"]) > 0 else obs_tail
@@ -521,7 +543,7 @@ def traceable(env, tail_python: bool = False) -> bool:
         if not c.enabled:
             return False
     if tail_python:
-        return True  # reset and observations run phase by phase: nothing about them is frozen
+        return True  # reset and observations run phase by phase unless StepTrace._tail_native_ok() lets their launches be replayed
     for om in env.managers["observation"]:
         if not om._traceable():
             return False

@@ -271,7 +271,8 @@ class ManagedEnvironment(GenesisEnv):
             return
         self._reset_with_mask(terminated, truncated, ids=None)
 
-    def _reset_with_mask(self, mask: torch.Tensor, mask2: Optional[torch.Tensor], ids) -> None:
+    def _reset_partition(self):
+        """(managers whose reset is a section of gf_masked_reset, managers that need ``reset(ids)`` with an index list)."""
         fused, indexed = [], []
         for m in self._all_managers():
             if not _most_derived_reset_is_ours(m):
@@ -282,6 +283,10 @@ class ManagedEnvironment(GenesisEnv):
                 pass  # no-op reset (termination / observation managers)
             else:
                 indexed.append(m)
+        return fused, indexed
+
+    def _reset_with_mask(self, mask: torch.Tensor, mask2: Optional[torch.Tensor], ids) -> None:
+        fused, indexed = self._reset_partition()
         a = self._reset_args  # persistent descriptor: a recorded step replays it in place
         C.memset(C.byref(a), 0, C.sizeof(a))
         a.mask = mask.data_ptr()

@@ -99,6 +99,58 @@ def test_reset_override_tail_is_adopted_when_the_first_reset_comes_late_cpu(orac
         assert x[4] == y[4], f"log differs at step {t}"
 
 
+def test_reset_override_with_python_on_reset_entry_keeps_the_python_tail(oracle_backend):
+    """an env that overrides reset() AND whose EntityManager has a second, Python-level on_reset entry.  That
+    manager needs ``reset(ids)`` — it never goes through the masked-reset launch — so the tail must not be replayed natively:
+    the user's function runs on every reset step and the trajectory equals the ordinary path's."""
+    class HookEnv(Go2CommandDirectionEnv):
+        calls_now = 0
+
+        def config(self):
+            super().config()
+            from genesis_forge_amd.managers.config import ConfigItem
+
+            def custom(env, entity, envs_idx):
+                type(self).calls_now += 1
+
+            self.robot_manager.on_reset["custom"] = ConfigItem({"fn": custom}, self, on_dirty=self.invalidate_trace)
+
+        def reset(self, env_ids=None):
+            return super().reset(env_ids)
+
+    def run(trace):
+        HookEnv.calls_now = 0
+        out, env = _run("cpu", trace, cls=HookEnv)
+        return out, env, HookEnv.calls_now
+
+    a, _, calls_a = run(False)
+    b, env, calls_b = run(True)
+    _same(a, b)
+    assert calls_a == calls_b > 10, f"the Python on_reset entry ran {calls_b} times in the recorded run, {calls_a} in the ordinary one"
+    assert env._trace is not None and env._trace.tail_python and not env._trace.tail_seg, "no native tail for a manager that needs reset(ids)"
+
+
+def test_mutation_inside_reset_override_reaches_the_same_steps_observation(oracle_backend):
+    """the reference gait example's pattern — reset() → update_curriculum() — mutating something the OBSERVATION
+    depends on inside the override.  The ordinary path reads the live value in the same step; the replayed step must too (its frozen
+    'obs' tail segment is stale from the moment of the mutation)."""
+    class HookEnv(Go2CommandDirectionEnv):
+        resets = 0
+
+        def reset(self, env_ids=None):
+            out = super().reset(env_ids)
+            if env_ids is not None:
+                self.resets += 1
+                if self.resets in (12, 20):
+                    self.observation_manager.noise = 0.05 if self.resets == 12 else 0.0
+            return out
+
+    a, e0 = _run("cpu", False, cls=HookEnv)
+    b, env = _run("cpu", True, cls=HookEnv)
+    assert e0.resets == env.resets >= 20
+    _same(a, b)
+
+
 @pytest.mark.parametrize("trace", [False, True])
 def test_params_dict_bulk_mutations_take_effect(oracle_backend, trace):
     """the reference re-reads **params every step, so params.update(...) / pop / setdefault / |= / clear take effect
