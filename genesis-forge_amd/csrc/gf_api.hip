@@ -209,6 +209,12 @@ static int replay_patch(const GfReplay* r, const void* actions, const void* cons
                 if (p->index < 0 || p->index >= num_params || !params) return GF_E_RANGE;
                 *(const void**)p->target = params[p->index];
                 break;
+            case GF_PATCH_PARAM_OFFSET:
+                if (!p->target) return GF_E_NULL;
+                if (p->index < 0 || p->index >= num_params || !params) return GF_E_RANGE;
+                if (!params[p->index]) return GF_E_NULL;
+                *(const char**)p->target = (const char*)params[p->index] + (intptr_t)p->aux;
+                break;
             case GF_PATCH_COPY:
                 if (!p->target || !p->aux) return GF_E_NULL;
                 *(uint64_t*)p->target = *(const uint64_t*)p->aux;

@@ -232,7 +232,8 @@ class GfGaitArgs(C.Structure):
                 ("state", P), ("selected", P), ("wave_flags", P), ("stats", P)]
 
 
-(GF_PATCH_ACTIONS, GF_PATCH_STREAM, GF_PATCH_COUNTER, GF_PATCH_ROTATE, GF_PATCH_PARAM, GF_PATCH_COPY, GF_PATCH_RING_SLOT) = range(1, 8)
+(GF_PATCH_ACTIONS, GF_PATCH_STREAM, GF_PATCH_COUNTER, GF_PATCH_ROTATE, GF_PATCH_PARAM, GF_PATCH_COPY, GF_PATCH_RING_SLOT,
+ GF_PATCH_PARAM_OFFSET) = range(1, 9)
 
 
 class GfRotor(C.Structure):

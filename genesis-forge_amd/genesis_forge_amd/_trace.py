@@ -43,8 +43,11 @@ from ._stats import LazyEpisodeLog, StatsSnapshot
 class Recorder:
     """Backend hook: collects (fn, descriptor, owner) while an ordinary step runs."""
 
-    def __init__(self):
+    def __init__(self, images: bool = False):
         self.calls: list = []
+        #: Genesis-shaped scene: byte image of every descriptor at the moment it was launched, by address — two consecutive steps'
+        #: images tell which pointer fields change from tick to tick (StepTrace._init_scene)
+        self.images: Optional[dict] = {} if images else None
         self.tail_python = False
         #: launches of the Python tail, by part ("reset": inside the user's reset() → ManagedEnvironment.reset of the done envs;
         #: "obs": get_observations()) — a recorded step replays each part with one native call when it was seen (StepTrace.tail_seg)
@@ -52,6 +55,8 @@ class Recorder:
         self.part = None
 
     def record(self, fn, args, owner):
+        if self.images is not None:
+            self.images[C.addressof(args)] = C.string_at(C.addressof(args), C.sizeof(args))
         if not self.tail_python:
             self.calls.append((fn, args, owner))
         elif self.part is not None:
@@ -66,9 +71,18 @@ class Recorder:
         return [(fn, C.addressof(args), id(owner)) for fn, args, owner in self.calls] + ([("tail",)] if self.tail_python else [])
 
 
+class Untraceable(Exception):
+    """The step cannot be recorded (the reason is kept on the env: ``env._untraceable``)."""
+
+
 class StepTrace:
-    def __init__(self, env, calls: list, tail_python: bool = False, tail_calls: Optional[dict] = None):
+    def __init__(self, env, calls: list, tail_python: bool = False, tail_calls: Optional[dict] = None, images: Optional[tuple] = None):
         self.env = env
+        #: a scene with Genesis' public surface only (fresh getter tensors, envs_idx setters): the scene step and the state fetch
+        #: run in Python in the middle of the replay, the snapshot's addresses reach the descriptors as call parameters
+        self.adapter = env._adapter
+        self.scene_plan: list = []
+        self._images = images
         self.tail_python = tail_python
         self.tail_seg: dict = {}   # "reset" / "obs" → native segment of the Python tail (see _build_tail_segment)
         self.backend = env.backend
@@ -112,6 +126,8 @@ class StepTrace:
                 k += 1
             self._cur_op = k - 2  # index of this call's op once the leading STATS_CLEAR op is dropped (below)
             self._hooks(fn, args, owner)
+            if fn == "action_step" and self.adapter is not None:
+                self.splits.append((self._cur_op + 1, self._scene_pre))   # control_dofs_position → scene.step() → state fetch
             pre = owner._trace_pre(args) if hasattr(owner, "_trace_pre") else None
             if pre is not None:
                 assert idx < first_post + (2 if self.post_split else 0) or idx in self._late, "a phase with Python-level terms cannot be part of the fused launch"
@@ -137,8 +153,10 @@ class StepTrace:
                 self.ops[k].phase, self.ops[k].args = nat.GF_OP_STATS_PACK, C.addressof(self.pack_args)
                 k += 1
         self.n_ops = k
-        # the statistics ring slots of a step arrive as call parameters (cur, next-to-zero, previous, its vector row, last_reset)
+        # the statistics ring slots of a step arrive as call parameters (cur, next-to-zero, previous, its vector row, last_reset);
+        # behind them, on a Genesis-shaped scene, the addresses of this tick's state tensors (_init_scene)
         self.params = (C.c_void_p * 5)()
+        self.n_params = 5
         if self.use_ring or self.fold_mode:
             P = nat.GfReplayPatch
             for a in self.stat_fields:
@@ -155,6 +173,8 @@ class StepTrace:
         #: the descriptors this recording froze: a phase call that goes through one of them from now on (a manager method the
         #: training script calls between steps) makes the recording stale (Backend._note_call, fresh())
         self.arg_set = {C.addressof(c[1]) for c in calls}
+        if self.adapter is not None:
+            self._init_scene([c[1] for c in calls])
         # (both parts or none: the observation descriptors of a step WITH a reset carry the stale-quaternion stash and the termination
         # masks — with all-false masks they also describe a step without one; the descriptors of a step without a reset do not)
         self._tail_tries = 0
@@ -193,6 +213,58 @@ class StepTrace:
             except Exception:
                 pass
 
+    # -- a scene with Genesis' public surface only --------------------------------------------------------------------------
+    def _scene_patches(self, descs: list) -> list:
+        """GF_PATCH_PARAM_OFFSET entries for every pointer field of ``descs`` that addresses a tensor of this tick's snapshot.
+        The fetch plan only ever grows (a tail adopted later may read state the main part does not): parameter indices stay."""
+        ad = self.adapter
+        plan = ad.plan()
+        if [k for k, _ in plan[:len(self.scene_plan)]] != [k for k, _ in self.scene_plan]:
+            raise Untraceable("the scene snapshot of this tick does not extend the recorded fetch plan")
+        if len(plan) > len(self.scene_plan):
+            self.scene_plan = plan
+            params = (C.c_void_p * (5 + len(plan)))()
+            for i in range(self.n_params):
+                params[i] = self.params[i]
+            for i, (key, _f) in enumerate(plan):
+                params[5 + i] = ad.peek(key).data_ptr()
+            self.params, self.n_params = params, 5 + len(plan)
+        skip = set()
+        for p in self.native:
+            skip.update(t for t in (p.target, p.target2) if t)
+        patches, covered = ad.attribute(descs, self.scene_plan, skip)
+        self._scene_covered = getattr(self, "_scene_covered", set()) | covered | skip
+        P = nat.GfReplayPatch
+        return [P(nat.GF_PATCH_PARAM_OFFSET, 5 + i, addr, None, off if off else None) for addr, i, off in patches]
+
+    def _init_scene(self, descs: list) -> None:
+        from ._scene_adapter import PER_STEP_FIELDS, changed_pointer_fields
+        tab = self._scene_patches(descs)
+        if not tab:
+            raise Untraceable("no descriptor reads the scene snapshot")
+        # every pointer field that differed between the two recorded steps must be explained: a snapshot tensor (patched above),
+        # a field another patch writes, or one of the per-step fields the step's own bookkeeping sets
+        if self._images is not None and self._images[0] is not None:
+            before, now = self._images
+            for addr, name in changed_pointer_fields(descs, [before.get(C.addressof(d)) for d in descs], [now.get(C.addressof(d)) for d in descs]):
+                leaf = name.rsplit(".", 1)[-1]
+                if addr in self._scene_covered or leaf in PER_STEP_FIELDS or leaf.startswith("ext["):
+                    continue
+                raise Untraceable(f"{name} changes from step to step and is neither scene state nor a per-step field")
+        self.scene_table = (nat.GfReplayPatch * len(tab))(*tab)
+        self.scene_desc = nat.GfReplay(None, 0, len(tab), C.addressof(self.scene_table), C.addressof(self.env._rng_c))
+
+    def _scene_pre(self) -> None:
+        """What the ordinary step does between the action phase and the first post-physics phase (managed_env.py:290-292,
+        position_action_manager.py:417), then the snapshot: each getter of the plan once, the new addresses into the descriptors."""
+        env, am = self.env, self.action_owner
+        env.robot.control_dofs_position(am._actions, am.dofs_idx)
+        env.scene.step()
+        pr = self.params
+        for i, t in enumerate(self.adapter.refetch(self.scene_plan)):
+            pr[5 + i] = t.data_ptr()
+        self.backend.replay_step(self.scene_desc, None, pr, self.n_params)
+
     # -- the Python tail of an env that overrides reset(), part by part ----------------------------------------------------
     def _build_tail_segment(self, calls):
         """The launches one part of the Python tail made in the ordinary step (the in-step reset of the done envs by the
@@ -216,6 +288,8 @@ class StepTrace:
                 self._hooks(fn, args, owner)
                 if hasattr(args, "stats") and args.stats:
                     self.native.append(P(nat.GF_PATCH_PARAM, 0, nat.field_addr(args, "stats"), None, None))
+            if self.adapter is not None:
+                self.native.extend(self._scene_patches([c[1] for c in calls]))
             table = (nat.GfReplayPatch * max(1, len(self.native)))(*self.native)
             desc = nat.GfReplay(C.addressof(ops), len(calls), len(self.native), C.addressof(table), C.addressof(self.env._rng_c))
             return {"ops": ops, "table": table, "desc": desc, "patches": self.patches, "afters": [f for _, f in self.afters],
@@ -243,7 +317,10 @@ class StepTrace:
         if not self._tail_native_ok():
             self._tail_tries = 1 << 30   # the tail stays a Python walk for the life of this recording
             return
-        segs = {part: self._build_tail_segment(tail_calls[part]) for part in ("reset", "obs")}
+        try:
+            segs = {part: self._build_tail_segment(tail_calls[part]) for part in ("reset", "obs")}
+        except Untraceable:
+            segs = {"reset": None}
         if any(v is None for v in segs.values()):
             self._tail_tries = 1 << 30   # a part that cannot be replayed natively (a Python-level observation item): stop trying
             return
@@ -265,7 +342,7 @@ class StepTrace:
             return False
         for p in seg["patches"]:
             p(None)
-        self.backend.replay_step(seg["desc"], None, self.params, 5)
+        self.backend.replay_step(seg["desc"], None, self.params, self.n_params)
         for f in seg["afters"]:
             f()
         return True
@@ -446,7 +523,7 @@ class StepTrace:
         done = 0        # afters already run
         ticked = False  # the scene op has been enqueued and the views cache invalidated for it
         if self.segments:
-            self.backend.replay_step(self.patch_desc, aptr, pr, 5)
+            self.backend.replay_step(self.patch_desc, aptr, pr, self.n_params)
             for first, count, sub, pre in self.segments:
                 if pre is not None:
                     # the ordinary path has finished every earlier phase — launch AND Python bookkeeping — when it calls a
@@ -461,10 +538,10 @@ class StepTrace:
                 if count:
                     self.backend.run_ops(sub, count)
         elif self.graph is not None and self.backend.graph_enabled:
-            self.backend.replay_step(self.patch_desc, aptr, pr, 5)
+            self.backend.replay_step(self.patch_desc, aptr, pr, self.n_params)
             self.backend.run_ops_graph(self.graph, self.ops, self.n_ops)
         else:
-            self.backend.replay_step(self.replay_desc, aptr, pr, 5)   # patch table + ops: the one native call of the step
+            self.backend.replay_step(self.replay_desc, aptr, pr, self.n_params)   # patch table + ops: the one native call of the step
         if self.fold_mode:
             env.stats.group_ring_after(slot)   # every K-th step: the single collective of the path, asynchronous, K rows
         elif not self.use_ring:
@@ -521,7 +598,7 @@ def traceable(env, tail_python: bool = False) -> bool:
         return False  # the per-step pack / all-reduce of a process group closes the statistics before the Python tail adds to them
     if type(env).get_observations is not ManagedEnvironment.get_observations:
         return False
-    if not getattr(env.scene, "gf_static_buffers", False):
+    if not getattr(env.scene, "gf_static_buffers", False) and env._adapter is None:
         return False
     if env._draws:
         return False

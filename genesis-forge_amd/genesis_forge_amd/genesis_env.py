@@ -104,6 +104,9 @@ class GenesisEnv:
         self._trace_epoch = 0
         self._recorder = None
         self._last_signature = None
+        #: snapshot + write-back for a scene with Genesis' public surface only (fresh getter tensors, envs_idx setters); None for
+        #: a scene whose state tensors are persistent and shared (``gf_static_buffers``); set by build()
+        self._adapter = None
 
     """
     Properties (genesis_env.py:95-148)
@@ -218,6 +221,15 @@ class GenesisEnv:
         every term: utils.py:23-24,37-38,51-55)."""
         key = id(entity)
         hit = self._views_cache.get(key)
+        ad = self._adapter
+        if ad is not None and not hasattr(entity, "gf_views"):
+            # Genesis-shaped scene: each getter is called once per tick (the snapshot); the masked reset of the tick writes the
+            # post-reset rows into these very tensors, so they stay valid until the scene steps again
+            if hit is not None and hit[0] == ("snap", ad.epoch):
+                return hit[1]
+            v = EntityViews(ad.base(entity, "pos"), ad.base(entity, "quat"), ad.base(entity, "vel"), ad.base(entity, "ang"))
+            self._views_cache[key] = (("snap", ad.epoch), v)
+            return v
         if hit is not None and hit[0] == self._tick:
             return hit[1]
         if hasattr(entity, "gf_views"):
@@ -230,6 +242,12 @@ class GenesisEnv:
     def invalidate_views(self) -> None:
         self._tick += 1
 
+    def scene_stepped(self) -> None:
+        """``scene.step()`` has run (or the scene was changed from outside): state read before it is stale."""
+        self._tick += 1
+        if self._adapter is not None:
+            self._adapter.invalidate()
+
     """
     Operations
     """
@@ -238,6 +256,9 @@ class GenesisEnv:
         """genesis_env.py:171-179"""
         assert self.scene is not None, "The scene must be constructed and assigned to the <env>.scene attribute before building."
         self.scene.build(n_envs=self.num_envs)
+        if not getattr(self.scene, "gf_static_buffers", False):
+            from ._scene_adapter import SceneAdapter
+            self._adapter = SceneAdapter(self)
 
     def _begin_step(self) -> None:
         self._extras = {}

@@ -75,6 +75,9 @@ class ManagedEnvironment(GenesisEnv):
         self._terminated_buf = torch.zeros((self.num_envs,), device=gs.device, dtype=gs.tc_bool)
         self._truncated_buf = torch.zeros((self.num_envs,), device=gs.device, dtype=gs.tc_bool)
         self._reset_args = nat.GfResetArgs()
+        self._last_images = None  # descriptor images of the previous recorded ordinary step (Genesis-shaped scene)
+        self._untraceable: Optional[str] = None   # why the last attempt to record the step was refused
+        self._no_trace_epoch = -1
         self._done_ids = None     # the index list of this step's done envs while a user reset() override holds it (reset() recognises it)
         self._tail_trace = None   # the recorded step whose Python tail is running (its reset / observation segments replay natively)
         #: record the step and replay it through gf_run_ops when possible (see _trace.py); GF_NO_TRACE=1 disables
@@ -171,7 +174,9 @@ class ManagedEnvironment(GenesisEnv):
                 self._trace = None
         if not self.trace_enabled or self._draws:
             return self._step_ordinary(actions)
-        rec = _trace.Recorder()
+        if self._no_trace_epoch == self._trace_epoch:
+            return self._step_ordinary(actions)   # recording was tried in this configuration and refused (self._untraceable)
+        rec = _trace.Recorder(images=self._adapter is not None)
         backend = self.backend
         backend.tracer = rec
         epoch = self._trace_epoch
@@ -182,8 +187,12 @@ class ManagedEnvironment(GenesisEnv):
         if epoch == self._trace_epoch:  # nothing was invalidated while the step ran
             sig = rec.signature()
             if sig == self._last_signature and _trace.traceable(self, rec.tail_python):
-                self._trace = _trace.StepTrace(self, rec.calls, rec.tail_python, rec.tail)
+                try:
+                    self._trace = _trace.StepTrace(self, rec.calls, rec.tail_python, rec.tail, images=(self._last_images, rec.images))
+                except _trace.Untraceable as why:
+                    self._untraceable, self._no_trace_epoch = str(why), self._trace_epoch
             self._last_signature = sig
+            self._last_images = rec.images
         return out
 
     def _begin_step_light(self) -> None:
@@ -202,6 +211,12 @@ class ManagedEnvironment(GenesisEnv):
         for em in self.managers["entity"]:
             em._after_fused_reset(tm._terminated_buf, tm._truncated_buf)
         self.invalidate_views()
+        ad = self._adapter
+        if ad is not None:   # Genesis-shaped scene: the simulator learns the reset rows through its envs_idx setters
+            if self._done_ids is not None:
+                ad.push(self._done_ids)   # (a reset() override already paid for the index list)
+            else:
+                ad.push_done(tm._terminated_buf, tm._truncated_buf)
 
     def _step_ordinary(self, actions: torch.Tensor):
         self._begin_step()
@@ -216,7 +231,7 @@ class ManagedEnvironment(GenesisEnv):
             if am is not None:
                 am.step(actions)
         self.scene.step()
-        self.invalidate_views()
+        self.scene_stepped()
 
         for m in self.managers["entity"]:
             m.step()
@@ -289,6 +304,9 @@ class ManagedEnvironment(GenesisEnv):
         fused, indexed = self._reset_partition()
         a = self._reset_args  # persistent descriptor: a recorded step replays it in place
         C.memset(C.byref(a), 0, C.sizeof(a))
+        ad = self._adapter
+        if ad is not None:
+            ad.begin_reset()   # the fused sections below register how their rows reach the simulator (SceneAdapter.on_push)
         a.mask = mask.data_ptr()
         a.mask2 = None if mask2 is None else mask2.data_ptr()
         self._fill_env_reset(a)
@@ -299,11 +317,14 @@ class ManagedEnvironment(GenesisEnv):
         self.backend.call("masked_reset", a, owner=self)
         for m in fused:
             m._after_fused_reset(mask, mask2)
-        if indexed:
+        pushes = ad is not None and bool(ad._pushes)
+        if indexed or pushes:
             if ids is None:
                 both = mask if mask2 is None else (mask | mask2)
-                ids = both.nonzero(as_tuple=False).reshape((-1,))  # host sync: only with managers that need index lists
+                ids = both.nonzero(as_tuple=False).reshape((-1,))  # host sync: managers that need index lists, Genesis' setters
             if ids is not None and (not isinstance(ids, torch.Tensor) or ids.numel() > 0):
+                if pushes:
+                    ad.push(torch.as_tensor(ids, device=gs.device, dtype=torch.long))
                 for m in indexed:
                     m.reset(ids)
         self.invalidate_views()
@@ -331,6 +352,8 @@ class ManagedEnvironment(GenesisEnv):
             # ITS masks — the ones a recorded step replays in place: drop the recording (two ordinary steps, then recorded again)
             self.invalidate_trace()
             self.stats.clear(self.backend)
+            if self._adapter is not None:
+                self._adapter.invalidate()   # between steps the simulator may have been edited: read it afresh
         mask = self._ids_to_mask(env_ids)
         ids = env_ids if env_ids is not None else torch.arange(self.num_envs, device=gs.device)
         self._reset_with_mask(mask, None, ids=ids)

@@ -161,6 +161,9 @@ class PositionActionManager(BaseActionManager):
         robot = self.env.robot
         if hasattr(robot, "gf_dofs"):
             return robot.gf_dofs(what, self.dofs_idx)
+        ad = self.env._adapter
+        if ad is not None:
+            return ad.dofs(robot, what, self.dofs_idx)   # Genesis-shaped scene: one getter call per tick, shared by every phase
         t = getattr(robot, "get_dofs_" + what)(self.dofs_idx)
         return t.to(torch.float32).contiguous()
 
@@ -347,7 +350,7 @@ class PositionActionManager(BaseActionManager):
         self.env.robot.set_dofs_position(position=position, dofs_idx_local=self.dofs_idx, envs_idx=envs_idx)
 
     def _can_fuse_reset(self) -> bool:
-        return hasattr(self.env.robot, "gf_masked_dofs")
+        return hasattr(self.env.robot, "gf_masked_dofs") or self.env._adapter is not None
 
     def _fill_reset(self, a: nat.GfResetArgs) -> None:
         """Scene-side section of the fused reset: dof_pos <- default (+noise), dof_vel <- 0.  PD gains are
@@ -356,7 +359,19 @@ class PositionActionManager(BaseActionManager):
         if not getattr(self, "_gains_uploaded", False) or self._noise_scale != 0.0:
             self._upload_gains(None)
             self._gains_uploaded = True
-        pos, vel = robot.gf_masked_dofs(self.dofs_idx)
+        if hasattr(robot, "gf_masked_dofs"):
+            pos, vel = robot.gf_masked_dofs(self.dofs_idx)
+        else:
+            # Genesis-shaped scene: the reset rows are written into this tick's snapshot (what the getters return once the setter
+            # below has run) and pushed into the simulator by index list (position_action_manager.py:455-464)
+            ad = self.env._adapter
+            idx = list(self.dofs_idx)
+            pos, vel = ad.dofs(robot, "position", idx), ad.dofs(robot, "velocity", idx)
+
+            def push(ids, robot=robot, ad=ad, idx=idx):
+                robot.set_dofs_position(position=ad.dofs(robot, "position", idx)[ids], dofs_idx_local=idx, envs_idx=ids)
+
+            ad.on_push("dofs", push)
         a.num_dofs = self.num_actions
         a.scene_dof_pos, a.scene_dof_vel = pos.data_ptr(), vel.data_ptr()
         a.default_dof_pos = self._k_default.data_ptr()

@@ -79,6 +79,7 @@ class ContactManager(BaseManager):
         if self._with_entity_attr or self._with_links_names:
             with_attr = self._with_entity_attr if self._with_entity_attr is not None else "robot"
             self._with_link_ids, self._with_local_link_ids = self._get_links_idx(with_attr, self._with_links_names)
+        self._local_ids_list = [int(v) for v in self._local_link_ids.tolist()]   # host copy (a .tolist() per step would be a sync)
         L = self._link_ids.shape[0]
         if L > nat.GF_MAX_LINK_IDS or self._with_link_ids.shape[0] > nat.GF_MAX_LINK_IDS:
             raise RuntimeError(f"ContactManager tracks at most {nat.GF_MAX_LINK_IDS} links")
@@ -133,8 +134,18 @@ class ContactManager(BaseManager):
             return
         env = self.env
         solver = env.scene.rigid_solver
+        ad = env._adapter
         if hasattr(solver, "gf_contacts"):
             c = solver.gf_contacts()  # synthetic scene: persistent buffers
+        elif ad is not None:
+            # Genesis-shaped scene: ONE get_contacts() / get_links_quat() per tick for all ContactManagers (the reference calls
+            # both per manager, contact_manager.py:391-404), so consecutive managers also share one launch
+            c = dict(ad.contacts())
+            c["links_quat"] = ad.links_quat()
+            for what in ("vel", "pos"):
+                t = ad.solver_links(what)
+                if t is not None:
+                    c["links_" + what] = t
         else:
             c = solver.collider.get_contacts(as_tensor=True, to_torch=True)
         force = c["force"].to(torch.float32).contiguous()
@@ -150,7 +161,7 @@ class ContactManager(BaseManager):
         a.force, a.position = force.data_ptr(), position.data_ptr()
         a.link_a, a.link_b, a.links_quat = link_a.data_ptr(), link_b.data_ptr(), links_quat.data_ptr()
         lv = c.get("links_vel") if isinstance(c, dict) else None
-        if lv is None and hasattr(solver, "get_links_vel"):
+        if lv is None and ad is None and hasattr(solver, "get_links_vel"):
             lv = solver.get_links_vel()
         if lv is not None:
             lv = lv.to(torch.float32).contiguous()
@@ -161,7 +172,7 @@ class ContactManager(BaseManager):
             a.links_vel = a.link_vel_out = None
             self._has_link_vel = False
         lp = c.get("links_pos") if isinstance(c, dict) else None
-        if lp is None and hasattr(solver, "get_links_pos"):
+        if lp is None and ad is None and hasattr(solver, "get_links_pos"):
             lp = solver.get_links_pos()
         if lp is not None:
             lp = lp.to(torch.float32).contiguous()
@@ -190,6 +201,9 @@ class ContactManager(BaseManager):
         keep = ()
         if need_link_vel and self._has_link_vel:
             v.link_vel = self.link_vel.data_ptr()   # persistent, filled by gf_contact_step
+        elif need_link_vel and self.env._adapter is not None:
+            # this tick's snapshot (a recorded step patches the pointer): not a per-launch temporary, so `keep` stays empty
+            v.link_vel = self.env._adapter.entity_links(getattr(self.env, self._entity_attr), "vel", self._local_ids_list).data_ptr()
         elif need_link_vel:
             robot = getattr(self.env, self._entity_attr)
             lv = robot.get_links_vel(links_idx_local=self._local_link_ids).to(torch.float32).contiguous()
@@ -199,6 +213,8 @@ class ContactManager(BaseManager):
             v.link_vel = None
         if need_link_pos and self._has_link_pos:
             v.link_pos = self.link_pos.data_ptr()   # persistent, filled by gf_contact_step
+        elif need_link_pos and self.env._adapter is not None:
+            v.link_pos = self.env._adapter.entity_links(getattr(self.env, self._entity_attr), "pos", self._local_ids_list).data_ptr()
         elif need_link_pos:
             robot = getattr(self.env, self._entity_attr)
             lp = robot.get_links_pos(links_idx_local=self._local_link_ids).to(torch.float32).contiguous()

@@ -127,7 +127,7 @@ class EntityManager(BaseManager):
     def _can_fuse_reset(self) -> bool:
         """True when the scene has masked setters and the on_reset entry is a fixed-pose ``mdp.reset.position`` or a
         ``mdp.reset.randomize_terrain_position`` whose arguments are static (see its ``gf_spawn``)."""
-        if not hasattr(self.entity, "gf_masked_base"):
+        if not hasattr(self.entity, "gf_masked_base") and self.env._adapter is None:
             return False
         from ..mdp import reset as reset_mdp
         items = list(self.on_reset.values())
@@ -150,11 +150,37 @@ class EntityManager(BaseManager):
                 self._stash_always = True  # a recorded step replays the same descriptor (quat_stash stays set)
             self._stash_armed = False
 
+    def _masked_base(self, cfg):
+        """The base-state tensors the masked reset writes.  Synthetic scene: the scene's own buffers.  Genesis-shaped scene: this
+        tick's snapshot, plus the write-back of the reset rows through ``set_pos`` / ``set_quat`` by index list, in the order
+        and with the ``zero_velocity`` argument of mdp/reset.py:102-124 / :213-226."""
+        ent = self.entity
+        if hasattr(ent, "gf_masked_base"):
+            return ent.gf_masked_base()
+        env = self.env
+        v = env.entity_views(ent)
+
+        def push(ids, self=self, cfg=cfg, ent=ent, env=env):
+            from ..mdp import reset as reset_mdp
+            fn = cfg.fn
+            v = env.entity_views(ent)
+            if isinstance(fn, reset_mdp.randomize_terrain_position):
+                _area, _off, rot, zero_velocity = fn.gf_spawn(**cfg.params)
+                with_quat = rot is not None
+            else:
+                zero_velocity, with_quat = fn.zero_velocity, fn.reset_quat is not None
+            ent.set_pos(v.pos[ids], envs_idx=ids, zero_velocity=zero_velocity)
+            if with_quat:
+                ent.set_quat(v.quat[ids], envs_idx=ids, zero_velocity=zero_velocity)
+
+        env._adapter.on_push("base:%d" % id(ent), push)
+        return v.pos, v.quat, v.lin_vel, v.ang_vel
+
     def _fill_reset(self, a: nat.GfResetArgs) -> None:
         from ..mdp import reset as reset_mdp
         for cfg in self.on_reset.values():
             fn = cfg.fn
-            pos, quat, lin, ang = self.entity.gf_masked_base()
+            pos, quat, lin, ang = self._masked_base(cfg)
             a.scene_pos, a.scene_quat = pos.data_ptr(), quat.data_ptr()
             a.scene_lin_vel, a.scene_ang_vel = lin.data_ptr(), ang.data_ptr()
             if isinstance(fn, reset_mdp.randomize_terrain_position):

@@ -10,6 +10,29 @@ from genesis_forge_amd.managers import (ContactManager, EntityManager, Observati
 from genesis_forge_amd.mdp import reset, rewards, terminations, observations
 from genesis_forge_amd.scene import SyntheticScene, morphs
 
+#: the scene class the task configs below build on.  Default: the synthetic stand-in with persistent, shared state buffers;
+#: ``use_scene(cls)`` swaps in another one with the same constructor (tests/genesis_like.py: Genesis' public surface only)
+_SCENE_CLS = [SyntheticScene]
+
+
+def new_scene(**kw):
+    return _SCENE_CLS[-1](**kw)
+
+
+class use_scene:
+    """``with use_scene(GenesisLikeScene): env = Go2CommandDirectionEnv(...)`` — envs constructed inside build on ``cls``."""
+
+    def __init__(self, cls):
+        self.cls = cls
+
+    def __enter__(self):
+        _SCENE_CLS.append(self.cls)
+        return self
+
+    def __exit__(self, *exc):
+        _SCENE_CLS.pop()
+
+
 INITIAL_BODY_POSITION = [0.0, 0.0, 0.4]
 INITIAL_QUAT = [1.0, 0.0, 0.0, 0.0]
 
@@ -45,7 +68,7 @@ class Go2SimpleEnv(ManagedEnvironment):
         from genesis_forge_amd import gs
         self.target_command = torch.zeros((self.num_envs, 3), device=gs.device, dtype=gs.tc_float)
         self.target_command[:, 0] = 0.5
-        self.scene = SyntheticScene(dt=self.dt, substeps=2, **dict(dict(max_collision_pairs=30), **(scene_kwargs or {})))
+        self.scene = new_scene(dt=self.dt, substeps=2, **dict(dict(max_collision_pairs=30), **(scene_kwargs or {})))
         self.terrain = self.scene.add_entity(morphs.Plane())
         self.robot = self.scene.add_entity(morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=INITIAL_BODY_POSITION, quat=INITIAL_QUAT))
 
@@ -76,7 +99,7 @@ class Go2ContactsEnv(ManagedEnvironment):
 
     def __init__(self, num_envs=1, dt=1 / 50, max_episode_length_s=20, scene_kwargs=None):
         super().__init__(num_envs=num_envs, dt=dt, max_episode_length_sec=max_episode_length_s, max_episode_random_scaling=0.1)
-        self.scene = SyntheticScene(dt=self.dt, substeps=2, **dict(dict(max_collision_pairs=30), **(scene_kwargs or {})))
+        self.scene = new_scene(dt=self.dt, substeps=2, **dict(dict(max_collision_pairs=30), **(scene_kwargs or {})))
         self.terrain = self.scene.add_entity(morphs.Plane())
         self.robot = self.scene.add_entity(morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=[0.0, 0.0, 0.35], quat=INITIAL_QUAT))
 
@@ -116,7 +139,7 @@ class BerkeleyHumanoidEnv(ManagedEnvironment):
 
     def __init__(self, num_envs=1, dt=1 / 50, max_episode_length_s=20, scene_kwargs=None):
         super().__init__(num_envs=num_envs, dt=dt, max_episode_length_sec=max_episode_length_s, max_episode_random_scaling=0.1)
-        self.scene = SyntheticScene(dt=self.dt, substeps=2, **(scene_kwargs or {}))
+        self.scene = new_scene(dt=self.dt, substeps=2, **(scene_kwargs or {}))
         self.terrain = self.scene.add_entity(morphs.Plane())
         self.robot = self.scene.add_entity(morphs.MJCF(file="./model/berkeley_humanoid.xml", pos=self.POS, quat=INITIAL_QUAT))
 
@@ -164,7 +187,7 @@ class Go2GaitTrainingEnv(ManagedEnvironment):
         super().__init__(num_envs=num_envs, dt=dt, max_episode_length_sec=max_episode_length_s, max_episode_random_scaling=0.4)
         self._curriculum = curriculum
         self._next_curriculum_check_step = self.CHECK_EVERY
-        self.scene = SyntheticScene(dt=self.dt, substeps=2, **dict(dict(max_collision_pairs=60), **(scene_kwargs or {})))
+        self.scene = new_scene(dt=self.dt, substeps=2, **dict(dict(max_collision_pairs=60), **(scene_kwargs or {})))
         self.terrain = self.scene.add_entity(morphs.Plane())
         self.robot = self.scene.add_entity(morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=INITIAL_BODY_POSITION, quat=INITIAL_QUAT,
                                                        links_to_keep=["FL_foot", "FR_foot", "RL_foot", "RR_foot"]))
@@ -265,7 +288,7 @@ class Go2CommandDirectionEnv(ManagedEnvironment):
         if contacts:
             kw.setdefault("max_collision_pairs", 12)
         self._contacts, self._history, self._cmd_resample_s, self._dofs = contacts, history, cmd_resample_s, dofs
-        self.scene = SyntheticScene(dt=self.dt, substeps=2, **kw)
+        self.scene = new_scene(dt=self.dt, substeps=2, **kw)
         self.terrain = self.scene.add_entity(morphs.Plane())
         if dofs == 12:
             self.robot = self.scene.add_entity(morphs.URDF(file="urdf/go2/urdf/go2.urdf", pos=INITIAL_BODY_POSITION, quat=INITIAL_QUAT))
@@ -341,7 +364,7 @@ class HumanoidGaitLikeEnv(ManagedEnvironment):
         from genesis_forge_amd.scene import humanoid_model
         kw = dict(max_collision_pairs=10, ang_noise=0.3, contact_prob=0.3, seed=21)
         kw.update(scene_kwargs or {})
-        self.scene = SyntheticScene(dt=self.dt, substeps=2, **kw)
+        self.scene = new_scene(dt=self.dt, substeps=2, **kw)
         self.terrain = self.scene.add_entity(morphs.Plane())
         self.robot = self.scene.add_entity(model=humanoid_model(dofs))
 
@@ -405,7 +428,7 @@ class Go2RoughTerrainEnv(ManagedEnvironment):
         kw = dict(scene_kwargs or {})
         kw.setdefault("max_collision_pairs", 12)
         self._height_reward, self._rotation, self._cmd_resample_s = height_reward, rotation, cmd_resample_s
-        self.scene = SyntheticScene(dt=self.dt, substeps=2, **kw)
+        self.scene = new_scene(dt=self.dt, substeps=2, **kw)
         tk = dict(pos=(-12, -12, 0), n_subterrains=(1, 1), subterrain_size=(24, 24), vertical_scale=0.001,
                   subterrain_types=[["random_uniform_terrain"]],
                   subterrain_parameters={"random_uniform_terrain": {"min_height": 0.0, "max_height": 0.1, "step": 0.05, "downsampled_scale": 0.25}})

@@ -757,9 +757,14 @@ enum {
                                 if target2: *(void**)target2 = r->slot[r->cur]                     (output slots, ping-pong buffers) */
     GF_PATCH_PARAM = 5,      /* *(const void**)target = params[index]                              (statistics ring slots) */
     GF_PATCH_COPY = 6,       /* *(uint64_t*)target = *(const uint64_t*)aux                         (a field that follows another) */
-    GF_PATCH_RING_SLOT = 7   /* c = (GfRingClock*)aux: *(int32_t*)target = (c->length - c->calls % c->length) % c->length + 1; ++c->calls;
+    GF_PATCH_RING_SLOT = 7,  /* c = (GfRingClock*)aux: *(int32_t*)target = (c->length - c->calls % c->length) % c->length + 1; ++c->calls;
                                 if target2: *(int32_t*)target2 = the same value
                                                               (GfObservationArgs.history_ring, GfHistoryUnrollArgs.ring_slot) */
+    GF_PATCH_PARAM_OFFSET = 8 /* *(const char**)target = (const char*)params[index] + (intptr_t)aux
+                                 (a scene with Genesis' public surface only: every getter — entity.get_pos() …,
+                                 collider.get_contacts(), rigid_solver.get_links_quat(); entity_manager.py:189-195,
+                                 contact_manager.py:384-400 — returns a NEW tensor each tick; params[index] is this tick's tensor,
+                                 aux the byte offset of the field's view inside it.  A NULL params[index] is refused: GF_E_NULL) */
 };
 typedef struct GfRotor {
     int32_t cur;

@@ -1,0 +1,197 @@
+"""The manager step on a scene with ONLY Genesis' public surface (tests/genesis_like.py: fresh getter tensors, envs_idx setters,
+collider.get_contacts() dict, rigid_solver.get_links_quat(), no gf_* extras) — the L0 side of the boundary.
+
+The double runs the same stand-in physics in private, so an env built on it must produce, step for step and bit for bit, what the
+same env produces on the synthetic scene (whose fast path is pinned to the reference by the golden trajectories): outputs, manager
+state AND the simulator's own state (the reset rows have to arrive through the setters).  Checked for the ordinary step and for
+the recorded + fused step, which must exist on such a scene: at most the one nonzero() the setters force, one call per getter
+and tick."""
+import pytest
+import torch
+
+import envs
+from genesis_forge_amd import tasks
+from genesis_like import GenesisLikeScene
+
+CASES = {
+    # name: (factory, action width)
+    "go2_cmd": (lambda n: envs.Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, contacts=True, history=2,
+                                                      obs_noise=True, scene_kwargs=dict(ang_noise=0.3, seed=3)), 12),
+    "go2_plain": (lambda n: envs.Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3,
+                                                        scene_kwargs=dict(ang_noise=0.3, seed=3)), 12),
+    "rough_terrain": (lambda n: envs.Go2RoughTerrainEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3,
+                                                        scene_kwargs=dict(ang_noise=0.3, seed=5, contact_prob=0.2)), 12),
+    "gait": (lambda n: envs.Go2GaitTrainingEnv(num_envs=n, max_episode_length_s=1,
+                                               scene_kwargs=dict(ang_noise=0.25, seed=7, contact_prob=0.05)), 12),
+    "gait_curriculum": (lambda n: envs.Go2GaitTrainingCurriculumEnv(num_envs=n, max_episode_length_s=1,
+                                                                    scene_kwargs=dict(ang_noise=0.25, seed=7, contact_prob=0.05)), 12),
+    "humanoid28": (lambda n: envs.HumanoidGaitLikeEnv(num_envs=n, dofs=28), 28),
+    "humanoid": (lambda n: envs.BerkeleyHumanoidEnv(num_envs=n, max_episode_length_s=1,
+                                                    scene_kwargs=dict(ang_noise=0.2, seed=9, contact_prob=0.02, max_collision_pairs=30)), 12),
+}
+
+
+def _sim_of(env):
+    sc = env.scene
+    sim = sc._sim if isinstance(sc, GenesisLikeScene) else sc
+    r = sim.robot
+    return [r.pos, r.quat, r.lin_vel, r.ang_vel, r.dof_pos, r.dof_vel]
+
+
+def run(name, dev, scene_cls, trace, n=70, steps=60, poison=True):
+    make, width = CASES[name]
+    if scene_cls is None:
+        env = make(n)
+    else:
+        with tasks.use_scene(scene_cls):
+            env = make(n)
+        env.scene.poison = poison
+    env.trace_enabled = trace
+    env.build()
+    env.seed(11)
+    env.reset()
+    g = torch.Generator().manual_seed(0)
+    outs = []
+    for t in range(steps):
+        o, r, te, tr, ex = env.step(torch.randn(n, width, generator=g).to(dev))
+        rec = [o, r, te, tr, env.episode_length] + _sim_of(env)
+        for m in env.managers["command"]:
+            rec.append(m.command)
+        for name_, ob in ex["observations"].items():
+            if name_ != "policy":
+                rec.append(ob)
+        for cm in env.managers["contact"]:
+            rec.append(cm.contacts)
+            if cm.current_air_time is not None:
+                rec += [cm.current_air_time, cm.last_air_time]
+        outs.append(([x.detach().cpu().clone() for x in rec], {k: float(v) for k, v in ex["episode"].items()}))
+    return outs, env
+
+
+def same(a, b):
+    assert len(a) == len(b)
+    for t, ((xs, lx), (ys, ly)) in enumerate(zip(a, b)):
+        assert len(xs) == len(ys)
+        for k, (x, y) in enumerate(zip(xs, ys)):
+            assert torch.equal(x, y), f"output {k} differs at step {t}: max |d| = {(x.float() - y.float()).abs().max()}"
+        assert lx == ly, f"log differs at step {t}: {lx} vs {ly}"
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_ordinary_step_on_genesis_like_scene_cpu(oracle_backend, name):
+    a, _ = run(name, "cpu", None, False)
+    b, env = run(name, "cpu", GenesisLikeScene, False)
+    same(a, b)
+    dones = sum(int((x[0][2] | x[0][3]).sum()) for x in b)
+    assert dones > 20, "the case should reset envs"
+    assert not any(hasattr(env.robot, k) for k in ("gf_views", "gf_dofs", "gf_masked_dofs", "gf_masked_base"))
+    assert not hasattr(env.scene, "gf_static_buffers") and not hasattr(env.scene.rigid_solver, "gf_contacts")
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_recorded_step_on_genesis_like_scene_cpu(oracle_backend, name):
+    a, _ = run(name, "cpu", None, False)
+    before = oracle_backend.replays
+    b, env = run(name, "cpu", GenesisLikeScene, True)
+    same(a, b)
+    tr = env._trace
+    assert tr is not None, f"the step on a Genesis-shaped scene was not recorded: {env._untraceable}"
+    assert oracle_backend.replays - before >= 50
+    if name != "gait_curriculum":
+        assert tr.post_refs is not None, "the post-physics phases should run as the fused launch"
+    else:
+        assert tr.tail_python and sorted(tr.tail_seg) == ["obs", "reset"]
+
+
+def test_one_getter_call_per_tick_and_one_index_list(oracle_backend, monkeypatch):
+    """A replayed step on the double: control_dofs_position + scene.step() once, every getter of the plan once, setters only on
+    steps that reset an env, and exactly one nonzero() (the index list the envs_idx setters need; managed_env.py:308-310)."""
+    _, env = run("go2_cmd", "cpu", GenesisLikeScene, True, steps=20)
+    tr = env._trace
+    assert tr is not None and len(tr.scene_plan) > 0
+    sc = env.scene
+    nz = {"n": 0}
+    real = torch.Tensor.nonzero
+
+    def counting(self, *a, **k):
+        nz["n"] += 1
+        return real(self, *a, **k)
+
+    monkeypatch.setattr(torch.Tensor, "nonzero", counting)
+    g = torch.Generator().manual_seed(5)
+    resets = 0
+    for _ in range(25):
+        sc.calls.clear()
+        nz["n"] = 0
+        f0 = env._adapter.fetches
+        o, r, te, tru, ex = env.step(torch.randn(70, 12, generator=g))
+        assert sc.calls["step"] == 1 and sc.calls["control_dofs_position"] == 1
+        assert env._adapter.fetches - f0 == len(tr.scene_plan)
+        for getter in ("get_pos", "get_quat", "get_vel", "get_ang", "get_dofs_position", "get_dofs_velocity", "get_contacts", "get_links_quat"):
+            assert sc.calls[getter] == 1, f"{getter} called {sc.calls[getter]} times in one tick"
+        assert nz["n"] == 1, f"{nz['n']} nonzero() calls in a replayed step"
+        done = bool((te | tru).any())
+        resets += done
+        for setter in ("set_dofs_position", "set_pos", "set_quat"):
+            assert sc.calls[setter] == (1 if done else 0)
+    assert resets > 3 and env._trace is tr
+
+
+def test_unexplained_pointer_change_refuses_the_recording(oracle_backend, monkeypatch):
+    """The recording's safety net: a descriptor pointer that changes from tick to tick and is neither scene state read through
+    the snapshot nor a known per-step field must refuse the recording (here: link velocities handed to the reward descriptor from
+    alternating buffers behind the snapshot's back) — the env keeps stepping phase by phase and says why."""
+    from genesis_forge_amd.managers import ContactManager
+
+    make, _ = CASES["humanoid28"]   # feet_slide reads the tracked links' velocities (GfContactView.link_vel)
+    with tasks.use_scene(GenesisLikeScene):
+        env = make(40)
+    real_view = ContactManager.view
+    bufs = {}
+
+    def view(self, v, need_link_vel=False, need_link_pos=False):
+        keep = real_view(self, v, need_link_vel=need_link_vel, need_link_pos=need_link_pos)
+        if need_link_vel:
+            pair = bufs.setdefault(id(self), [torch.zeros(40, self.contacts.shape[1], 3), torch.zeros(40, self.contacts.shape[1], 3)])
+            pair.reverse()
+            v.link_vel = pair[0].data_ptr()
+        return keep
+
+    monkeypatch.setattr(ContactManager, "view", view)
+    env.build()
+    env.reset()
+    for _ in range(6):
+        env.step(torch.zeros(40, 28))
+    assert env._trace is None
+    assert env._untraceable is not None and "link_vel" in env._untraceable, env._untraceable
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_recorded_step_on_genesis_like_scene_hip_equals_oracle(hip_backend, oracle_lib_path, name):
+    """-m gpu: HIP on the Genesis-shaped double == oracle on the synthetic scene (masks / counters bit-exact, floats <= 1e-5)."""
+    from genesis_forge_amd import _native as nat
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+
+    n = 130
+    b, env = run(name, "cuda", GenesisLikeScene, True, n=n)
+    tr = env._trace
+    assert tr is not None, f"not recorded: {env._untraceable}"
+    c, _ = run(name, "cuda", None, True, n=n)
+    same(b, c)   # HIP on the double == HIP on the synthetic scene, bit for bit
+    torch.cuda.synchronize()
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(oracle_lib_path))
+    try:
+        a, _ = run(name, "cpu", None, False, n=n)
+    finally:
+        nat.set_backend(None)
+        gs.set_device("cuda:0")
+    for t, ((xs, lx), (ys, ly)) in enumerate(zip(a, b)):
+        for k, (x, y) in enumerate(zip(xs, ys)):
+            if x.dtype in (torch.bool, torch.int32, torch.int64, torch.uint8):
+                assert torch.equal(x, y), f"output {k} differs at step {t}"
+            else:
+                assert torch.allclose(x, y, atol=1e-5, rtol=0), f"output {k} at step {t}: {(x - y).abs().max()}"
+        assert set(lx) == set(ly)

@@ -27,6 +27,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--configs", default="")
     ap.add_argument("--num-envs", type=int, default=0, help="override every config's size")
+    ap.add_argument("--scene", default="synthetic", choices=("synthetic", "genesis_like"),
+                    help="genesis_like: the test double with Genesis' public surface only (tests/genesis_like.py: fresh getter tensors, "
+                         "envs_idx setters, no gf_* extras); the line then also carries the double's own cost per tick")
+    ap.add_argument("--no-trace", action="store_true", help="time the ordinary (phase by phase) step")
     args = ap.parse_args()
     import torch
     from genesis_forge_amd import gs
@@ -39,10 +43,23 @@ def main():
     gs.set_device("cuda:0")
     cfgs = _configs()
     names = [c for c in args.configs.split(",") if c] or list(cfgs)
+    scene_cls = None
+    if args.scene == "genesis_like":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))   # the double is test infrastructure
+        from genesis_like import GenesisLikeScene
+        from genesis_forge_amd import tasks
+
+        GenesisLikeScene.poison = False   # (the NaN-poisoning of stale getter tensors is a test aid, not part of a tick)
+        scene_cls = GenesisLikeScene
     for name in names:
         n0, make = cfgs[name]
         n = args.num_envs or n0
-        env = make(n)
+        if scene_cls is not None:
+            with tasks.use_scene(scene_cls):
+                env = make(n)
+        else:
+            env = make(n)
+        env.trace_enabled = not args.no_trace
         env.build()
         env.seed(1234)
         env.reset()
@@ -59,10 +76,29 @@ def main():
         dt = time.perf_counter() - t0
         log = dict(env.extras["episode"])
         tr = env._trace
-        print(json.dumps({"config": name, "num_envs": n, "us_per_step": dt / args.steps * 1e6, "env_steps_per_s": n * args.steps / dt,
-                          "recorded": tr is not None, "fused_post": bool(tr is not None and tr.post_refs is not None),
-                          "ops_per_step": tr.n_ops if tr is not None else None,
-                          "resets_last_step_frac": sum(float(v) for k, v in log.items() if k.startswith("Terminations /"))}), flush=True)
+        row = {"config": name, "scene": args.scene, "num_envs": n, "us_per_step": dt / args.steps * 1e6, "env_steps_per_s": n * args.steps / dt,
+               "recorded": tr is not None, "fused_post": bool(tr is not None and tr.post_refs is not None),
+               "ops_per_step": tr.n_ops if tr is not None else None,
+               "resets_last_step_frac": sum(float(v) for k, v in log.items() if k.startswith("Terminations /"))}
+        if scene_cls is not None:
+            row["why_not_recorded"] = env._untraceable
+            ad = env._adapter
+            plan = tr.scene_plan if tr is not None else ad.plan()
+            row["getters_per_tick"] = len(plan)
+            # the double's own cost: what a tick costs before any manager work — control_dofs_position + scene.step() + every getter
+            # of the plan once + the nonzero() the envs_idx setters force (synchronising like the step does)
+            am, tm = env.managers["action"], env.managers["termination"]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                env.robot.control_dofs_position(am._actions, am.dofs_idx)
+                env.scene.step()
+                held = [f() for _k, f in plan]
+                (tm._terminated_buf | tm._truncated_buf).nonzero()
+            torch.cuda.synchronize()
+            row["scene_double_us_per_tick"] = (time.perf_counter() - t0) / args.steps * 1e6
+            row["manager_us_per_step"] = row["us_per_step"] - row["scene_double_us_per_tick"]
+        print(json.dumps(row), flush=True)
         del env
 
 
