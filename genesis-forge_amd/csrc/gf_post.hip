@@ -19,9 +19,13 @@
 // exactly that); tests compare the two paths bit for bit.
 // Algorithmic traffic, Go2 command config: R 13·4 + 5 rows·48 + cmd 12 + ep/max 8 + secs 4 + sums 24 = 340,
 // W masks 2 + reward 4 + sums 24 + secs 4 + obs 192 = 226  →  566 B/env.
+#include <dlfcn.h>
+
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "gf_post_args.h"
 #include "gf_post_ws.h"
@@ -924,10 +928,63 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_check(cons
     return gf::pack(r, pk);
 }
 
-template <class P>
-static size_t lds_ws_floats(int omax, int n_gait) {
-    return (size_t)(gf::x_fields(n_gait) + gf::ws_sum_rows<P>() + gf::ws_aux_rows<P>()) * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock;
+using gf::lds_ws_floats;
+
+// ---- programs compiled at run time (include/gf_step.h: gf_post_program_register) ---------------------------------------------
+// A plugin is a small shared object built from csrc/gf_post_ws.h + ONE generated program struct (genesis_forge_amd/_programs.py):
+// it carries post_ws_kernel<P> in its own code object and exports the matcher, the kernel's host handle and its LDS size.  The
+// library only keeps the table; ids start at kDynBase.  Registration is rare and append-only (fixed-size table, the count is
+// published last), selection walks it on every launch of a config no built-in program matches.
+namespace {
+constexpr int kDynBase = 100, kDynMax = 64;
+struct DynProgram {
+    void* dl;
+    char name[64];
+    int (*matches)(const gf::GfPostArgs*);
+    const void* kernel;
+    size_t (*lds_bytes)(int, int);
+};
+DynProgram g_dyn[kDynMax];
+std::atomic<int> g_dyn_count{0};
+std::mutex g_dyn_mutex;
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) int gf_post_program_register(const char* path, int* id_out) {
+    if (!path) return GF_E_NULL;
+    void* dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return GF_E_UNSUPPORTED;
+    auto abi = (int (*)(void))dlsym(dl, "gfp_abi_version");
+    auto asz = (int (*)(void))dlsym(dl, "gfp_args_size");
+    auto nm = (const char* (*)(void))dlsym(dl, "gfp_name");
+    auto mt = (int (*)(const gf::GfPostArgs*))dlsym(dl, "gfp_matches");
+    auto kn = (const void* (*)(void))dlsym(dl, "gfp_kernel");
+    auto ld = (size_t (*)(int, int))dlsym(dl, "gfp_lds_bytes");
+    // the packed descriptor is the interface between library and plugin: both must come from the same headers
+    if (!abi || !asz || !nm || !mt || !kn || !ld || abi() != GF_ABI_VERSION || asz() != (int)sizeof(gf::GfPostArgs)) {
+        dlclose(dl);
+        return GF_E_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lock(g_dyn_mutex);
+    const int n = g_dyn_count.load();
+    for (int i = 0; i < n; ++i)
+        if (!strncmp(g_dyn[i].name, nm(), sizeof(g_dyn[i].name) - 1)) {   // already there (same signature hash in the name)
+            dlclose(dl);
+            if (id_out) *id_out = kDynBase + i;
+            return GF_OK;
+        }
+    if (n >= kDynMax) { dlclose(dl); return GF_E_RANGE; }
+    DynProgram& d = g_dyn[n];
+    d.dl = dl;
+    snprintf(d.name, sizeof(d.name), "%s", nm());
+    d.matches = mt;
+    d.kernel = kn();
+    d.lds_bytes = ld;
+    g_dyn_count.store(n + 1);
+    if (id_out) *id_out = kDynBase + n;
+    return GF_OK;
 }
+
+extern "C" __attribute__((visibility("default"))) int gf_post_program_count(void) { return g_dyn_count.load(); }
 
 // Static programs in registration order; program id = 1 + index (0 = table interpreter).
 #define GF_POST_PROGRAMS(X)                                                                                                \
@@ -941,6 +998,9 @@ static int select_program(const gf::GfPostArgs& a) {
     if (gf::program_matches<P>(a)) return id;
     GF_POST_PROGRAMS(GF_MATCH)
 #undef GF_MATCH
+    const int n = g_dyn_count.load();
+    for (int i = 0; i < n; ++i)
+        if (g_dyn[i].matches(&a)) return kDynBase + i;
     return 0;
 }
 
@@ -955,6 +1015,7 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_describe(c
     if (id == pid) name = P::name;
     GF_POST_PROGRAMS(GF_NAME)
 #undef GF_NAME
+    if (id >= kDynBase) name = g_dyn[id - kDynBase].name;
     int n = snprintf(buf, (size_t)cap, "program %d (%s): ", id, name);
     if (n < cap) gf::describe_program(pk.a, buf + n, cap - n);
     return GF_OK;
@@ -981,7 +1042,18 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     if (gf::g_options[GF_OPT_POST_VARIANT] == 0 && !ws_only) {
         if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid, gf::kEnvBlock, lds, s, a);
         else GF_LAUNCH(scope, gf::post_kernel<3>, grid, gf::kEnvBlock, lds, s, a);
-    } else if (const int prog = select_program(a)) {
+    } else if (const int prog = select_program(a); prog >= kDynBase) {
+        // a program compiled at run time: the plugin's kernel handle, launched like any other (launch sink, dispatch events)
+        const DynProgram& d = g_dyn[prog - kDynBase];
+        const size_t lds_dyn = d.lds_bytes(omax, a.n_gait);
+        void* kargs[1] = {const_cast<gf::GfPostArgs*>(&a)};
+        if (scope.active()) {
+            scope.use_dispatch_events();
+            (void)hipExtLaunchKernel(d.kernel, dim3(grid), dim3(gf::kWsBlock), kargs, lds_dyn, s, scope.start(), scope.stop(), 0);
+        } else {
+            gf::sink_launch(d.kernel, dim3(grid), dim3(gf::kWsBlock), lds_dyn, s, kargs);
+        }
+    } else if (prog) {
 #define GF_RUN(id, P) \
         if (prog == id) GF_LAUNCH(scope, gf::post_ws_kernel<P>, grid, gf::kWsBlock, lds_ws_floats<P>(omax, a.n_gait) * sizeof(float), s, a);
         GF_POST_PROGRAMS(GF_RUN)

@@ -208,9 +208,15 @@ struct ProgHumanoid28Stress {
     static constexpr int n_gait = 0;
 };
 
+// dynamic LDS of post_ws_kernel<P>, in floats (a static program keeps no copy of the descriptor in LDS; the interpreter adds one)
+template <class P>
+inline size_t lds_ws_floats(int omax, int n_gait) {
+    return (size_t)(x_fields(n_gait) + ws_sum_rows<P>() + ws_aux_rows<P>()) * kEnvBlock + (size_t)(omax + 1) * kEnvBlock;
+}
+
 template <class P>
 bool program_matches(const GfPostArgs& a) {
-    if (a.term_done || a.num_dofs != 4 * P::DV || a.num_term != P::n_term || a.num_rew != P::n_rew || a.n_cmd != P::n_cmd || a.n_obs != P::n_obs || a.n_air != P::n_air ||
+    if ((a.term_done != 0) != prog_term_done<P>::value || a.num_dofs != 4 * P::DV || a.num_term != P::n_term || a.num_rew != P::n_rew || a.n_cmd != P::n_cmd || a.n_obs != P::n_obs || a.n_air != P::n_air ||
         a.n_gait != P::n_gait)
         return false;
     for (int k = 0; k < P::n_term; ++k)
@@ -258,6 +264,7 @@ inline int describe_program(const GfPostArgs& a, char* buf, int cap) {
         put("%s", "};");
     }
     put(" n_air = %d; n_gait = %d", a.n_air, a.n_gait);
+    if (a.term_done) put("%s", "; term_done = 1");
     return n;
 }
 

@@ -42,6 +42,12 @@ struct TermSig { int op, flags; };
 struct RewSig { int op, flags, i0, i1; };
 struct ItemSig { int op, width, i0; bool scaled, noisy; };
 
+// optional signature member `static constexpr bool term_done` (absent = false)
+template <class P, class = void>
+struct prog_term_done : std::false_type {};
+template <class P>
+struct prog_term_done<P, std::void_t<decltype(P::term_done)>> : std::bool_constant<P::term_done> {};
+
 template <int DV_, bool TAIL_ = false>
 struct Interp {
     static constexpr bool kStatic = false;
@@ -223,11 +229,16 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         }
         // ---- body-frame vectors, termination -----------------------------------------------------------------------------
         const V3 blin = rot_inv(q, lin), bang = rot_inv(q, ang), grav = rot_inv(q, V3{0.f, 0.f, -1.f});
-        if constexpr (!P::kStatic) {   // (a static program has its termination table: a launch with none never selects one)
-            if (UNI(a.term_done)) {    // the termination phase ran as a launch of its own (Python-level terms in the step): its masks are inputs
+        // the termination phase ran as a launch of its own (Python-level terms in the step): its masks are inputs.  A static program
+        // says so in its signature (`term_done`, programs compiled at run time); the built-in ones all have their termination table
+        if constexpr (!P::kStatic) {
+            if (UNI(a.term_done)) {
                 term = live ? (int)G(UNI(a.terminated))[n] : 0;
                 trunc = live ? (int)G(UNI(a.truncated))[n] : 0;
             }
+        } else if constexpr (prog_term_done<P>::value) {
+            term = live ? (int)G(UNI(a.terminated))[n] : 0;
+            trunc = live ? (int)G(UNI(a.truncated))[n] : 0;
         }
         TermRegs tr;
         const int has_maxlen = UNI(a.has_maxlen);

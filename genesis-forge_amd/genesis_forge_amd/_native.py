@@ -456,6 +456,8 @@ class HipBackend(Backend):
         self.lib.gf_post_physics_check.argtypes = [C.POINTER(GfPostRefs)]
         self.lib.gf_post_physics_describe.restype = C.c_int
         self.lib.gf_post_physics_describe.argtypes = [C.POINTER(GfPostRefs), C.c_char_p, C.c_int]
+        self.lib.gf_post_program_register.restype = C.c_int
+        self.lib.gf_post_program_register.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
         self.lib.gf_event_create.restype = C.c_void_p
         self.lib.gf_event_synchronize.restype = C.c_int
         self.lib.gf_event_synchronize.argtypes = [C.c_void_p]
@@ -525,6 +527,14 @@ class HipBackend(Backend):
         if rc != 0:
             self._raise("post_physics_describe", rc)
         return buf.value.decode()
+
+    def register_program(self, plugin_path: str) -> int:
+        """Register a static program compiled at run time (genesis_forge_amd/_programs.py); returns its program id."""
+        pid = C.c_int(-1)
+        rc = self.lib.gf_post_program_register(plugin_path.encode(), C.byref(pid))
+        if rc != 0:
+            self._raise(f"post_program_register({plugin_path})", rc)
+        return pid.value
 
     def stats_pack(self, src_ptr: int, dst_ptr: int) -> None:
         a = GfStatsPackArgs()

@@ -1,0 +1,244 @@
+"""
+Static programs compiled at run time for configs the library was not built with.
+
+The fused post-physics kernel exists in two forms (csrc/gf_post_ws.h): a table interpreter that runs any configuration, and
+``post_ws_kernel<Program>`` — the same code with one configuration's STRUCTURE (opcode sequences, slots, widths, observation
+layout) as compile-time constants, about 1.3 × faster.  The reference's configs are live Python dicts
+(genesis_forge/managers/config/config_item.py:31-44): a user's task is not one of the structures compiled into the library.
+So, once a step has been recorded and its fused launch turns out to be the interpreter's, this module
+
+1. takes the signature of the recorded descriptors (``gf_post_physics_describe``, host-only),
+2. writes the program struct it denotes + six ``extern "C"`` exports into a ~40-line ``.hip`` file that includes the kernel's
+   headers from ``csrc/``,
+3. compiles it for gfx950 with ``hipcc -shared`` (≈ 5 s) into ``<package>/../programs/gfp_<hash>.so`` — the hash covers the
+   signature AND the kernel headers, so a changed kernel never meets a stale plugin — and
+4. registers it (``gf_post_program_register``): every later launch whose descriptor matches runs the compiled kernel.
+
+Only structure is compiled in.  Weights, parameters, thresholds, ranges, scales, noise levels stay run-time arguments, so the
+reference's live mutation (``cfg[name].weight = …``, ``params[k] = v``) keeps working without recompiling; a mutation that changes
+the structure (a term enabled / disabled, a scale from 1 to something else) stops matching and runs the interpreter until its own
+program is there.
+
+Policy (``GF_JIT``): ``off``; ``sync`` — compile when the step is recorded, blocking; ``async`` — compile in a child process,
+register when it is done (polled every 32 steps), the interpreter runs meanwhile.  Default: ``async`` from 16 384 envs on
+(below that a step is host-bound and the kernel's 2–3 µs do not show), ``off`` otherwise.  Missing ``hipcc`` = ``off``.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import re
+import shutil
+import subprocess
+import time
+from typing import Optional
+
+from . import _native as nat
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
+_HEADERS = ("gf_post_args.h", "gf_post_ws.h", "gf_post_programs.h", "gf_terms.h", "gf_device.h", "gf_obs_hist.h", "gf_prefetch.h",
+            "gf_launch.h")
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-fvisibility=hidden", "-Wno-unused-value"]
+
+
+def cache_dir() -> str:
+    return os.environ.get("GF_PROGRAM_CACHE") or os.path.join(PKG_DIR, "programs")
+
+
+def hipcc() -> Optional[str]:
+    return shutil.which(os.environ.get("HIPCC", "hipcc")) or (os.path.exists("/opt/rocm/bin/hipcc") and "/opt/rocm/bin/hipcc") or None
+
+
+# -- signature → program struct (the notation of csrc/gf_post_programs.h; gf_post_physics_describe prints it) -----------------
+def parse(sig: str) -> dict:
+    body = sig.split(": ", 1)[1]
+    g = lambda pat: re.search(pat, body)
+    out = {"DV": int(g(r"DV = (\d+)").group(1)), "n_term": int(g(r"n_term = (\d+)").group(1)), "n_rew": int(g(r"n_rew = (-?\d+)").group(1)),
+           "n_cmd": int(g(r"n_cmd = (\d+)").group(1)), "n_obs": int(g(r"n_obs = (\d+)").group(1)), "n_air": int(g(r"n_air = (\d+)").group(1)),
+           "n_gait": int(g(r"n_gait = (\d+)").group(1))}
+    out["term_done"] = g(r"term_done = 1") is not None
+    out["term"] = g(r"term = (\{.*?\}); n_rew").group(1)
+    out["rew"] = g(r"rew = (\{.*?\}); n_cmd").group(1)
+    out["cmd_width"] = [int(x) for x in re.findall(r"\d+", g(r"cmd_width = \{(.*?)\}").group(1))]
+    out["obs"] = [(int(w), int(h), items) for w, h, items in re.findall(r"obs\[\d+\]: width (\d+) history (\d+) items (\{.*?\});", body)]
+    return out
+
+
+def struct_text(p: dict, name: str, cls: str, comment: str) -> str:
+    pad = lambda xs, n: ", ".join(str(x) for x in (list(xs) + [0] * n)[:n])
+    items = ",\n".join("        " + (it if it != "{}" else "{}") for it in [o[2] for o in p["obs"]] + ["{}"] * (2 - len(p["obs"])))
+    arr = lambda n: max(1, n)
+    return f'''
+// {comment}
+struct {cls} {{
+    static constexpr bool kStatic = true;
+    static constexpr const char* name = "{name}";
+    static constexpr int DV = {p["DV"]};
+    static constexpr int n_term = {p["n_term"]};
+    static constexpr TermSig term[{arr(p["n_term"])}] = {p["term"] if p["n_term"] else "{}"};
+    static constexpr int n_rew = {p["n_rew"]};
+    static constexpr RewSig rew[{arr(p["n_rew"])}] = {p["rew"] if p["n_rew"] > 0 else "{}"};
+    static constexpr int n_cmd = {p["n_cmd"]};
+    static constexpr int cmd_width[GF_POST_MAX_CMD] = {{{pad(p["cmd_width"], 2)}}};
+    static constexpr int n_obs = {p["n_obs"]};
+    static constexpr int obs_width[GF_POST_MAX_OBS] = {{{pad([o[0] for o in p["obs"]], 2)}}};
+    static constexpr int obs_history[GF_POST_MAX_OBS] = {{{pad([o[1] for o in p["obs"]], 2)}}};
+    static constexpr int obs_items[GF_POST_MAX_OBS] = {{{pad([o[2].count("{") - 1 for o in p["obs"]], 2)}}};
+    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {{
+{items}}};
+    static constexpr int n_air = {p["n_air"]};
+    static constexpr int n_gait = {p["n_gait"]};{"""
+    static constexpr bool term_done = true;   // the termination masks are inputs (Python-level terms ran behind a termination launch of its own)""" if p.get("term_done") else ""}
+}};
+'''
+
+
+def _headers_digest() -> str:
+    h = hashlib.sha1()
+    for f in [os.path.join(CSRC, n) for n in _HEADERS] + [os.path.join(INCLUDE, "gf_step.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def plugin_source(sig: str, key: str) -> str:
+    body = sig.split(": ", 1)[1]
+    struct = struct_text(parse(sig), "jit_" + key, "ProgJit", f"signature: {body}")
+    return f'''// generated by genesis_forge_amd/_programs.py — a static program of the fused post-physics kernel, compiled at run time
+#include "gf_post_args.h"
+#include "gf_post_ws.h"
+#include "gf_post_programs.h"
+
+namespace gf {{
+{struct}
+}}  // namespace gf
+
+#define GFP_EXPORT extern "C" __attribute__((visibility("default")))
+GFP_EXPORT int gfp_abi_version(void) {{ return GF_ABI_VERSION; }}
+GFP_EXPORT int gfp_args_size(void) {{ return (int)sizeof(gf::GfPostArgs); }}
+GFP_EXPORT const char* gfp_name(void) {{ return gf::ProgJit::name; }}
+GFP_EXPORT int gfp_matches(const gf::GfPostArgs* a) {{ return gf::program_matches<gf::ProgJit>(*a) ? 1 : 0; }}
+GFP_EXPORT const void* gfp_kernel(void) {{ return (const void*)&gf::post_ws_kernel<gf::ProgJit>; }}
+GFP_EXPORT size_t gfp_lds_bytes(int omax, int n_gait) {{ return gf::lds_ws_floats<gf::ProgJit>(omax, n_gait) * sizeof(float); }}
+'''
+
+
+def plugin_key(sig: str) -> str:
+    body = sig.split(": ", 1)[1]
+    return hashlib.sha1((body + "|" + _headers_digest() + "|" + " ".join(_FLAGS)).encode()).hexdigest()[:16]
+
+
+def plugin_paths(sig: str) -> tuple:
+    key = plugin_key(sig)
+    d = cache_dir()
+    return key, os.path.join(d, f"gfp_{key}.hip"), os.path.join(d, f"gfp_{key}.so")
+
+
+def compile_command(src: str, out: str) -> list:
+    return [hipcc()] + _FLAGS + ["-I", CSRC, "-I", INCLUDE, src, "-o", out]
+
+
+def start_compile(sig: str):
+    """Write the source and start ``hipcc`` as a child process.  Returns ``(so_path, Popen | None)`` — None when the plugin is
+    already in the cache."""
+    key, src, so = plugin_paths(sig)
+    if os.path.exists(so):
+        return so, None
+    if hipcc() is None:
+        raise RuntimeError("hipcc not found: static programs cannot be compiled at run time")
+    os.makedirs(os.path.dirname(src), exist_ok=True)
+    with open(src, "w") as fh:
+        fh.write(plugin_source(sig, key))
+    tmp = f"{so}.{os.getpid()}.tmp"
+    proc = subprocess.Popen(compile_command(src, tmp), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    proc._gf_tmp, proc._gf_so, proc._gf_t0 = tmp, so, time.perf_counter()
+    return so, proc
+
+
+def finish_compile(proc) -> str:
+    """Wait for a compile started by ``start_compile``; the finished plugin is moved into place atomically."""
+    _out, err = proc.communicate()
+    if proc.returncode != 0:
+        try:
+            os.unlink(proc._gf_tmp)
+        except OSError:
+            pass
+        raise RuntimeError(f"hipcc failed on a generated program ({proc.returncode}):\n{err[-2000:]}")
+    os.replace(proc._gf_tmp, proc._gf_so)
+    proc._gf_seconds = time.perf_counter() - proc._gf_t0
+    return proc._gf_so
+
+
+def compile_sync(sig: str) -> tuple:
+    """(plugin path, seconds spent compiling — 0.0 for a cache hit)."""
+    so, proc = start_compile(sig)
+    if proc is None:
+        return so, 0.0
+    finish_compile(proc)
+    return so, proc._gf_seconds
+
+
+def register(backend, so: str) -> int:
+    return backend.register_program(so)
+
+
+# -- the hook ManagedEnvironment.step calls when a step has just been recorded ---------------------------------------------------
+def mode_for(env) -> str:
+    m = os.environ.get("GF_JIT")
+    if m is None:
+        m = getattr(env, "jit_programs", None) or ("async" if env.num_envs >= 16384 else "off")
+    return m if m in ("off", "sync", "async") else "off"
+
+
+class Pending:
+    """An ``async`` compile in flight for one env."""
+
+    def __init__(self, env, sig: str, proc, so: str):
+        self.env, self.sig, self.proc, self.so = env, sig, proc, so
+        self.countdown = 32
+
+    def poll(self) -> bool:
+        """True when done (registered, or failed: the interpreter stays)."""
+        self.countdown -= 1
+        if self.countdown > 0:
+            return False
+        self.countdown = 32
+        if self.proc.poll() is None:
+            return False
+        try:
+            register(self.env.backend, finish_compile(self.proc))
+            self.env._program_info = {"signature": self.sig, "plugin": self.so, "compile_s": self.proc._gf_seconds, "mode": "async"}
+        except Exception as e:   # a failed compile must never take the run down: the interpreter is correct, just slower
+            self.env._program_info = {"signature": self.sig, "error": str(e), "mode": "async"}
+        return True
+
+
+def on_recorded(env) -> None:
+    """A step has just been recorded.  If its fused launch is the interpreter's, get the config its own program."""
+    tr = env._trace
+    backend = env.backend
+    if tr is None or tr.post_refs is None or not hasattr(backend, "post_describe") or not hasattr(backend, "register_program"):
+        return
+    mode = mode_for(env)
+    if mode == "off":
+        return
+    sig = backend.post_describe(tr.post_refs)
+    if not sig.startswith("program 0 "):
+        return   # a built-in program, or one registered earlier
+    if hipcc() is None and not os.path.exists(plugin_paths(sig)[2]):
+        return
+    try:
+        so, proc = start_compile(sig)
+        if proc is None or mode == "sync":
+            secs = 0.0
+            if proc is not None:
+                finish_compile(proc)
+                secs = proc._gf_seconds
+            register(backend, so)
+            env._program_info = {"signature": sig, "plugin": so, "compile_s": secs, "mode": mode}
+        else:
+            env._program_pending = Pending(env, sig, proc, so)
+    except Exception as e:
+        env._program_info = {"signature": sig, "error": str(e), "mode": mode}

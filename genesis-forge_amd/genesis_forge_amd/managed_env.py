@@ -78,6 +78,11 @@ class ManagedEnvironment(GenesisEnv):
         self._last_images = None  # descriptor images of the previous recorded ordinary step (Genesis-shaped scene)
         self._untraceable: Optional[str] = None   # why the last attempt to record the step was refused
         self._no_trace_epoch = -1
+        self._program_pending = None   # a static program of this config being compiled in a child process (_programs.Pending)
+        self._program_info: Optional[dict] = None   # what became of it: signature, plugin path, compile seconds (or the error)
+        #: "off" / "sync" / "async": compile a static program of the fused post-physics kernel for this config's structure when no
+        #: built-in one matches (None: by size, see _programs.mode_for; GF_JIT overrides)
+        self.jit_programs: Optional[str] = None
         self._done_ids = None     # the index list of this step's done envs while a user reset() override holds it (reset() recognises it)
         self._tail_trace = None   # the recorded step whose Python tail is running (its reset / observation segments replay natively)
         #: record the step and replay it through gf_run_ops when possible (see _trace.py); GF_NO_TRACE=1 disables
@@ -167,6 +172,8 @@ class ManagedEnvironment(GenesisEnv):
         if tr is not None:
             if tr.epoch == self._trace_epoch and not self._draws:
                 if tr.fresh():
+                    if self._program_pending is not None and self._program_pending.poll():
+                        self._program_pending = None   # the config's own static program is registered: the next launch matches it
                     return tr.replay(actions)
                 tr = None
                 self.invalidate_trace()  # a manager method called between steps went through one of its descriptors
@@ -189,6 +196,9 @@ class ManagedEnvironment(GenesisEnv):
             if sig == self._last_signature and _trace.traceable(self, rec.tail_python):
                 try:
                     self._trace = _trace.StepTrace(self, rec.calls, rec.tail_python, rec.tail, images=(self._last_images, rec.images))
+                    if self._trace.post_refs is not None:
+                        from . import _programs
+                        _programs.on_recorded(self)   # a config no built-in program matches gets its own (GF_JIT, _programs.py)
                 except _trace.Untraceable as why:
                     self._untraceable, self._no_trace_epoch = str(why), self._trace_epoch
             self._last_signature = sig

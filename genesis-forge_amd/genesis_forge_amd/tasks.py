@@ -517,5 +517,8 @@ BASELINE_CONFIGS = {
     # berkeley_humanoid example, "humanoid" above, has 12 actuated joints)
     "humanoid28": (8192, lambda n, **kw: HumanoidGaitLikeEnv(num_envs=n, dofs=28, **kw)),
     "gait": (65536, lambda n, **kw: Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.001), **kw)),
+    # a USER's config: the Go2 task with observation noise — a structure none of the library's built-in programs has, so its fused
+    # launch runs the program compiled for it at run time (genesis_forge_amd/_programs.py; GF_JIT) instead of the interpreter
+    "go2_user": (65536, lambda n, **kw: bench_env(n, obs_noise=True, **kw)),
     "gait_8192": (8192, lambda n, **kw: Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.001), **kw)),
 }

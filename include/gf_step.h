@@ -704,6 +704,18 @@ int gf_post_physics_step(const GfPostRefs* r, void* stream);  /* replaces manage
  * gf_post_physics_step would launch (id 0 = table interpreter, >0 = a static program compiled for exactly this
  * structure) and the signature in the notation of csrc/gf_post_programs.h.  Host-only, no GPU needed. */
 int gf_post_physics_describe(const GfPostRefs* r, char* buf, int cap);
+/* Static programs for configs the library was not built with.  The reference's configs are live Python dicts
+ * (managers/config/config_item.py:31-44; reward_manager.py:166-195 walks whatever the dict holds), so a user's task is not
+ * one of the compiled-in structures; it would run the table interpreter (about 1.3 x the kernel time).  Instead the host
+ * generates the program struct of the recorded step's signature (gf_post_physics_describe), compiles csrc/gf_post_ws.h with it
+ * for gfx950 into a small shared object (hipcc, a few seconds, cached by signature; genesis_forge_amd/_programs.py) and
+ * registers it here: from then on gf_post_physics_step launches the plugin's post_ws_kernel<Program> for every descriptor
+ * that matches it — ids from 100 upwards in gf_post_physics_describe.  Structure only: weights, parameters, ranges, scales
+ * stay run-time kernel arguments, a config whose STRUCTURE changes simply stops matching (interpreter until its own program is
+ * there).  The plugin exports gfp_abi_version / gfp_args_size (checked against this library: GF_E_UNSUPPORTED on a mismatch or
+ * an unloadable file) / gfp_name / gfp_matches / gfp_kernel / gfp_lds_bytes.  Append-only, at most 64, thread-safe. */
+int gf_post_program_register(const char* plugin_path, int* program_id_out);
+int gf_post_program_count(void);
 
 /* ------------------------------------------------------------------------------------------
  * Recorded step: the fixed launch sequence of one ManagedEnvironment.step() replayed with a single

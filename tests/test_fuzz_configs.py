@@ -197,6 +197,7 @@ def _run(seed, dev, steps=STEPS):
             state[f"contacts_{len([k for k in state if k.startswith('contacts_')])}"] = cm.contacts
         out.append(({k: f(v) for k, v in state.items()}, {k: float(v) for k, v in extras["episode"].items()}))
     info = {"n": n, "recorded": env._trace is not None, "fused": bool(env._trace is not None and env._trace.post_refs is not None),
+            "program": env._program_info, "post_refs": env._trace.post_refs if env._trace is not None else None, "env": env,
             "user_term": env.has_user_term, "user_obs": env.has_user_obs, "third_obs": env.third_obs, "overrides_reset": env.overrides_reset}
     return out, info
 

@@ -1,0 +1,136 @@
+"""Static programs compiled at run time (genesis_forge_amd/_programs.py, gf_post_program_register): a config the library was not
+built with gets post_ws_kernel<its own structure> instead of the table interpreter.
+
+The signature of a recorded step comes from gf_post_physics_describe, which is host-only — so the whole chain up to the launch
+(signature → generated source → hipcc for gfx950 → dlopen → matcher) is tested without a GPU, for every fuzz config; the GPU leg
+runs the compiled kernels against the oracle."""
+import concurrent.futures
+import os
+import re
+
+import pytest
+import torch
+
+import test_fuzz_configs as fz
+from genesis_forge_amd import _native as nat
+from genesis_forge_amd import _programs
+from helpers import FLOAT_TOL
+
+FUSED_SEEDS = None   # filled by signatures(): the fuzz seeds whose recorded step has a fused post-physics launch
+
+
+def _host_describe(refs) -> str:
+    """gf_post_physics_describe through the HIP library — no launch, no GPU: packing a descriptor is host work."""
+    hip = _host_describe.hip = getattr(_host_describe, "hip", None) or nat.HipBackend()
+    return hip.post_describe(refs)
+
+
+@pytest.fixture(scope="session")
+def signatures(oracle_lib_path):
+    """{seed: signature} of every fuzz config's fused launch, from 4 steps on the CPU oracle; and the plugins of all of them,
+    compiled in parallel (≈ 5 s each, one hipcc per core) unless the cache already holds them."""
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+
+    if _programs.hipcc() is None:
+        pytest.skip("no hipcc")
+    old_dev, old_backend = gs.device, nat._backend
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(oracle_lib_path))
+    os.environ["GF_JIT"] = "off"
+    sigs = {}
+    try:
+        for seed in fz.SEEDS:
+            _out, info = fz._run(seed, "cpu", steps=4)
+            if info["fused"]:
+                sigs[seed] = _host_describe(info["post_refs"])
+    finally:
+        del os.environ["GF_JIT"]
+        nat.set_backend(old_backend)
+        gs.device = old_dev
+    todo = {}
+    for seed, sig in sigs.items():
+        if sig.startswith("program 0 "):
+            todo.setdefault(_programs.plugin_paths(sig)[2], sig)
+    missing = [sig for so, sig in todo.items() if not os.path.exists(so)]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        times = list(pool.map(lambda sig: _programs.compile_sync(sig)[1], missing))
+    sigs["_compile_seconds"] = times
+    return sigs
+
+
+def test_every_fuzz_config_gets_a_program_without_a_gpu(signatures):
+    """signature → source → hipcc (gfx950) → dlopen → the library's matcher picks the plugin for exactly that descriptor."""
+    hip = nat.HipBackend()   # loads the library; nothing is launched
+    seeds = [s for s in signatures if isinstance(s, int)]
+    assert len(seeds) >= 20
+    ids = {}
+    for seed in seeds:
+        sig = signatures[seed]
+        if not sig.startswith("program 0 "):
+            continue   # one of the library's built-in structures
+        so = _programs.plugin_paths(sig)[2]
+        assert os.path.exists(so), f"seed {seed}: plugin was not built"
+        ids[seed] = hip.register_program(so)
+        assert ids[seed] >= 100
+    assert len(ids) >= 20, "the fuzz configs should not match built-in programs"
+    # every config now selects ITS program (not the interpreter, not another config's): re-run 4 steps on the oracle for the
+    # descriptors and ask the library which kernel it would launch
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+
+    old_dev, old_backend = gs.device, nat._backend
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libgf_oracle.so")))
+    os.environ["GF_JIT"] = "off"
+    try:
+        for seed in list(ids)[:6]:
+            _out, info = fz._run(seed, "cpu", steps=4)
+            now = hip.post_describe(info["post_refs"])
+            m = re.match(r"program (\d+) \((jit_[0-9a-f]+)\)", now)
+            assert m and int(m.group(1)) == ids[seed], f"seed {seed}: {now[:80]}"
+            assert now.split(": ", 1)[1] == signatures[seed].split(": ", 1)[1]
+    finally:
+        del os.environ["GF_JIT"]
+        nat.set_backend(old_backend)
+        gs.device = old_dev
+    t = signatures["_compile_seconds"]
+    if t:
+        print(f"compiled {len(t)} programs, {min(t):.1f} … {max(t):.1f} s each (in parallel)")
+
+
+def test_a_stale_or_foreign_plugin_is_refused(tmp_path):
+    hip = nat.HipBackend()
+    bogus = tmp_path / "gfp_bogus.so"
+    bogus.write_bytes(b"not an ELF file")
+    with pytest.raises(nat.GfError, match="GF_E_UNSUPPORTED"):
+        hip.register_program(str(bogus))
+    with pytest.raises(nat.GfError, match="GF_E_UNSUPPORTED"):
+        hip.register_program(nat.lib_path())   # a shared object without the gfp_* exports
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [s for s in fz.SEEDS])
+def test_compiled_program_equals_oracle_hip(hip_backend, oracle_lib_path, signatures, seed, monkeypatch):
+    """-m gpu: the fuzz config runs on ITS compiled program (GF_JIT=sync; the fixture has filled the cache) and equals the oracle."""
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+
+    if seed not in signatures:
+        pytest.skip("this config's step has no fused post-physics launch (reset() override)")
+    monkeypatch.setenv("GF_JIT", "sync")
+    hip, info = fz._run(seed, "cuda")
+    torch.cuda.synchronize()
+    if signatures[seed].startswith("program 0 "):
+        assert info["program"] is not None and "plugin" in info["program"], info["program"]
+        now = hip_backend.post_describe(info["post_refs"])
+        assert re.match(r"program 1\d\d \(jit_", now), now[:60]
+    monkeypatch.setenv("GF_JIT", "off")
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(oracle_lib_path))
+    try:
+        ref, _ = fz._run(seed, "cpu")
+    finally:
+        nat.set_backend(None)
+        gs.set_device("cuda:0")
+    fz._compare(hip, ref, FLOAT_TOL, f"seed {seed} compiled program")

@@ -76,28 +76,38 @@ def main():
         dt = time.perf_counter() - t0
         log = dict(env.extras["episode"])
         tr = env._trace
+        info = getattr(env, "_program_info", None) or {}
+        try:
+            post_kernel = env.backend.post_describe(tr.post_refs).split(":")[0] if tr is not None and tr.post_refs is not None else None
+        except Exception:
+            post_kernel = None
         row = {"config": name, "scene": args.scene, "num_envs": n, "us_per_step": dt / args.steps * 1e6, "env_steps_per_s": n * args.steps / dt,
                "recorded": tr is not None, "fused_post": bool(tr is not None and tr.post_refs is not None),
                "ops_per_step": tr.n_ops if tr is not None else None,
-               "resets_last_step_frac": sum(float(v) for k, v in log.items() if k.startswith("Terminations /"))}
+               "resets_last_step_frac": sum(float(v) for k, v in log.items() if k.startswith("Terminations /")),
+               "post_kernel": post_kernel, "jit_compile_s": info.get("compile_s"), "jit_error": info.get("error")}
         if scene_cls is not None:
             row["why_not_recorded"] = env._untraceable
             ad = env._adapter
             plan = tr.scene_plan if tr is not None else ad.plan()
             row["getters_per_tick"] = len(plan)
-            # the double's own cost: what a tick costs before any manager work — control_dofs_position + scene.step() + every getter
-            # of the plan once + the nonzero() the envs_idx setters force (synchronising like the step does)
+            # the L0 share: what a tick costs on the simulator's side of the boundary, with no manager work at all —
+            # control_dofs_position + scene.step() + every getter of the plan once + the nonzero() its envs_idx setters force
+            # (synchronising, as in the step) + those setters for the done envs (the masks of the last timed step, every tick).
+            # On real Genesis each of these calls is a Taichi kernel plus a tensor conversion; here each is one torch op.
             am, tm = env.managers["action"], env.managers["termination"]
+            m1, m2 = tm._terminated_buf.clone(), tm._truncated_buf.clone()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(args.steps):
                 env.robot.control_dofs_position(am._actions, am.dofs_idx)
                 env.scene.step()
-                held = [f() for _k, f in plan]
-                (tm._terminated_buf | tm._truncated_buf).nonzero()
+                ad.refetch(plan)
+                ad.push_done(m1, m2)
             torch.cuda.synchronize()
-            row["scene_double_us_per_tick"] = (time.perf_counter() - t0) / args.steps * 1e6
-            row["manager_us_per_step"] = row["us_per_step"] - row["scene_double_us_per_tick"]
+            row["l0_us_per_tick"] = (time.perf_counter() - t0) / args.steps * 1e6
+            row["done_envs_in_l0_loop"] = int((m1 | m2).sum())
+            row["manager_us_per_step"] = row["us_per_step"] - row["l0_us_per_tick"]
         print(json.dumps(row), flush=True)
         del env
 

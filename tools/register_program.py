@@ -37,45 +37,7 @@ def describe(make_env, n):
     return env.backend.post_describe(tr.post_refs)
 
 
-def parse(sig: str) -> dict:
-    body = sig.split(": ", 1)[1]
-    g = lambda pat: re.search(pat, body)
-    out = {"DV": int(g(r"DV = (\d+)").group(1)), "n_term": int(g(r"n_term = (\d+)").group(1)), "n_rew": int(g(r"n_rew = (-?\d+)").group(1)),
-           "n_cmd": int(g(r"n_cmd = (\d+)").group(1)), "n_obs": int(g(r"n_obs = (\d+)").group(1)), "n_air": int(g(r"n_air = (\d+)").group(1)),
-           "n_gait": int(g(r"n_gait = (\d+)").group(1))}
-    out["term"] = g(r"term = (\{.*?\}); n_rew").group(1)
-    out["rew"] = g(r"rew = (\{.*?\}); n_cmd").group(1)
-    out["cmd_width"] = [int(x) for x in re.findall(r"\d+", g(r"cmd_width = \{(.*?)\}").group(1))]
-    out["obs"] = [(int(w), int(h), items) for w, h, items in re.findall(r"obs\[\d+\]: width (\d+) history (\d+) items (\{.*?\});", body)]
-    return out
-
-
-def struct_text(p: dict, name: str, cls: str, comment: str) -> str:
-    pad = lambda xs, n: ", ".join(str(x) for x in (list(xs) + [0] * n)[:n])
-    items = ",\n".join("        " + (it if it != "{}" else "{}") for it in [o[2] for o in p["obs"]] + ["{}"] * (2 - len(p["obs"])))
-    arr = lambda n: max(1, n)
-    return f'''
-// {comment}
-struct {cls} {{
-    static constexpr bool kStatic = true;
-    static constexpr const char* name = "{name}";
-    static constexpr int DV = {p["DV"]};
-    static constexpr int n_term = {p["n_term"]};
-    static constexpr TermSig term[{arr(p["n_term"])}] = {p["term"] if p["n_term"] else "{}"};
-    static constexpr int n_rew = {p["n_rew"]};
-    static constexpr RewSig rew[{arr(p["n_rew"])}] = {p["rew"] if p["n_rew"] > 0 else "{}"};
-    static constexpr int n_cmd = {p["n_cmd"]};
-    static constexpr int cmd_width[GF_POST_MAX_CMD] = {{{pad(p["cmd_width"], 2)}}};
-    static constexpr int n_obs = {p["n_obs"]};
-    static constexpr int obs_width[GF_POST_MAX_OBS] = {{{pad([o[0] for o in p["obs"]], 2)}}};
-    static constexpr int obs_history[GF_POST_MAX_OBS] = {{{pad([o[1] for o in p["obs"]], 2)}}};
-    static constexpr int obs_items[GF_POST_MAX_OBS] = {{{pad([o[2].count("{") - 1 for o in p["obs"]], 2)}}};
-    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {{
-{items}}};
-    static constexpr int n_air = {p["n_air"]};
-    static constexpr int n_gait = {p["n_gait"]};
-}};
-'''
+from genesis_forge_amd._programs import parse, struct_text  # noqa: E402  (the generator the run-time compiler uses too)
 
 
 def main():
