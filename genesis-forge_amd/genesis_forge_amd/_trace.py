@@ -193,6 +193,16 @@ class StepTrace:
             for (a0, a1), pre in zip(zip(cuts[:-1], cuts[1:]), pres):
                 sub = (nat.GfOp * (a1 - a0)).from_buffer(self.ops, a0 * C.sizeof(nat.GfOp)) if a1 > a0 else None
                 self.segments.append((a0, a1 - a0, sub, pre))
+            # fewer native calls: the patch table and the ops in front of the first split go out together, and on a Genesis-shaped
+            # scene the ops behind the scene split ride on the call that patches the snapshot's addresses (_scene_pre)
+            a0, cnt, sub, pre = self.segments[0]
+            if pre is None and cnt:
+                self.patch_desc = nat.GfReplay(C.addressof(self.ops), cnt, len(self.native), C.addressof(self.patch_table), C.addressof(env._rng_c))
+                self.segments[0] = (a0, 0, None, None)
+            for j, (a0, cnt, sub, pre) in enumerate(self.segments):
+                if cnt and self.adapter is not None and pre == self._scene_pre:
+                    self.scene_desc.ops, self.scene_desc.num_ops = C.addressof(self.ops) + a0 * C.sizeof(nat.GfOp), cnt
+                    self.segments[j] = (a0, 0, None, pre)
 
     def fresh(self) -> bool:
         """No descriptor of this recording has been used by a phase call outside its replay since it was made."""
