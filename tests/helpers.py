@@ -26,8 +26,8 @@ def set_step_draws(env, seed, step, n, n_ranges, obs_width, dev):
     })
 
 
-def replay_trajectory(fix, dev="cpu", steps=None):
-    """Drive the package's env with a golden fixture's actions/draws; returns per-step outputs like the fixture's."""
+def _trajectory_env(fix):
+    """The package's env a trajectory fixture describes (built); returns (env, n, seed, frame width, history)."""
     from envs import Go2CommandDirectionEnv, Go2RoughTerrainEnv
 
     n, seed = int(fix["n"]), int(fix["seed"])
@@ -42,6 +42,12 @@ def replay_trajectory(fix, dev="cpu", steps=None):
                                      contacts=contacts, history=history if history > 1 else None, cmd_resample_s=float(fix["cmd_resample_s"]))
     env.build()
     frame = fix["obs"].shape[-1] // history
+    return env, n, seed, frame, history
+
+
+def replay_trajectory(fix, dev="cpu", steps=None):
+    """Drive the package's env with a golden fixture's actions/draws; returns per-step outputs like the fixture's."""
+    env, n, seed, frame, history = _trajectory_env(fix)
     set_step_draws(env, seed, 0, n, 3, frame, dev)
     obs0, _ = env.reset()
     obs0 = obs0.cpu().numpy().copy()  # the returned tensor is a ring slot, reused two calls later
@@ -181,3 +187,111 @@ def compare_example(fix, res, tol=FLOAT_TOL):
         assert set(got) == set(want), f"log keys differ at step {t}: {sorted(got)} vs {sorted(want)}"
         for k in want:
             assert abs(got[k] - want[k]) <= 1e-5 + 1e-5 * abs(want[k]), f"log {k} at step {t}: {got[k]} vs {want[k]}"
+
+
+# ----------------------------------------------------------------------------------------------------
+# The reference at the sizes that get timed (tools/gen_golden.py at_size; fixtures atsize_go2_<n>.npz)
+# ----------------------------------------------------------------------------------------------------
+AT_SIZE_SAMPLE = 64   # envs of the strided sample a compact fixture keeps
+
+
+def at_size_sample(n):
+    return np.arange(AT_SIZE_SAMPLE, dtype=np.int64) * (n // AT_SIZE_SAMPLE) + (n // AT_SIZE_SAMPLE) // 2
+
+
+def at_size_actions(n, steps):
+    """The action stream of tools/gen_golden.py run_trajectory (not stored in the compact fixtures: 63 MB at 65 536 envs)."""
+    rng = np.random.RandomState(7)
+    acts = []
+    for t in range(steps):
+        act = rng.standard_normal((n, 12)).astype(np.float32)
+        if t == 5:
+            act[0, 0] = 1e9  # clip path
+        acts.append(act)
+    return np.stack(acts)
+
+
+def compact_at_size(out, n):
+    """What of an at-size trajectory travels to the GPU box: per-step mask popcounts, sums and sums of squares of reward,
+    observation and command (f64), integer sums of the episode counters, the per-step logs, and every output for a strided sample
+    of 64 envs.  Applied to the reference's trajectory by the generator and to the package's by the tests."""
+    idx = at_size_sample(n)
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    c = {"n": np.int64(n), "sample": idx, "obs0_sample": out["obs0"][idx], "obs0_sum": f64(out["obs0"]).sum()}
+    for k in ("obs", "reward", "command"):
+        a = f64(out[k]).reshape(out[k].shape[0], -1)
+        c[k + "_sum"], c[k + "_sumsq"] = a.sum(axis=1), (a * a).sum(axis=1)
+        c[k + "_sample"] = out[k][:, idx]
+    for k in ("terminated", "truncated"):
+        c[k + "_count"] = out[k].reshape(out[k].shape[0], -1).sum(axis=1).astype(np.int64)
+        c[k + "_sample"] = out[k][:, idx]
+    for k in ("episode_length", "max_episode_length"):
+        c[k + "_sum"] = out[k].astype(np.int64).sum(axis=1)
+        c[k + "_sample"] = out[k][:, idx]
+    for k in ("log_keys", "log_values", "seed", "steps", "contacts", "history", "episode_s", "cmd_resample_s", "scene_kwargs", "variant", "rotation"):
+        if k in out:
+            c[k] = out[k]
+    return c
+
+
+def replay_at_size(fix, dev="cpu"):
+    """Run the package on a compact at-size fixture's inputs (regenerated actions, Philox draws) and compact its outputs the same
+    way — streaming: per step only the sums and the sampled rows are kept (the full trajectory at 65 536 envs is 0.5 GB)."""
+    n, steps = int(fix["n"]), int(fix["steps"])
+    full = {k: fix[k] for k in ("n", "seed", "contacts", "history", "scene_kwargs", "variant", "episode_s", "cmd_resample_s", "steps", "rotation")}
+    full["obs"] = np.empty((0, fix["obs_sample"].shape[-1]), dtype=np.float32)   # (the frame width is read off it)
+    env, n, seed, frame, history = _trajectory_env(full)
+    idx = torch.from_numpy(at_size_sample(n)).to(dev)
+    set_step_draws(env, seed, 0, n, 3, frame, dev)
+    obs0, _ = env.reset()
+    c = {"n": np.int64(n), "obs0_sample": obs0[idx].cpu().numpy().copy(), "obs0_sum": float(obs0.double().sum())}
+    rec: dict = {}
+    logs = []
+    rng = np.random.RandomState(7)   # at_size_actions(), one step at a time
+    for t in range(steps):
+        act = rng.standard_normal((n, 12)).astype(np.float32)
+        if t == 5:
+            act[0, 0] = 1e9
+        set_step_draws(env, seed, t + 1, n, 3, frame, dev)
+        obs, rew, term, trunc, extras = env.step(torch.from_numpy(act).to(dev))
+        vals = {"obs": obs, "reward": rew, "command": env.velocity_command._command}
+        for k, v in vals.items():
+            d = v.double()
+            rec.setdefault(k + "_sum", []).append(float(d.sum()))
+            rec.setdefault(k + "_sumsq", []).append(float((d * d).sum()))
+            rec.setdefault(k + "_sample", []).append(v[idx].cpu().numpy().copy())
+        for k, v in (("terminated", term), ("truncated", trunc)):
+            rec.setdefault(k + "_count", []).append(int(v.sum()))
+            rec.setdefault(k + "_sample", []).append(v[idx].cpu().numpy().copy())
+        for k, v in (("episode_length", env.episode_length), ("max_episode_length", env.max_episode_length)):
+            rec.setdefault(k + "_sum", []).append(int(v.long().sum()))
+            rec.setdefault(k + "_sample", []).append(v[idx].cpu().numpy().copy())
+        logs.append({k: float(v) for k, v in extras["episode"].items()})
+    for k, v in rec.items():
+        c[k] = np.stack(v) if k.endswith("_sample") else np.asarray(v)
+    return c, logs
+
+
+def compare_at_size(fix, got, logs, tol=FLOAT_TOL):
+    n, T = int(fix["n"]), int(fix["steps"])
+    np.testing.assert_allclose(got["obs0_sample"], fix["obs0_sample"], atol=tol, rtol=0)
+    for k in ("terminated", "truncated"):
+        assert np.array_equal(got[k + "_count"], fix[k + "_count"]), f"{k}: popcount per step differs: {got[k + '_count']} vs {fix[k + '_count']}"
+        assert np.array_equal(got[k + "_sample"], fix[k + "_sample"]), f"{k}: sampled envs differ"
+    for k in ("episode_length", "max_episode_length"):
+        assert np.array_equal(got[k + "_sum"], fix[k + "_sum"]), f"{k}: per-step integer sum differs"
+        assert np.array_equal(got[k + "_sample"], fix[k + "_sample"]), f"{k}: sampled envs differ"
+    for k in ("obs", "reward", "command"):
+        np.testing.assert_allclose(got[k + "_sample"], fix[k + "_sample"], atol=tol, rtol=0, err_msg=f"{k}: sampled envs")
+        width = fix[k + "_sample"].reshape(T, AT_SIZE_SAMPLE, -1).shape[-1]
+        # N*width values per step, each within tol of the reference's: the f64 sums agree to N*width*tol, the sums of squares to
+        # 2*max|x|*tol per value (|x| <= 1e9 only for the one clipped action at step 5, which no output carries)
+        np.testing.assert_allclose(got[k + "_sum"], fix[k + "_sum"], atol=n * width * tol, rtol=0, err_msg=f"{k}: sum over all envs")
+        scale = 2.0 * float(np.abs(fix[k + "_sample"]).max() + 1.0) * 4.0
+        np.testing.assert_allclose(got[k + "_sumsq"], fix[k + "_sumsq"], atol=n * width * tol * scale, rtol=0, err_msg=f"{k}: sum of squares over all envs")
+    keys = [str(k) for k in fix["log_keys"]]
+    for t in range(T):
+        want = {k: fix["log_values"][t, j] for j, k in enumerate(keys) if not np.isnan(fix["log_values"][t, j])}
+        assert set(logs[t]) == set(want), f"log keys differ at step {t}"
+        for k in want:
+            assert abs(logs[t][k] - want[k]) <= 1e-5 + 1e-5 * abs(want[k]), f"log {k} at step {t}: {logs[t][k]} vs {want[k]}"

@@ -23,14 +23,19 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def uniform(seed: int, stream: int, n_env: int, n_col: int) -> np.ndarray:
-    """[n_env, n_col] float32 U[0,1): element (e, c) == philox_uniform(seed, stream, e, c) of the C/HIP code."""
-    env = np.arange(n_env, dtype=np.uint32)[:, None]
-    col = np.arange(n_col, dtype=np.uint32)[None, :]
-    x = philox4x32_10(env, col >> np.uint32(2), np.uint32(stream & 0xFFFFFFFF), np.uint32((stream >> 32) & 0xFFFFFFFF),
-                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    sel = np.broadcast_to(col & np.uint32(3), x[0].shape)
-    v = np.choose(sel, x)
-    return ((v >> np.uint32(8)).astype(np.float32) * np.float32(5.9604644775390625e-8)).astype(np.float32)
+    """[n_env, n_col] float32 U[0,1): element (e, c) == philox_uniform(seed, stream, e, c) of the C/HIP code — word c & 3 of the
+    block with counter (e, c >> 2, stream).  One block per FOUR columns (not one per column), in chunks of 8 192 envs so the u64
+    temporaries stay in cache: 65 536 x 96 draws take 0.3 s instead of 4."""
+    groups = (n_col + 3) // 4
+    out = np.empty((n_env, groups * 4), dtype=np.float32)
+    grp = np.arange(groups, dtype=np.uint32)[None, :]
+    for e0 in range(0, n_env, 8192):
+        env = np.arange(e0, min(e0 + 8192, n_env), dtype=np.uint32)[:, None]
+        x = philox4x32_10(env, grp, np.uint32(stream & 0xFFFFFFFF), np.uint32((stream >> 32) & 0xFFFFFFFF),
+                          seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        v = np.stack(x, axis=-1).reshape(env.shape[0], groups * 4)
+        out[e0:e0 + env.shape[0]] = (v >> np.uint32(8)).astype(np.float32) * np.float32(5.9604644775390625e-8)
+    return np.ascontiguousarray(out[:, :n_col])
 
 
 def draws(seed: int, step: int, kind: int, n_env: int, n_col: int) -> np.ndarray:

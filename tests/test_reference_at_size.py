@@ -1,0 +1,49 @@
+"""The reference at the sizes that get timed.
+
+Every other reference-derived fixture holds at most 130 envs; above that the comparisons were HIP against the oracle, both
+behind the same host logic.  Two legs close the chain (missing #4):
+
+* container only (``/root/reference`` present): the reference's own ``ManagedEnvironment.step`` (managed_env.py:274-334, imported
+  under the stubs of tools/ref_stubs.py) at 4 096 and 65 536 envs for 20 steps against this package on the CPU oracle — the same
+  actions, the same Philox draws, EVERY env of every step, no fixture file in between (``tools/gen_golden.py check_at_size``, run
+  in a child process: the stubs patch ``torch.Tensor.uniform_`` and install fake ``genesis`` modules);
+* everywhere: compact fixtures recorded from the same reference runs (``tools/gen_golden.py at_size``; per-step mask popcounts,
+  f64 sums and sums of squares of reward / observation / command over ALL envs, integer sums of the episode counters, the logged
+  scalars, and all outputs of a strided 64-env sample) against the oracle (CPU) and against the HIP kernels (``-m gpu``) at
+  4 096 and 65 536 envs.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_REFERENCE = os.path.isdir("/root/reference/genesis_forge")
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="the reference only exists in the build container")
+@pytest.mark.parametrize("n", [4096, 65536])
+def test_reference_itself_equals_package_at_size(n, oracle_lib_path):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden.py"), "check_at_size", str(n)],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, GF_DEVICE="cpu"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert f"reference == package (oracle backend) at {n} envs" in p.stdout
+
+
+@pytest.mark.parametrize("n", [4096, 65536])
+def test_at_size_fixture_oracle(oracle_backend, n):
+    fix = helpers.load(f"atsize_go2_{n}")
+    got, logs = helpers.replay_at_size(fix, dev="cpu")
+    helpers.compare_at_size(fix, got, logs)
+    assert int(fix["terminated_count"].sum() + fix["truncated_count"].sum()) > n // 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4096, 65536])
+def test_at_size_fixture_hip(hip_backend, n):
+    fix = helpers.load(f"atsize_go2_{n}")
+    got, logs = helpers.replay_at_size(fix, dev="cuda")
+    helpers.compare_at_size(fix, got, logs)

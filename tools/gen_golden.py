@@ -351,7 +351,7 @@ def episode_scalars(extras):
     return {k: float(v) for k, v in extras["episode"].items()}
 
 
-def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2, variant="cmd", rotation="default"):
+def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2, variant="cmd", rotation="default", save=True):
     torch.manual_seed(0)
     if variant == "rough":
         env = RefGo2RoughEnv(n, episode_s=episode_s, scene_kwargs=scene_kwargs, rotation=rotation)
@@ -394,9 +394,86 @@ def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2,
                steps=np.int64(steps), contacts=np.int64(contacts), history=np.int64(history or 1), episode_s=np.float64(episode_s),
                cmd_resample_s=np.float64(CMD_RESAMPLE_S), scene_kwargs=np.array(repr(scene_kwargs)), variant=np.array(variant),
                rotation=np.array(repr(rotation)))
-    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    if save:
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     print(name, "steps", steps, "terminated", int(out["terminated"].sum()), "truncated", int(out["truncated"].sum()),
           "log keys", len(keys))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# The reference at the sizes that get timed: every other fixture is <= 130 envs
+# ------------------------------------------------------------------------------------------------
+AT_SIZE = {"steps": 20, "episode_s": 0.3, "cmd_resample_s": 0.2, "contacts": False, "history": 2,
+           "scene_kwargs": dict(ang_noise=0.35, lin_noise=0.05, seed=17, contact_prob=0.3, contact_force=30.0)}
+def run_reference_at_size(n):
+    """The reference's own ManagedEnvironment.step (managed_env.py:274-334) at n envs — in memory, no file."""
+    global CMD_RESAMPLE_S
+    keep, CMD_RESAMPLE_S = CMD_RESAMPLE_S, AT_SIZE["cmd_resample_s"]
+    try:
+        return run_trajectory(f"atsize_go2_{n}", n=n, steps=AT_SIZE["steps"], contacts=AT_SIZE["contacts"], history=AT_SIZE["history"],
+                              scene_kwargs=AT_SIZE["scene_kwargs"], episode_s=AT_SIZE["episode_s"], save=False)
+    finally:
+        CMD_RESAMPLE_S = keep
+
+
+def gen_at_size():
+    """Compact, reference-derived fixtures for the GPU box (tests/helpers.py: compact_at_size says what they hold)."""
+    import helpers
+    for n in (4096, 65536):
+        out = run_reference_at_size(n)
+        assert np.array_equal(out["actions"], helpers.at_size_actions(n, int(out["steps"]))), "the tests regenerate the actions from the same stream"
+        np.savez_compressed(os.path.join(GOLD, f"atsize_go2_{n}.npz"), **helpers.compact_at_size(out, n))
+
+
+def check_at_size(n):
+    """Container only: the reference itself at n envs against this package on the CPU oracle — the same actions, the same draws,
+    every env of every step, compared in lockstep (nothing is stored: a 65 536-env trajectory is 0.5 GB)."""
+    import helpers
+    global CMD_RESAMPLE_S
+    keep, CMD_RESAMPLE_S = CMD_RESAMPLE_S, AT_SIZE["cmd_resample_s"]
+    try:
+        torch.manual_seed(0)
+        ref_env = RefGo2Env(n, episode_s=AT_SIZE["episode_s"], scene_kwargs=AT_SIZE["scene_kwargs"], contacts=AT_SIZE["contacts"],
+                            history=AT_SIZE["history"])
+        width = (48 + (4 if AT_SIZE["contacts"] else 0)) * (AT_SIZE["history"] or 1)
+        draws = Draws(n, 3, width)
+        install_contexts(ref_env, draws)
+        draws.step = 0
+        ref_env.build()
+        meta = dict(n=n, seed=SEED, contacts=int(AT_SIZE["contacts"]), history=AT_SIZE["history"] or 1, scene_kwargs=repr(AT_SIZE["scene_kwargs"]),
+                    variant="cmd", episode_s=AT_SIZE["episode_s"], cmd_resample_s=AT_SIZE["cmd_resample_s"], obs=np.empty((0, width), dtype=np.float32))
+        env, _n, seed, frame, _h = helpers._trajectory_env(meta)
+    finally:
+        CMD_RESAMPLE_S = keep
+    tol = helpers.FLOAT_TOL
+    helpers.set_step_draws(env, seed, 0, n, 3, frame, "cpu")
+    a0, _ = ref_env.reset()
+    b0, _ = env.reset()
+    np.testing.assert_allclose(b0.numpy(), a0.numpy(), atol=tol, rtol=0)
+    rng = np.random.RandomState(7)
+    dones = 0
+    for t in range(AT_SIZE["steps"]):
+        draws.step = t + 1
+        act = rng.standard_normal((n, 12)).astype(np.float32)
+        if t == 5:
+            act[0, 0] = 1e9
+        helpers.set_step_draws(env, seed, t + 1, n, 3, frame, "cpu")
+        ra = ref_env.step(torch.from_numpy(act))
+        rb = env.step(torch.from_numpy(act.copy()))
+        for name, x, y in (("terminated", ra[2], rb[2]), ("truncated", ra[3], rb[3]), ("episode_length", ref_env.episode_length, env.episode_length),
+                           ("max_episode_length", ref_env.max_episode_length, env.max_episode_length)):
+            assert np.array_equal(x.numpy(), y.numpy()), f"{name} differs at step {t}"
+        for name, x, y in (("obs", ra[0], rb[0]), ("reward", ra[1], rb[1]), ("command", ref_env.velocity_command._command, env.velocity_command._command),
+                           ("pos", ref_env.robot.get_pos(), env.robot.get_pos()), ("quat", ref_env.robot.get_quat(), env.robot.get_quat())):
+            np.testing.assert_allclose(y.numpy(), x.numpy(), atol=tol, rtol=0, err_msg=f"{name} step {t}")
+        la, lb = episode_scalars(ra[4]), {k: float(v) for k, v in rb[4]["episode"].items()}
+        assert set(la) == set(lb), f"log keys differ at step {t}: {sorted(la)} vs {sorted(lb)}"
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 1e-5 + 1e-5 * abs(la[k]), f"log {k} at step {t}: {lb[k]} vs {la[k]}"
+        dones += int(ra[2].sum() + ra[3].sum())
+    assert dones > n // 10, f"only {dones} resets at {n} envs"
+    print(f"reference == package (oracle backend) at {n} envs x {AT_SIZE['steps']} steps, {dones} resets, every env compared")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -871,6 +948,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "contact_kernel":
         gen_contact_kernel()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "at_size":
+        gen_at_size()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "check_at_size":
+        check_at_size(int(sys.argv[2]))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "examples":
         import example_cases
