@@ -511,8 +511,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             const float secs_new = rew.secs_in + dt;
             float buf = 0.f;
             const bool log_reset = logging && done_mask != 0;
-            auto reward_body = [&](int k, const GfTerm& t) GF_INLINE_LAMBDA {
-                float v = eval_reward_term(t, a, rr);
+            auto fold_body = [&](int k, const GfTerm& t, float v) GF_INLINE_LAMBDA {
                 v = v * t.w;
                 buf += v;
                 if (logging) {
@@ -533,16 +532,36 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 }
             };
             if constexpr (P::kStatic) {
-                static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
+                // Two passes.  Terms that read contact rows, link velocities / positions or a gait row load them from memory HERE,
+                // behind the barrier; evaluated inside the fold, every such term waited for its own loads behind the previous term's
+                // sum store (a store the compiler must assume may alias the next term's loads) — a chain of round trips: 6.3 of the
+                // gait program's 18 µs at 8 192 envs (profiles/r02_c_gait_fused_attribution.txt).  Pass 1 computes every term's VALUE
+                // with no store in between, so all those loads go out back to back and are waited for once; the stateful term
+                // (body acceleration: it stores its state) goes last.  Pass 2 is the fold — the reference's order, the same
+                // arithmetic per term, so the results are bit-identical — with the sum / statistics stores.
+                float vals[P::n_rew > 0 ? P::n_rew : 1];
+                auto term_of = [&](auto K) GF_INLINE_LAMBDA {
                     constexpr int k_ = decltype(K)::value;
                     GfTerm t = karg.rterms[k_];
                     t.op = P::rew[k_].op; t.flags = P::rew[k_].flags; t.i[0] = P::rew[k_].i0; t.i[1] = P::rew[k_].i1;
-                    reward_body(k_, t);
+                    return t;
+                };
+                static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
+                    constexpr int k_ = decltype(K)::value;
+                    if constexpr (P::rew[k_].op != GF_R_BODY_ACCEL_EXP) vals[k_] = eval_reward_term(term_of(K), a, rr);
+                });
+                static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
+                    constexpr int k_ = decltype(K)::value;
+                    if constexpr (P::rew[k_].op == GF_R_BODY_ACCEL_EXP) vals[k_] = eval_reward_term(term_of(K), a, rr);
+                });
+                static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
+                    constexpr int k_ = decltype(K)::value;
+                    fold_body(k_, term_of(K), vals[k_]);
                 });
             } else {
                 for (int k = 0; k < n_rew; ++k) {
                     const GfTerm t = a.rterms[k];
-                    reward_body(k, t);
+                    fold_body(k, t, eval_reward_term(t, a, rr));
                 }
             }
             if (live) {

@@ -91,6 +91,10 @@ class ContactManager(BaseManager):
         self.link_pos = torch.zeros((N, L, 3), device=gs.device)  # world position of each tracked link, refreshed by step()
         self._has_link_vel = False
         self._has_link_pos = False
+        #: set by view(): some term reads this manager's link velocities / positions.  Only then does step() keep the compact
+        #: per-manager copy — the gait task's 9 thigh / calf / base links do not need one (24 B read + 24 B written per link and env)
+        self._want_link_vel = False
+        self._want_link_pos = False
         if self._track_air_time:
             self.last_air_time = torch.zeros((N, L), device=gs.device)
             self.current_air_time = torch.zeros_like(self.last_air_time)
@@ -166,8 +170,10 @@ class ContactManager(BaseManager):
         if lv is not None:
             lv = lv.to(torch.float32).contiguous()
             self._keep = self._keep + (lv,)
-            a.links_vel, a.link_vel_out = lv.data_ptr(), self.link_vel.data_ptr()
-            self._has_link_vel = True
+            # (the scene array is named in every manager's descriptor — managers that share the arrays share one launch — the copy
+            # only where a consumer exists)
+            a.links_vel, a.link_vel_out = lv.data_ptr(), (self.link_vel.data_ptr() if self._want_link_vel else None)
+            self._has_link_vel = self._want_link_vel
         else:
             a.links_vel = a.link_vel_out = None
             self._has_link_vel = False
@@ -177,8 +183,8 @@ class ContactManager(BaseManager):
         if lp is not None:
             lp = lp.to(torch.float32).contiguous()
             self._keep = self._keep + (lp,)
-            a.links_pos, a.link_pos_out = lp.data_ptr(), self.link_pos.data_ptr()
-            self._has_link_pos = True
+            a.links_pos, a.link_pos_out = lp.data_ptr(), (self.link_pos.data_ptr() if self._want_link_pos else None)
+            self._has_link_pos = self._want_link_pos
         else:
             a.links_pos = a.link_pos_out = None
             self._has_link_pos = False
@@ -199,6 +205,8 @@ class ContactManager(BaseManager):
         v.last_air_time = None if self.last_air_time is None else self.last_air_time.data_ptr()
         v.current_contact_time = None if self.current_contact_time is None else self.current_contact_time.data_ptr()
         keep = ()
+        self._want_link_vel = self._want_link_vel or need_link_vel   # from the next step() on the launch keeps a compact copy
+        self._want_link_pos = self._want_link_pos or need_link_pos
         if need_link_vel and self._has_link_vel:
             v.link_vel = self.link_vel.data_ptr()   # persistent, filled by gf_contact_step
         elif need_link_vel and self.env._adapter is not None:
