@@ -7,6 +7,11 @@ dependency and stays one; this module provides the two pieces of it that touch t
   storage with three ``copy_`` launches per step; attached to a ``ManagedEnvironment`` the step's own kernel stores the three
   rows (``gf_rollout_write`` phase by phase, the fused post-physics launch writes them from the tile it holds) — no extra
   launch, no re-read of the observation.
+  The policy's half of a transition (actions, value, log-probability, action mean / std — five more ``copy_`` launches in rsl_rl's
+  ``add_transitions``, after ``rewards += gamma * values * time_outs``) is one ``gf_rollout_policy_write`` launch
+  (``add_policy``), and the end-of-rollout return computation (rsl_rl ``compute_returns``: a backwards loop of eight
+  elementwise launches per step, then the advantage normalisation) is ``gf_gae`` (``compute_returns``): one lane per env
+  walks its T steps, rows are coalesced, the recurrence is the torch loop's arithmetic operation for operation.
 * :class:`GradientAllReduce` — the multi-GPU half: every rank owns a shard of envs and a replica of the policy; after
   ``backward()`` the gradients of all parameters are averaged with ONE all-reduce over a flat bucket (RCCL over xGMI on GPUs;
   the 512-256-128 actor + critic MLPs of the reference configs are 1.5 MB), overlapped with nothing because nothing follows
@@ -47,6 +52,12 @@ class RolloutStorage:
         self.step = 0            # transitions written in the current rollout
         self._args = nat.GfRolloutArgs()
         self._args.num_envs, self._args.obs_width = n, self.obs_width
+        # the policy's rows and the return computation (allocated on first use: a storage that only takes the env's rows stays small)
+        self.num_actions = None
+        self.actions = self.values = self.actions_log_prob = self.mu = self.sigma = self.returns = self.advantages = None
+        self._pol_args = nat.GfRolloutPolicyArgs()
+        self._gae_args = nat.GfGaeArgs()
+        self._moments = None
 
     @property
     def full(self) -> bool:
@@ -86,6 +97,58 @@ class RolloutStorage:
         self._next_rows(a)
         self._keep = (obs, reward, terminated, truncated)
         self.env.backend.call("rollout_write", a, owner=self)
+
+    # -- the policy's half of a transition, returns ---------------------------------------------------------------------------
+    def _ensure_policy_rows(self, num_actions: int) -> None:
+        if self.actions is not None and self.num_actions == num_actions:
+            return
+        T, n = self.num_steps, self.env.num_envs
+        z = lambda *shape: torch.zeros(shape, device=gs.device, dtype=torch.float32)
+        self.num_actions = int(num_actions)
+        self.actions, self.mu, self.sigma = z(T, n, num_actions), z(T, n, num_actions), z(T, n, num_actions)
+        self.values, self.actions_log_prob, self.returns, self.advantages = z(T, n), z(T, n), z(T, n), z(T, n)
+        self._moments = torch.zeros(2, device=gs.device, dtype=torch.float64)
+
+    def add_policy(self, actions: torch.Tensor, values: torch.Tensor, log_prob: torch.Tensor, mu: torch.Tensor, sigma: torch.Tensor,
+                   time_outs: Optional[torch.Tensor] = None, gamma: float = 0.99) -> None:
+        """What the policy produced for the transition the last ``env.step()`` wrote (row ``step - 1``): rsl_rl's
+        ``add_transitions`` for actions / values / actions_log_prob / mu / sigma, after ``rewards[t] += gamma * values *
+        time_outs`` (PPO.process_env_step) when ``time_outs`` (this step's truncated flags) is given.  One launch."""
+        if self.step < 1:
+            raise RuntimeError("add_policy() follows the env.step() whose transition it completes")
+        f = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+        actions, mu, sigma = f(actions), f(mu), f(sigma)
+        values, log_prob = f(values.reshape(-1)), f(log_prob.reshape(-1))
+        self._ensure_policy_rows(actions.shape[-1])
+        t, a = self.step - 1, self._pol_args
+        a.num_envs, a.num_actions = self.env.num_envs, self.num_actions
+        a.actions, a.values, a.log_prob, a.mu, a.sigma = (x.data_ptr() for x in (actions, values, log_prob, mu, sigma))
+        a.actions_out, a.mu_out, a.sigma_out = (x.data_ptr() + t * x.stride(0) * 4 for x in (self.actions, self.mu, self.sigma))
+        a.values_out, a.log_prob_out = (x.data_ptr() + t * x.stride(0) * 4 for x in (self.values, self.actions_log_prob))
+        if time_outs is not None:
+            if time_outs.dtype != torch.bool and time_outs.dtype != torch.uint8:
+                time_outs = time_outs != 0
+            time_outs = time_outs.contiguous()
+            a.time_outs, a.reward_row, a.gamma = time_outs.data_ptr(), self.rewards.data_ptr() + t * self.rewards.stride(0) * 4, float(gamma)
+        else:
+            a.time_outs, a.reward_row, a.gamma = None, None, 0.0
+        self._keep_pol = (actions, values, log_prob, mu, sigma, time_outs)
+        self.env.backend.call("rollout_policy_write", a, owner=None)
+
+    def compute_returns(self, last_values: torch.Tensor, gamma: float = 0.99, lam: float = 0.95, normalize: bool = True) -> None:
+        """``returns`` / ``advantages`` of the finished rollout (rsl_rl ``RolloutStorage.compute_returns``; gamma / lam as
+        examples/simple/train.py:41-47) — GAE over the T steps, then ``(adv - mean) / (std + 1e-8)`` over all T*N entries."""
+        if self.values is None:
+            raise RuntimeError("compute_returns() needs the value estimates: call add_policy() for every transition")
+        last_values = last_values.reshape(-1).to(torch.float32).contiguous()
+        g = self._gae_args
+        g.num_envs, g.num_steps = self.env.num_envs, self.num_steps
+        g.rewards, g.values, g.dones, g.last_values = self.rewards.data_ptr(), self.values.data_ptr(), self.dones.data_ptr(), last_values.data_ptr()
+        g.gamma, g.lam = float(gamma), float(lam)
+        g.returns, g.advantages, g.moments = self.returns.data_ptr(), self.advantages.data_ptr(), self._moments.data_ptr()
+        g.normalize = 1 if normalize else 0
+        self._keep_gae = last_values
+        self.env.backend.call("gae", g, owner=None)
 
     def _trace_patch(self, args, via_unroll=None):
         """Recorded step: advance the rows.  ``via_unroll`` = the policy ObservationManager when it keeps its history as a ring and
@@ -142,8 +205,12 @@ class GradientAllReduce:
     by the world size in the same pass.  With one rank (or no process group) it is a no-op, so a training script is the same
     on one GPU and on eight."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, force: bool = False):
+        """``force``: run the collective even in a group of ONE rank (the only RCCL group a one-GPU box can form: every call of the
+        path executes, the sum over one rank is the identity — tests/test_learner.py)."""
         import torch.distributed as dist
+
+        self.force = bool(force) and dist.is_available() and dist.is_initialized()
 
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
@@ -167,7 +234,7 @@ class GradientAllReduce:
 
     def average(self, async_op: bool = False):
         """Sum over ranks, divide by the world size.  ``async_op``: returns at once; call ``wait()`` before the optimizer step."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return None
         import torch.distributed as dist
 
@@ -185,7 +252,7 @@ class GradientAllReduce:
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """Make every replica start from rank ``src``'s weights."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         import torch.distributed as dist
 

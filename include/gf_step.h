@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 4
+#define GF_ABI_VERSION 5
 
 #define GF_MAX_TERMS 24          /* reward terms per manager          */
 #define GF_MAX_TERM_TERMS 16     /* termination terms per manager     */
@@ -591,6 +591,58 @@ typedef struct GfRolloutArgs {
 } GfRolloutArgs;
 
 /* ------------------------------------------------------------------------------------------
+ * The policy's half of a transition and the return computation (remainder).  rsl_rl's OnPolicyRunner
+ * (third-party; configured and called by the reference at examples/simple/train.py:37-79,125-129: PPO, gamma 0.99, lam 0.95,
+ * num_steps_per_env 24) stores, besides the env's outputs, what the policy produced for the step — actions, value estimate,
+ * log-probability, action mean and std: five more `copy_` launches in RolloutStorage.add_transitions — after bootstrapping
+ * time-outs into the reward (PPO.process_env_step: rewards += gamma * values * time_outs), and at the end of a rollout runs
+ * RolloutStorage.compute_returns: a loop over the T steps, backwards, of eight elementwise launches each (GAE, Schulman et
+ * al. 2016), then normalises the advantages — ~200 launches for T = 24.
+ *   gf_rollout_policy_write: the five rows and the time-out bootstrap in ONE launch.
+ *   gf_gae:  for each env (one lane; rows of the time-major arrays are read and written coalesced), t = T-1 … 0:
+ *       next  = t == T-1 ? last_values[n] : values[t+1][n];   live = 1 - dones[t][n]
+ *       delta = rewards[t][n] + live * gamma * next - values[t][n]
+ *       adv   = delta + live * gamma * lam * adv;            returns[t][n] = adv + values[t][n]
+ *     advantages[t][n] = returns[t][n] - values[t][n]; with `normalize`, a second launch maps them to
+ *     (adv - mean) / (std + 1e-8) over all T*N entries (unbiased std, as torch.std), from f64 moments the first launch
+ *     accumulates (one atomic pair per wave).  One f32 operation per step of the recurrence in this order: bit-identical
+ *     to the torch loop before normalisation.  Algorithmic traffic: R 9 + W 8 bytes per (step, env) (+ R/W 8 to normalise).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct GfRolloutPolicyArgs {
+    int32_t num_envs;
+    int32_t num_actions;        /* A */
+    const float* actions;       /* [N, A] sampled actions, or NULL (each source may be NULL together with its row) */
+    const float* values;        /* [N] value estimates */
+    const float* log_prob;      /* [N] */
+    const float* mu;            /* [N, A] action mean */
+    const float* sigma;         /* [N, A] action std */
+    float* actions_out;         /* &actions[t][0][0] of the time-major storage */
+    float* values_out;          /* &values[t][0] */
+    float* log_prob_out;        /* &actions_log_prob[t][0] */
+    float* mu_out;              /* &mu[t][0][0] */
+    float* sigma_out;           /* &sigma[t][0][0] */
+    const uint8_t* time_outs;   /* [N] truncated flags of this step, or NULL: reward_row[n] += gamma * values[n] * time_outs[n] */
+    float* reward_row;          /* &rewards[t][0] (read-modify-write), required with time_outs */
+    float gamma;
+    int32_t _pad;
+} GfRolloutPolicyArgs;
+
+typedef struct GfGaeArgs {
+    int32_t num_envs;
+    int32_t num_steps;          /* T >= 1 */
+    const float* rewards;       /* [T, N] */
+    const float* values;        /* [T, N] */
+    const uint8_t* dones;       /* [T, N] */
+    const float* last_values;   /* [N] value of the bootstrap observation */
+    float gamma, lam;
+    float* returns;             /* [T, N] */
+    float* advantages;          /* [T, N] */
+    double* moments;            /* [2] scratch: sum and sum of squares of the advantages; required with normalize */
+    int32_t normalize;          /* 1: advantages <- (advantages - mean) / (std + 1e-8) */
+    int32_t _pad;
+} GfGaeArgs;
+
+/* ------------------------------------------------------------------------------------------
  * History ring -> the reference's observation layout.  The reference keeps a list of H frames, pops the oldest, inserts the new
  * one in front and returns `torch.cat(self._history, dim=-1)` (observation_manager.py:219-226): every call writes a NEW
  * [N, H*O] tensor, newest frame first.  With the history kept as an in-place ring (GfObservationArgs.history_ring: the step
@@ -628,7 +680,7 @@ int gf_abi_version(void);
  * chains — termination → reward → command.step…, and reset → command.reset… → observe… — one launch each (csrc/gf_chain.hip). */
 enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_GRAPH = 2, GF_OPT_CHAIN = 3, GF_OPT_COUNT = 4 };
 int gf_set_option(int option, int value);
-int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView, 17 GfPostRefs, 18 GfRolloutArgs, 19 GfHistoryUnrollArgs): binding self-check */
+int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView, 17 GfPostRefs, 18 GfRolloutArgs, 19 GfHistoryUnrollArgs, 20 GfRolloutPolicyArgs, 21 GfGaeArgs): binding self-check */
 const char* gf_build_info(void);
 const char* gf_error_string(int code);
 
@@ -647,6 +699,8 @@ int gf_terrain_height(const GfTerrainHeightArgs* a, void* stream);/* replaces te
 int gf_synth_scene_step(const GfSynthSceneArgs* a, void* stream); /* stands in for scene.step() (managed_env.py:292) */
 int gf_rollout_write(const GfRolloutArgs* a, void* stream);       /* replaces the RolloutStorage copy_ launches of the RL library (examples/simple/train.py:125-129) */
 int gf_history_unroll(const GfHistoryUnrollArgs* a, void* stream);/* replaces the torch.cat of observation_manager.py:226 */
+int gf_rollout_policy_write(const GfRolloutPolicyArgs* a, void* stream);   /* the policy's rows of a transition + time-out bootstrap (rsl_rl add_transitions; call site examples/simple/train.py:125-129) */
+int gf_gae(const GfGaeArgs* a, void* stream);                     /* returns and advantages of a finished rollout (rsl_rl compute_returns; gamma / lam: examples/simple/train.py:41-47) */
 
 /* ------------------------------------------------------------------------------------------
  * Fused post-physics step: everything ManagedEnvironment.step() does after scene.step() and the
@@ -817,7 +871,7 @@ int gf_event_synchronize(void* event);   /* blocks the host until the event has 
  * immediately around the kernel launch of the selected phase). */
 enum { GF_PHASE_ACTION = 0, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
        GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_ROLLOUT,
-       GF_PHASE_UNROLL, GF_PHASE_COUNT };
+       GF_PHASE_UNROLL, GF_PHASE_ROLLOUT_POLICY, GF_PHASE_GAE, GF_PHASE_COUNT };
 int gf_profile_begin(int phase, int max_samples);     /* start recording event pairs for `phase` */
 int gf_profile_end(double* total_ms, int* samples);    /* sync events, return Σ elapsed + count, free them */
 

@@ -1092,6 +1092,60 @@ GFO_EXPORT int gfo_rollout_write(const GfRolloutArgs* a) {
     return GF_OK;
 }
 
+/* The policy's rows of a transition + time-out bootstrap (rsl_rl RolloutStorage.add_transitions / PPO.process_env_step — a
+ * third-party package, not under /root/reference: configured and called at examples/simple/train.py:37-79,125-129; the
+ * algorithm is restated in include/gf_step.h). */
+GFO_EXPORT int gfo_rollout_policy_write(const GfRolloutPolicyArgs* a) {
+    if (!a) return GF_E_NULL;
+    if (a->num_envs < 0 || a->num_actions < 0) return GF_E_RANGE;
+    if ((a->actions_out && !a->actions) || (a->mu_out && !a->mu) || (a->sigma_out && !a->sigma) || (a->values_out && !a->values) ||
+        (a->log_prob_out && !a->log_prob) || (a->time_outs && (!a->reward_row || !a->values)))
+        return GF_E_NULL;
+    const size_t N = (size_t)a->num_envs, row = N * (size_t)a->num_actions * sizeof(float);
+    if (a->actions_out) memcpy(a->actions_out, a->actions, row);
+    if (a->mu_out) memcpy(a->mu_out, a->mu, row);
+    if (a->sigma_out) memcpy(a->sigma_out, a->sigma, row);
+    if (a->values_out) memcpy(a->values_out, a->values, N * sizeof(float));
+    if (a->log_prob_out) memcpy(a->log_prob_out, a->log_prob, N * sizeof(float));
+    if (a->time_outs)
+        for (size_t n = 0; n < N; ++n) a->reward_row[n] = a->reward_row[n] + (a->gamma * a->values[n]) * (a->time_outs[n] ? 1.0f : 0.0f);
+    return GF_OK;
+}
+
+/* GAE (rsl_rl RolloutStorage.compute_returns; gamma / lam from examples/simple/train.py:41-47): the torch loop, scalar. */
+GFO_EXPORT int gfo_gae(const GfGaeArgs* a) {
+    if (!a || !a->rewards || !a->values || !a->dones || !a->last_values || !a->returns || !a->advantages) return GF_E_NULL;
+    if (a->num_envs < 0 || a->num_steps < 1) return GF_E_RANGE;
+    if (a->normalize && !a->moments) return GF_E_NULL;
+    const int64_t N = a->num_envs;
+    const int T = a->num_steps;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t n = 0; n < N; ++n) {
+        float next = a->last_values[n], adv = 0.0f;
+        for (int t = T - 1; t >= 0; --t) {
+            const int64_t at = (int64_t)t * N + n;
+            const float nt = 1.0f - (a->dones[at] ? 1.0f : 0.0f);
+            const float delta = (a->rewards[at] + (nt * a->gamma) * next) - a->values[at];
+            adv = delta + ((nt * a->gamma) * a->lam) * adv;
+            const float ret = adv + a->values[at];
+            a->returns[at] = ret;
+            a->advantages[at] = ret - a->values[at];
+            s1 += (double)a->advantages[at];
+            s2 += (double)a->advantages[at] * (double)a->advantages[at];
+            next = a->values[at];
+        }
+    }
+    if (a->moments) { a->moments[0] = s1; a->moments[1] = s2; }
+    if (a->normalize) {
+        const int64_t total = N * T;
+        const double cnt = (double)total, mean = total ? s1 / cnt : 0.0;
+        const double var = total > 1 ? (s2 - s1 * mean) / (cnt - 1.0) : 0.0;
+        const float mu = (float)mean, denom = (float)sqrt(var > 0.0 ? var : 0.0) + 1e-8f;
+        for (int64_t i = 0; i < total; ++i) a->advantages[i] = (a->advantages[i] - mu) / denom;
+    }
+    return GF_OK;
+}
+
 /* Host twin of gf_post_physics_step: BY DEFINITION the phases in the reference's order (managed_env.py:303-326). */
 GFO_EXPORT int gfo_post_physics_check(const GfPostRefs* r) { return (r && r->termination && r->reset) ? GF_OK : GF_E_NULL; }
 
@@ -1199,6 +1253,8 @@ GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
             case GF_OP_POST_PHYSICS: rc = gfo_post_physics_step((const GfPostRefs*)a); break;
             case GF_PHASE_ROLLOUT: rc = gfo_rollout_write((const GfRolloutArgs*)a); break;
             case GF_PHASE_UNROLL: rc = gfo_history_unroll((const GfHistoryUnrollArgs*)a); break;
+            case GF_PHASE_ROLLOUT_POLICY: rc = gfo_rollout_policy_write((const GfRolloutPolicyArgs*)a); break;
+            case GF_PHASE_GAE: rc = gfo_gae((const GfGaeArgs*)a); break;
             case GF_OP_STATS_PACK: rc = gfo_stats_pack((const GfStatsPackArgs*)a); break;
             case GF_OP_STATS_COPY: {
                 const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
@@ -1299,6 +1355,8 @@ GFO_EXPORT int gfo_sizeof(int which) {
         case 17: return (int)sizeof(GfPostRefs);
         case 18: return (int)sizeof(GfRolloutArgs);
         case 19: return (int)sizeof(GfHistoryUnrollArgs);
+        case 20: return (int)sizeof(GfRolloutPolicyArgs);
+        case 21: return (int)sizeof(GfGaeArgs);
         default: return -1;
     }
 }

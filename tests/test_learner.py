@@ -212,3 +212,188 @@ def test_gradient_allreduce_matches_unsharded_batch():
     # mean over two equal shards == mean over the whole batch (up to f32 summation order)
     assert torch.allclose(shards[0]["grads"], full["grads"], atol=1e-6, rtol=1e-4)
     assert torch.allclose(shards[0]["params"], full["params"], atol=1e-5, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# §8f-5 remainder: the policy's rows of a transition, the time-out bootstrap, GAE / returns, the gradient bucket on a GPU
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _torch_compute_returns(rewards, values, dones, last_values, gamma, lam, normalize=True):
+    """rsl_rl RolloutStorage.compute_returns, statement for statement (the torch reference of gf_gae)."""
+    T = rewards.shape[0]
+    returns = torch.zeros_like(rewards)
+    advantage = 0
+    for step in reversed(range(T)):
+        next_values = last_values if step == T - 1 else values[step + 1]
+        next_is_not_terminal = 1.0 - dones[step].float()
+        delta = rewards[step] + next_is_not_terminal * gamma * next_values - values[step]
+        advantage = delta + next_is_not_terminal * gamma * lam * advantage
+        returns[step] = advantage + values[step]
+    advantages = returns - values
+    raw = advantages.clone()
+    if normalize:
+        advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+    return returns, advantages, raw
+
+
+def _policy_rollout(dev, n, horizon=24, rollouts=2, trace=True):
+    """A PPO-style collection loop on the Go2 task: act → env.step (the step's kernel writes obs / reward / done rows) → add_policy
+    (policy rows + time-out bootstrap) … → compute_returns; next to it rsl_rl's storage semantics in plain torch."""
+    from genesis_forge_amd.learner import ActorCriticMLP, RolloutStorage
+
+    env = _make("go2", n)
+    env.trace_enabled = trace
+    env.build()
+    env.seed(7)
+    obs, _ = env.reset()
+    ro = RolloutStorage(env, horizon).attach()
+    ro.begin(obs)
+    torch.manual_seed(3)
+    net = ActorCriticMLP(48, 12).to(dev)
+    g = torch.Generator().manual_seed(11)
+    gamma, lam = 0.99, 0.95
+    results = []
+    for r in range(rollouts):
+        ref = {k: [] for k in ("actions", "values", "logp", "mu", "sigma", "rewards", "dones")}
+        for t in range(horizon):
+            with torch.no_grad():
+                mu = net.act_mean(obs)
+                sigma = net.std.expand_as(mu).contiguous()
+                actions = mu + sigma * torch.randn(mu.shape, generator=g).to(dev)
+                values = net.evaluate(obs)
+                logp = torch.distributions.Normal(mu, sigma).log_prob(actions).sum(dim=-1)
+            obs, rew, term, trunc, extras = env.step(actions)
+            ro.add_policy(actions, values, logp, mu, sigma, time_outs=trunc, gamma=gamma)
+            # rsl_rl: PPO.process_env_step (bootstrap on time-outs) then RolloutStorage.add_transitions (copy_ of everything)
+            rew_ref = rew.clone() + gamma * torch.squeeze(values * trunc.unsqueeze(1).float(), 1)
+            for k, v in (("actions", actions), ("values", values.reshape(-1)), ("logp", logp), ("mu", mu), ("sigma", sigma), ("rewards", rew_ref),
+                         ("dones", term | trunc)):
+                ref[k].append(v.clone())
+        with torch.no_grad():
+            last_values = net.evaluate(obs)
+        ro.compute_returns(last_values, gamma=gamma, lam=lam, normalize=True)
+        ref = {k: torch.stack(v) for k, v in ref.items()}
+        want_ret, want_adv, _raw = _torch_compute_returns(ref["rewards"], ref["values"], ref["dones"], last_values.reshape(-1), gamma, lam)
+        results.append((ref, want_ret, want_adv, {k: getattr(ro, k).clone() for k in ("actions", "values", "actions_log_prob", "mu", "sigma", "rewards",
+                                                                                      "dones", "returns", "advantages")}))
+    return results, env
+
+
+def _check_policy_rollout(results):
+    for ref, want_ret, want_adv, got in results:
+        for a, b in (("actions", "actions"), ("values", "values"), ("logp", "actions_log_prob"), ("mu", "mu"), ("sigma", "sigma"), ("dones", "dones")):
+            assert torch.equal(ref[a], got[b]), f"{b} rows differ from the copy_ storage"
+        assert torch.equal(ref["rewards"], got["rewards"]), "rewards after the time-out bootstrap differ"
+        assert float((ref["rewards"].abs()).sum()) > 0
+        assert torch.equal(want_ret, got["returns"]), f"returns differ from the torch loop: {(want_ret - got['returns']).abs().max()}"
+        assert torch.allclose(want_adv, got["advantages"], atol=1e-5, rtol=1e-5), f"normalised advantages: {(want_adv - got['advantages']).abs().max()}"
+    assert any(bool(r[0]["dones"].any()) for r in results), "no env finished an episode in any rollout: the done / time-out paths went untested"
+
+
+def test_policy_rows_and_gae_cpu(oracle_backend):
+    results, env = _policy_rollout("cpu", 70, horizon=12, rollouts=2)
+    _check_policy_rollout(results)
+    assert env._trace is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,horizon", [(70, 13), (1000, 24), (4096, 24)])
+def test_policy_rows_and_gae_hip(hip_backend, n, horizon):
+    results, env = _policy_rollout("cuda", n, horizon=horizon, rollouts=2)
+    _check_policy_rollout(results)
+    assert env._trace is not None and env._trace.post_refs is not None
+
+
+def test_gae_abi_validation_and_shapes(oracle_backend):
+    """gf_gae / gf_rollout_policy_write through the raw ABI (the oracle twin): refusals, T = 1, unnormalised advantages == returns - values."""
+    import ctypes as C
+    from genesis_forge_amd import _native as nat
+
+    g = nat.GfGaeArgs()
+    with pytest.raises(nat.GfError, match="GF_E_NULL"):
+        oracle_backend.call("gae", g)
+    N, T = 37, 1
+    gen = torch.Generator().manual_seed(0)
+    rew, val, last = torch.randn(T, N, generator=gen), torch.randn(T, N, generator=gen), torch.randn(N, generator=gen)
+    dones = torch.rand(T, N, generator=gen) < 0.3
+    ret, adv, mom = torch.zeros(T, N), torch.zeros(T, N), torch.zeros(2, dtype=torch.float64)
+    g.num_envs, g.num_steps, g.gamma, g.lam = N, T, 0.9, 0.8
+    g.rewards, g.values, g.dones, g.last_values = rew.data_ptr(), val.data_ptr(), dones.data_ptr(), last.data_ptr()
+    g.returns, g.advantages = ret.data_ptr(), adv.data_ptr()
+    g.normalize = 1
+    with pytest.raises(nat.GfError, match="GF_E_NULL"):   # normalisation needs the moments scratch
+        oracle_backend.call("gae", g)
+    g.normalize, g.moments = 0, mom.data_ptr()
+    oracle_backend.call("gae", g)
+    want_ret, _adv, raw = _torch_compute_returns(rew, val, dones, last, 0.9, 0.8, normalize=False)
+    assert torch.equal(ret, want_ret) and torch.equal(adv, raw)
+    assert abs(float(mom[0]) - float(raw.double().sum())) < 1e-9
+    g.num_steps = 0
+    with pytest.raises(nat.GfError, match="GF_E_RANGE"):
+        oracle_backend.call("gae", g)
+    p = nat.GfRolloutPolicyArgs()
+    p.num_envs, p.num_actions = N, 3
+    out = torch.zeros(N, 3)
+    p.actions_out = out.data_ptr()
+    with pytest.raises(nat.GfError, match="GF_E_NULL"):   # a destination without its source
+        oracle_backend.call("rollout_policy_write", p)
+
+
+@pytest.mark.gpu
+def test_gae_kernel_hip_equals_torch_at_size(hip_backend):
+    """gf_gae alone at the benchmark size (65 536 envs x 24 steps): returns bit-identical to the torch loop, advantages to 1e-5."""
+    from genesis_forge_amd import _native as nat
+
+    N, T = 65536 + 37, 24
+    gen = torch.Generator().manual_seed(1)
+    rew, val, last = (torch.randn(T, N, generator=gen).cuda(), torch.randn(T, N, generator=gen).cuda(), torch.randn(N, generator=gen).cuda())
+    dones = (torch.rand(T, N, generator=gen) < 0.05).cuda()
+    ret, adv, mom = torch.zeros(T, N, device="cuda"), torch.zeros(T, N, device="cuda"), torch.zeros(2, dtype=torch.float64, device="cuda")
+    g = nat.GfGaeArgs()
+    g.num_envs, g.num_steps, g.gamma, g.lam, g.normalize = N, T, 0.99, 0.95, 1
+    g.rewards, g.values, g.dones, g.last_values = rew.data_ptr(), val.data_ptr(), dones.data_ptr(), last.data_ptr()
+    g.returns, g.advantages, g.moments = ret.data_ptr(), adv.data_ptr(), mom.data_ptr()
+    hip_backend.call("gae", g)
+    want_ret, want_adv, _raw = _torch_compute_returns(rew, val, dones, last, 0.99, 0.95)
+    assert torch.equal(ret, want_ret)
+    assert torch.allclose(adv, want_adv, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_gradient_allreduce_on_rccl_group_of_one(hip_backend):
+    """The gradient bucket on a GPU through real RCCL: a forced group of one rank runs every call of the path (in-place division,
+    all-reduce of the flat 1.5 MB bucket — synchronous and asynchronous + wait —, the parameter broadcast); the sum over one rank
+    is the identity, so gradients and the optimizer step equal a run without a process group."""
+    import torch.distributed as dist
+    from genesis_forge_amd.learner import ActorCriticMLP, GradientAllReduce
+
+    def run(force):
+        torch.manual_seed(100)
+        net = ActorCriticMLP(48, 12).cuda()
+        sync = GradientAllReduce(net.parameters(), force=force)
+        sync.broadcast_parameters(0)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        g = torch.Generator().manual_seed(5)
+        grads = []
+        for it in range(3):
+            obs, tgt = torch.randn(256, 48, generator=g).cuda(), torch.randn(256, 12, generator=g).cuda()
+            sync.zero_grad()
+            loss = ((net.act_mean(obs) - tgt) ** 2).mean() + (net.evaluate(obs) ** 2).mean() + (net.std ** 2).sum()
+            loss.backward()
+            work = sync.average(async_op=(it % 2 == 1))
+            assert (work is not None) == force
+            sync.wait()
+            grads.append(sync.bucket.clone())
+            opt.step()
+        return grads, torch.cat([p.detach().reshape(-1) for p in net.parameters()]), sync.nbytes
+
+    want = run(False)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        got = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert 1.4e6 < got[2] < 1.7e6
+    for a, b in zip(want[0], got[0]):
+        assert torch.equal(a, b)
+    assert torch.equal(want[1], got[1])

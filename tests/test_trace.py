@@ -294,7 +294,10 @@ def test_fused_post_physics_equals_phase_by_phase_hip(hip_backend, post_variant,
         assert env._trace is not None and (env._trace.post_refs is not None) == fuse
         if fuse:
             static = post_variant == 2 and not obs_noise
-            assert hip_backend.post_describe(env._trace.post_refs).startswith("program 1 (go2_command_direction)" if static else "program 0 (interpreter)")
+            what = hip_backend.post_describe(env._trace.post_refs).split(":")[0]
+            # (a noisy config matches no built-in program: the interpreter — or, when an earlier test of this process has compiled this
+            # very structure at run time, tests/test_jit_programs.py, that program; GF_OPT_POST_VARIANT < 2 always selects the interpreter)
+            assert what == "program 1 (go2_command_direction)" if static else (what == "program 0 (interpreter)" or (post_variant == 2 and "(jit_" in what)), what
         outs.append(seq)
     for t, (x, y) in enumerate(zip(*outs)):
         for k in (0, 1, 2, 3, 5, 6, 7, 8, 9, 10):
