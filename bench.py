@@ -314,6 +314,8 @@ def run_rank(args):
     g = torch.Generator().manual_seed(1234 + rank)
     acts = [torch.randn(N, D, generator=g).to(gs.device) for _ in range(8)]
 
+    local_times: list = []
+
     def barrier():
         sync()
         if dist_on:
@@ -331,6 +333,7 @@ def run_rank(args):
             sync()
             dt = time.perf_counter() - t0
             barrier()
+            local_times.append(dt)   # this rank's own clock, before the max over ranks (reported per rank)
             if dist_on:
                 t = torch.tensor([dt], device=gs.device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -368,6 +371,13 @@ def run_rank(args):
         env.step(acts[i % 8])
     times = timed_batches(env, acts, args.steps)
     batch = statistics.median(times)
+    # what each rank ran on and measured by its own clock: makes the one line checkable against the launcher's view of the node
+    mine = {"rank": rank, "device": ("cpu (rehearsal)" if rehearsal else torch.cuda.get_device_name(gs.device)), "device_index": (None if rehearsal else gs.device.index),
+            "num_envs": N, "env_offset": env.env_offset, "batch_ms_median": statistics.median(local_times) * 1e3, "batch_ms_max": max(local_times) * 1e3}
+    per_rank = [mine]
+    if dist_on:
+        per_rank = [None] * dist.get_world_size()
+        dist.all_gather_object(per_rank, mine)
     _ = dict(env.extras["episode"])   # keep the logging path honest: read one step's global statistics (on every rank)
 
     fused = env._trace is not None and env._trace.post_refs is not None
@@ -409,6 +419,8 @@ def run_rank(args):
                        "batch_ms_max": max(times) * 1e3, "rule": f"batches of exactly {args.steps} steps (barrier + synchronize both sides, max over ranks) "
                                                                   f"until >= {MIN_TIMED_S} s are timed; median batch reported"},
             "roofline": roof,
+            "rccl_ranks": (dist.get_world_size() if dist_on else 1),   # read back from the process group, not from --gpus
+            "ranks": per_rank,
         }
     del env
     if world == 1 and not rehearsal:

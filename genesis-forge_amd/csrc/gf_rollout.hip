@@ -80,8 +80,8 @@ __global__ __launch_bounds__(kRollBlock) void rollout_policy_kernel(const GfRoll
 
 // ---- GAE (rsl_rl RolloutStorage.compute_returns) -------------------------------------------------------------------------------
 // One lane per env, t = T-1 … 0; row t of each time-major array is one coalesced wave access.  All T loads of a lane are
-// independent of the recurrence, so they are issued in batches of 8 steps ahead of the arithmetic that consumes them.
-constexpr int kGaeBatch = 8;
+// independent of the recurrence, so they are issued in batches of 12 steps (T = 24: two round trips) ahead of the arithmetic that consumes them.
+constexpr int kGaeBatch = 12;
 __global__ __launch_bounds__(kRollBlock) void gae_kernel(const GfGaeArgs a) {
     const int64_t n = (int64_t)blockIdx.x * kRollBlock + threadIdx.x;
     const int64_t N = a.num_envs;

@@ -44,11 +44,28 @@ def test_gpus_2_self_launch_strong_gait():
     assert out["value"] > 0
 
 
+@pytest.mark.timeout(420)
+def test_gpus_8_self_launch_strong_gait():
+    """The driver's scaling run in small: 8 ranks, BASELINE config 5 (gait), a global env count split into contiguous shards, the
+    statistics ring reduced 32 steps at a time, one JSON line whose per-rank entries come from the process group."""
+    out = _bench("--gpus", "8", "--steps", "40", "--warmup", "2", "--scaling", "strong", "--global-envs", "520", "--config", "gait", "--no-cpu-baseline",
+                 timeout=400)
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "strong"
+    assert out["config"]["global_num_envs"] == 520 and out["config"]["num_envs_per_gpu"] == 65 and out["config"]["stats_allreduce_every_steps"] == 32
+    ranks = out["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8))
+    assert [r["env_offset"] for r in ranks] == [65 * r for r in range(8)] and all(r["num_envs"] == 65 for r in ranks)
+    assert all(r["batch_ms_median"] > 0 for r in ranks)
+    assert out["ms_per_step"] * 40 >= max(r["batch_ms_median"] for r in ranks) * 0.5   # the reported time is the max over ranks, per batch
+    assert out["value"] > 0
+
+
 @pytest.mark.timeout(300)
 def test_single_rank_line_and_torchrun_env():
     """N = 1 is unchanged (no process group), and ranks started by an external launcher (WORLD_SIZE set) do not self-launch."""
     out = _bench("--gpus", "1", "--steps", "4", "--warmup", "1", "--num-envs", "64", "--no-cpu-baseline")
     assert out["n_gpus"] == 1 and out["config"]["parallelism"] == "env-shard x1" and out["config"]["dist_backend"] is None
+    assert out["rccl_ranks"] == 1 and len(out["ranks"]) == 1 and out["ranks"][0]["num_envs"] == 64
 
 
 def test_spawn_ranks_propagates_failure_and_environment(tmp_path):

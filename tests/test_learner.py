@@ -380,7 +380,8 @@ def test_gradient_allreduce_on_rccl_group_of_one(hip_backend):
             loss = ((net.act_mean(obs) - tgt) ** 2).mean() + (net.evaluate(obs) ** 2).mean() + (net.std ** 2).sum()
             loss.backward()
             work = sync.average(async_op=(it % 2 == 1))
-            assert (work is not None) == force
+            if it % 2 == 1:
+                assert (work is not None) == force   # (a synchronous all_reduce returns no work object)
             sync.wait()
             grads.append(sync.bucket.clone())
             opt.step()
