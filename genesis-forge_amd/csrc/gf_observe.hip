@@ -52,6 +52,24 @@ struct ObsUnit {
     float scale, noise;
 };
 
+// The stand-alone kernel gets the unit table resolved by the HOST (observe_prep) inside its kernel arguments: a lane reads its unit
+// straight from the kernel-argument segment and wave 0 walks the per-env items with scalar loads — no LDS tables, none of the two
+// barriers every workgroup otherwise spends before its first gather load is in flight.  Frames with more units than fit (or a
+// phase chain, whose descriptors sit elsewhere in the argument segment) build the tables in LDS as before.
+constexpr int kPlanUnits = 48, kPlanOwners = 8;
+struct ObsOwner { int32_t op, col; float scale, noise; };
+struct ObsPlan {
+    int32_t num_units, num_owners;   // num_units == 0: no plan (build the tables in the kernel)
+    ObsOwner owner[kPlanOwners];
+    ObsUnit unit[kPlanUnits];
+};
+struct ObsKernelArgs {
+    GfObservationArgs a;
+    uint32_t needs, _pad;
+    ObsPlan plan;
+};
+static_assert(sizeof(ObsKernelArgs) <= 4096, "kernarg segment");
+
 __device__ __forceinline__ float finish(const GfObservationArgs& a, const float scale, const float noise, float v, int64_t n, int col) {
     if (scale != 1.0f) v = v * scale;  // observation_manager.py:242-244
     if (noise != 0.0f) {               // observation_manager.py:247-250
@@ -63,9 +81,11 @@ __device__ __forceinline__ float finish(const GfObservationArgs& a, const float 
 
 // V = floats per memory operation of the frame write-out and the history shift: 4 when O % 4 == 0, 2 when O is even, else 1.
 // A run-time value here (wave-uniform branches); the stand-alone kernels pass a constant, which folds the branches away.
-__device__ __forceinline__ void observe_body(const int V, const GfObservationArgs& a, const uint32_t needs, float* tile, const uint32_t karg_off) {
+__device__ __forceinline__ void observe_body(const int V, const GfObservationArgs& a, const uint32_t needs, float* tile, const uint32_t karg_off,
+                                             const ObsPlan* plan = nullptr, const uint32_t plan_off = 0u) {
     __shared__ ObsItemRec s_item[GF_MAX_OBS_ITEMS];
     __shared__ ObsUnit s_unit[GF_MAX_OBS_WIDTH];
+    const bool planned = plan != nullptr && plan->num_units > 0;   // wave-uniform (kernel argument)
     const int tid = threadIdx.x;
     const int64_t n0 = (int64_t)blockIdx.x * kEnvBlock;
     const int64_t N = a.num_envs;
@@ -106,7 +126,7 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
     if (hist) hist_load(hb, prev, hfirst, units, O, (int)OH, dr);
 
     // item i → its source (lane i); `a` sits `karg_off` bytes into the kernel-argument segment
-    if (tid < num_items) {
+    if (!planned && tid < num_items) {
         const auto* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
         const auto* ip = (const __attribute__((address_space(4))) int32_t*)(kp + karg_off + offsetof(GfObservationArgs, items) + (size_t)tid * sizeof(GfObsItem));
         const int op = ip[0], w = ip[1], i0 = ip[2];
@@ -143,10 +163,10 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
         const int vec = (kind == OS_ROWS && (w & 3) == 0 && (stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) ? 1 : 0;
         s_item[tid] = ObsItemRec{src, stride, w, kind, op, scale, noise, kind == OS_OWNER ? 0 : (vec ? w >> 2 : w), vec};
     }
-    __syncthreads();
+    if (!planned) __syncthreads();
     // unit u → its source (lane u): which item, which of its columns
-    int U = 0;
-    {
+    int U = planned ? plan->num_units : 0;
+    if (!planned) {
         int cacc = 0, it = -1, ust = 0, cst = 0;
         for (int i = 0; i < num_items; ++i) {
             const int un = s_item[i].units;
@@ -161,7 +181,7 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
                                 : ObsUnit{r.src + (r.kind == OS_NORM3 ? 3 * j : j), r.stride, r.kind, cst + j, 1, r.scale, r.noise};
         }
     }
-    __syncthreads();
+    if (!planned) __syncthreads();
 
     // gather: every [N,w] element of the tile.  A lane keeps ONE unit (its source is looked up once) and walks rows: with
     // P = the power of two >= U (the number of units), lane t has unit t mod P and rows t/P, t/P + 256/P, … — consecutive lanes
@@ -170,7 +190,19 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
     // history batches run between the two halves of the first pass.
     const int lgP = U > 1 ? 32 - __builtin_clz((unsigned)(U - 1)) : 0;
     const int gun = tid & ((1 << lgP) - 1), grow0 = tid >> lgP, grstep = kObsBlock >> lgP;
-    const ObsUnit gc = s_unit[gun < U ? gun : 0];
+    ObsUnit gc;
+    if (planned) {   // this lane's unit, straight from the kernel-argument segment (a vector load: the index is lane-dependent)
+        const auto* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+        typedef int32_t i32x4k __attribute__((ext_vector_type(4)));
+        static_assert(sizeof(ObsUnit) == 32 && offsetof(ObsUnit, stride) == 8 && offsetof(ObsUnit, scale) == 24, "two 16-byte loads");
+        const auto* up = (const __attribute__((address_space(4))) i32x4k*)(kp + plan_off + offsetof(ObsPlan, unit) + (size_t)(gun < U ? gun : 0) * sizeof(ObsUnit));
+        const i32x4k w0 = up[0], w1 = up[1];
+        gc.p = reinterpret_cast<const float*>(((uint64_t)(uint32_t)w0.y << 32) | (uint64_t)(uint32_t)w0.x);
+        gc.stride = w0.z; gc.kind = w0.w; gc.col0 = w1.x; gc.w = w1.y;
+        gc.scale = __int_as_float(w1.z); gc.noise = __int_as_float(w1.w);
+    } else {
+        gc = s_unit[gun < U ? gun : 0];
+    }
     const bool gactive = gun < U;
     const bool gvec = gactive && gc.w == 4;
     const int64_t gstep = (int64_t)grstep * gc.stride;
@@ -230,7 +262,18 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
         gather_store(row);
     }
     // per-env items (their inputs were requested first and have long landed)
-    if (live && needs) {
+    if (live && needs && planned) {
+#pragma unroll
+        for (int j = 0; j < kPlanOwners; ++j) {
+            if (j >= plan->num_owners) break;
+            const ObsOwner it = plan->owner[j];
+            const V3 v = it.op == GF_O_ANG_VEL_BODY ? rot_inv(q, ang) : (it.op == GF_O_LIN_VEL_BODY ? rot_inv(q, lin) : rot_inv(q, V3{0.f, 0.f, -1.f}));
+            float* r = tile + tid * S + it.col;
+            r[0] = finish(a, it.scale, it.noise, v.x, n, it.col);
+            r[1] = finish(a, it.scale, it.noise, v.y, n, it.col + 1);
+            r[2] = finish(a, it.scale, it.noise, v.z, n, it.col + 2);
+        }
+    } else if (live && needs) {
         int col = 0;
         for (int i = 0; i < num_items; ++i) {
             const ObsItemRec it = s_item[i];
@@ -275,10 +318,10 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
 
 #ifndef GF_BODIES_ONLY
 template <int V>
-__global__ __launch_bounds__(kObsBlock) void observe_kernel(const GfObservationArgs a, const uint32_t needs) {
+__global__ __launch_bounds__(kObsBlock) void observe_kernel(const ObsKernelArgs k) {
     prefetch_args<GfObservationArgs>();
     extern __shared__ __attribute__((aligned(16))) float tile[];
-    observe_body(V, a, needs, tile, 0u);
+    observe_body(V, k.a, k.needs, tile, (uint32_t)offsetof(ObsKernelArgs, a), &k.plan, (uint32_t)offsetof(ObsKernelArgs, plan));
 }
 #endif
 
@@ -354,12 +397,59 @@ int observe_prep(const GfObservationArgs* a, uint32_t* needs_out, int* vec_out) 
 }
 }  // namespace gf
 
+namespace gf {
+// The unit / per-env item tables of a validated descriptor, as the kernel would build them (observe_body) — resolved on the host.
+static void observe_plan(const GfObservationArgs* a, ObsPlan* pl) {
+    pl->num_units = pl->num_owners = 0;
+    const int D = a->num_dofs;
+    int col = 0, units = 0, owners = 0;
+    for (int i = 0; i < a->num_items; ++i) {
+        const GfObsItem& it = a->items[i];
+        const float* src = nullptr;
+        int stride = 0, kind = OS_ROWS;
+        switch (it.op) {
+            case GF_O_COMMAND: src = a->command[it.i0].command; stride = a->command[it.i0].stride ? a->command[it.i0].stride : a->command[it.i0].width; break;
+            case GF_O_DOF_POS: src = a->dof_pos; stride = D; break;
+            case GF_O_DOF_VEL: src = a->dof_vel; stride = D; break;
+            case GF_O_DOF_FORCE: src = a->dof_force; stride = D; break;
+            case GF_O_ACTIONS: src = a->targets; stride = D; break;
+            case GF_O_RAW_ACTIONS: src = a->env_actions; stride = D; break;
+            case GF_O_EXTERNAL: src = a->ext[it.i0]; stride = it.width; break;
+            case GF_O_BASE_POS: src = a->entity.pos; stride = 3; break;
+            case GF_O_BASE_QUAT: src = a->entity.quat; stride = 4; break;
+            case GF_O_CONTACT_FORCE_NORM: src = a->contact[it.i0].contacts; stride = 3 * a->contact[it.i0].num_links; kind = OS_NORM3; break;
+            default: kind = OS_OWNER; break;
+        }
+        if (kind == OS_OWNER) {
+            if (owners >= kPlanOwners) return;
+            pl->owner[owners++] = ObsOwner{it.op, col, it.scale, it.noise};
+        } else {
+            const bool vec = kind == OS_ROWS && (it.width & 3) == 0 && (stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+            const int n = vec ? it.width >> 2 : it.width;
+            if (units + n > kPlanUnits) return;
+            for (int j = 0; j < n; ++j)
+                pl->unit[units++] = vec ? ObsUnit{src + 4 * j, stride, kind, col + 4 * j, 4, it.scale, it.noise}
+                                        : ObsUnit{src + (kind == OS_NORM3 ? 3 * j : j), stride, kind, col + j, 1, it.scale, it.noise};
+        }
+        col += it.width;
+    }
+    if (units == 0) return;   // (a frame of per-env items only: the in-kernel path handles the empty gather)
+    pl->num_units = units;
+    pl->num_owners = owners;
+}
+}  // namespace gf
+
 extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObservationArgs* a, void* stream) {
     uint32_t needs = 0;
     int vec = 1;
     const int rc = gf::observe_prep(a, &needs, &vec);
     if (rc) return rc;
     if (a->num_envs == 0) return GF_OK;
+    gf::ObsKernelArgs k;
+    k.a = *a;
+    k.needs = needs;
+    k._pad = 0;
+    gf::observe_plan(a, &k.plan);
     const bool vec4 = vec == 4, vec2 = vec == 2;
     const int O = a->obs_width;
     hipStream_t s = (hipStream_t)stream;
@@ -367,9 +457,9 @@ extern "C" __attribute__((visibility("default"))) int gf_observe(const GfObserva
     gf::PhaseScope scope(GF_PHASE_OBSERVE, s);
     scope.begin_bracket();
     const unsigned grid = gf::env_grid(a->num_envs);  // one 256-thread workgroup per 64-env tile
-    if (vec4) gf::klaunch(gf::observe_kernel<4>, dim3(grid), dim3(gf::kObsBlock), lds, s, *a, needs);
-    else if (vec2) gf::klaunch(gf::observe_kernel<2>, dim3(grid), dim3(gf::kObsBlock), lds, s, *a, needs);
-    else gf::klaunch(gf::observe_kernel<1>, dim3(grid), dim3(gf::kObsBlock), lds, s, *a, needs);
+    if (vec4) gf::klaunch(gf::observe_kernel<4>, dim3(grid), dim3(gf::kObsBlock), lds, s, k);
+    else if (vec2) gf::klaunch(gf::observe_kernel<2>, dim3(grid), dim3(gf::kObsBlock), lds, s, k);
+    else gf::klaunch(gf::observe_kernel<1>, dim3(grid), dim3(gf::kObsBlock), lds, s, k);
     return gf::launch_status();
 }
 #endif

@@ -62,13 +62,21 @@ class Recorder:
         elif self.part is not None:
             self.tail.setdefault(self.part, []).append((fn, args, owner))
 
+    def python(self, fn) -> None:
+        """A piece of user code the step runs between native phases (the ``step()`` / ``reset(ids)`` of a user-defined manager
+        class): the recorded step calls ``fn`` again at this very point — after the launches recorded so far, before the next."""
+        if not self.tail_python:
+            self.calls.append(("__python__", fn, None))
+        elif self.part is not None:
+            self.tail.setdefault(self.part, []).append(("__python__", fn, None))
+
     def cut_tail(self):
         """Everything the step does from here on stays Python in the recorded step (an env that overrides ``reset()``: the
         index-list reset with its host sync, then the observations, run phase by phase exactly as in an ordinary step)."""
         self.tail_python = True
 
     def signature(self):
-        return [(fn, C.addressof(args), id(owner)) for fn, args, owner in self.calls] + ([("tail",)] if self.tail_python else [])
+        return [(fn, C.addressof(args), id(owner)) if fn != "__python__" else (fn,) for fn, args, owner in self.calls] + ([("tail",)] if self.tail_python else [])
 
 
 class Untraceable(Exception):
@@ -87,8 +95,19 @@ class StepTrace:
         self.tail_seg: dict = {}   # "reset" / "obs" → native segment of the Python tail (see _build_tail_segment)
         self.backend = env.backend
         self.epoch = env._trace_epoch
+        #: user code between native phases (Recorder.python): (index of the recorded call it precedes, callable) — replayed as splits
+        marks = []
+        plain = []
+        for c in calls:
+            if c[0] == "__python__":
+                marks.append((len(plain), c[1]))
+            else:
+                plain.append(c)
+        calls = plain
+        self.py_marks = marks
         self.patches: list[Callable] = []   # Python-side per-step work that has Python semantics (live ranges, log registration)
         self.native: list = []              # GfReplayPatch entries: every per-step descriptor field, applied by gf_replay_step
+        self.native_op: list = []           # … and the index of the op each entry belongs to (-1: none, applied first)
         self.afters: list = []   # (index of the op it follows, callable)
         self.splits: list = []   # (index of the op it precedes, callable): Python that must run in the middle of the step
         self._cur_op = 0
@@ -101,13 +120,22 @@ class StepTrace:
         k += 1
         self._gait_swaps: list = []
         self._late: set = set()
-        self.post_refs = self._fuse_post(calls) if env.fuse_post_physics else None
+        first_post0 = self._post_start(calls)
+        # (user code in the middle of the post-physics phases — a user manager's step() between reward and reset — keeps them off
+        # the single fused launch: the phases on either side of it run as phase chains, gf_run_ops)
+        marks_in_post = any(at > first_post0 for at, _ in marks)
+        self.post_refs = self._fuse_post(calls) if env.fuse_post_physics and not marks_in_post else None
         if self.post_refs is None:
             self._gait_swaps = []
             self._late = set()
         first_post = self._post_start(calls) if self.post_refs is not None else len(calls)
         self.post_split = self.post_refs is not None and bool(self.post_refs.flags & nat.GF_POST_TERMINATION_DONE)
+        mark_i = 0
         for idx, (fn, args, owner) in enumerate(calls):
+            while mark_i < len(marks) and marks[mark_i][0] <= idx:   # user code that ran before this call: a split in front of its op
+                assert idx <= first_post or self.post_refs is None
+                self.splits.append((k - 1, marks[mark_i][1]))
+                mark_i += 1
             if idx < first_post:
                 self.ops[k].phase = nat.PHASE_OF_FN[fn]
                 self.ops[k].args = C.addressof(args)
@@ -126,13 +154,18 @@ class StepTrace:
                 k += 1
             self._cur_op = k - 2  # index of this call's op once the leading STATS_CLEAR op is dropped (below)
             self._hooks(fn, args, owner)
+            self.native_op.extend([self._cur_op] * (len(self.native) - len(self.native_op)))
             if fn == "action_step" and self.adapter is not None:
                 self.splits.append((self._cur_op + 1, self._scene_pre))   # control_dofs_position → scene.step() → state fetch
             pre = owner._trace_pre(args) if hasattr(owner, "_trace_pre") else None
             if pre is not None:
                 assert idx < first_post + (2 if self.post_split else 0) or idx in self._late, "a phase with Python-level terms cannot be part of the fused launch"
                 self.splits.append((self._cur_op, pre))
+        for _at, f in marks[mark_i:]:   # user code behind the last launch
+            self.splits.append((k - 1, f))
         self.native.extend(self._gait_swaps)   # after the gait managers' own patches (those refill the descriptors)
+        post_at = next((i - 1 for i in range(k) if self.ops[i].phase == nat.GF_OP_POST_PHYSICS), -1)
+        self.native_op.extend([post_at] * (len(self.native) - len(self.native_op)))   # (they serve the fused launch)
         # single process: statistics go to a device ring slot per step (no memset, no copy); with a process group the
         # per-step all-reduce path is kept (clear op here, packed + reduced + copied by StepStats.snapshot)
         self.use_ring = stats.group is None
@@ -167,6 +200,7 @@ class StepTrace:
             self._last_reset_ptr = stats.last_reset.data_ptr() if self.use_ring else None   # (group ring: gf_stats_last_reset)
         # gf_replay_step: the whole table, then the ops, in ONE native call (the patch-only variant serves steps whose ops are
         # replayed in pieces around Python-level terms, or as a hipGraph)
+        self.native_op.extend([-1] * (len(self.native) - len(self.native_op)))   # statistics slots: call parameters, no order
         self.patch_table = (nat.GfReplayPatch * max(1, len(self.native)))(*self.native)
         self.replay_desc = nat.GfReplay(C.addressof(self.ops), k, len(self.native), C.addressof(self.patch_table), C.addressof(env._rng_c))
         self.patch_desc = nat.GfReplay(None, 0, len(self.native), C.addressof(self.patch_table), C.addressof(env._rng_c))
@@ -193,16 +227,25 @@ class StepTrace:
             for (a0, a1), pre in zip(zip(cuts[:-1], cuts[1:]), pres):
                 sub = (nat.GfOp * (a1 - a0)).from_buffer(self.ops, a0 * C.sizeof(nat.GfOp)) if a1 > a0 else None
                 self.segments.append((a0, a1 - a0, sub, pre))
-            # fewer native calls: the patch table and the ops in front of the first split go out together, and on a Genesis-shaped
-            # scene the ops behind the scene split ride on the call that patches the snapshot's addresses (_scene_pre)
-            a0, cnt, sub, pre = self.segments[0]
-            if pre is None and cnt:
-                self.patch_desc = nat.GfReplay(C.addressof(self.ops), cnt, len(self.native), C.addressof(self.patch_table), C.addressof(env._rng_c))
-                self.segments[0] = (a0, 0, None, None)
+            # Each piece of the op list goes out with ITS patches (one native call per piece): user code that runs between two
+            # pieces may draw Philox streams itself (a user manager's step() calling the base class' resample), and the ordinary
+            # step hands out stream ids in call order — so a piece's GF_PATCH_STREAM entries must not run before the user code in
+            # front of it.  On a Genesis-shaped scene the pieces behind the scene split also carry the snapshot's pointer patches.
+            scene_tab = list(getattr(self, "_scene_tab", []))
+            after_scene = False
+            segs = []
             for j, (a0, cnt, sub, pre) in enumerate(self.segments):
-                if cnt and self.adapter is not None and pre == self._scene_pre:
-                    self.scene_desc.ops, self.scene_desc.num_ops = C.addressof(self.ops) + a0 * C.sizeof(nat.GfOp), cnt
-                    self.segments[j] = (a0, 0, None, pre)
+                if self.adapter is not None and pre == self._scene_pre:
+                    after_scene = True
+                    mine = list(scene_tab)   # every descriptor's snapshot pointers, once, right after the fetch
+                else:
+                    mine = []
+                mine += [p for p, at in zip(self.native, self.native_op) if (a0 <= at < a0 + cnt) or (j == 0 and at < 0)]
+                table = (nat.GfReplayPatch * max(1, len(mine)))(*mine)
+                desc = nat.GfReplay(C.addressof(self.ops) + a0 * C.sizeof(nat.GfOp) if cnt else None, cnt, len(mine), C.addressof(table), C.addressof(env._rng_c))
+                segs.append((a0, cnt, pre, desc, table))
+            self.segments = segs
+            assert sum(len(t) if d.num_patches else 0 for *_x, d, t in segs) >= len(self.native)
 
     def fresh(self) -> bool:
         """No descriptor of this recording has been used by a phase call outside its replay since it was made."""
@@ -261,8 +304,8 @@ class StepTrace:
                 if addr in self._scene_covered or leaf in PER_STEP_FIELDS or leaf.startswith("ext["):
                     continue
                 raise Untraceable(f"{name} changes from step to step and is neither scene state nor a per-step field")
+        self._scene_tab = tab
         self.scene_table = (nat.GfReplayPatch * len(tab))(*tab)
-        self.scene_desc = nat.GfReplay(None, 0, len(tab), C.addressof(self.scene_table), C.addressof(self.env._rng_c))
 
     def _scene_pre(self) -> None:
         """What the ordinary step does between the action phase and the first post-physics phase (managed_env.py:290-292,
@@ -272,8 +315,7 @@ class StepTrace:
         env.scene.step()
         pr = self.params
         for i, t in enumerate(self.adapter.refetch(self.scene_plan)):
-            pr[5 + i] = t.data_ptr()
-        self.backend.replay_step(self.scene_desc, None, pr, self.n_params)
+            pr[5 + i] = t.data_ptr()   # (applied by the piece of the op list that follows: its table carries the pointer patches)
 
     # -- the Python tail of an env that overrides reset(), part by part ----------------------------------------------------
     def _build_tail_segment(self, calls):
@@ -533,8 +575,7 @@ class StepTrace:
         done = 0        # afters already run
         ticked = False  # the scene op has been enqueued and the views cache invalidated for it
         if self.segments:
-            self.backend.replay_step(self.patch_desc, aptr, pr, self.n_params)
-            for first, count, sub, pre in self.segments:
+            for first, count, pre, desc, _table in self.segments:
                 if pre is not None:
                     # the ordinary path has finished every earlier phase — launch AND Python bookkeeping — when it calls a
                     # Python-level term: views of the scene are stale after the scene op, earlier phases' hooks have run
@@ -545,8 +586,8 @@ class StepTrace:
                         self.afters[done][1]()
                         done += 1
                     pre()
-                if count:
-                    self.backend.run_ops(sub, count)
+                if count or desc.num_patches:
+                    self.backend.replay_step(desc, aptr, pr, self.n_params)
         elif self.graph is not None and self.backend.graph_enabled:
             self.backend.replay_step(self.patch_desc, aptr, pr, self.n_params)
             self.backend.run_ops_graph(self.graph, self.ops, self.n_ops)
@@ -615,9 +656,16 @@ def traceable(env, tail_python: bool = False) -> bool:
     am, tm, rm = env.managers["action"], env.managers["termination"], env.managers["reward"]
     if am is None or tm is None or not isinstance(am, PositionActionManager) or not am.enabled or not tm.enabled:
         return False
+    # User-defined manager classes.  The step() / reset(ids) of a user's entity, contact or command manager is code BETWEEN native
+    # phases: the recording keeps its place (Recorder.python) and the replay calls it there, exactly as the ordinary step does.
+    # Overrides that produce the step's native outputs themselves (action, termination, reward, observation managers) are not
+    # something a recording can stand in for.
+    between = set(map(id, env.managers["entity"] + env.managers["contact"] + env.managers["command"]))
     for m in env._all_managers() + env.managers["terrain"]:
         for meth in ("step", "reset", "get_observations", "_perform_observation", "handle_actions"):
             if hasattr(m, meth) and not _most_derived_is_ours(m, meth):
+                if id(m) in between and meth in ("step", "reset"):
+                    continue
                 return False
     if tm._dirty or tm._program.slots.volatile:
         return False

@@ -78,6 +78,7 @@ class ManagedEnvironment(GenesisEnv):
         self._last_images = None  # descriptor images of the previous recorded ordinary step (Genesis-shaped scene)
         self._untraceable: Optional[str] = None   # why the last attempt to record the step was refused
         self._no_trace_epoch = -1
+        self._partition_cache = None
         self._program_pending = None   # a static program of this config being compiled in a child process (_programs.Pending)
         self._program_info: Optional[dict] = None   # what became of it: signature, plugin path, compile seconds (or the error)
         #: "off" / "sync" / "async": compile a static program of the fused post-physics kernel for this config's structure when no
@@ -244,9 +245,9 @@ class ManagedEnvironment(GenesisEnv):
         self.scene_stepped()
 
         for m in self.managers["entity"]:
-            m.step()
+            self._manager_step(m)
         for m in self.managers["contact"]:
-            m.step()
+            self._manager_step(m)
 
         truncated, terminated = self._truncated_buf, self._terminated_buf
         tm = self.managers["termination"]
@@ -258,7 +259,7 @@ class ManagedEnvironment(GenesisEnv):
             rewards = self.managers["reward"].step()
 
         for m in self.managers["command"]:
-            m.step()
+            self._manager_step(m)
 
         if tm is not None:
             if type(self).reset is not ManagedEnvironment.reset and self.backend.tracer is not None:
@@ -273,6 +274,26 @@ class ManagedEnvironment(GenesisEnv):
             ro.write(pol._last_out if pol is not None else obs, rewards, terminated, truncated)
         self._end_step()
         return obs, rewards, terminated, truncated, self.extras
+
+    def _manager_step(self, m) -> None:
+        """``m.step()`` — for a user-defined manager class while the step is being recorded: as user code between native phases
+        (the recording keeps its place and calls it again there; launches it makes itself belong to it, not to the recording)."""
+        rec = self.backend.tracer
+        if rec is None or _most_derived_is_ours(m, "step"):
+            m.step()
+            return
+        from .managers._program import call_untraced
+        rec.python(m.step)
+        call_untraced(self, m.step)
+
+    def _indexed_reset(self, indexed: list, mask: torch.Tensor, mask2: Optional[torch.Tensor]) -> None:
+        """``reset(ids)`` of the managers that need an index list (user-defined classes, Python on_reset entries), for the done
+        envs of this step: the one ``nonzero()`` the reference pays too (managed_env.py:308-310)."""
+        both = mask if mask2 is None else (mask | mask2)
+        ids = both.nonzero(as_tuple=False).reshape((-1,))
+        if ids.numel() > 0:
+            for m in indexed:
+                m.reset(ids)
 
     def _end_step(self) -> None:
         super()._end_step()
@@ -297,7 +318,12 @@ class ManagedEnvironment(GenesisEnv):
         self._reset_with_mask(terminated, truncated, ids=None)
 
     def _reset_partition(self):
-        """(managers whose reset is a section of gf_masked_reset, managers that need ``reset(ids)`` with an index list)."""
+        """(managers whose reset is a section of gf_masked_reset, managers that need ``reset(ids)`` with an index list).
+        Cached per configuration epoch: everything it depends on (manager classes, ``enabled``, on_reset entries and their params)
+        drops the recorded step — and with it this cache — when it changes."""
+        hit = self._partition_cache
+        if hit is not None and hit[0] == self._trace_epoch:
+            return hit[1], hit[2]
         fused, indexed = [], []
         for m in self._all_managers():
             if not _most_derived_reset_is_ours(m):
@@ -308,6 +334,7 @@ class ManagedEnvironment(GenesisEnv):
                 pass  # no-op reset (termination / observation managers)
             else:
                 indexed.append(m)
+        self._partition_cache = (self._trace_epoch, fused, indexed)
         return fused, indexed
 
     def _reset_with_mask(self, mask: torch.Tensor, mask2: Optional[torch.Tensor], ids) -> None:
@@ -328,7 +355,15 @@ class ManagedEnvironment(GenesisEnv):
         for m in fused:
             m._after_fused_reset(mask, mask2)
         pushes = ad is not None and bool(ad._pushes)
-        if indexed or pushes:
+        rec = self.backend.tracer
+        if indexed and ids is None and not pushes and rec is not None and rec.part is None and not rec.tail_python:
+            # the in-step reset while the step is being recorded: user code between native phases (see _manager_step) — the replay
+            # finds the done envs of ITS step from the termination masks and calls the same managers
+            from .managers._program import call_untraced
+            fn = lambda self=self, indexed=list(indexed), mask=mask, mask2=mask2: self._indexed_reset(indexed, mask, mask2)
+            rec.python(fn)
+            call_untraced(self, fn)
+        elif indexed or pushes:
             if ids is None:
                 both = mask if mask2 is None else (mask | mask2)
                 ids = both.nonzero(as_tuple=False).reshape((-1,))  # host sync: managers that need index lists, Genesis' setters

@@ -204,6 +204,7 @@ class SyntheticEntity:
         self._lower = torch.tensor([j[1] for j in model.joints], dtype=torch.float32)
         self._upper = torch.tensor([j[2] for j in model.joints], dtype=torch.float32)
         self._built = False
+        self._cols_cache: dict = {}
         self.gains: dict = {}
 
     # -- allocation ---------------------------------------------------------------------------------
@@ -233,10 +234,12 @@ class SyntheticEntity:
     def _cols(self, dofs_idx) -> Optional[list[int]]:
         if dofs_idx is None:
             return None
-        cols = [int(i) - 6 for i in (dofs_idx.tolist() if isinstance(dofs_idx, torch.Tensor) else dofs_idx)]
-        if cols == list(range(self.n_act)):
-            return None
-        return cols
+        key = tuple(dofs_idx.tolist() if isinstance(dofs_idx, torch.Tensor) else dofs_idx)
+        hit = self._cols_cache.get(key)
+        if hit is None:
+            cols = [int(i) - 6 for i in key]
+            hit = self._cols_cache[key] = (None if cols == list(range(self.n_act)) else cols,)
+        return hit[0]
 
     def gf_dofs(self, what: str, dofs_idx) -> torch.Tensor:
         t = {"position": self.dof_pos, "velocity": self.dof_vel, "force": self.dof_force}[what]

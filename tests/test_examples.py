@@ -212,8 +212,9 @@ def test_recorded_step_equals_ordinary_hip(hip_backend, name):
 @pytest.mark.parametrize("name", EXAMPLES)
 def test_reference_example_file_takes_the_fast_path(oracle_backend, name):
     """The unchanged example files are not only correct on this package, they get the recorded step and the fused post-physics
-    launch (observation lambdas are fused by provenance) — except gait_trainer, whose user-level Python manager and
-    step / reset overrides keep it on the reference's call-by-call path."""
+    launch (observation lambdas are fused by provenance).  gait_trainer — a user-defined CommandManager class with its own
+    step() / reset(), an env reset() override — is recorded too (round 3): the user manager's step() is replayed as user code
+    between the native phases, the reset() override keeps the tail Python."""
     from genesis_forge_amd import compat
 
     case = example_cases.CASES[name]
@@ -229,7 +230,9 @@ def test_reference_example_file_takes_the_fast_path(oracle_backend, name):
         for _ in range(6):
             env.step(torch.zeros(64, d))
         if name == "gait_trainer":
-            assert env._trace is None
+            tr = env._trace
+            assert tr is not None and tr.tail_python and tr.post_refs is None
+            assert len(tr.py_marks) >= 1, "the user manager's step() is a split of the recording"
         else:
             assert env._trace is not None and env._trace.post_refs is not None
             assert env._trace.n_ops <= 5

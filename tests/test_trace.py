@@ -251,6 +251,94 @@ def test_user_overrides_limit_what_is_recorded(oracle_backend):
             assert env._trace is None
 
 
+def _user_manager_env():
+    """A user-defined CommandManager class (its own step() and reset(), Python + torch inside — the shape of the reference's
+    examples/gait_trainer/gait_command_manager.py), a reward term and an observation item that read it."""
+    from genesis_forge_amd.managers import CommandManager
+
+    class PhaseClock(CommandManager):
+        steps = resets = 0
+
+        def __init__(self, env):
+            super().__init__(env, range=(0.5, 1.5), resample_time_sec=0.2)
+            self.phase = torch.zeros(env.num_envs)
+
+        def step(self):
+            type(self).steps += 1
+            super().step()                                    # (the base class' native resample launch, made from user code)
+            self.phase = (self.phase + self.env.dt * self._command[:, 0]) % 1.0
+
+        def reset(self, env_ids=None):
+            type(self).resets += 1
+            super().reset(env_ids)
+            if env_ids is None:
+                self.phase = torch.zeros_like(self.phase)
+            else:
+                self.phase[env_ids] = 0.0
+
+    class Env(Go2CommandDirectionEnv):
+        def config(self):
+            super().config()
+            from genesis_forge_amd.managers import ObservationManager, RewardManager
+            self.clock = PhaseClock(self)
+            rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in self.reward_manager.cfg.items()}
+            rc["in_phase"] = {"weight": 0.2, "fn": lambda env: torch.cos(6.2831853 * self.clock.phase)}
+            self.managers["reward"] = None
+            self.reward_manager = RewardManager(self, logging_enabled=True, cfg=rc)
+            om = self.observation_manager
+            oc = {k: {"fn": v.fn, "params": dict(v.params), "scale": v.scale, "noise": v.noise} for k, v in om.cfg.items()}
+            oc["clock"] = {"fn": lambda env: torch.stack([torch.sin(6.2831853 * self.clock.phase), self.clock.phase], dim=-1)}
+            self.managers["observation"].remove(om)
+            self.observation_manager = ObservationManager(self, cfg=oc, history_len=2)
+
+    return Env, PhaseClock
+
+
+def test_user_manager_class_is_replayed_between_native_phases(oracle_backend):
+    """Round 3: a user-defined manager class no longer takes the whole step off the recording.  Its step() / reset(ids) run as user
+    code between the native phases — same place, same arguments, as often as in the ordinary step — and the trajectory is the
+    ordinary step's bit for bit."""
+    Env, Clock = _user_manager_env()
+    Clock.steps = Clock.resets = 0
+    a, _ = _run("cpu", False, cls=Env)
+    counts_a = (Clock.steps, Clock.resets)
+    Clock.steps = Clock.resets = 0
+    before = oracle_backend.replays
+    b, env = _run("cpu", True, cls=Env)
+    counts_b = (Clock.steps, Clock.resets)
+    _same(a, b)
+    tr = env._trace
+    assert tr is not None and len(tr.py_marks) == 2 and tr.post_refs is None, "recorded, with the user manager's step() and reset(ids) as splits"
+    assert oracle_backend.replays - before >= 40
+    assert counts_a == counts_b and counts_a[0] == 50 and counts_a[1] > 10, (counts_a, counts_b)
+
+
+@pytest.mark.gpu
+def test_user_manager_class_recorded_hip(hip_backend):
+    Env, _Clock = _user_manager_env()
+
+    def run(trace):
+        env = Env(num_envs=1000, max_episode_length_s=1, cmd_resample_s=0.3, contacts=True, history=2, scene_kwargs=dict(ang_noise=0.3, seed=3))
+        env.clock_dev = "cuda"
+        env.trace_enabled = trace
+        env.build()
+        env.clock.phase = env.clock.phase.cuda()
+        env.seed(5)
+        env.reset()
+        g = torch.Generator().manual_seed(0)
+        outs = []
+        for t in range(50):
+            o, r, te, tr, ex = env.step(torch.randn(1000, 12, generator=g).cuda())
+            outs.append((o.cpu().clone(), r.cpu().clone(), te.cpu().clone(), tr.cpu().clone(), {k: float(v) for k, v in ex["episode"].items()},
+                         env.velocity_command._command.cpu().clone()))
+        return outs, env
+
+    a, _ = run(False)
+    b, env = run(True)
+    assert env._trace is not None and len(env._trace.py_marks) == 2
+    _same(a, b)
+
+
 @pytest.mark.gpu
 def test_traced_step_equals_ordinary_hip(hip_backend):
     a, _ = _run("cuda", False, n=1000)

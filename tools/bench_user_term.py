@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Step time of a config with one user-level (Python) term — a reward lambda (default) or an observation item (`obs`): recorded step
-(cut around the call) vs phase by phase.      python tools/bench_user_term.py [num_envs] [reward|obs]"""
+(cut around the call) vs phase by phase — or (`manager`) a user-defined CommandManager CLASS with its own step() / reset(), a reward
+term and an observation item reading it (the shape of the reference's examples/gait_trainer/gait_command_manager.py).
+    python tools/bench_user_term.py [num_envs] [reward|obs|manager]"""
 import os
 import sys
 import time
@@ -39,6 +41,38 @@ def run(n, trace, steps=400):
             om = env.observation_manager
             oc = {k: {"fn": v.fn, "params": dict(v.params), "scale": v.scale, "noise": v.noise} for k, v in om.cfg.items()}
             oc["user_xy"] = {"fn": lambda env: env.robot.get_pos()[:, :2] * 2.0}
+            env.managers["observation"].remove(om)
+            env.observation_manager = ObservationManager(env, cfg=oc)
+
+    if KIND == "manager":
+        from genesis_forge_amd.managers import CommandManager, ObservationManager, RewardManager
+
+        class PhaseClock(CommandManager):
+            def __init__(self, env):
+                super().__init__(env, range=(0.5, 1.5), resample_time_sec=0.2)
+                self.phase = torch.zeros(env.num_envs, device=gs.device)
+
+            def step(self):
+                super().step()
+                self.phase = (self.phase + self.env.dt * self._command[:, 0]) % 1.0
+
+            def reset(self, env_ids=None):
+                super().reset(env_ids)
+                if env_ids is None:
+                    self.phase = torch.zeros_like(self.phase)
+                else:
+                    self.phase[env_ids] = 0.0
+
+        def config():   # noqa: F811
+            orig()
+            env.clock = PhaseClock(env)
+            rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in env.reward_manager.cfg.items()}
+            rc["in_phase"] = {"weight": 0.2, "fn": lambda e: torch.cos(6.2831853 * env.clock.phase)}
+            env.managers["reward"] = None
+            env.reward_manager = RewardManager(env, logging_enabled=True, cfg=rc)
+            om = env.observation_manager
+            oc = {k: {"fn": v.fn, "params": dict(v.params), "scale": v.scale, "noise": v.noise} for k, v in om.cfg.items()}
+            oc["clock"] = {"fn": lambda e: torch.stack([torch.sin(6.2831853 * env.clock.phase), env.clock.phase], dim=-1)}
             env.managers["observation"].remove(om)
             env.observation_manager = ObservationManager(env, cfg=oc)
 
