@@ -40,25 +40,28 @@ def set_rotation(env, entity, envs_idx, x=0, y=0, z=0):
 
 
 class position(ResetMdpFnClass):
-    """Reset the entity to a fixed position and (optional) rotation (reset.py:67-124)."""
+    """Fixed spawn pose: ``params = {"position": (x, y, z), "quat": (w, x, y, z) | None, "zero_velocity": bool}`` — the
+    ``on_reset`` entry of every shipped example but rough_terrain (reference: mdp/reset.py:67-124).
+
+    Inside a step this object is only DESCRIBED to the native reset (``EntityManager._fill_reset`` reads ``reset_pos`` /
+    ``reset_quat`` / ``zero_velocity``; the pose is written per lane by ``gf_masked_reset`` / the fused launch).  Calling it with
+    an index list — the public signature — hands the pose to the entity's ``envs_idx`` setters as a broadcast view: one row
+    per listed env, no per-env staging buffer to scatter into and gather back from."""
 
     def __init__(self, env, entity, position, quat=None, zero_velocity: bool = True):
         self.env = env
-        self.zero_velocity = zero_velocity
-        self.reset_pos = torch.tensor(position, device=gs.device, dtype=gs.tc_float)
-        self._pos_buffer = torch.zeros((env.num_envs, 3), device=gs.device, dtype=gs.tc_float)
-        self.reset_quat = None
-        self._quat_buffer = None
-        if quat is not None:
-            self.reset_quat = torch.tensor(quat, device=gs.device, dtype=gs.tc_float)
-            self._quat_buffer = torch.zeros((env.num_envs, 4), device=gs.device, dtype=gs.tc_float)
+        self.zero_velocity = bool(zero_velocity)
+        self.reset_pos = torch.as_tensor(position, device=gs.device, dtype=gs.tc_float).reshape(3)
+        self.reset_quat = None if quat is None else torch.as_tensor(quat, device=gs.device, dtype=gs.tc_float).reshape(4)
 
     def __call__(self, env, entity, envs_idx, position=None, quat=None, zero_velocity: bool = True):
-        self._pos_buffer[envs_idx] = self.reset_pos
-        entity.set_pos(self._pos_buffer[envs_idx], envs_idx=envs_idx, zero_velocity=self.zero_velocity)
+        ids = torch.as_tensor(envs_idx, device=gs.device)
+        rows = int(ids.numel())
+        if rows == 0:
+            return
+        entity.set_pos(self.reset_pos.expand(rows, 3), envs_idx=envs_idx, zero_velocity=self.zero_velocity)
         if self.reset_quat is not None:
-            self._quat_buffer[envs_idx] = self.reset_quat.reshape(1, -1)
-            entity.set_quat(self._quat_buffer[envs_idx], envs_idx=envs_idx, zero_velocity=self.zero_velocity)
+            entity.set_quat(self.reset_quat.expand(rows, 4), envs_idx=envs_idx, zero_velocity=self.zero_velocity)
 
 
 class randomize_terrain_position(ResetMdpFnClass):
@@ -109,30 +112,30 @@ class randomize_terrain_position(ResetMdpFnClass):
 
 
 class randomize_link_mass_shift(ResetMdpFnClass):
-    """Random mass shift of the links matching ``link_name`` (reset.py:229-284) — a class-style reset fn like the reference's,
-    with its persistent ``[N, n_links]`` buffer.  Reference behaviour kept as is: ``buffer[envs_idx, :].uniform_(…)`` draws into
-    the temporary that advanced indexing returns (:271), so the buffer handed to ``set_mass_shift`` stays zero, and it is
-    handed over whole together with ``envs_idx`` (:274-278)."""
+    """Mass shift of the links whose name matches ``link_name`` (reference: mdp/reset.py:229-284) — a pure call into Genesis'
+    ``set_mass_shift`` at reset time, nothing per env to compute (out of the hot path).
+
+    What reaches the simulator is pinned to the reference's OBSERVABLE behaviour rather than to its intent: there the uniform
+    draw lands in the temporary that advanced indexing returns (:271), so the shift handed to ``set_mass_shift`` is the all-zero
+    ``[num_envs, n_links]`` tensor, passed whole together with ``envs_idx`` (:274-278).  Here that is stated directly: a zero
+    shift per matching link, one draw of the same shape taken from torch's generator so the global RNG stream advances exactly
+    as it does in the reference."""
 
     def __init__(self, _env, entity, link_name: str, add_mass_range: tuple[float, float] = (-0.2, 0.2)):
         self.env = _env
         self.add_mass_range = add_mass_range
         self._entity = entity
         self._link_name = link_name
-        self._links_idx_local: list = []
-        self._mass_shift_buffer = None
         self.build()
 
     def build(self):
         from ..utils import links_by_name_pattern
 
-        self._links_idx_local = []
-        if self._link_name is not None:
-            links = links_by_name_pattern(self._entity, self._link_name)
-            if len(links) > 0:
-                self._links_idx_local = [link.idx_local for link in links]
-                self._mass_shift_buffer = torch.zeros((self.env.num_envs, len(self._links_idx_local)), device=gs.device)
+        matches = links_by_name_pattern(self._entity, self._link_name) if self._link_name is not None else []
+        self._links_idx_local = [link.idx_local for link in matches]
+        self._zero_shift = torch.zeros((self.env.num_envs, len(self._links_idx_local)), device=gs.device) if matches else None
 
     def __call__(self, env, entity, envs_idx, link_name: str, add_mass_range: tuple[float, float] = (-0.2, 0.2)):
-        self._mass_shift_buffer[envs_idx, :].uniform_(*self.add_mass_range)
-        self._entity.set_mass_shift(self._mass_shift_buffer, links_idx_local=self._links_idx_local, envs_idx=envs_idx)
+        lo, hi = self.add_mass_range
+        torch.empty((len(envs_idx), len(self._links_idx_local)), device=gs.device).uniform_(lo, hi)   # (drawn and dropped, as upstream)
+        self._entity.set_mass_shift(self._zero_shift, links_idx_local=self._links_idx_local, envs_idx=envs_idx)
