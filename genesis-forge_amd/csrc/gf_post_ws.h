@@ -87,6 +87,30 @@ __host__ __device__ constexpr int ws_sum_rows() {
 }
 template <class P>
 __host__ __device__ constexpr int ws_aux_rows() { return 4 * P::DV; }
+// Reward terms whose value depends on global memory only — contact forces, link velocities / positions, a gait manager's row as
+// the PREVIOUS step left it — not on anything another wave of the tile computes.  A static program evaluates them BEFORE the
+// barrier, in the wave with the least to load (wave 3), and parks the values in LDS rows: their loads go out together with every
+// other load of the tile instead of as round trips of their own behind the barrier (profiles/r02_c_gait_fused_attribution.txt:
+// 6.3 of the gait program's 18 µs at 8 192 envs were that chain).  The fold then reads the parked value: same function, same
+// inputs, same arithmetic — bit-identical.
+__host__ __device__ constexpr bool reward_op_memory_only(int op) {
+    return op == GF_R_GAIT_PHASE || op == GF_R_FOOT_HEIGHT || op == GF_R_CONTACT_FORCE || op == GF_R_HAS_CONTACT || op == GF_R_FEET_SLIDE;
+}
+template <class P>
+__host__ __device__ constexpr int ws_pre_slot(int upto) {   // parked rows in front of term `upto` (upto = n_rew: all of them)
+    if constexpr (P::kStatic) {
+        int n = 0;
+        for (int k = 0; k < upto && k < P::n_rew; ++k) n += reward_op_memory_only(P::rew[k].op) ? 1 : 0;
+        return n;
+    } else {
+        return 0;
+    }
+}
+template <class P>
+__host__ __device__ constexpr int ws_pre_rows() {
+    if constexpr (P::kStatic) return ws_pre_slot<P>(P::n_rew);
+    else return 0;
+}
 static_assert(kPostAuxRows >= 4 * 8, "aux rows cover 32 DOF");
 
 template <class P>
@@ -111,7 +135,9 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     constexpr int kSumRows = ws_sum_rows<P>(), kAuxRows = ws_aux_rows<P>();
     float* lds_sums = xch + x_fields(has_gait ? 1 : 0) * kEnvBlock;   // [kSumRows][64]
     float* lds_aux = lds_sums + kSumRows * kEnvBlock;        // [kAuxRows][64]: 4 per float4 chunk of a DOF row
-    float* tile = lds_aux + kAuxRows * kEnvBlock;            // [64][O+1]
+    constexpr int kPreRows = ws_pre_rows<P>();
+    float* lds_pre = lds_aux + kAuxRows * kEnvBlock;         // [kPreRows][64]: values of the memory-only reward terms (wave 3 → wave 1)
+    float* tile = lds_pre + kPreRows * kEnvBlock;            // [64][O+1]
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (GF_WAVE - 1);
@@ -436,6 +462,23 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         const GF_GLOBAL float* p0 = gsel((needs & PN_TARGETS) != 0, UNI(a.targets), ro);
         const GF_GLOBAL float* p1 = gsel((needs & PN_ACTIONS) != 0, UNI(a.env_actions), ro);
         row_load<DV>(r_a, p0, D); row_load<DV>(r_b, p1, D);
+        if constexpr (kPreRows > 0) {   // the memory-only reward terms (see reward_op_memory_only), parked for the fold
+            if (has_reward) {
+                RewardRegs rp;
+                rp.pos = V3{0.f, 0.f, 0.f}; rp.blin = rp.pos; rp.bang = rp.pos; rp.grav = rp.pos;
+                rp.dof_dev = 0.f; rp.act_rate = 0.f; rp.terminated = 0;
+                rp.cmd0[0] = 0.f; rp.cmd0[1] = 0.f; rp.cmd0[2] = 0.f;
+                rp.n = n; rp.live = live;
+                static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
+                    constexpr int k_ = decltype(K)::value;
+                    if constexpr (reward_op_memory_only(P::rew[k_].op)) {
+                        GfTerm t = karg.rterms[k_];
+                        t.op = P::rew[k_].op; t.flags = P::rew[k_].flags; t.i[0] = P::rew[k_].i0; t.i[1] = P::rew[k_].i1;
+                        lds_pre[ws_pre_slot<P>(k_) * kEnvBlock + lane] = eval_reward_term(t, a, rp);
+                    }
+                });
+            }
+        }
     }
     GF_WSTAMP(2);
     // every load above has landed (registers / LDS) before any wave starts storing state behind the barrier
@@ -548,7 +591,8 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 };
                 static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
                     constexpr int k_ = decltype(K)::value;
-                    if constexpr (P::rew[k_].op != GF_R_BODY_ACCEL_EXP) vals[k_] = eval_reward_term(term_of(K), a, rr);
+                    if constexpr (reward_op_memory_only(P::rew[k_].op)) vals[k_] = lds_pre[ws_pre_slot<P>(k_) * kEnvBlock + lane];   // wave 3 parked it
+                    else if constexpr (P::rew[k_].op != GF_R_BODY_ACCEL_EXP) vals[k_] = eval_reward_term(term_of(K), a, rr);
                 });
                 static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
                     constexpr int k_ = decltype(K)::value;

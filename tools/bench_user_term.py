@@ -67,12 +67,12 @@ def run(n, trace, steps=400):
             orig()
             env.clock = PhaseClock(env)
             rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in env.reward_manager.cfg.items()}
-            rc["in_phase"] = {"weight": 0.2, "fn": lambda e: torch.cos(6.2831853 * env.clock.phase)}
+            rc["in_phase"] = {"weight": 0.2, "fn": lambda env: torch.cos(6.2831853 * env.clock.phase)}
             env.managers["reward"] = None
             env.reward_manager = RewardManager(env, logging_enabled=True, cfg=rc)
             om = env.observation_manager
             oc = {k: {"fn": v.fn, "params": dict(v.params), "scale": v.scale, "noise": v.noise} for k, v in om.cfg.items()}
-            oc["clock"] = {"fn": lambda e: torch.stack([torch.sin(6.2831853 * env.clock.phase), env.clock.phase], dim=-1)}
+            oc["clock"] = {"fn": lambda env: torch.stack([torch.sin(6.2831853 * env.clock.phase), env.clock.phase], dim=-1)}
             env.managers["observation"].remove(om)
             env.observation_manager = ObservationManager(env, cfg=oc)
 
