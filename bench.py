@@ -63,6 +63,53 @@ def post_bytes_per_env(D: int, T: int, cmd_width: int, O: int, H: int = 1) -> in
     return reads + writes
 
 
+def pmc_traffic(num_envs: int, kernel_substr: str = "post_ws_kernel", timeout_s: float = 150.0):
+    """HBM traffic per launch of the dominant kernel from the PMC counters, measured NOW: two child runs of this very file (short,
+    nothing but the recorded step) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` — separate passes, no tracing domain
+    besides the kernel trace, as MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes — and its gfx950 correction: FETCH_SIZE
+    reports half of the bytes of wide coalesced reads, WRITE_SIZE is exact; both in KB.  traffic = 2 * FETCH_SIZE + WRITE_SIZE,
+    median over the kernel's launches.  Returns (bytes per launch, details) or (None, reason): a missing profiler, a refused
+    counter or a timeout leaves `traffic` null, it never costs the bench line."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    med = {}
+    work = tempfile.mkdtemp(prefix="gf_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "5", "--num-envs", str(num_envs),
+                   "--no-cpu-baseline", "--no-profile", "--no-sweep", "--no-hbm-point", "--no-pmc"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} timed out after {timeout_s:.0f} s"
+            if p.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited with {p.returncode}: {p.stderr[-200:]}"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {counter} wrote no counter_collection.csv"
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                    if r.get("Counter_Name") == counter and kernel_substr in r.get("Kernel_Name", "")]
+            if len(vals) < 10:
+                return None, f"only {len(vals)} launches of {kernel_substr} in the {counter} pass"
+            med[counter] = (statistics.median(vals), len(vals))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    fetch_kb, write_kb = med["FETCH_SIZE"][0], med["WRITE_SIZE"][0]
+    traffic = (2.0 * fetch_kb + write_kb) * 1024.0
+    return traffic, {"FETCH_SIZE_KB_median": fetch_kb, "WRITE_SIZE_KB_median": write_kb, "launches": [med["FETCH_SIZE"][1], med["WRITE_SIZE"][1]],
+                     "rule": "traffic = 2 x FETCH_SIZE (gfx950: the counter tallies 128-B read requests at 64 B) + WRITE_SIZE, KB -> bytes, "
+                             "median over the kernel's launches of two separate rocprofv3 --pmc child runs of this file"}
+
+
 def make_env(num_envs: int, config: str = "go2_cmd", dofs: int = 12):
     from genesis_forge_amd import tasks
     from genesis_forge_amd.managers import ObservationManager
@@ -224,6 +271,9 @@ def parse_args(argv):
     ap.add_argument("--no-sweep", action="store_true", help="skip the 4096 / 16384-env side measurements")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the 1 048 576-env roofline_hbm measurement")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event stamping pass (roofline)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip roofline.traffic: two short child runs of this file under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` "
+                         "(separate passes, as MI355X_MICROARCH.md's HBM section prescribes) after everything else has been measured")
     ap.add_argument("--profile-samples", type=int, default=200, help="stamped launches of the dominant kernel in the stamping pass")
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="the stamping pass stamps every k-th launch: a stamped launch blocks the host for ~12 us and drains the queue, "
@@ -401,8 +451,8 @@ def run_rank(args):
                                  "from draining while the host pays for the stamped launch).  An event-stamped dispatch measures ~1.5 us "
                                  "(65 536 envs) / ~7 us (1 M envs) longer than the same kernel in the rocprofv3 --kernel-trace --stats "
                                  "summary of this command (profiles/): it completes with a system-scope release that back-to-back launches "
-                                 "do not pay, so achieved / frac are lower bounds.  traffic (PMC) comes from separate rocprofv3 --pmc "
-                                 "passes (profiles/, DESIGN.md) and is not repeated here"}, **m)
+                                 "do not pay, so achieved / frac are lower bounds.  traffic: PMC FETCH_SIZE / WRITE_SIZE of this "
+                                 "kernel from two child runs of this file under rocprofv3 --pmc (traffic_source), null when skipped"}, **m)
 
     if rank == 0:
         out = {
@@ -461,6 +511,14 @@ def run_rank(args):
                                             "ms_per_step": b * 1e3, "value": n_h / b,
                                             "note": "same run, same kernel, 1 048 576 envs: the working set no longer fits the Infinity Cache"}, **m)
             del env_h
+        if not args.no_pmc and not args.no_profile and go2 and out.get("roofline") is not None:
+            # last of the GPU legs (the child processes need the device to themselves): PMC traffic of the dominant kernel
+            sync()
+            traffic, how = pmc_traffic(N)
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_source"] = how
+            if traffic:
+                out["roofline"]["traffic_over_algorithmic"] = traffic / out["roofline"]["algorithmic_bytes_per_launch"]
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, min(16, os.cpu_count() or 1))   # the GPU box gives one GPU's share of the host: 16 cores
