@@ -6,6 +6,8 @@ same env produces on the synthetic scene (whose fast path is pinned to the refer
 state AND the simulator's own state (the reset rows have to arrive through the setters).  Checked for the ordinary step and for
 the recorded + fused step, which must exist on such a scene: at most the one nonzero() the setters force, one call per getter
 and tick."""
+import os
+
 import pytest
 import torch
 
@@ -164,6 +166,44 @@ def test_unexplained_pointer_change_refuses_the_recording(oracle_backend, monkey
         env.step(torch.zeros(40, 28))
     assert env._trace is None
     assert env._untraceable is not None and "link_vel" in env._untraceable, env._untraceable
+
+
+def _fuzz_on(scene_cls, seed, dev, trace, steps=40):
+    import test_fuzz_configs as fz
+
+    fz.SCENE_CLS[0] = scene_cls
+    if not trace:
+        os.environ["GF_NO_TRACE"] = "1"
+    try:
+        return fz._run(seed, dev, steps=steps)
+    finally:
+        fz.SCENE_CLS[0] = None
+        os.environ.pop("GF_NO_TRACE", None)
+
+
+@pytest.mark.parametrize("seed", list(range(0, 28, 2)) + [123])
+def test_random_configs_on_genesis_like_scene_cpu(oracle_backend, seed):
+    """The randomised task configs (tests/test_fuzz_configs.py: drawn reward / termination / observation tables, Python-level terms,
+    a third ObservationManager, reset() overrides, output / history modes) on the double, recorded, against the same config on the
+    synthetic scene stepped phase by phase: bit for bit — every output, every manager buffer, the simulator's pose."""
+    import test_fuzz_configs as fz
+
+    want, _ = _fuzz_on(None, seed, "cpu", trace=False)
+    got, info = _fuzz_on(GenesisLikeScene, seed, "cpu", trace=True)
+    assert info["recorded"], info["env"]._untraceable
+    fz._compare(got, want, 0, f"seed {seed} on the Genesis-shaped double")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(1, 28, 3)) + [140])
+def test_random_configs_on_genesis_like_scene_hip(hip_backend, seed):
+    """-m gpu: the same on the HIP kernels — recorded step on the double == recorded step on the synthetic scene, bit for bit."""
+    import test_fuzz_configs as fz
+
+    want, _ = _fuzz_on(None, seed, "cuda", trace=True)
+    got, info = _fuzz_on(GenesisLikeScene, seed, "cuda", trace=True)
+    assert info["recorded"], info["env"]._untraceable
+    fz._compare(got, want, 0, f"seed {seed} on the Genesis-shaped double (HIP)")
 
 
 @pytest.mark.gpu
