@@ -65,6 +65,7 @@ GF_EXPORT int gf_sizeof(int which) {
         case 19: return (int)sizeof(GfHistoryUnrollArgs);
         case 20: return (int)sizeof(GfRolloutPolicyArgs);
         case 21: return (int)sizeof(GfGaeArgs);
+        case 22: return (int)sizeof(GfCompactArgs);
         default: return -1;
     }
 }
@@ -287,6 +288,7 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
             case GF_PHASE_ROLLOUT: rc = gf_rollout_write((const GfRolloutArgs*)a, stream); break;
             case GF_PHASE_ROLLOUT_POLICY: rc = gf_rollout_policy_write((const GfRolloutPolicyArgs*)a, stream); break;
             case GF_PHASE_GAE: rc = gf_gae((const GfGaeArgs*)a, stream); break;
+            case GF_PHASE_COMPACT: rc = gf_done_compact((const GfCompactArgs*)a, stream); break;
             case GF_PHASE_UNROLL: {   // the gathers of two managers (policy + critic) share a launch
                 int fused = 0;
                 if (a && i + 1 < num_ops && ops[i + 1].phase == GF_PHASE_UNROLL && ops[i + 1].args)

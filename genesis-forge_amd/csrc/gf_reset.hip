@@ -127,6 +127,106 @@ __global__ __launch_bounds__(kEnvBlock) void reset_kernel(const GfResetArgs a) {
 
 #ifndef GF_BODIES_ONLY
 namespace gf {
+
+// ---- gf_done_compact: the ascending index list of the done envs --------------------------------------------------------------
+// A workgroup of 256 lanes owns 4 096 envs, a lane 16 consecutive mask bytes (one dwordx4 per mask when the rows are 16-byte
+// aligned).  Launch 1 leaves each block's count; launch 2 adds up the counts in front of its block (at most 256 of them at 1 M
+// envs), scans its lanes' counts (wave prefix by DPP-free shuffles + 4 wave totals through LDS) and writes the indices in order.
+constexpr int kCompactBlock = 256, kCompactPerLane = 16, kCompactEnvs = kCompactBlock * kCompactPerLane;
+
+__device__ __forceinline__ uint32_t compact_bits(const GfCompactArgs& a, const int64_t first) {
+    // bit j: env first + j is listed (first is a multiple of 16)
+    uint32_t bits = 0;
+    const int64_t N = a.num_envs;
+    if (first >= N) return 0u;
+    const bool vec = first + kCompactPerLane <= N && ((reinterpret_cast<uintptr_t>(a.mask) | reinterpret_cast<uintptr_t>(a.mask2)) & 15u) == 0;
+    if (vec) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 w = *reinterpret_cast<const GF_GLOBAL u32x4*>(G(a.mask) + first);
+        if (a.mask2) w |= *reinterpret_cast<const GF_GLOBAL u32x4*>(G(a.mask2) + first);
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bits |= ((ws[k] >> (8 * b)) & 0xffu) ? 1u << (4 * k + b) : 0u;
+    } else {
+        for (int j = 0; j < kCompactPerLane && first + j < N; ++j)
+            if (G(a.mask)[first + j] || (a.mask2 && G(a.mask2)[first + j])) bits |= 1u << j;
+    }
+    return bits;
+}
+
+__global__ __launch_bounds__(kCompactBlock) void compact_count_kernel(const GfCompactArgs a) {
+    const int64_t first = ((int64_t)blockIdx.x * kCompactBlock + threadIdx.x) * kCompactPerLane;
+    const int mine = __builtin_popcount(compact_bits(a, first));
+    const int w = (int)wave_sum((double)mine);   // (exact: counts are far below 2^53)
+    __shared__ int s_w[kCompactBlock / GF_WAVE];
+    if ((threadIdx.x & (GF_WAVE - 1)) == 0) s_w[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < kCompactBlock / GF_WAVE; ++i) t += s_w[i];
+        a.block_counts[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kCompactBlock) void compact_write_kernel(const GfCompactArgs a, const int num_blocks) {
+    __shared__ int s_base, s_w[kCompactBlock / GF_WAVE];
+    // the counts in front of this block (every lane sums a strided share; num_blocks <= 256 at 1 M envs)
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += kCompactBlock) part += a.block_counts[b];
+    const int wpart = (int)wave_sum((double)part);
+    if ((threadIdx.x & (GF_WAVE - 1)) == 0) s_w[threadIdx.x >> 6] = wpart;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < kCompactBlock / GF_WAVE; ++i) t += s_w[i];
+        s_base = t;
+    }
+    __syncthreads();
+    const int base = s_base;
+    const int64_t first = ((int64_t)blockIdx.x * kCompactBlock + threadIdx.x) * kCompactPerLane;
+    uint32_t bits = compact_bits(a, first);
+    const int mine = __builtin_popcount(bits);
+    // exclusive prefix inside the wave, then across the four waves
+    const int lane = threadIdx.x & (GF_WAVE - 1);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < GF_WAVE; o <<= 1) {
+        const int up = __shfl_up(incl, o, GF_WAVE);
+        if (lane >= o) incl += up;
+    }
+    __syncthreads();   // (s_w is reused)
+    if (lane == GF_WAVE - 1) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int off = base + incl - mine;
+    for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) off += s_w[i];
+    while (bits) {
+        const int j = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        G(a.ids_out)[off++] = first + j;
+    }
+    if (blockIdx.x == (unsigned)num_blocks - 1 && threadIdx.x == kCompactBlock - 1) *a.count_out = off;   // the last lane of the last block ends at the total
+}
+
+}  // namespace gf
+
+extern "C" __attribute__((visibility("default"))) int gf_done_compact(const GfCompactArgs* a, void* stream) {
+    if (!a || !a->mask || !a->ids_out || !a->count_out || !a->block_counts) return GF_E_NULL;
+    if (a->num_envs < 0 || a->num_envs >= ((int64_t)1 << 31)) return GF_E_RANGE;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->num_envs == 0) {
+        GF_HIP_CHECK(hipMemsetAsync(a->count_out, 0, sizeof(int32_t), s));
+        return GF_OK;
+    }
+    const int blocks = (int)((a->num_envs + gf::kCompactEnvs - 1) / gf::kCompactEnvs);
+    gf::PhaseScope scope(GF_PHASE_COMPACT, s);
+    gf::klaunch(gf::compact_count_kernel, dim3(blocks), dim3(gf::kCompactBlock), 0, s, *a);
+    gf::klaunch(gf::compact_write_kernel, dim3(blocks), dim3(gf::kCompactBlock), 0, s, *a, blocks);
+    return gf::launch_status();
+}
+
+namespace gf {
 int reset_prep(const GfResetArgs* a) {
     if (!a || !a->mask) return GF_E_NULL;
     if (a->num_envs < 0 || a->num_dofs < 0) return GF_E_RANGE;

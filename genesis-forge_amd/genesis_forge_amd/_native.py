@@ -83,7 +83,7 @@ GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
 
 (GF_PHASE_ACTION, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
  GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_ROLLOUT, GF_PHASE_UNROLL,
- GF_PHASE_ROLLOUT_POLICY, GF_PHASE_GAE, GF_PHASE_COUNT) = range(17)
+ GF_PHASE_ROLLOUT_POLICY, GF_PHASE_GAE, GF_PHASE_COMPACT, GF_PHASE_COUNT) = range(18)
 
 GF_OPT_PROFILE_STRIDE = 1  # gf_set_option: stamp every k-th launch of the profiled phase
 GF_OPT_CHAIN = 3           # gf_set_option: 1 (default) = fold runs of per-env phases of a recorded step into phase-chain launches
@@ -293,6 +293,10 @@ class GfGaeArgs(C.Structure):
                 ("normalize", C.c_int32), ("_pad", C.c_int32)]
 
 
+class GfCompactArgs(C.Structure):
+    _fields_ = [("num_envs", C.c_int64), ("mask", P), ("mask2", P), ("ids_out", P), ("count_out", P), ("block_counts", P)]
+
+
 class GfPostRefs(C.Structure):
     _fields_ = [("termination", P), ("reward", P), ("reset", P), ("num_command", C.c_int32), ("num_observe", C.c_int32),
                 ("command_step", P * GF_POST_MAX_CMD), ("command_reset", P * GF_POST_MAX_CMD), ("observe", P * GF_POST_MAX_OBS),
@@ -301,7 +305,7 @@ class GfPostRefs(C.Structure):
 
 ABI_STRUCTS = [GfStepStats, GfActionArgs, GfContactArgs, GfTerminationArgs, GfRewardArgs, GfCommandArgs,
                GfResetArgs, GfObservationArgs, GfRotateArgs, GfSynthSceneArgs, GfTerm, GfObsItem, GfTerrainView, GfTerrainHeightArgs, GfGaitArgs, GfContactView, GfCommandView,
-               GfPostRefs, GfRolloutArgs, GfHistoryUnrollArgs, GfRolloutPolicyArgs, GfGaeArgs]
+               GfPostRefs, GfRolloutArgs, GfHistoryUnrollArgs, GfRolloutPolicyArgs, GfGaeArgs, GfCompactArgs]
 
 PHASE_FUNCS = {
     "action_step": GfActionArgs,
@@ -319,6 +323,7 @@ PHASE_FUNCS = {
     "history_unroll": GfHistoryUnrollArgs,
     "rollout_policy_write": GfRolloutPolicyArgs,
     "gae": GfGaeArgs,
+    "done_compact": GfCompactArgs,
 }
 
 
@@ -327,7 +332,7 @@ PHASE_OF_FN = {
     "reward_step": GF_PHASE_REWARD, "command_step": GF_PHASE_COMMAND, "masked_reset": GF_PHASE_RESET,
     "observe": GF_PHASE_OBSERVE, "entity_rotate": GF_PHASE_ROTATE, "synth_scene_step": GF_PHASE_SCENE,
     "terrain_height": GF_PHASE_TERRAIN, "gait_step": GF_PHASE_GAIT, "rollout_write": GF_PHASE_ROLLOUT,
-    "history_unroll": GF_PHASE_UNROLL, "rollout_policy_write": GF_PHASE_ROLLOUT_POLICY, "gae": GF_PHASE_GAE,
+    "history_unroll": GF_PHASE_UNROLL, "rollout_policy_write": GF_PHASE_ROLLOUT_POLICY, "gae": GF_PHASE_GAE, "done_compact": GF_PHASE_COMPACT,
 }
 
 

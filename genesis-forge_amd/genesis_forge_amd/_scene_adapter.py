@@ -199,12 +199,11 @@ class SceneAdapter:
             fn(ids)
 
     def push_done(self, mask: torch.Tensor, mask2: Optional[torch.Tensor]) -> None:
-        """The in-step reset: index list of the done envs — the one ``nonzero()`` of the step (managed_env.py:308-310) —
-        then the setters."""
+        """The in-step reset: index list of the done envs — the one synchronisation of the step, where the reference has its
+        ``nonzero()`` (managed_env.py:308-310); here ``gf_done_compact`` + a stream sync — then the setters."""
         if not self._pushes:
             return
-        both = mask if mask2 is None else (mask | mask2)
-        ids = both.nonzero(as_tuple=False).reshape((-1,))
+        ids = self.env.done_ids(mask, mask2)   # (a view of the env's index buffer: the setters gather with it right away)
         if ids.numel() > 0:
             self.push(ids)
 

@@ -43,6 +43,40 @@ class EntityViews:
         view.ang_vel = self.ang_vel.data_ptr()
 
 
+class DoneIds:
+    """The ascending index list of a step's done envs — what the reference gets from ``(terminated | truncated).nonzero()``
+    (managed_env.py:308-310) — through ``gf_done_compact``: two small launches write the list into a persistent buffer and the
+    count into a pinned host word, the host synchronises the stream and takes a view.  torch's ``nonzero()`` costs an OR launch, a
+    two-pass select, a device-to-host copy and an allocation for the same sync."""
+
+    def __init__(self, num_envs: int):
+        dev = gs.device
+        self.ids = torch.empty(max(num_envs, 1), device=dev, dtype=torch.int64)
+        self.count = torch.zeros(1, dtype=torch.int32)
+        if dev.type == "cuda":
+            self.count = self.count.pin_memory()   # the kernel stores into it through the host mapping
+        self.scratch = torch.zeros((num_envs + 4095) // 4096 + 1, device=dev, dtype=torch.int32)
+        self.args = nat.GfCompactArgs()
+        self.args.num_envs = num_envs
+        self.args.ids_out, self.args.count_out, self.args.block_counts = self.ids.data_ptr(), self.count.data_ptr(), self.scratch.data_ptr()
+
+    def __call__(self, backend, mask: torch.Tensor, mask2: Optional[torch.Tensor] = None, own: bool = False) -> torch.Tensor:
+        """``own``: a tensor of the caller's own (handed to user code, which may keep it); otherwise a view of the buffer, valid
+        until the next call."""
+        a = self.args
+        a.mask, a.mask2 = mask.data_ptr(), (None if mask2 is None else mask2.data_ptr())
+        tracer, backend.tracer = backend.tracer, None   # (never part of a recording: the list is taken where it is needed)
+        try:
+            backend.call("done_compact", a)
+        finally:
+            backend.tracer = tracer
+        if mask.device.type == "cuda":
+            torch.cuda.current_stream().synchronize()   # the one sync of the step (the reference's nonzero() is one too)
+        k = int(self.count[0])
+        out = self.ids[:k]
+        return out.clone() if own and k else out
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.to(torch.float32)
@@ -107,6 +141,7 @@ class GenesisEnv:
         #: snapshot + write-back for a scene with Genesis' public surface only (fresh getter tensors, envs_idx setters); None for
         #: a scene whose state tensors are persistent and shared (``gf_static_buffers``); set by build()
         self._adapter = None
+        self._done_ids_native: Optional[DoneIds] = None
 
     """
     Properties (genesis_env.py:95-148)
@@ -238,6 +273,12 @@ class GenesisEnv:
             v = EntityViews(_f32c(entity.get_pos()), _f32c(entity.get_quat()), _f32c(entity.get_vel()), _f32c(entity.get_ang()))
         self._views_cache[key] = (self._tick, v)
         return v
+
+    def done_ids(self, mask: torch.Tensor, mask2: Optional[torch.Tensor] = None, own: bool = False) -> torch.Tensor:
+        """Ascending indices of the envs whose ``mask`` (or ``mask2``) is set — see :class:`DoneIds`."""
+        if self._done_ids_native is None:
+            self._done_ids_native = DoneIds(self.num_envs)
+        return self._done_ids_native(self.backend, mask, mask2, own)
 
     def invalidate_views(self) -> None:
         self._tick += 1

@@ -289,8 +289,7 @@ class ManagedEnvironment(GenesisEnv):
     def _indexed_reset(self, indexed: list, mask: torch.Tensor, mask2: Optional[torch.Tensor]) -> None:
         """``reset(ids)`` of the managers that need an index list (user-defined classes, Python on_reset entries), for the done
         envs of this step: the one ``nonzero()`` the reference pays too (managed_env.py:308-310)."""
-        both = mask if mask2 is None else (mask | mask2)
-        ids = both.nonzero(as_tuple=False).reshape((-1,))
+        ids = self.done_ids(mask, mask2, own=True)   # (user code may keep the list: a tensor of its own)
         if ids.numel() > 0:
             for m in indexed:
                 m.reset(ids)
@@ -307,7 +306,7 @@ class ManagedEnvironment(GenesisEnv):
         """managed_env.py:303-323 without the nonzero() sync when every reset can be expressed as a mask."""
         if type(self).reset is not ManagedEnvironment.reset:
             # a user subclass overrides reset(): honour it exactly like the reference does
-            ids = (terminated | truncated).nonzero(as_tuple=False).reshape((-1,)).detach()
+            ids = self.done_ids(terminated, truncated, own=True)
             if ids.numel() > 0:
                 self._done_ids = ids   # (reset() recognises THIS index list: the done envs, i.e. the termination masks)
                 try:
@@ -365,8 +364,7 @@ class ManagedEnvironment(GenesisEnv):
             call_untraced(self, fn)
         elif indexed or pushes:
             if ids is None:
-                both = mask if mask2 is None else (mask | mask2)
-                ids = both.nonzero(as_tuple=False).reshape((-1,))  # host sync: managers that need index lists, Genesis' setters
+                ids = self.done_ids(mask, mask2, own=bool(indexed))  # host sync: managers that need index lists, Genesis' setters
             if ids is not None and (not isinstance(ids, torch.Tensor) or ids.numel() > 0):
                 if pushes:
                     ad.push(torch.as_tensor(ids, device=gs.device, dtype=torch.long))

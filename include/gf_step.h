@@ -643,6 +643,24 @@ typedef struct GfGaeArgs {
 } GfGaeArgs;
 
 /* ------------------------------------------------------------------------------------------
+ * The index list of a step's done envs.  The reference compacts `(terminated | truncated).nonzero()` on every step
+ * (managed_env.py:308-310) and hands the list to `reset(ids)`; on the masked path nothing needs it — except code that takes
+ * index lists by contract: Genesis' `envs_idx` setters (position_action_manager.py:455-464, mdp/reset.py:102-124), a user's
+ * `reset(ids)` override, user-defined manager classes.  torch's `nonzero()` there is an OR launch, a two-pass select, a
+ * device-to-host copy of the count and an allocation.  gf_done_compact: two small launches — per-block counts, then
+ * offsets + ordered writes — produce the ascending list in a caller-owned buffer and the count in a word the host reads after
+ * synchronising the stream (pinned host memory).  Same order as nonzero(), so everything downstream is unchanged.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct GfCompactArgs {
+    int64_t num_envs;
+    const uint8_t* mask;      /* [N] nonzero = listed */
+    const uint8_t* mask2;     /* [N] OR-ed in, or NULL */
+    int64_t* ids_out;         /* [N] capacity; the first *count_out entries are the indices, ascending */
+    int32_t* count_out;       /* one word: device memory or pinned host memory */
+    int32_t* block_counts;    /* scratch, ceil(N / 4096) + 1 words */
+} GfCompactArgs;
+
+/* ------------------------------------------------------------------------------------------
  * History ring -> the reference's observation layout.  The reference keeps a list of H frames, pops the oldest, inserts the new
  * one in front and returns `torch.cat(self._history, dim=-1)` (observation_manager.py:219-226): every call writes a NEW
  * [N, H*O] tensor, newest frame first.  With the history kept as an in-place ring (GfObservationArgs.history_ring: the step
@@ -680,7 +698,7 @@ int gf_abi_version(void);
  * chains — termination → reward → command.step…, and reset → command.reset… → observe… — one launch each (csrc/gf_chain.hip). */
 enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_GRAPH = 2, GF_OPT_CHAIN = 3, GF_OPT_COUNT = 4 };
 int gf_set_option(int option, int value);
-int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView, 17 GfPostRefs, 18 GfRolloutArgs, 19 GfHistoryUnrollArgs, 20 GfRolloutPolicyArgs, 21 GfGaeArgs): binding self-check */
+int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView, 17 GfPostRefs, 18 GfRolloutArgs, 19 GfHistoryUnrollArgs, 20 GfRolloutPolicyArgs, 21 GfGaeArgs, 22 GfCompactArgs): binding self-check */
 const char* gf_build_info(void);
 const char* gf_error_string(int code);
 
@@ -700,6 +718,7 @@ int gf_synth_scene_step(const GfSynthSceneArgs* a, void* stream); /* stands in f
 int gf_rollout_write(const GfRolloutArgs* a, void* stream);       /* replaces the RolloutStorage copy_ launches of the RL library (examples/simple/train.py:125-129) */
 int gf_history_unroll(const GfHistoryUnrollArgs* a, void* stream);/* replaces the torch.cat of observation_manager.py:226 */
 int gf_rollout_policy_write(const GfRolloutPolicyArgs* a, void* stream);   /* the policy's rows of a transition + time-out bootstrap (rsl_rl add_transitions; call site examples/simple/train.py:125-129) */
+int gf_done_compact(const GfCompactArgs* a, void* stream);       /* replaces the nonzero() of managed_env.py:308-310 where an index list is still needed */
 int gf_gae(const GfGaeArgs* a, void* stream);                     /* returns and advantages of a finished rollout (rsl_rl compute_returns; gamma / lam: examples/simple/train.py:41-47) */
 
 /* ------------------------------------------------------------------------------------------
@@ -871,7 +890,7 @@ int gf_event_synchronize(void* event);   /* blocks the host until the event has 
  * immediately around the kernel launch of the selected phase). */
 enum { GF_PHASE_ACTION = 0, GF_PHASE_CONTACT, GF_PHASE_TERMINATION, GF_PHASE_REWARD, GF_PHASE_COMMAND,
        GF_PHASE_RESET, GF_PHASE_OBSERVE, GF_PHASE_ROTATE, GF_PHASE_SCENE, GF_PHASE_POST, GF_PHASE_TERRAIN, GF_PHASE_GAIT, GF_PHASE_ROLLOUT,
-       GF_PHASE_UNROLL, GF_PHASE_ROLLOUT_POLICY, GF_PHASE_GAE, GF_PHASE_COUNT };
+       GF_PHASE_UNROLL, GF_PHASE_ROLLOUT_POLICY, GF_PHASE_GAE, GF_PHASE_COMPACT, GF_PHASE_COUNT };
 int gf_profile_begin(int phase, int max_samples);     /* start recording event pairs for `phase` */
 int gf_profile_end(double* total_ms, int* samples);    /* sync events, return Σ elapsed + count, free them */
 

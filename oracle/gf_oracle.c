@@ -1112,6 +1112,17 @@ GFO_EXPORT int gfo_rollout_policy_write(const GfRolloutPolicyArgs* a) {
     return GF_OK;
 }
 
+/* The ascending index list of the listed envs: torch's `(terminated | truncated).nonzero()` (managed_env.py:308-310). */
+GFO_EXPORT int gfo_done_compact(const GfCompactArgs* a) {
+    if (!a || !a->mask || !a->ids_out || !a->count_out || !a->block_counts) return GF_E_NULL;
+    if (a->num_envs < 0 || a->num_envs >= ((int64_t)1 << 31)) return GF_E_RANGE;
+    int32_t k = 0;
+    for (int64_t n = 0; n < a->num_envs; ++n)
+        if (a->mask[n] || (a->mask2 && a->mask2[n])) a->ids_out[k++] = n;
+    *a->count_out = k;
+    return GF_OK;
+}
+
 /* GAE (rsl_rl RolloutStorage.compute_returns; gamma / lam from examples/simple/train.py:41-47): the torch loop, scalar. */
 GFO_EXPORT int gfo_gae(const GfGaeArgs* a) {
     if (!a || !a->rewards || !a->values || !a->dones || !a->last_values || !a->returns || !a->advantages) return GF_E_NULL;
@@ -1255,6 +1266,7 @@ GFO_EXPORT int gfo_run_ops(const GfOp* ops, int num_ops, int* failed_index) {
             case GF_PHASE_UNROLL: rc = gfo_history_unroll((const GfHistoryUnrollArgs*)a); break;
             case GF_PHASE_ROLLOUT_POLICY: rc = gfo_rollout_policy_write((const GfRolloutPolicyArgs*)a); break;
             case GF_PHASE_GAE: rc = gfo_gae((const GfGaeArgs*)a); break;
+            case GF_PHASE_COMPACT: rc = gfo_done_compact((const GfCompactArgs*)a); break;
             case GF_OP_STATS_PACK: rc = gfo_stats_pack((const GfStatsPackArgs*)a); break;
             case GF_OP_STATS_COPY: {
                 const GfStatsCopyArgs* c = (const GfStatsCopyArgs*)a;
@@ -1357,6 +1369,7 @@ GFO_EXPORT int gfo_sizeof(int which) {
         case 19: return (int)sizeof(GfHistoryUnrollArgs);
         case 20: return (int)sizeof(GfRolloutPolicyArgs);
         case 21: return (int)sizeof(GfGaeArgs);
+        case 22: return (int)sizeof(GfCompactArgs);
         default: return -1;
     }
 }

@@ -107,7 +107,8 @@ def test_recorded_step_on_genesis_like_scene_cpu(oracle_backend, name):
 
 def test_one_getter_call_per_tick_and_one_index_list(oracle_backend, monkeypatch):
     """A replayed step on the double: control_dofs_position + scene.step() once, every getter of the plan once, setters only on
-    steps that reset an env, and exactly one nonzero() (the index list the envs_idx setters need; managed_env.py:308-310)."""
+    steps that reset an env, and exactly one index-list compaction (gf_done_compact + sync: what the envs_idx setters need, where the
+    reference has its nonzero(); managed_env.py:308-310)."""
     _, env = run("go2_cmd", "cpu", GenesisLikeScene, True, steps=20)
     tr = env._trace
     assert tr is not None and len(tr.scene_plan) > 0
@@ -126,12 +127,14 @@ def test_one_getter_call_per_tick_and_one_index_list(oracle_backend, monkeypatch
         sc.calls.clear()
         nz["n"] = 0
         f0 = env._adapter.fetches
+        calls0 = len(oracle_backend.calls)
         o, r, te, tru, ex = env.step(torch.randn(70, 12, generator=g))
         assert sc.calls["step"] == 1 and sc.calls["control_dofs_position"] == 1
         assert env._adapter.fetches - f0 == len(tr.scene_plan)
         for getter in ("get_pos", "get_quat", "get_vel", "get_ang", "get_dofs_position", "get_dofs_velocity", "get_contacts", "get_links_quat"):
             assert sc.calls[getter] == 1, f"{getter} called {sc.calls[getter]} times in one tick"
-        assert nz["n"] == 1, f"{nz['n']} nonzero() calls in a replayed step"
+        # the index list the envs_idx setters need (managed_env.py:308-310): ONE compaction + sync per tick, and not torch's nonzero()
+        assert nz["n"] == 0 and oracle_backend.calls[calls0:].count("done_compact") == 1, (nz["n"], oracle_backend.calls[calls0:])
         done = bool((te | tru).any())
         resets += done
         for setter in ("set_dofs_position", "set_pos", "set_quat"):
