@@ -201,60 +201,43 @@ class PositionActionManager(BaseActionManager):
         return _tag(self._actions, ("actions", self))
 
     # -- build --------------------------------------------------------------------------------------
+    #: (attribute, constructor cfg) of the optional per-DOF gain vectors — resolved in one loop instead of a block per gain
+    _GAIN_TABLE = (("_scale_values", "_scale_cfg"), ("_kp_values", "_pd_kp_cfg"), ("_kv_values", "_pd_kv_cfg"),
+                   ("_damping_values", "_damping_cfg"), ("_stiffness_values", "_stiffness_cfg"), ("_frictionloss_values", "_frictionloss_cfg"))
+
     def build(self):
-        """Resolve joints and per-DOF constants (position_action_manager.py:295-374)."""
-        self._enabled_dof = dict()
-        for joint in self.env.robot.joints:
-            if joint.type != gs.JOINT_TYPE.REVOLUTE:
-                continue
-            for pattern in self._joint_name_cfg:
-                if re.match(f"^{pattern}$", joint.name):
-                    self._enabled_dof[joint.name] = joint.dof_start
-                    break
-        D = self.num_actions
-        N = self.env.num_envs
+        """Resolve the controlled joints and every per-DOF constant (what position_action_manager.py:295-374 computes): revolute joints
+        whose name fully matches one of ``joint_names``, in the robot's joint order; then each ``{pattern: value}`` table onto them."""
+        def wanted(name):
+            return any(re.match(f"^{pattern}$", name) for pattern in self._joint_name_cfg)
 
-        if self._default_pos_cfg is not None:
-            self._default_vec = self._get_dof_value_tensor(self._default_pos_cfg)
-        else:
-            self._default_vec = torch.zeros(D, device=gs.device)
+        self._enabled_dof = {j.name: j.dof_start for j in self.env.robot.joints if j.type == gs.JOINT_TYPE.REVOLUTE and wanted(j.name)}
+        D, N = self.num_actions, self.env.num_envs
+        vec = lambda table, **kw: torch.tensor(self._per_dof(table, **kw), device=gs.device, dtype=gs.tc_float)
+
+        self._default_vec = vec(self._default_pos_cfg) if self._default_pos_cfg is not None else torch.zeros(D, device=gs.device)
         self._default_dofs_pos = self._default_vec.unsqueeze(0).expand(N, -1)
+        for attr, cfg_attr in self._GAIN_TABLE:
+            table = getattr(self, cfg_attr)
+            setattr(self, attr, None if table is None else vec(table))
 
-        lower_limit, upper_limit = self.env.robot.get_dofs_limit(self.dofs_idx)
-        self._scale_values = None
-        self._kp_values = self._kv_values = self._damping_values = self._stiffness_values = self._frictionloss_values = None
-        self._clip_values = torch.stack([lower_limit.to(gs.tc_float), upper_limit.to(gs.tc_float)], dim=1)
-        if self._scale_cfg is not None:
-            self._scale_values = self._get_dof_value_tensor(self._scale_cfg)
-        if self._clip_cfg is not None:
-            self._clip_values = self._get_dof_value_tensor(self._clip_cfg, output=[list(map(float, r)) for r in self._clip_values.tolist()])
-        if self._pd_kp_cfg is not None:
-            self._kp_values = self._get_dof_value_tensor(self._pd_kp_cfg)
-        if self._pd_kv_cfg is not None:
-            self._kv_values = self._get_dof_value_tensor(self._pd_kv_cfg)
-        if self._damping_cfg is not None:
-            self._damping_values = self._get_dof_value_tensor(self._damping_cfg)
-        if self._stiffness_cfg is not None:
-            self._stiffness_values = self._get_dof_value_tensor(self._stiffness_cfg)
-        if self._frictionloss_cfg is not None:
-            self._frictionloss_values = self._get_dof_value_tensor(self._frictionloss_cfg)
+        lower, upper = self.env.robot.get_dofs_limit(self.dofs_idx)
+        limits = torch.stack([lower.to(gs.tc_float), upper.to(gs.tc_float)], dim=1)            # [D, 2]: the joint limits …
+        self._clip_values = limits if self._clip_cfg is None else vec(self._clip_cfg, start=[list(map(float, r)) for r in limits.tolist()])   # … unless `clip` narrows them
+
         if self._use_default_offset:
-            self._offset_values = self._default_dofs_pos
-            self._offset_vec = self._default_vec
+            self._offset_values, self._offset_vec = self._default_dofs_pos, self._default_vec
         else:
-            offset = self._offset_cfg if self._offset_cfg is not None else {".*": 0.0}
-            self._offset_vec = self._get_dof_value_tensor(offset)
+            self._offset_vec = vec(self._offset_cfg if self._offset_cfg is not None else {".*": 0.0})
             self._offset_values = self._offset_vec
 
+        # max_force: a bound b means (-b, b), a pair means (lo, hi) — decided, as upstream, by the FIRST joint's entry
         self._force_range = None
         if self._max_force_cfg is not None:
-            max_force = self._get_dof_value_array(self._max_force_cfg)
-            lo, hi = [0.0] * D, [0.0] * D
-            for i, value in enumerate(max_force):
-                if isinstance(max_force[0], (list, tuple)):
-                    lo[i], hi[i] = value[0], value[1]
-                else:
-                    lo[i], hi[i] = -value, value
+            entries = self._per_dof(self._max_force_cfg)
+            paired = isinstance(entries[0], (list, tuple))
+            lo = [e[0] if paired else -e for e in entries]
+            hi = [e[1] if paired else e for e in entries]
             self._force_range = (torch.tensor(lo, device=gs.device), torch.tensor(hi, device=gs.device))
 
         self._build_native()
@@ -380,30 +363,33 @@ class PositionActionManager(BaseActionManager):
         self._keep = d
         a.dof_draws = None if d is None else d.data_ptr()
 
-    # -- helpers (position_action_manager.py:470-525) -------------------------------------------------
-    def _get_dof_value_array(self, values, default_value=0.0, output=None):
-        is_set = [False] * self.num_actions
-        if output is None:
-            output = [default_value] * self.num_actions
-        for pattern, value in values.items():
-            found = False
-            for i, name in enumerate(self._enabled_dof.keys()):
-                if not is_set[i] and re.match(f"^{pattern}$", name):
-                    is_set[i] = True
-                    output[i] = list(value) if isinstance(value, (tuple, list)) else value
-                    found = True
-            if not found:
+    # -- helpers ------------------------------------------------------------------------------------------
+    def _per_dof(self, table: dict, start=None, fill=0.0) -> list:
+        """``{joint-name pattern: value}`` → one value per controlled DOF.  Patterns are tried in dict order against the DOFs no
+        earlier pattern has claimed (the first match wins); a pattern that claims nothing is an error, as in the reference
+        (position_action_manager.py:470-501: ``Joint DOF '<pattern>' not found.``).  ``start``: initial values (the joint limits
+        for ``clip``); sequences are stored as lists."""
+        names = list(self._enabled_dof)
+        out = list(start) if start is not None else [fill] * len(names)
+        unclaimed = list(range(len(names)))
+        for pattern, value in table.items():
+            rx = re.compile(f"^{pattern}$")
+            hits = [i for i in unclaimed if rx.match(names[i])]
+            if not hits:
                 raise RuntimeError(f"Joint DOF '{pattern}' not found.")
-        return output
+            for i in hits:
+                out[i] = list(value) if isinstance(value, (tuple, list)) else value
+            unclaimed = [i for i in unclaimed if i not in hits]
+        return out
 
-    def _get_dof_value_tensor(self, values, default_value=0.0, output=None) -> torch.Tensor:
-        values = self._get_dof_value_array(values, default_value, output)
-        return torch.tensor(values, device=gs.device, dtype=gs.tc_float)
+    def _get_dof_value_array(self, values, default_value=0.0, output=None):   # (the reference's private name, kept as an alias)
+        return self._per_dof(values, start=output, fill=default_value)
 
     def _add_random_noise(self, values: torch.Tensor, noise_scale: float = 0.0) -> torch.Tensor:
+        """``values + U(-1, 1) * noise_scale`` (torch's generator: gains are uploaded outside the step's kernels)."""
         if noise_scale == 0.0:
             return values
-        return values + torch.empty_like(values).uniform_(-1, 1) * noise_scale
+        return values + (torch.rand_like(values) * 2.0 - 1.0) * noise_scale
 
 
 class PositionWithinLimitsActionManager(PositionActionManager):
