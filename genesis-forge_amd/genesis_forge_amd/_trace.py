@@ -131,7 +131,9 @@ class StepTrace:
         first_post = self._post_start(calls) if self.post_refs is not None else len(calls)
         self.post_split = self.post_refs is not None and bool(self.post_refs.flags & nat.GF_POST_TERMINATION_DONE)
         mark_i = 0
+        post_index = -1   # final index of the fused launch's op
         for idx, (fn, args, owner) in enumerate(calls):
+            k_before = k
             while mark_i < len(marks) and marks[mark_i][0] <= idx:   # user code that ran before this call: a split in front of its op
                 assert idx <= first_post or self.post_refs is None
                 self.splits.append((k - 1, marks[mark_i][1]))
@@ -148,11 +150,16 @@ class StepTrace:
                 self.ops[k].phase = nat.GF_OP_POST_PHYSICS
                 self.ops[k].args = C.addressof(self.post_refs)
                 k += 1
+                post_index = k - 2
             elif fn == "history_unroll" or idx in self._late:   # the gather of a ring-kept history — and an observation manager with a
                 self.ops[k].phase = nat.PHASE_OF_FN[fn]         # Python-level item — follow the fused launch as ops of their own
                 self.ops[k].args = C.addressof(args)
                 k += 1
-            self._cur_op = k - 2  # index of this call's op once the leading STATS_CLEAR op is dropped (below)
+            # index of this call's op once the leading STATS_CLEAR op is dropped (below).  A call that is PART of the fused launch has
+            # no op of its own: its per-step fields belong to the fused launch's op — not to whatever op was assigned last (a late
+            # observation manager's launch can sit between two fused calls in the recorded order, and with per-piece patch tables its
+            # output rotation would then be applied one piece too late: fuzz seeds 57 / 115 / 132 / 139)
+            self._cur_op = k - 2 if (k != k_before or post_index < 0) else post_index
             self._hooks(fn, args, owner)
             self.native_op.extend([self._cur_op] * (len(self.native) - len(self.native_op)))
             if fn == "action_step" and self.adapter is not None:
@@ -227,25 +234,32 @@ class StepTrace:
             for (a0, a1), pre in zip(zip(cuts[:-1], cuts[1:]), pres):
                 sub = (nat.GfOp * (a1 - a0)).from_buffer(self.ops, a0 * C.sizeof(nat.GfOp)) if a1 > a0 else None
                 self.segments.append((a0, a1 - a0, sub, pre))
-            # Each piece of the op list goes out with ITS patches (one native call per piece): user code that runs between two
-            # pieces may draw Philox streams itself (a user manager's step() calling the base class' resample), and the ordinary
-            # step hands out stream ids in call order — so a piece's GF_PATCH_STREAM entries must not run before the user code in
-            # front of it.  On a Genesis-shaped scene the pieces behind the scene split also carry the snapshot's pointer patches.
+            # Each piece of the op list goes out with its patches (one native call per piece).  The table stays in CALL order — stream
+            # ids are handed out in the order the ordinary step draws them — and a piece applies the not yet applied PREFIX of it up
+            # to the last entry one of its own ops needs: user code that runs between two pieces may draw Philox streams itself (a
+            # user manager's step() calling the base class' resample), so the entries of the calls behind it must not run before it;
+            # but an observation manager that is part of the fused launch can sit BEHIND a late manager's launch in call order, and
+            # then the late manager's entries go out early with it (fuzz seeds 57 / 115 / 132: its stream id comes first).  The
+            # statistics slots (call parameters, no order) go with the first piece; on a Genesis-shaped scene the piece behind the
+            # scene split also carries every descriptor's snapshot pointers.
             scene_tab = list(getattr(self, "_scene_tab", []))
-            after_scene = False
+            ordered = [i for i, at in enumerate(self.native_op) if at >= 0]
+            unordered = [self.native[i] for i, at in enumerate(self.native_op) if at < 0]
+            done_upto = 0
             segs = []
             for j, (a0, cnt, sub, pre) in enumerate(self.segments):
-                if self.adapter is not None and pre == self._scene_pre:
-                    after_scene = True
-                    mine = list(scene_tab)   # every descriptor's snapshot pointers, once, right after the fetch
-                else:
-                    mine = []
-                mine += [p for p, at in zip(self.native, self.native_op) if (a0 <= at < a0 + cnt) or (j == 0 and at < 0)]
+                mine = list(scene_tab) if (self.adapter is not None and pre == self._scene_pre) else []
+                if j == 0:
+                    mine += unordered
+                need = [pos for pos, i in enumerate(ordered) if a0 <= self.native_op[i] < a0 + cnt]
+                end = len(ordered) if j == len(self.segments) - 1 else max([done_upto] + [pos + 1 for pos in need])
+                mine += [self.native[i] for i in ordered[done_upto:end]]
+                done_upto = max(done_upto, end)
                 table = (nat.GfReplayPatch * max(1, len(mine)))(*mine)
                 desc = nat.GfReplay(C.addressof(self.ops) + a0 * C.sizeof(nat.GfOp) if cnt else None, cnt, len(mine), C.addressof(table), C.addressof(env._rng_c))
                 segs.append((a0, cnt, pre, desc, table))
             self.segments = segs
-            assert sum(len(t) if d.num_patches else 0 for *_x, d, t in segs) >= len(self.native)
+            assert sum(d.num_patches for *_x, d, _t in segs) == len(self.native) + len(scene_tab)
 
     def fresh(self) -> bool:
         """No descriptor of this recording has been used by a phase call outside its replay since it was made."""

@@ -142,6 +142,7 @@ class GenesisEnv:
         #: a scene whose state tensors are persistent and shared (``gf_static_buffers``); set by build()
         self._adapter = None
         self._done_ids_native: Optional[DoneIds] = None
+        self._done_ids_cache = None
 
     """
     Properties (genesis_env.py:95-148)
@@ -278,7 +279,16 @@ class GenesisEnv:
         """Ascending indices of the envs whose ``mask`` (or ``mask2``) is set — see :class:`DoneIds`."""
         if self._done_ids_native is None:
             self._done_ids_native = DoneIds(self.num_envs)
-        return self._done_ids_native(self.backend, mask, mask2, own)
+        # only ever asked for the termination masks of the current step, which are written once per step: a second request within
+        # the step — the setters' push, then a user manager's reset(ids) — takes the list the first one compacted
+        key = (self.step_count, self._in_step, mask.data_ptr(), None if mask2 is None else mask2.data_ptr())
+        hit = self._done_ids_cache
+        if hit is not None and hit[0] == key:
+            ids = hit[1]
+            return ids.clone() if own and ids.numel() else ids
+        ids = self._done_ids_native(self.backend, mask, mask2, False)
+        self._done_ids_cache = (key, ids)
+        return ids.clone() if own and ids.numel() else ids
 
     def invalidate_views(self) -> None:
         self._tick += 1

@@ -354,22 +354,26 @@ class ManagedEnvironment(GenesisEnv):
         for m in fused:
             m._after_fused_reset(mask, mask2)
         pushes = ad is not None and bool(ad._pushes)
-        rec = self.backend.tracer
-        if indexed and ids is None and not pushes and rec is not None and rec.part is None and not rec.tail_python:
-            # the in-step reset while the step is being recorded: user code between native phases (see _manager_step) — the replay
-            # finds the done envs of ITS step from the termination masks and calls the same managers
-            from .managers._program import call_untraced
-            fn = lambda self=self, indexed=list(indexed), mask=mask, mask2=mask2: self._indexed_reset(indexed, mask, mask2)
-            rec.python(fn)
-            call_untraced(self, fn)
-        elif indexed or pushes:
+        if pushes:   # Genesis-shaped scene: the reset rows reach the simulator through its envs_idx setters
             if ids is None:
-                ids = self.done_ids(mask, mask2, own=bool(indexed))  # host sync: managers that need index lists, Genesis' setters
-            if ids is not None and (not isinstance(ids, torch.Tensor) or ids.numel() > 0):
-                if pushes:
-                    ad.push(torch.as_tensor(ids, device=gs.device, dtype=torch.long))
-                for m in indexed:
-                    m.reset(ids)
+                ad.push_done(mask, mask2)
+            elif not isinstance(ids, torch.Tensor) or ids.numel() > 0:
+                ad.push(torch.as_tensor(ids, device=gs.device, dtype=torch.long))
+        if indexed:
+            rec = self.backend.tracer
+            if ids is None and rec is not None and rec.part is None and not rec.tail_python:
+                # the in-step reset while the step is being recorded: user code between native phases (see _manager_step) — the replay
+                # finds the done envs of ITS step from the termination masks and calls the same managers
+                from .managers._program import call_untraced
+                fn = lambda self=self, indexed=list(indexed), mask=mask, mask2=mask2: self._indexed_reset(indexed, mask, mask2)
+                rec.python(fn)
+                call_untraced(self, fn)
+            else:
+                if ids is None:
+                    ids = self.done_ids(mask, mask2, own=True)  # host sync: managers that need index lists
+                if not isinstance(ids, torch.Tensor) or ids.numel() > 0:
+                    for m in indexed:
+                        m.reset(ids)
         self.invalidate_views()
 
     def reset(self, env_ids: list[int] | None = None):

@@ -19,7 +19,9 @@ from helpers import FLOAT_TOL
 # GF_FUZZ_SEEDS="first:last" runs another range (a soak run hunts with hundreds; the committed default is what CI affords)
 # 123 / 140: found by such a run — the control wave's pre-reset quaternion was not loaded when only the stale-quaternion stash needed it
 # (termination done by a launch of its own; the body-frame items in a manager that observes behind the fused launch)
-SEEDS = list(range(*map(int, os.environ["GF_FUZZ_SEEDS"].split(":")))) if os.environ.get("GF_FUZZ_SEEDS") else list(range(28)) + [123, 140]
+# 57 / 132 (round 3): a late observation manager's launch in front of a manager that is part of the fused launch, in call order — the
+# per-piece patch tables applied the fused manager's output rotation / stream id one piece too late
+SEEDS = list(range(*map(int, os.environ["GF_FUZZ_SEEDS"].split(":")))) if os.environ.get("GF_FUZZ_SEEDS") else list(range(28)) + [57, 123, 132, 140]
 STEPS = 48
 
 
@@ -65,6 +67,32 @@ def make_fuzz_env(seed: int):
             vc = self.velocity_command = VelocityCommandManager(
                 self, range={"lin_vel_x": [-1.0, uni(0.2, 1.5)], "lin_vel_y": rnd.choice([[0, 0], [-0.5, 0.5]]), "ang_vel_z": [-uni(0.2, 1.0), 1.0]},
                 standing_probability=0.0, resample_time_sec=uni(0.15, 0.5))
+            # a user-defined manager CLASS (its own step() / reset(), the base class' resample launched from user code, torch state of its
+            # own) — replayed between the native phases of a recorded step (round 3).  A random stream of its own: the other draws of a
+            # seed are what they were before this existed.
+            rnd_mgr = random.Random(99000 + seed)
+            self.user_manager = rnd_mgr.random() < 0.3
+            if self.user_manager:
+                from genesis_forge_amd import gs
+                from genesis_forge_amd.managers import CommandManager
+
+                class Clock(CommandManager):
+                    def __init__(s, env):
+                        super().__init__(env, range=(0.5, round(rnd_mgr.uniform(1.0, 2.0), 3)), resample_time_sec=round(rnd_mgr.uniform(0.1, 0.4), 3))
+                        s.phase = torch.zeros(env.num_envs, device=gs.device)
+
+                    def step(s):
+                        super().step()
+                        s.phase = (s.phase + s.env.dt * s._command[:, 0]) % 1.0
+
+                    def reset(s, env_ids=None):
+                        super().reset(env_ids)
+                        if env_ids is None:
+                            s.phase = torch.zeros_like(s.phase)
+                        else:
+                            s.phase[env_ids] = 0.0
+
+                self.clock = Clock(self)
             feet = body = None
             if pick(0.7):
                 feet = self.foot_contacts = ContactManager(self, link_names=[".*_foot"], track_air_time=True, air_time_contact_threshold=uni(1.0, 8.0))
@@ -105,6 +133,8 @@ def make_fuzz_env(seed: int):
             self.has_user_obs = False   # a Python-level OBSERVATION item (sees the post-reset state: nothing behind it can be fused)
             if self.has_user_term:  # a user-level Python term: evaluated in torch on both sides, in the middle of the recorded step
                 rcfg["user_height"] = {"weight": 0.3, "fn": lambda env: torch.tanh(env.robot.get_pos()[:, 2])}
+            if self.user_manager:
+                rcfg["in_phase"] = {"weight": 0.2, "fn": lambda env: torch.cos(6.2831853 * self.clock.phase)}
             self.reward_manager = RewardManager(self, logging_enabled=pick(0.85), cfg=rcfg)
 
             tcfg = {"timeout": {"fn": terminations.timeout, "time_out": True}}
@@ -196,12 +226,15 @@ def _run(seed, dev, steps=STEPS):
         for name, o in extras["observations"].items():
             if name != "policy":
                 state["obs_" + name] = o
+        if env.user_manager:
+            state["clock_phase"], state["clock_command"] = env.clock.phase, env.clock.command
         for cm in env.managers["contact"]:
             state[f"contacts_{len([k for k in state if k.startswith('contacts_')])}"] = cm.contacts
         out.append(({k: f(v) for k, v in state.items()}, {k: float(v) for k, v in extras["episode"].items()}))
     info = {"n": n, "recorded": env._trace is not None, "fused": bool(env._trace is not None and env._trace.post_refs is not None),
             "program": env._program_info, "post_refs": env._trace.post_refs if env._trace is not None else None, "env": env,
-            "user_term": env.has_user_term, "user_obs": env.has_user_obs, "third_obs": env.third_obs, "overrides_reset": env.overrides_reset}
+            "user_term": env.has_user_term, "user_obs": env.has_user_obs, "third_obs": env.third_obs, "overrides_reset": env.overrides_reset,
+            "user_manager": env.user_manager}
     return out, info
 
 
@@ -251,7 +284,8 @@ def test_random_config_hip_equals_oracle(hip_backend, oracle_lib_path, seed):
         # Python-level reward / termination terms leave everything behind the termination phase fused (termination runs as a launch of
         # its own, GF_POST_TERMINATION_DONE); a manager with a Python-level observation item, or a third ObservationManager, observes
         # behind the fused launch; only a reset() override keeps the post-physics phases off it (the user's code runs in the middle)
-        assert info["fused"] == (not info["overrides_reset"]), info
+        # … and a user-defined manager class, whose step() sits between reward and reset (the phases on either side run as chains)
+        assert info["fused"] == (not info["overrides_reset"] and not info["user_manager"]), {k: v for k, v in info.items() if k not in ("env", "post_refs")}
 
 
 @pytest.mark.gpu
