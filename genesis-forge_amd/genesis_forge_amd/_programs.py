@@ -199,6 +199,22 @@ class Pending:
         self.env, self.sig, self.proc, self.so = env, sig, proc, so
         self.countdown = 32
 
+    def __del__(self):
+        # the env went away before the compile finished: stop the child, leave no half-written plugin behind
+        proc = getattr(self, "proc", None)
+        if proc is not None and proc.poll() is None:
+            try:
+                proc.kill()
+                proc.wait(timeout=5)
+            except Exception:
+                pass
+        tmp = getattr(proc, "_gf_tmp", None)
+        if tmp and os.path.exists(tmp) and (proc is None or proc.returncode != 0 or not os.path.exists(getattr(proc, "_gf_so", ""))):
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+
     def poll(self) -> bool:
         """True when done (registered, or failed: the interpreter stays)."""
         self.countdown -= 1

@@ -32,6 +32,7 @@ def main():
                          "envs_idx setters, no gf_* extras); the line then also carries the double's own cost per tick")
     ap.add_argument("--no-trace", action="store_true", help="time the ordinary (phase by phase) step")
     args = ap.parse_args()
+    os.environ.setdefault("GF_JIT", "sync")   # a config without a built-in program is timed on its compiled one from the first timed step on
     import torch
     from genesis_forge_amd import gs
     from genesis_forge_amd.managers import ObservationManager
