@@ -915,7 +915,7 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     UNSUP((needs & PN_ACTIONS) && !a.env_actions);
     UNSUP((needs & PN_LAST) && !a.env_last_actions);
     UNSUP((needs & PN_DOFDEV) && !a.default_dof_pos);
-    const void* al[] = {a.quat, a.dof_pos, a.dof_vel, a.targets, a.env_actions, a.env_last_actions, a.default_dof_pos, a.quat_stash};
+    const void* al[] = {a.quat, a.dof_pos, a.dof_vel, a.targets, a.env_actions, a.env_last_actions, a.default_dof_pos, a.quat_stash, a.dof_force};
     for (const void* p : al) UNSUP(reinterpret_cast<uintptr_t>(p) & 15u);
     UNSUP((int64_t)N * (D > 4 ? D : 4) * 4 >= (int64_t)1 << 32);
     return GF_OK;

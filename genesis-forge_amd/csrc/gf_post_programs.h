@@ -211,7 +211,7 @@ struct ProgHumanoid28Stress {
 // dynamic LDS of post_ws_kernel<P>, in floats (a static program keeps no copy of the descriptor in LDS; the interpreter adds one)
 template <class P>
 inline size_t lds_ws_floats(int omax, int n_gait) {
-    return (size_t)(x_fields(n_gait) + ws_sum_rows<P>() + ws_aux_rows<P>() + ws_pre_rows<P>()) * kEnvBlock + (size_t)(omax + 1) * kEnvBlock;
+    return (size_t)(x_fields(n_gait) + ws_sum_rows<P>() + ws_aux_rows<P>() + ws_pre_rows<P>() + ws_obs_norm_rows<P>()) * kEnvBlock + (size_t)(omax + 1) * kEnvBlock;
 }
 
 template <class P>

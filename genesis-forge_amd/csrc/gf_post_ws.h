@@ -111,6 +111,36 @@ __host__ __device__ constexpr int ws_pre_rows() {
     if constexpr (P::kStatic) return ws_pre_slot<P>(P::n_rew);
     else return 0;
 }
+// The same idea for OBSERVATION items that read global memory the reset does not touch: contact-force norms (parked as LDS rows by
+// wave 3 before the barrier) and the dof_force row (loaded into wave 3's third, otherwise unused row register set).  Behind the
+// barrier such a load was a round trip of its own — for a second manager (the gait task's critic) behind the first manager's tile
+// barrier as well.
+template <class P>
+__host__ __device__ constexpr int ws_obs_norm_slot(int m_upto, int i_upto) {   // norm rows in front of item (m_upto, i_upto)
+    if constexpr (P::kStatic) {
+        int n = 0;
+        for (int m = 0; m < P::n_obs && m <= m_upto; ++m)
+            for (int i = 0; i < P::obs_items[m] && (m < m_upto || i < i_upto); ++i)
+                n += P::item[m][i].op == GF_O_CONTACT_FORCE_NORM ? P::item[m][i].width : 0;
+        return n;
+    } else {
+        return 0;
+    }
+}
+template <class P>
+__host__ __device__ constexpr int ws_obs_norm_rows() {
+    if constexpr (P::kStatic) return ws_obs_norm_slot<P>(P::n_obs - 1, P::n_obs > 0 ? P::obs_items[P::n_obs - 1] : 0);
+    else return 0;
+}
+template <class P>
+__host__ __device__ constexpr bool ws_obs_has(int op) {
+    if constexpr (P::kStatic) {
+        for (int m = 0; m < P::n_obs; ++m)
+            for (int i = 0; i < P::obs_items[m]; ++i)
+                if (P::item[m][i].op == op) return true;
+    }
+    return false;
+}
 static_assert(kPostAuxRows >= 4 * 8, "aux rows cover 32 DOF");
 
 template <class P>
@@ -135,9 +165,10 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     constexpr int kSumRows = ws_sum_rows<P>(), kAuxRows = ws_aux_rows<P>();
     float* lds_sums = xch + x_fields(has_gait ? 1 : 0) * kEnvBlock;   // [kSumRows][64]
     float* lds_aux = lds_sums + kSumRows * kEnvBlock;        // [kAuxRows][64]: 4 per float4 chunk of a DOF row
-    constexpr int kPreRows = ws_pre_rows<P>();
+    constexpr int kPreRows = ws_pre_rows<P>(), kNormRows = ws_obs_norm_rows<P>();
     float* lds_pre = lds_aux + kAuxRows * kEnvBlock;         // [kPreRows][64]: values of the memory-only reward terms (wave 3 → wave 1)
-    float* tile = lds_pre + kPreRows * kEnvBlock;            // [64][O+1]
+    float* lds_norm = lds_pre + kPreRows * kEnvBlock;        // [kNormRows][64]: contact-force norms of observation items (wave 3, before the barrier)
+    float* tile = lds_norm + kNormRows * kEnvBlock;          // [64][O+1]
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (GF_WAVE - 1);
@@ -462,6 +493,24 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         const GF_GLOBAL float* p0 = gsel((needs & PN_TARGETS) != 0, UNI(a.targets), ro);
         const GF_GLOBAL float* p1 = gsel((needs & PN_ACTIONS) != 0, UNI(a.env_actions), ro);
         row_load<DV>(r_a, p0, D); row_load<DV>(r_b, p1, D);
+        if constexpr (P::kStatic && ws_obs_has<P>(GF_O_DOF_FORCE)) {   // the dof_force row: this wave's third row set is free
+            row_load<DV>(r_c, gsel(UNI(a.dof_force) != nullptr, UNI(a.dof_force), ro), D);
+        }
+        if constexpr (kNormRows > 0) {   // contact-force norms of observation items
+            static_for<P::n_obs>([&](auto M) GF_INLINE_LAMBDA {
+                constexpr int m_ = decltype(M)::value;
+                static_for<P::obs_items[m_]>([&](auto I) GF_INLINE_LAMBDA {
+                    constexpr int i_ = decltype(I)::value;
+                    if constexpr (P::item[m_][i_].op == GF_O_CONTACT_FORCE_NORM) {
+                        const GfContactView cv = a.contact[P::item[m_][i_].i0];
+                        const GF_GLOBAL float* r = G(cv.contacts) + n * cv.num_links * 3;
+#pragma unroll
+                        for (int l = 0; l < P::item[m_][i_].width; ++l)
+                            lds_norm[(ws_obs_norm_slot<P>(m_, i_) + l) * kEnvBlock + lane] = norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]);
+                    }
+                });
+            });
+        }
         if constexpr (kPreRows > 0) {   // the memory-only reward terms (see reward_op_memory_only), parked for the fold
             if (has_reward) {
                 RewardRegs rp;
@@ -709,7 +758,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             const bool rows_wave = wave == 2;
             const bool zeroed = done && scene_reset && zero_velocity;
             int col = 0;
-            auto item_body = [&](const GfObsItem& it, const bool scaled, const bool noisy) GF_INLINE_LAMBDA {
+            auto item_body = [&](const GfObsItem& it, const bool scaled, const bool noisy, const int norm_slot) GF_INLINE_LAMBDA {
                 const int op = it.op, it_w = it.width;
                 const ObsFin f{it.scale, scaled};
                 const bool row_item = op == GF_O_DOF_POS || op == GF_O_DOF_VEL;
@@ -744,13 +793,21 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                             row[col + 2] = obs_finish(f, z ? 0.f : xch[(base + 2) * kEnvBlock + lane], col + 2);
                         } break;
                         case GF_O_DOF_FORCE: {
-                            const GF_GLOBAL float* r = G(a.dof_force) + n * D;
-                            for (int j = 0; j < it_w; ++j) row[col + j] = obs_finish(f, r[j], col + j);
+                            if constexpr (P::kStatic) {   // loaded with the tile's other rows, before the barrier (wave 3's third row set)
+                                put_row<DV>(f, r_c, row, col, D);
+                            } else {
+                                const GF_GLOBAL float* r = G(a.dof_force) + n * D;
+                                for (int j = 0; j < it_w; ++j) row[col + j] = obs_finish(f, r[j], col + j);
+                            }
                         } break;
                         case GF_O_CONTACT_FORCE_NORM: {
-                            const GfContactView cv = a.contact[it.i0];
-                            const GF_GLOBAL float* r = G(cv.contacts) + n * cv.num_links * 3;
-                            for (int l = 0; l < it_w; ++l) row[col + l] = obs_finish(f, norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]), col + l);
+                            if constexpr (P::kStatic) {   // parked by this wave before the barrier
+                                for (int l = 0; l < it_w; ++l) row[col + l] = obs_finish(f, lds_norm[(norm_slot + l) * kEnvBlock + lane], col + l);
+                            } else {
+                                const GfContactView cv = a.contact[it.i0];
+                                const GF_GLOBAL float* r = G(cv.contacts) + n * cv.num_links * 3;
+                                for (int l = 0; l < it_w; ++l) row[col + l] = obs_finish(f, norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]), col + l);
+                            }
                         } break;
                         default: break;
                     }
@@ -838,7 +895,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                     GfObsItem it = karg.obs[m_].items[i_];
                     constexpr ItemSig sig = P::item[m_][i_];
                     it.op = sig.op; it.width = sig.width; it.i0 = sig.i0;
-                    item_body(it, sig.scaled, sig.noisy);
+                    item_body(it, sig.scaled, sig.noisy, ws_obs_norm_slot<P>(m_, i_));
                 });
             });
         });
@@ -850,7 +907,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 for (int i = 0; i < n_items; ++i) {
                     GfObsItem it = ob.items[i];  // by value: the tile stores must not force reloads of the item
                     it.op = uni(it.op); it.width = uni(it.width); it.scale = uni(it.scale); it.noise = uni(it.noise);
-                    item_body(it, it.scale != 1.0f, it.noise != 0.0f);
+                    item_body(it, it.scale != 1.0f, it.noise != 0.0f, 0);
                 }
             });
         }
