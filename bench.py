@@ -235,7 +235,11 @@ def cpu_baseline(headline_envs: int, workers: int) -> dict:
             "grid_multicore": multi,
             "grid_note": "BASELINE.md plan B2: N in {64, 4096, 16384, 65536} x D in {12, 28}; D = 28 is the same manager stack over a synthetic "
                          "28-joint robot (O = 96); one thread = median of >= 200 steps; multicore = sum over worker processes each stepping "
-                         "N / workers envs for 0.8 s, all workers on the same grid point at the same time"}
+                         "N / workers envs for 0.8 s, all workers on the same grid point at the same time",
+            # not measured by this run — quoted so the line carries it: the REFERENCE's own PyTorch managers cannot travel to the GPU box
+            "reference_quoted": {"value": 5.50e6, "unit": "env-steps/s", "cores": 8, "num_envs": 65536,
+                                 "what": "genesis-forge's own ManagedEnvironment.step (PyTorch CPU, stub physics), 8-core Xeon 2.1 GHz build container",
+                                 "source": "BASELINE.md section 2 (survey probe); one thread: 2.07e6"}}
 
 
 def cpu_single() -> None:

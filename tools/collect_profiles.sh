@@ -6,16 +6,24 @@ tag=$1
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$root"
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_steps20.json 2>> gpurun_out/${tag}_bench.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > gpurun_out/${tag}_bench_steps20.json 2>> gpurun_out/${tag}_bench.err
 python3 tools/bench_configs.py > gpurun_out/${tag}_configs.jsonl 2> gpurun_out/${tag}_configs.err
 GF_OBS_OUTPUT=ring python3 tools/bench_configs.py --configs gait,gait_8192 > gpurun_out/${tag}_configs_ring.jsonl 2>> gpurun_out/${tag}_configs.err
-tools/prof_by_grid.sh ${tag}_bench bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point > /dev/null
-tools/prof_by_grid.sh ${tag}_bench1m bench.py --steps 100 --warmup 10 --num-envs 1048576 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point > /dev/null
+GF_JIT=off python3 tools/bench_configs.py --configs go2_user > gpurun_out/${tag}_configs_nojit.jsonl 2>> gpurun_out/${tag}_configs.err
+python3 tools/bench_configs.py --scene genesis_like --configs go2_cmd,go2_cmd_65536,rough_terrain,humanoid,gait,gait_8192 > gpurun_out/${tag}_configs_genesis_like.jsonl 2>> gpurun_out/${tag}_configs.err
+python3 tools/bench_configs.py --scene genesis_like --no-trace --configs go2_cmd_65536,gait_8192 > gpurun_out/${tag}_configs_genesis_like_ordinary.jsonl 2>> gpurun_out/${tag}_configs.err
+tools/microbench 1048576 > gpurun_out/${tag}_microbench_1m.txt 2>&1 || true
+tools/microbench 65536 > gpurun_out/${tag}_microbench_65536.txt 2>&1 || true
+python3 tools/bench_rollout.py 65536 > gpurun_out/${tag}_rollout.jsonl 2>> gpurun_out/${tag}_configs.err
+{ python3 tools/bench_user_term.py 65536 reward; python3 tools/bench_user_term.py 65536 obs; python3 tools/bench_user_term.py 65536 manager; python3 tools/bench_user_term.py 4096 manager; } > gpurun_out/${tag}_user_term.txt 2>> gpurun_out/${tag}_configs.err
+python3 tools/bench_reset_override.py > gpurun_out/${tag}_reset_override.txt 2>> gpurun_out/${tag}_configs.err
+tools/prof_by_grid.sh ${tag}_bench bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point --no-pmc > /dev/null
+tools/prof_by_grid.sh ${tag}_bench1m bench.py --steps 100 --warmup 10 --num-envs 1048576 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point --no-pmc > /dev/null
 tools/prof_by_grid.sh ${tag}_cfg tools/bench_configs.py > /dev/null
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$root/gpurun_out/${tag}_pmc_${c}_bench" -o pmc -- python3 "$root/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point > /dev/null 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$root/gpurun_out/${tag}_pmc_${c}_bench1m" -o pmc -- python3 "$root/bench.py" --steps 40 --warmup 10 --num-envs 1048576 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$root/gpurun_out/${tag}_pmc_${c}_bench" -o pmc -- python3 "$root/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point --no-pmc > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$root/gpurun_out/${tag}_pmc_${c}_bench1m" -o pmc -- python3 "$root/bench.py" --steps 40 --warmup 10 --num-envs 1048576 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point --no-pmc > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$root/gpurun_out/${tag}_pmc_${c}_cfg" -o pmc -- python3 "$root/tools/bench_configs.py" --steps 60 --configs gait,rough_terrain,humanoid > /dev/null 2>&1
 done
 cd "$root"
