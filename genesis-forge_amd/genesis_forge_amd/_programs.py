@@ -184,6 +184,86 @@ def register(backend, so: str) -> int:
     return backend.register_program(so)
 
 
+# -- ahead of time: a config's program without a GPU ---------------------------------------------------------------------------
+class _DryRunBackend(nat.HipBackend):
+    """Host logic only: phase calls are recorded and validated by nobody, nothing is launched.  Two steps through it are enough
+    for a step to be recorded, and a recorded step's descriptors are all ``gf_post_physics_describe`` needs — packing a descriptor
+    is host work, its signature is structure (opcodes, slots, widths), not values."""
+
+    name = "dry-run"
+    device_type = "cpu"
+
+    def call(self, fn: str, args, owner=None) -> None:
+        if self.tracer is not None:
+            self.tracer.record(fn, args, owner)
+        self._note_call(args)
+
+    def stats_clear(self, stats_ptr: int) -> None:
+        pass
+
+    def stats_pack(self, src_ptr: int, dst_ptr: int) -> None:
+        pass
+
+    def stats_last_reset(self, rows_ptr: int, num_rows: int, dst_ptr: int) -> None:
+        pass
+
+    def run_ops(self, ops, n: int) -> None:
+        pass
+
+    def replay_step(self, replay, actions_ptr: int, params, num_params: int) -> None:
+        pass
+
+    def event_create(self):
+        return None
+
+    def event_synchronize(self, ev) -> None:
+        pass
+
+
+def signature_of(make_env, num_envs: int = 64) -> Optional[str]:
+    """The structure signature of ``make_env(num_envs)``'s recorded step — no GPU, no kernels: the env is built on CPU tensors
+    and stepped twice through a backend that launches nothing.  None when the config's step is not recorded with a fused
+    post-physics launch (a ``reset()`` override, a user manager class in the middle of it)."""
+    import torch
+
+    from . import gs
+
+    old_dev, old_backend, old_jit = gs.device, nat._backend, os.environ.get("GF_JIT")
+    os.environ["GF_JIT"] = "off"
+    try:
+        gs.set_device("cpu")
+        dry = _DryRunBackend()
+        nat.set_backend(dry)
+        env = make_env(num_envs)
+        env.build()
+        env.reset()
+        width = env.action_space.shape[0]
+        for _ in range(3):
+            env.step(torch.zeros(env.num_envs, width))
+        tr = env._trace
+        if tr is None or tr.post_refs is None:
+            return None
+        return dry.post_describe(tr.post_refs)
+    finally:
+        nat.set_backend(old_backend)
+        gs.device = old_dev
+        if old_jit is None:
+            os.environ.pop("GF_JIT", None)
+        else:
+            os.environ["GF_JIT"] = old_jit
+
+
+def precompile(make_env, num_envs: int = 64) -> Optional[dict]:
+    """Compile (or find in the cache) the static program of a config ahead of time — e.g. on a build machine without a GPU:
+    ``python -m genesis_forge_amd._programs my_pkg.envs:make_env``.  Returns what happened, or None when the config runs a built-in
+    program / has no fused launch."""
+    sig = signature_of(make_env, num_envs)
+    if sig is None or not sig.startswith("program 0 "):
+        return None
+    so, secs = compile_sync(sig)
+    return {"signature": sig, "plugin": so, "compile_s": secs}
+
+
 # -- the hook ManagedEnvironment.step calls when a step has just been recorded ---------------------------------------------------
 def mode_for(env) -> str:
     m = os.environ.get("GF_JIT")
@@ -258,3 +338,12 @@ def on_recorded(env) -> None:
             env._program_pending = Pending(env, sig, proc, so)
     except Exception as e:
         env._program_info = {"signature": sig, "error": str(e), "mode": mode}
+
+
+if __name__ == "__main__":   # python -m genesis_forge_amd._programs module:callable [num_envs]
+    import importlib
+    import sys
+
+    mod, fn = sys.argv[1].split(":")
+    info = precompile(getattr(importlib.import_module(mod), fn), int(sys.argv[2]) if len(sys.argv) > 2 else 64)
+    print(info if info is not None else "nothing to compile: a built-in program matches, or the step has no fused post-physics launch")

@@ -99,6 +99,16 @@ def test_every_fuzz_config_gets_a_program_without_a_gpu(signatures):
         print(f"compiled {len(t)} programs, {min(t):.1f} … {max(t):.1f} s each (in parallel)")
 
 
+def test_dry_run_signature_equals_the_recorded_steps(signatures):
+    """``_programs.signature_of``: the structure signature from two steps through a backend that launches NOTHING (ahead-of-time
+    compilation on a machine without a GPU; ``__graft_entry__.build()`` uses it) is the signature of the really recorded step."""
+    import test_fuzz_configs as fz2
+
+    for seed in [s for s in signatures if isinstance(s, int)][:8]:
+        got = _programs.signature_of(lambda n, seed=seed: fz2.make_fuzz_env(seed), num_envs=0)
+        assert got is not None and got.split(": ", 1)[1] == signatures[seed].split(": ", 1)[1], f"seed {seed}"
+
+
 def test_a_stale_or_foreign_plugin_is_refused(tmp_path):
     hip = nat.HipBackend()
     bogus = tmp_path / "gfp_bogus.so"
