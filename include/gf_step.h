@@ -12,8 +12,9 @@
  * calls: everything a launch reads or writes is named by its descriptor, so they are re-entrant per
  * (device, stream) and ownership never crosses the ABI.  What IS process-global, and
  * therefore not re-entrant, is diagnostic: the tuning switches of gf_set_option() (read once per
- * launch) and the single-phase event profiler gf_profile_begin() / gf_profile_end().  The opaque
- * handles of gf_run_ops_graph() / gf_event_create() belong to the caller that created them.
+ * launch), the single-phase event profiler gf_profile_begin() / gf_profile_end() and the append-only
+ * table of run-time programs (gf_post_program_register, thread-safe).  The opaque handles of
+ * gf_run_ops_graph() / gf_event_create() belong to the caller that created them.
  * No torch types appear here; the Python host (genesis_forge_amd) hands over `tensor.data_ptr()`
  * values via ctypes.
  *
