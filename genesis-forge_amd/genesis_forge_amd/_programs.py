@@ -125,9 +125,25 @@ GFP_EXPORT size_t gfp_lds_bytes(int omax, int n_gait) {{ return gf::lds_ws_float
 '''
 
 
+def _build_tag() -> str:
+    """What a plugin was built against: the kernel headers and the compiler flags (8 hex digits, first part of its file name)."""
+    return hashlib.sha1((_headers_digest() + "|" + " ".join(_FLAGS)).encode()).hexdigest()[:8]
+
+
 def plugin_key(sig: str) -> str:
     body = sig.split(": ", 1)[1]
-    return hashlib.sha1((body + "|" + _headers_digest() + "|" + " ".join(_FLAGS)).encode()).hexdigest()[:16]
+    return _build_tag() + hashlib.sha1(body.encode()).hexdigest()[:12]
+
+
+def _sweep_stale(directory: str) -> None:
+    """Plugins built against other kernel headers can never be loaded again (their name no longer comes up): remove them."""
+    tag = _build_tag()
+    try:
+        for name in os.listdir(directory):
+            if name.startswith("gfp_") and not name.startswith("gfp_" + tag) and name.endswith((".so", ".hip")):
+                os.unlink(os.path.join(directory, name))
+    except OSError:
+        pass
 
 
 def plugin_paths(sig: str) -> tuple:
@@ -149,6 +165,7 @@ def start_compile(sig: str):
     if hipcc() is None:
         raise RuntimeError("hipcc not found: static programs cannot be compiled at run time")
     os.makedirs(os.path.dirname(src), exist_ok=True)
+    _sweep_stale(os.path.dirname(src))
     with open(src, "w") as fh:
         fh.write(plugin_source(sig, key))
     tmp = f"{so}.{os.getpid()}.tmp"
