@@ -124,15 +124,28 @@ __device__ __forceinline__ int cmd_stride(const GfCommandView& c) { return c.str
 
 // torch's `%` on float tensors (aten remainder): fmod, then moved to the divisor's sign
 __device__ __forceinline__ float torch_remainder(float a, float b) {
-    float m = fmodf(a, b);
+    // fmod is exact by definition, so the two cheap cases give libm's bits: a in [0, b) is its own remainder and a in [b, 2b) leaves
+    // a − b (exact, Sterbenz).  A periodic clock advanced by one tick is always one of the two; libm's generic fmodf — a data-dependent
+    // loop — runs only for the rest (negative, huge, inf / NaN operands)
+    float m;
+    if (a >= 0.0f && a < b) m = a;
+    else if (a >= b && a < b + b) m = a - b;
+    else m = fmodf(a, b);
     if ((m != 0.0f) && ((b < 0.0f) != (m < 0.0f))) m += b;
+    return m;
+}
+// torch.remainder(a, 1): fmodf(a, 1) is the fraction with a's sign, and a − trunc(a) is exact in f32 (inf − inf and NaN give NaN as
+// fmodf does; −2 → −0).  Branch-free: behind libm's loop the compiler could issue none of the loads that follow it
+__device__ __forceinline__ float torch_remainder_one(float a) {
+    float m = copysignf(a - truncf(a), a);
+    if (m < 0.0f) m += 1.0f;
     return m;
 }
 
 // swing / stance of one foot in the gait cycle (examples/gait_trainer/gait_command_manager.py:331-338): bit 0 = swing
 // (0 <= phi < π), bit 1 = stance (π <= phi < 2π), phi = fmod(phase + offset, 1)·(float)2π; NaN is neither
 __device__ __forceinline__ int gait_foot_flags(float phase, float offset, float two_pi, float pi) {
-    const float phi = torch_remainder(phase + offset, 1.0f) * two_pi;
+    const float phi = torch_remainder_one(phase + offset) * two_pi;
     return (((phi >= 0.0f) && (phi < pi)) ? 1 : 0) | (((phi >= pi) && (phi < two_pi)) ? 2 : 0);
 }
 
@@ -294,11 +307,27 @@ __device__ __forceinline__ void fold_stats_block256(const GfStepStats* src, doub
     for (int v = (int)(threadIdx.x / GF_WAVE); v < GF_STATS_VECTOR_LEN; v += 4) fold_stats_entry(src, dst, last_reset, v);
 }
 
+// four [3]-rows of a per-link array, links l0 … l0+3 of L: every load issued before the first use (a link at a time was a round trip
+// per link — the link count is a run-time value, so the loop over it is not unrolled); rows past the last link re-read it
+__device__ __forceinline__ void link_rows4(float (&f)[4][3], const GF_GLOBAL float* r, int l0, int L) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int l = l0 + j < L ? l0 + j : L - 1;
+        f[j][0] = r[3 * l]; f[j][1] = r[3 * l + 1]; f[j][2] = r[3 * l + 2];
+    }
+}
+
 // contact predicates shared by termination / reward terms
 __device__ __forceinline__ int contact_count_over(const GfContactView& v, int64_t n, float thr) {
     int cnt = 0;
-    const GF_GLOBAL float* r = G(v.contacts) + n * v.num_links * 3;
-    for (int l = 0; l < v.num_links; ++l) cnt += norm3(r[3 * l], r[3 * l + 1], r[3 * l + 2]) > thr ? 1 : 0;
+    const int L = v.num_links;
+    const GF_GLOBAL float* r = G(v.contacts) + n * L * 3;
+    for (int l0 = 0; l0 < L; l0 += 4) {
+        float f[4][3];
+        link_rows4(f, r, l0, L);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cnt += (l0 + j < L && norm3(f[j][0], f[j][1], f[j][2]) > thr) ? 1 : 0;
+    }
     return cnt;
 }
 

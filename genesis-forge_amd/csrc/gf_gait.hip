@@ -79,7 +79,7 @@ __device__ __forceinline__ void gait_body(const GfGaitArgs& a, const bool flags_
         phase = gtime / period;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const float fp = torch_remainder(phase + off[f], 1.0f);
+            const float fp = torch_remainder_one(phase + off[f]);
             sincos_det(a.two_pi * fp, &clock[f], &clock[4 + f]);
         }
     }

@@ -23,7 +23,7 @@ extern "C" unsigned long long* gf_debug_stamps;  // host variable set by the too
     do {                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         if (a.stamps && blockIdx.x == a.stamp_block && (threadIdx.x & 63) == 0)                              \
-            a.stamps[64 + 16 * (threadIdx.x >> 6) + i] = __builtin_amdgcn_s_memrealtime();                   \
+            a.stamps[64 + 16 * wave + i] = __builtin_amdgcn_s_memrealtime();                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     } while (0)
 #else

@@ -89,13 +89,11 @@ template <class P>
 __host__ __device__ constexpr int ws_aux_rows() { return 4 * P::DV; }
 // Reward terms whose value depends on global memory only — contact forces, link velocities / positions, a gait manager's row as
 // the PREVIOUS step left it — not on anything another wave of the tile computes.  A static program evaluates them BEFORE the
-// barrier, in the wave with the least to load (wave 3), and parks the values in LDS rows: their loads go out together with every
+// barrier, in the wave with the least to do there (wave 2: three row loads), and parks the values in LDS rows: their loads go out together with every
 // other load of the tile instead of as round trips of their own behind the barrier (profiles/r02_c_gait_fused_attribution.txt:
 // 6.3 of the gait program's 18 µs at 8 192 envs were that chain).  The fold then reads the parked value: same function, same
 // inputs, same arithmetic — bit-identical.
-__host__ __device__ constexpr bool reward_op_memory_only(int op) {
-    return op == GF_R_GAIT_PHASE || op == GF_R_FOOT_HEIGHT || op == GF_R_CONTACT_FORCE || op == GF_R_HAS_CONTACT || op == GF_R_FEET_SLIDE;
-}
+__host__ __device__ constexpr bool reward_op_memory_only(int op) { return reward_op_has_rows(op); }   // (gf_terms.h: term_rows / term_value)
 template <class P>
 __host__ __device__ constexpr int ws_pre_slot(int upto) {   // parked rows in front of term `upto` (upto = n_rew: all of them)
     if constexpr (P::kStatic) {
@@ -105,6 +103,19 @@ __host__ __device__ constexpr int ws_pre_slot(int upto) {   // parked rows in fr
     } else {
         return 0;
     }
+}
+template <class P>
+__host__ __device__ constexpr int ws_term_rows() {
+    if constexpr (P::kStatic) return P::n_term > 0 ? P::n_term : 1;
+    else return 1;
+}
+template <class P>
+__host__ __device__ constexpr bool ws_rew_body_frame() {   // does any reward term of the program read a body-frame vector?
+    if constexpr (P::kStatic) {
+        for (int k = 0; k < P::n_rew; ++k)
+            if (reward_op_body_frame(P::rew[k].op)) return true;
+    }
+    return false;
 }
 template <class P>
 __host__ __device__ constexpr int ws_pre_rows() {
@@ -155,7 +166,6 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         __syncthreads();
     }
     const GfPostArgs& a = pick_args<P>(karg, lds);
-    GF_WSTAMP(1);
     bool has_gait = false;
     if constexpr (P::kStatic) has_gait = P::n_gait > 0;
     else has_gait = UNI(a.n_gait) > 0;
@@ -166,11 +176,12 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     float* lds_sums = xch + x_fields(has_gait ? 1 : 0) * kEnvBlock;   // [kSumRows][64]
     float* lds_aux = lds_sums + kSumRows * kEnvBlock;        // [kAuxRows][64]: 4 per float4 chunk of a DOF row
     constexpr int kPreRows = ws_pre_rows<P>(), kNormRows = ws_obs_norm_rows<P>();
-    float* lds_pre = lds_aux + kAuxRows * kEnvBlock;         // [kPreRows][64]: values of the memory-only reward terms (wave 3 → wave 1)
+    float* lds_pre = lds_aux + kAuxRows * kEnvBlock;         // [kPreRows][64]: values of the memory-only reward terms (wave 2 → wave 1)
     float* lds_norm = lds_pre + kPreRows * kEnvBlock;        // [kNormRows][64]: contact-force norms of observation items (wave 3, before the barrier)
     float* tile = lds_norm + kNormRows * kEnvBlock;          // [64][O+1]
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    GF_WSTAMP(1);
     const int lane = threadIdx.x & (GF_WAVE - 1);
     const int64_t N = UNI(a.num_envs);
     const int64_t n0 = (int64_t)blockIdx.x * kEnvBlock;
@@ -224,12 +235,15 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         int ep_len, term, trunc;
         float grow[GF_GAIT_ROW];                        // the gait manager's state row, stored after the last barrier
         int gait_sel, gait_resampled;
+        uint32_t log_bits;                              // what the statistics count, taken behind the barrier: bit k = termination term k
+        int gait_logged;                                //   fired, bit 16 + c = command c resampled; the gait selected before the reset
     };
     struct RowState { float4 r_a[R], r_b[R], r_c[R]; __device__ RowState() {} }; // wave 1: dof_pos/actions/last; wave 2: dof_pos/dof_vel/default; wave 3: targets/actions
     struct RewState {                                   // wave 1: what is left of its rows once they are reduced (written at the END of
         __device__ RewState() {}                        // its pre-barrier block, when it has read the rows for the last time)
         V3 pos;
         float dof_dev, act_rate, secs_in, cmd0[3];
+        float vals[kPostMaxReward];                     // a static program's term values, computed BEFORE the barrier (see wave 1)
     };
     union Persist {
         CtlState ctl;
@@ -254,11 +268,16 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
 #pragma unroll
         for (int j = 0; j < GF_GAIT_ROW; ++j) grow[j] = 0.f;
         gait_sel = 0; gait_resampled = 0;
+        ctl.log_bits = 0u; ctl.gait_logged = 0;
     } else {
 #pragma unroll
         for (int c = 0; c < DV; ++c) { r_a[c] = z4; r_b[c] = z4; r_c[c] = z4; }
     }
 
+    // a static program's reward weights and sum rows, read from the kernel arguments BEFORE the barrier by the reward wave: uniform
+    // values (scalar registers) — the fold behind the barrier then starts with them in hand instead of a scalar load per term
+    float fold_w[kSumRows > 0 ? kSumRows : 1];
+    int32_t fold_row[kSumRows > 0 ? kSumRows : 1];
     if (wave == 0) {
         // ---- control: loads -------------------------------------------------------------------------------------------
         q = ldg4(gsel((needs & PN_QUAT) != 0, UNI(a.quat), 4u * e));
@@ -284,6 +303,16 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             grow[8] = g2.x; grow[9] = g2.y; grow[10] = g2.z; grow[11] = g2.w; grow[12] = g3.x; grow[13] = g3.y; grow[14] = g3.z; grow[15] = g3.w;
             gait_sel = (int)G(UNI(a.gait.selected))[e];
         }
+        // a static program's contact-count terminations: the counts are taken HERE, so the contact rows are requested together with
+        // the loads above instead of as a round trip of their own between two terms' statistics branches
+        int pre_cnt[ws_term_rows<P>()] = {};
+        if constexpr (P::kStatic) {
+            static_for<P::n_term>([&](auto K) GF_INLINE_LAMBDA {
+                constexpr int k_ = decltype(K)::value;
+                if constexpr (term_op_counts_contacts(P::term[k_].op))
+                    pre_cnt[k_] = contact_count_over(a.contact[karg.tterms[k_].i[0]], n, karg.tterms[k_].p[0]);
+            });
+        }
         // ---- body-frame vectors, termination -----------------------------------------------------------------------------
         const V3 blin = rot_inv(q, lin), bang = rot_inv(q, ang), grav = rot_inv(q, V3{0.f, 0.f, -1.f});
         // the termination phase ran as a launch of its own (Python-level terms in the step): its masks are inputs.  A static program
@@ -301,41 +330,36 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         const int has_maxlen = UNI(a.has_maxlen);
         tr.ep_len = ep_len; tr.max_len = max_len; tr.has_maxlen = has_maxlen != 0; tr.pos = pos; tr.m = n;
         tr.tilt_sin = clamp_max(norm2(grav.x, grav.y), 0.99f);
-        auto term_body = [&](int k, const GfTerm& t) GF_INLINE_LAMBDA {
-            int v = eval_termination_term(t, a, tr, (uint32_t)has_maxlen);
+        auto term_body = [&](int k, const GfTerm& t, int v) GF_INLINE_LAMBDA {
             v = live ? v : 0;
             const int is_to = (t.flags & GF_TERM_FLAG_TIME_OUT) ? 1 : 0;   // (selects on values: an `if … trunc |= v; else term |= v;` makes the
             trunc |= is_to ? v : 0;                                        //  compiler pick an ADDRESS inside the union below → scratch)
             term |= is_to ? 0 : v;
-            if (shard) {
-                const unsigned long long hit = __ballot(v);
-                if (hit && lane == 0) atomicAdd(&shard->term_fired[k], popc64(hit));
-            }
+            ctl.log_bits |= v ? (1u << k) : 0u;   // counted behind the barrier (this wave is the tile's longest before it, idle after)
         };
         if constexpr (P::kStatic) {
             static_for<P::n_term>([&](auto K) GF_INLINE_LAMBDA {
                 constexpr int k_ = decltype(K)::value;
                 GfTerm t = karg.tterms[k_];
                 t.op = P::term[k_].op; t.flags = P::term[k_].flags;
-                term_body(k_, t);
+                if constexpr (term_op_counts_contacts(P::term[k_].op)) term_body(k_, t, termination_from_count(t, pre_cnt[k_], ep_len));
+                else term_body(k_, t, eval_termination_term(t, a, tr, (uint32_t)has_maxlen));
             });
         } else {
             for (int k = 0; k < n_term; ++k) {
                 const GfTerm t = a.tterms[k];
-                term_body(k, t);
+                term_body(k, t, eval_termination_term(t, a, tr, (uint32_t)has_maxlen));
             }
         }
         const bool done0 = live && (term | trunc);
+        GF_WSTAMP(9);
         // ---- command.step then command.reset draws (values only; stores wait for the barrier) ------------------------------
 #pragma unroll
         for (int c = 0; c < GF_POST_MAX_CMD; ++c) {
             if (c < n_cmd) {
                 const PostCmd cm = cmd_row(c);
                 const bool go = live && (ep_len % UNI(cm.resample_steps)) == 0;
-                if (shard) {
-                    const unsigned long long m = __ballot(go);
-                    if (m && lane == 0) atomicAdd(&shard->resample_count, popc64(m));
-                }
+                ctl.log_bits |= go ? (0x10000u << c) : 0u;
                 if (go) {
                     const float4 u4 = draw_unit4(seed, cm.stream_step, genv, 0u);
                     const float nv[kPostMaxRanges] = {uniform_range(u4.x, cm.lo[0], cm.hi[0]), uniform_range(u4.y, cm.lo[1], cm.hi[1]),
@@ -356,6 +380,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 }
             }
         }
+        GF_WSTAMP(10);
         // ---- GaitCommandManager.step, then .reset for done envs (gf_gait.hip: gait_body in both modes), on registers ------------
         if (has_gait) {
             const PostGait& gg = a.gait;
@@ -379,13 +404,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 gait_resampled = 1;
             };
             if (live && (ep_len % UNI(gg.resample_steps)) == 0) resample(gg.stream_step);
-            if (shard) {   // _log_metrics (:430-441): envs per gait, after this step's resample
-#pragma unroll
-                for (int g = 0; g < GF_MAX_GAITS; ++g) {
-                    const unsigned long long b = __ballot(live && gait_sel == g);
-                    if (b && lane == 0) atomicAdd(&shard->gait_count[g], popc64(b));
-                }
-            }
+            ctl.gait_logged = gait_sel;   // _log_metrics (:430-441) counts envs per gait after this step's resample, before the reset's
             {   // the periodic clock (:231-239), for every env
                 const float period = grow[GF_GAIT_PERIOD];
                 const float gtime = torch_remainder(grow[GF_GAIT_TIME] + g_dt, period);
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 grow[GF_GAIT_PHASE] = phase;
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
-                    const float fp = torch_remainder(phase + grow[GF_GAIT_OFFSET + f], 1.0f);
+                    const float fp = torch_remainder_one(phase + grow[GF_GAIT_OFFSET + f]);
                     sincos_det(two_pi * fp, &grow[GF_GAIT_CLOCK + f], &grow[GF_GAIT_CLOCK + 4 + f]);
                 }
             }
@@ -405,21 +424,10 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 grow[GF_GAIT_TIME] = 0.0f;
                 grow[GF_GAIT_PHASE] = 0.0f;
             }
-            uint8_t* const fout = UNI(gg.flags_out);
-            if (fout) {   // this block's "any env in swing / stance" byte for the state the launch leaves — into the OTHER buffer
-                const float pi = 0.5f * two_pi;
-                uint32_t byte = 0;
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const int fl = gait_foot_flags(grow[GF_GAIT_PHASE], grow[GF_GAIT_OFFSET + f], two_pi, pi);
-                    if (__ballot(live && (fl & 1))) byte |= 1u << (2 * f);
-                    if (__ballot(live && (fl & 2))) byte |= 2u << (2 * f);
-                }
-                if (lane == 0) G(fout)[blockIdx.x] = (uint8_t)byte;
-            }
 #pragma unroll
             for (int j = 0; j < GF_GAIT_ROW; ++j) xch[(X_GAIT + j) * kEnvBlock + lane] = grow[j];
         }
+        GF_WSTAMP(11);
         // ---- publish ---------------------------------------------------------------------------------------------------------
         xch[X_TERM * kEnvBlock + lane] = (float)term;
         xch[X_TRUNC * kEnvBlock + lane] = (float)trunc;
@@ -453,6 +461,17 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         row_load<DV>(r_a, p0, D); row_load<DV>(r_b, p1, D); row_load<DV>(r_c, p2, D); row_load<DV>(r_def, p3, D);
         const GF_GLOBAL float* pp = gsel((needs & PN_POS) != 0, UNI(a.pos), 3u * e);
         const V3 pos{pp[0], pp[1], pp[2]};
+        // a static program whose terms read body-frame vectors: this wave derives them itself (see below) — the rows it needs for that
+        // are requested here, with the tile's other loads
+        float4 qb = make_float4(1.f, 0.f, 0.f, 0.f);
+        V3 wlin{0.f, 0.f, 0.f}, wang{0.f, 0.f, 0.f};
+        if constexpr (ws_rew_body_frame<P>()) {
+            qb = ldg4(gsel((needs & PN_QUAT) != 0, UNI(a.quat), 4u * e));
+            const GF_GLOBAL float* lp = gsel((needs & PN_LIN) != 0, UNI(a.lin_vel), 3u * e);
+            const GF_GLOBAL float* ap = gsel((needs & PN_ANG) != 0, UNI(a.ang_vel), 3u * e);
+            wlin = V3{lp[0], lp[1], lp[2]};
+            wang = V3{ap[0], ap[1], ap[2]};
+        }
         const float* k_secs = UNI(a.episode_seconds);
         const float secs_in = *gsel(has_reward && k_secs != nullptr, k_secs, e);
         float dof_dev = 0.f, act_rate = 0.f, cmd0[3];
@@ -479,16 +498,78 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             d = r_c[c].z - r_b[c].z; act_rate += d * d;
             d = r_c[c].w - r_b[c].w; act_rate += d * d;
         }
+        // A static program evaluates its terms HERE, before the barrier: a term needs this wave's own reductions, memory nothing in
+        // the launch writes before its last barrier, and at most the body-frame vectors — which this wave derives itself from the same
+        // quaternion / velocity rows with the same rot_inv the control wave uses (same inputs, same arithmetic: the same bits) instead of
+        // waiting for them at the barrier.  Behind the barrier only the fold is left (sums, statistics, stores): the wave used to sit
+        // idle here until the control wave was done and then evaluate every term with the other three waiting for it at the tile
+        // barrier (profiles/r03_n_stamps.txt: 2.7 of 10.5 µs at 8 192 envs).  The two terms that read the termination mask stay behind.
+        float vals[kPostMaxReward];
+        GF_WSTAMP(9);
+        if constexpr (P::kStatic) {
+            if constexpr (P::n_rew > 0) {   // (a program with reward terms matches only a launch that has the reward manager: no branch)
+                RewardRegs rp;
+                rp.pos = pos; rp.blin = V3{0.f, 0.f, 0.f}; rp.bang = rp.blin; rp.grav = rp.blin;
+                if constexpr (ws_rew_body_frame<P>()) {
+                    rp.blin = rot_inv(qb, wlin);
+                    rp.bang = rot_inv(qb, wang);
+                    rp.grav = rot_inv(qb, V3{0.f, 0.f, -1.f});
+                }
+                rp.dof_dev = dof_dev; rp.act_rate = act_rate; rp.terminated = 0;
+                rp.cmd0[0] = cmd0[0]; rp.cmd0[1] = cmd0[1]; rp.cmd0[2] = cmd0[2];
+                rp.n = n; rp.live = live;
+                auto term_of = [&](auto K) GF_INLINE_LAMBDA {
+                    constexpr int k_ = decltype(K)::value;
+                    GfTerm t = karg.rterms[k_];
+                    t.op = P::rew[k_].op; t.flags = P::rew[k_].flags; t.i[0] = P::rew[k_].i0; t.i[1] = P::rew[k_].i1;
+                    return t;
+                };
+                static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {   // the stateful term (body acceleration stores its state) goes last
+                    constexpr int k_ = decltype(K)::value;
+                    constexpr int op = P::rew[k_].op;
+                    if constexpr (!reward_op_memory_only(op) && !reward_op_reads_terminated(op) && op != GF_R_BODY_ACCEL_EXP)
+                        vals[k_] = eval_reward_term(term_of(K), a, rp);
+                });
+                static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
+                    constexpr int k_ = decltype(K)::value;
+                    if constexpr (P::rew[k_].op == GF_R_BODY_ACCEL_EXP) vals[k_] = eval_reward_term(term_of(K), a, rp);
+                });
+            }
+        }
         // the rows have been read for the last time: what is left of them takes their place in the union
         rew.pos = pos;
         rew.dof_dev = dof_dev; rew.act_rate = act_rate; rew.secs_in = secs_in;
         rew.cmd0[0] = cmd0[0]; rew.cmd0[1] = cmd0[1]; rew.cmd0[2] = cmd0[2];
+        if constexpr (P::kStatic) {
+            static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
+                constexpr int k_ = decltype(K)::value;
+                rew.vals[k_] = vals[k_];
+                fold_w[k_] = karg.rterms[k_].w; fold_row[k_] = karg.rterms[k_].row;
+                asm volatile("" : "+s"(fold_w[k_]), "+s"(fold_row[k_]));   // (loaded HERE: not sunk to their use behind the barrier)
+            });
+        }
     } else if (wave == 2) {
         const GF_GLOBAL float* p0 = gsel((needs & PN_DOFPOS) != 0, UNI(a.dof_pos), ro);
         const GF_GLOBAL float* p1 = gsel((needs & PN_DOFVEL) != 0, UNI(a.dof_vel), ro);
         const float* k_def = UNI(a.default_dof_pos);
         const GF_GLOBAL float* p2 = gsel(k_def != nullptr, k_def, 0u);
         row_load<DV>(r_a, p0, D); row_load<DV>(r_b, p1, D); row_load<DV>(r_c, p2, D);
+        GF_WSTAMP(9);
+        if constexpr (kPreRows > 0) {   // the memory-only reward terms (see reward_op_memory_only), parked for the fold
+            RewardRegs rp;   // (parked rows exist only in a program with reward terms, which matches only a launch that has the reward manager)
+            rp.pos = V3{0.f, 0.f, 0.f}; rp.blin = rp.pos; rp.bang = rp.pos; rp.grav = rp.pos;
+            rp.dof_dev = 0.f; rp.act_rate = 0.f; rp.terminated = 0;
+            rp.cmd0[0] = 0.f; rp.cmd0[1] = 0.f; rp.cmd0[2] = 0.f;
+            rp.n = n; rp.live = live;
+            static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
+                constexpr int k_ = decltype(K)::value;
+                if constexpr (reward_op_memory_only(P::rew[k_].op)) {
+                    GfTerm t = karg.rterms[k_];
+                    t.op = P::rew[k_].op; t.flags = P::rew[k_].flags; t.i[0] = P::rew[k_].i0; t.i[1] = P::rew[k_].i1;
+                    lds_pre[ws_pre_slot<P>(k_) * kEnvBlock + lane] = eval_reward_term(t, a, rp);
+                }
+            });
+        }
     } else {
         const GF_GLOBAL float* p0 = gsel((needs & PN_TARGETS) != 0, UNI(a.targets), ro);
         const GF_GLOBAL float* p1 = gsel((needs & PN_ACTIONS) != 0, UNI(a.env_actions), ro);
@@ -511,23 +592,6 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 });
             });
         }
-        if constexpr (kPreRows > 0) {   // the memory-only reward terms (see reward_op_memory_only), parked for the fold
-            if (has_reward) {
-                RewardRegs rp;
-                rp.pos = V3{0.f, 0.f, 0.f}; rp.blin = rp.pos; rp.bang = rp.pos; rp.grav = rp.pos;
-                rp.dof_dev = 0.f; rp.act_rate = 0.f; rp.terminated = 0;
-                rp.cmd0[0] = 0.f; rp.cmd0[1] = 0.f; rp.cmd0[2] = 0.f;
-                rp.n = n; rp.live = live;
-                static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
-                    constexpr int k_ = decltype(K)::value;
-                    if constexpr (reward_op_memory_only(P::rew[k_].op)) {
-                        GfTerm t = karg.rterms[k_];
-                        t.op = P::rew[k_].op; t.flags = P::rew[k_].flags; t.i[0] = P::rew[k_].i0; t.i[1] = P::rew[k_].i1;
-                        lds_pre[ws_pre_slot<P>(k_) * kEnvBlock + lane] = eval_reward_term(t, a, rp);
-                    }
-                });
-            }
-        }
     }
     GF_WSTAMP(2);
     // every load above has landed (registers / LDS) before any wave starts storing state behind the barrier
@@ -549,6 +613,41 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             if (rd) G(rd)[n_raw] = (uint8_t)((term | trunc) != 0);   // dones[t] of the rollout storage
         }
         if (shard && done_mask && lane == 0) atomicAdd(&shard->reset_count, popc64(done_mask));
+        if (shard) {   // the step's counters, from the bits the pre-barrier block left
+            auto count_bits = [&](int k, int32_t* dst) GF_INLINE_LAMBDA {
+                const unsigned long long hit = __ballot((ctl.log_bits >> k) & 1u);
+                if (hit && lane == 0) atomicAdd(dst, popc64(hit));
+            };
+            if constexpr (P::kStatic) {
+                static_for<P::n_term>([&](auto K) GF_INLINE_LAMBDA { count_bits(decltype(K)::value, &shard->term_fired[decltype(K)::value]); });
+            } else {
+                for (int k = 0; k < n_term; ++k) count_bits(k, &shard->term_fired[k]);
+            }
+#pragma unroll
+            for (int c = 0; c < GF_POST_MAX_CMD; ++c)
+                if (c < n_cmd) count_bits(16 + c, &shard->resample_count);
+            if (has_gait) {
+#pragma unroll
+                for (int g = 0; g < GF_MAX_GAITS; ++g) {
+                    const unsigned long long b = __ballot(live && ctl.gait_logged == g);
+                    if (b && lane == 0) atomicAdd(&shard->gait_count[g], popc64(b));
+                }
+            }
+        }
+        if (has_gait) {
+            uint8_t* const fout = UNI(a.gait.flags_out);
+            if (fout) {   // this block's "any env in swing / stance" byte for the state the launch leaves — into the OTHER buffer
+                const float two_pi = UNI(a.gait.two_pi), pi = 0.5f * two_pi;
+                uint32_t byte = 0;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int fl = gait_foot_flags(grow[GF_GAIT_PHASE], grow[GF_GAIT_OFFSET + f], two_pi, pi);
+                    if (__ballot(live && (fl & 1))) byte |= 1u << (2 * f);
+                    if (__ballot(live && (fl & 2))) byte |= 2u << (2 * f);
+                }
+                if (lane == 0) G(fout)[blockIdx.x] = (uint8_t)byte;
+            }
+        }
         if (done) {
             if ((reset_env & 1) && a.env_actions) {
                 float4 zr[R];
@@ -602,36 +701,32 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             const uint32_t log_mask = UNI(a.reward_log_mask);
             const float secs_new = rew.secs_in + dt;
             float buf = 0.f;
+            GF_WSTAMP(10);
             const bool log_reset = logging && done_mask != 0;
-            auto fold_body = [&](int k, const GfTerm& t, float v) GF_INLINE_LAMBDA {
-                v = v * t.w;
+            auto fold_body = [&](int k, const float t_w, const int32_t t_row, float v) GF_INLINE_LAMBDA {
+                v = v * t_w;
                 buf += v;
                 if (logging) {
                     float s = lds_sums[k * kEnvBlock + lane] + v;
                     if (log_reset) {
                         const float per_sec = done ? s / secs_new : 0.f;
-                        if (shard && (log_mask & (1u << t.row))) {
+                        if (shard && (log_mask & (1u << t_row))) {
                             if (popc64(done_mask) > 4) {
                                 const double w = wave_sum((double)per_sec);
-                                if (lane == 0) unsafeAtomicAdd(&shard->reward_episode_sum[t.row], w);
+                                if (lane == 0) unsafeAtomicAdd(&shard->reward_episode_sum[t_row], w);
                             } else if (done) {
-                                unsafeAtomicAdd(&shard->reward_episode_sum[t.row], (double)per_sec);
+                                unsafeAtomicAdd(&shard->reward_episode_sum[t_row], (double)per_sec);
                             }
                         }
                         if (done) s = 0.f;
                     }
-                    if (live) G(k_sums)[(int64_t)t.row * N + n_raw] = s;
+                    if (live) G(k_sums)[(int64_t)t_row * N + n_raw] = s;
                 }
             };
             if constexpr (P::kStatic) {
-                // Two passes.  Terms that read contact rows, link velocities / positions or a gait row load them from memory HERE,
-                // behind the barrier; evaluated inside the fold, every such term waited for its own loads behind the previous term's
-                // sum store (a store the compiler must assume may alias the next term's loads) — a chain of round trips: 6.3 of the
-                // gait program's 18 µs at 8 192 envs (profiles/r02_c_gait_fused_attribution.txt).  Pass 1 computes every term's VALUE
-                // with no store in between, so all those loads go out back to back and are waited for once; the stateful term
-                // (body acceleration: it stores its state) goes last.  Pass 2 is the fold — the reference's order, the same
-                // arithmetic per term, so the results are bit-identical — with the sum / statistics stores.
-                float vals[P::n_rew > 0 ? P::n_rew : 1];
+                // The values were computed before the barrier — by this wave (everything it can evaluate from its own loads) and by
+                // wave 2 (the memory-only terms, parked in LDS rows); the two terms that read the termination mask are evaluated here.
+                // What is left is the fold: the reference's order, the same arithmetic per term, with the sum / statistics stores.
                 auto term_of = [&](auto K) GF_INLINE_LAMBDA {
                     constexpr int k_ = decltype(K)::value;
                     GfTerm t = karg.rterms[k_];
@@ -640,23 +735,20 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 };
                 static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
                     constexpr int k_ = decltype(K)::value;
-                    if constexpr (reward_op_memory_only(P::rew[k_].op)) vals[k_] = lds_pre[ws_pre_slot<P>(k_) * kEnvBlock + lane];   // wave 3 parked it
-                    else if constexpr (P::rew[k_].op != GF_R_BODY_ACCEL_EXP) vals[k_] = eval_reward_term(term_of(K), a, rr);
-                });
-                static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
-                    constexpr int k_ = decltype(K)::value;
-                    if constexpr (P::rew[k_].op == GF_R_BODY_ACCEL_EXP) vals[k_] = eval_reward_term(term_of(K), a, rr);
-                });
-                static_for<P::n_rew>([&](auto K) GF_INLINE_LAMBDA {
-                    constexpr int k_ = decltype(K)::value;
-                    fold_body(k_, term_of(K), vals[k_]);
+                    constexpr int op = P::rew[k_].op;
+                    float v;
+                    if constexpr (reward_op_memory_only(op)) v = lds_pre[ws_pre_slot<P>(k_) * kEnvBlock + lane];
+                    else if constexpr (reward_op_reads_terminated(op)) v = eval_reward_term(term_of(K), a, rr);
+                    else v = rew.vals[k_];
+                    fold_body(k_, fold_w[k_], fold_row[k_], v);
                 });
             } else {
                 for (int k = 0; k < n_rew; ++k) {
                     const GfTerm t = a.rterms[k];
-                    fold_body(k, t, eval_reward_term(t, a, rr));
+                    fold_body(k, t.w, t.row, eval_reward_term(t, a, rr));
                 }
             }
+            GF_WSTAMP(11);
             if (live) {
                 G(k_reward)[n_raw] = buf;
                 G(UNI(a.episode_seconds))[n_raw] = done ? 1e-10f : secs_new;
