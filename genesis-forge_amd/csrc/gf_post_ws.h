@@ -903,15 +903,18 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                         } break;
                         default: break;
                     }
-                    if (noisy) {
+                    if (noisy) {   // column c draws word c & 3 of Philox block c >> 2: one block per four columns the item covers
                         const float it_noise = it.noise;
+                        const int c_end = col + it_w;
 #pragma nounroll
-                        for (int j = 0; j < it_w; ++j) {
-                            const uint32_t cj = (uint32_t)(col + j);
-                            const float4 u4 = draw_unit4(seed, ob_stream, genv, cj >> 2);
-                            const uint32_t sel = cj & 3u;
-                            const float u = sel == 0 ? u4.x : (sel == 1 ? u4.y : (sel == 2 ? u4.z : u4.w));
-                            row[col + j] = row[col + j] + uniform_range(u, -1.0f, 1.0f) * it_noise;
+                        for (int b = col >> 2; b <= ((c_end - 1) >> 2); ++b) {
+                            const float4 u4 = draw_unit4(seed, ob_stream, genv, (uint32_t)b);
+                            const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+                            for (int w4 = 0; w4 < 4; ++w4) {
+                                const int c = 4 * b + w4;
+                                if (c >= col && c < c_end) row[c] = row[c] + uniform_range(uu[w4], -1.0f, 1.0f) * it_noise;
+                            }
                         }
                     }
                 }

@@ -82,14 +82,31 @@ __device__ __forceinline__ void reset_body(const GfResetArgs& a) {
 
     // ---- scene side (synthetic scene exposes masked setters; NULL for real Genesis) ----------------
     if (a.scene_dof_pos) {
-        for (int d = 0; d < D; ++d) {
-            float p = a.default_dof_pos[d];
+        // four DOFs per pass: the draws of columns 4 + d0 … 4 + d0 + 3 are the four words of ONE Philox block (block 1 + d0 / 4) — a
+        // block per DOF computed the same ten rounds four times over (12 blocks instead of 3 for a Go2: most of what a wave with a
+        // done env spent here)
+        const uint32_t genv = (uint32_t)n + a.env_offset;
+        for (int d0 = 0; d0 < D; d0 += 4) {
+            float u[4] = {0.f, 0.f, 0.f, 0.f};
             if (a.dof_noise_scale != 0.0f) {
-                const float u = draw_u(a.dof_draws, n * D + d, a.seed, a.stream, (uint32_t)n + a.env_offset, (uint32_t)(4 + d));
-                p = p + uniform_range(u, -1.0f, 1.0f) * a.dof_noise_scale;
+                if (a.dof_draws) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = a.dof_draws[n * D + (d0 + j < D ? d0 + j : D - 1)];
+                } else {
+                    const U4 r = philox4x32_10(genv, (uint32_t)(4 + d0) >> 2, (uint32_t)a.stream, (uint32_t)(a.stream >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                    u[0] = u24_to_unit(r.x); u[1] = u24_to_unit(r.y); u[2] = u24_to_unit(r.z); u[3] = u24_to_unit(r.w);
+                }
             }
-            a.scene_dof_pos[n * D + d] = p;
-            if (a.scene_dof_vel) a.scene_dof_vel[n * D + d] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = d0 + j;
+                if (d < D) {
+                    float p = a.default_dof_pos[d];
+                    if (a.dof_noise_scale != 0.0f) p = p + uniform_range(u[j], -1.0f, 1.0f) * a.dof_noise_scale;
+                    a.scene_dof_pos[n * D + d] = p;
+                    if (a.scene_dof_vel) a.scene_dof_vel[n * D + d] = 0.0f;
+                }
+            }
         }
     }
     if (a.scene_pos) {
@@ -217,13 +234,17 @@ extern "C" __attribute__((visibility("default"))) int gf_done_compact(const GfCo
     hipStream_t s = (hipStream_t)stream;
     if (a->num_envs == 0) {
         GF_HIP_CHECK(hipMemsetAsync(a->count_out, 0, sizeof(int32_t), s));
+        if (a->wait) GF_HIP_CHECK(hipStreamSynchronize(s));
         return GF_OK;
     }
     const int blocks = (int)((a->num_envs + gf::kCompactEnvs - 1) / gf::kCompactEnvs);
     gf::PhaseScope scope(GF_PHASE_COMPACT, s);
     gf::klaunch(gf::compact_count_kernel, dim3(blocks), dim3(gf::kCompactBlock), 0, s, *a);
     gf::klaunch(gf::compact_write_kernel, dim3(blocks), dim3(gf::kCompactBlock), 0, s, *a, blocks);
-    return gf::launch_status();
+    const int rc = gf::launch_status();
+    if (rc != GF_OK || !a->wait) return rc;
+    GF_HIP_CHECK(hipStreamSynchronize(s));
+    return GF_OK;
 }
 
 namespace gf {

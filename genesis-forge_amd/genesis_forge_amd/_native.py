@@ -13,7 +13,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-GF_ABI_VERSION = 5
+GF_ABI_VERSION = 6
 GF_MAX_TERMS = 24
 GF_MAX_TERM_TERMS = 16
 GF_MAX_OBS_ITEMS = 24
@@ -294,7 +294,8 @@ class GfGaeArgs(C.Structure):
 
 
 class GfCompactArgs(C.Structure):
-    _fields_ = [("num_envs", C.c_int64), ("mask", P), ("mask2", P), ("ids_out", P), ("count_out", P), ("block_counts", P)]
+    _fields_ = [("num_envs", C.c_int64), ("mask", P), ("mask2", P), ("ids_out", P), ("count_out", P), ("block_counts", P),
+                ("wait", C.c_int32), ("_pad", C.c_int32)]
 
 
 class GfPostRefs(C.Structure):

@@ -45,36 +45,41 @@ class EntityViews:
 
 class DoneIds:
     """The ascending index list of a step's done envs — what the reference gets from ``(terminated | truncated).nonzero()``
-    (managed_env.py:308-310) — through ``gf_done_compact``: two small launches write the list into a persistent buffer and the
-    count into a pinned host word, the host synchronises the stream and takes a view.  torch's ``nonzero()`` costs an OR launch, a
-    two-pass select, a device-to-host copy and an allocation for the same sync."""
+    (managed_env.py:308-310) — through ``gf_done_compact``: two small launches write the list and leave the count in a pinned
+    host word; the call itself waits for the stream (``wait``), so the one synchronisation of the step costs no second trip into
+    the runtime.  torch's ``nonzero()`` costs an OR launch, a two-pass select, a device-to-host copy and an allocation for the
+    same sync.
+
+    Every compaction writes into a buffer of its own (the caching allocator hands back the block of a few steps ago): the list
+    goes to user code — a ``reset(envs_idx)`` override may keep it — so it must never be rewritten by a later step, and a fresh
+    block costs less than cloning the list out of a persistent one (an allocation against an allocation plus a copy launch)."""
 
     def __init__(self, num_envs: int):
+        import ctypes as C
+
         dev = gs.device
-        self.ids = torch.empty(max(num_envs, 1), device=dev, dtype=torch.int64)
+        self.num_envs = num_envs
         self.count = torch.zeros(1, dtype=torch.int32)
         if dev.type == "cuda":
             self.count = self.count.pin_memory()   # the kernel stores into it through the host mapping
+        self._count_word = C.c_int32.from_address(self.count.data_ptr())   # read without building a tensor
         self.scratch = torch.zeros((num_envs + 4095) // 4096 + 1, device=dev, dtype=torch.int32)
         self.args = nat.GfCompactArgs()
         self.args.num_envs = num_envs
-        self.args.ids_out, self.args.count_out, self.args.block_counts = self.ids.data_ptr(), self.count.data_ptr(), self.scratch.data_ptr()
+        self.args.count_out, self.args.block_counts = self.count.data_ptr(), self.scratch.data_ptr()
+        self.args.wait = 1 if dev.type == "cuda" else 0
 
-    def __call__(self, backend, mask: torch.Tensor, mask2: Optional[torch.Tensor] = None, own: bool = False) -> torch.Tensor:
-        """``own``: a tensor of the caller's own (handed to user code, which may keep it); otherwise a view of the buffer, valid
-        until the next call."""
+    def __call__(self, backend, mask: torch.Tensor, mask2: Optional[torch.Tensor] = None) -> torch.Tensor:
         a = self.args
+        ids = torch.empty(max(self.num_envs, 1), device=mask.device, dtype=torch.int64)
+        a.ids_out = ids.data_ptr()
         a.mask, a.mask2 = mask.data_ptr(), (None if mask2 is None else mask2.data_ptr())
         tracer, backend.tracer = backend.tracer, None   # (never part of a recording: the list is taken where it is needed)
         try:
-            backend.call("done_compact", a)
+            backend.call("done_compact", a)   # returns when the stream has drained (the reference's nonzero() is a sync too)
         finally:
             backend.tracer = tracer
-        if mask.device.type == "cuda":
-            torch.cuda.current_stream().synchronize()   # the one sync of the step (the reference's nonzero() is one too)
-        k = int(self.count[0])
-        out = self.ids[:k]
-        return out.clone() if own and k else out
+        return ids[:self._count_word.value]
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -276,7 +281,8 @@ class GenesisEnv:
         return v
 
     def done_ids(self, mask: torch.Tensor, mask2: Optional[torch.Tensor] = None, own: bool = False) -> torch.Tensor:
-        """Ascending indices of the envs whose ``mask`` (or ``mask2``) is set — see :class:`DoneIds`."""
+        """Ascending indices of the envs whose ``mask`` (or ``mask2``) is set — see :class:`DoneIds`.  The list is the caller's to
+        keep (``own`` is accepted for older call sites: every list is in a buffer of its own)."""
         if self._done_ids_native is None:
             self._done_ids_native = DoneIds(self.num_envs)
         # only ever asked for the termination masks of the current step, which are written once per step: a second request within
@@ -284,11 +290,10 @@ class GenesisEnv:
         key = (self.step_count, self._in_step, mask.data_ptr(), None if mask2 is None else mask2.data_ptr())
         hit = self._done_ids_cache
         if hit is not None and hit[0] == key:
-            ids = hit[1]
-            return ids.clone() if own and ids.numel() else ids
-        ids = self._done_ids_native(self.backend, mask, mask2, False)
+            return hit[1]
+        ids = self._done_ids_native(self.backend, mask, mask2)
         self._done_ids_cache = (key, ids)
-        return ids.clone() if own and ids.numel() else ids
+        return ids
 
     def invalidate_views(self) -> None:
         self._tick += 1

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 5
+#define GF_ABI_VERSION 6
 
 #define GF_MAX_TERMS 24          /* reward terms per manager          */
 #define GF_MAX_TERM_TERMS 16     /* termination terms per manager     */
@@ -659,6 +659,10 @@ typedef struct GfCompactArgs {
     int64_t* ids_out;         /* [N] capacity; the first *count_out entries are the indices, ascending */
     int32_t* count_out;       /* one word: device memory or pinned host memory */
     int32_t* block_counts;    /* scratch, ceil(N / 4096) + 1 words */
+    int32_t wait;             /* 1: the call returns after the stream has drained — *count_out (pinned host memory) is then valid
+                               * for the caller to read: the one synchronisation of a step that needs the list, taken inside the
+                               * call instead of through a second trip into the runtime */
+    int32_t _pad;
 } GfCompactArgs;
 
 /* ------------------------------------------------------------------------------------------

@@ -69,3 +69,24 @@ def test_done_compact_hip(hip_backend):
     assert int(count[0]) == want.numel() and torch.equal(ids[:want.numel()], want)
     with pytest.raises(nat.GfError, match="GF_E_NULL"):
         hip_backend.call("done_compact", nat.GfCompactArgs())
+
+
+@pytest.mark.gpu
+def test_done_compact_waits_when_asked_hip(hip_backend):
+    """``wait = 1``: the call returns with the stream drained — the pinned count is valid without any further synchronisation (what
+    genesis_env.DoneIds relies on); queued behind a long-running launch so that an early return would read the stale word."""
+    import ctypes as C
+
+    n = 1 << 20
+    m = torch.rand(n, device="cuda") < 0.01
+    want = m.nonzero().reshape(-1)
+    a, ids, _count, _s = _args(n, m, None, "cuda")
+    pinned = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+    a.count_out, a.wait = pinned.data_ptr(), 1
+    big = torch.randn(1 << 26, device="cuda")
+    for _ in range(8):
+        big = big * 1.0001 + 0.5   # a queue of work in front of the compaction
+    hip_backend.call("done_compact", a)
+    k = C.c_int32.from_address(pinned.data_ptr()).value   # no torch.cuda.synchronize()
+    assert k == want.numel()
+    assert torch.equal(ids[:k], want)
