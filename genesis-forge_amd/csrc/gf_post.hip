@@ -568,14 +568,20 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     const GfResetArgs& RS = *r->reset;
     const GfRewardArgs* RW = r->reward;
     const int N = T.num_envs;
+    // GF_POST_OBSERVE_ONLY: the step's phases up to the reset have run as launches of their own; `reset` is the descriptor that reset
+    // ran with (its masks, its stale-quaternion stash, the seed every phase shares) and nothing in it is applied again
+    const bool obs_only = (r->flags & GF_POST_OBSERVE_ONLY) != 0;
+    UNSUP(obs_only && (r->reward || r->num_command || r->num_gait || r->rollout || r->num_observe < 1));
+    a.obs_only = obs_only ? 1 : 0;
     UNSUP(N <= 0 || T.num_terms > kPostMaxTerm || T.term_out);
     UNSUP(r->num_command < 0 || r->num_command > GF_POST_MAX_CMD || r->num_observe < 0 || r->num_observe > GF_POST_MAX_OBS);
     UNSUP(RS.num_envs != N || RS.mask != T.terminated || RS.mask2 != T.truncated);
     UNSUP(RS.len_draws || RS.dof_draws);
     bool have_terrain = false;  // one terrain map per fused step: the reward's and the spawn's must be the same
     a.num_envs = N;
-    a.terminated = T.terminated; a.truncated = T.truncated; a.stats = T.stats ? T.stats : RS.stats;
-    UNSUP(RS.stats && T.stats && RS.stats != T.stats);
+    a.terminated = T.terminated; a.truncated = T.truncated;
+    a.stats = obs_only ? nullptr : (T.stats ? T.stats : RS.stats);   // (an observation-only launch counts nothing)
+    UNSUP(!obs_only && RS.stats && T.stats && RS.stats != T.stats);
     a.episode_length = const_cast<int32_t*>(T.episode_length);
     a.max_episode_length = const_cast<int32_t*>(T.max_episode_length);
     a.has_maxlen = T.max_episode_length != nullptr;
@@ -633,7 +639,7 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     }
 
     // termination terms (not evaluated when the phase has already run as a launch of its own: the masks are inputs then)
-    a.term_done = (r->flags & GF_POST_TERMINATION_DONE) ? 1 : 0;
+    a.term_done = ((r->flags & GF_POST_TERMINATION_DONE) || obs_only) ? 1 : 0;
     a.num_term = a.term_done ? 0 : T.num_terms;
     for (int k = 0; k < a.num_term; ++k) {
         GfTerm t = T.terms[k];
@@ -766,7 +772,7 @@ static int pack(const GfPostRefs* r, Packer& pk) {
         a.uncovered_rows = 0;
         for (int row = 0; row < RS.num_reward_terms; ++row)
             if (!(covered & (1u << row))) a.uncovered_rows |= 1u << row;
-    } else {
+    } else if (!obs_only) {
         UNSUP(RS.episode_seconds || RS.episode_sums);
     }
 
@@ -830,7 +836,7 @@ static int pack(const GfPostRefs* r, Packer& pk) {
 
     // observations
     a.n_obs = r->num_observe;
-    int omax = 0;
+    int omax = 0, stale_seen = 0;
     for (int m = 0; m < a.n_obs; ++m) {
         const GfObservationArgs* ob = r->observe[m];
         UNSUP(!ob || ob->num_envs != N || ob->num_items > kPostMaxItems || ob->noise_draws || !ob->obs);
@@ -879,9 +885,21 @@ static int pack(const GfPostRefs* r, Packer& pk) {
             UNSUP(!same_entity(cur, ob->entity));
             merge_entity(a, ob->entity);
             // stale quaternion source must be this step's reset (or absent when the reset does not touch quat)
-            if (a.scene_reset && (a.spawn_mode ? a.spawn_set_quat : a.set_quat)) UNSUP(ob->stale_quat != a.quat_stash || ob->stale_mask != T.terminated || ob->stale_mask2 != T.truncated);
-            else UNSUP(ob->stale_quat != nullptr);
+            if (obs_only) {
+                // the reset ran (or, in a step without a done env, did not run) as a launch of its own: the manager's descriptor says
+                // whether this tick has a stash to read, and every manager of the launch must say the same
+                UNSUP(ob->stale_quat && (ob->stale_quat != RS.quat_stash || ob->stale_mask != T.terminated || ob->stale_mask2 != T.truncated));
+                stale_seen |= ob->stale_quat ? 1 : 2;
+            } else if (a.scene_reset && (a.spawn_mode ? a.spawn_set_quat : a.set_quat)) {
+                UNSUP(ob->stale_quat != a.quat_stash || ob->stale_mask != T.terminated || ob->stale_mask2 != T.truncated);
+            } else {
+                UNSUP(ob->stale_quat != nullptr);
+            }
         }
+    }
+    if (obs_only) {
+        UNSUP(stale_seen == 3);
+        a.quat_stash = (stale_seen & 1) ? RS.quat_stash : nullptr;
     }
     UNSUP(omax >= GF_MAX_OBS_WIDTH);
 
@@ -997,7 +1015,7 @@ extern "C" __attribute__((visibility("default"))) int gf_post_program_count(void
     X(7, gf::ProgHumanoid28Stress)
 
 static int select_program(const gf::GfPostArgs& a) {
-    if (gf::g_options[GF_OPT_POST_VARIANT] < 2) return 0;
+    if (gf::g_options[GF_OPT_POST_VARIANT] < 2 || a.obs_only) return 0;   // (the observation-only launch is the interpreter's)
 #define GF_MATCH(id, P) \
     if (gf::program_matches<P>(a)) return id;
     GF_POST_PROGRAMS(GF_MATCH)

@@ -124,6 +124,8 @@ struct alignas(16) GfPostArgs {
     uint8_t* roll_done;
     int32_t roll_obs_index;
     int32_t term_done;   // GF_POST_TERMINATION_DONE: the masks are inputs, the termination table is not evaluated
+    int32_t obs_only;    // GF_POST_OBSERVE_ONLY: the masks are inputs and nothing is reset; the observation waves run (interpreter only)
+    int32_t _pad_obs_only;
     const uint8_t* gait_wave_flags;   // == gait.flags_in when the reward terms reproduce the env-0 quirk (GF_R_GAIT_PHASE)
     PostGait gait;
     GfTerm tterms[kPostMaxTerm];

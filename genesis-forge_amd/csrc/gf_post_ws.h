@@ -202,6 +202,10 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         n_term = UNI(a.num_term); n_rew = UNI(a.num_rew); n_cmd = UNI(a.n_cmd); n_obs = UNI(a.n_obs);
     }
     const uint64_t seed = UNI(a.seed);
+    // GF_POST_OBSERVE_ONLY (interpreter): everything up to the reset has run as launches of their own — the masks are inputs, no env
+    // is "done" as far as this launch is concerned, the observation waves do their part
+    bool obs_only = false;
+    if constexpr (!P::kStatic) obs_only = UNI(a.obs_only) != 0;
     constexpr int R = DV;
     const uint32_t ro = e * (uint32_t)D;
     GfStepStats* const k_stats = UNI(a.stats);
@@ -303,6 +307,14 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             grow[8] = g2.x; grow[9] = g2.y; grow[10] = g2.z; grow[11] = g2.w; grow[12] = g3.x; grow[13] = g3.y; grow[14] = g3.z; grow[15] = g3.w;
             gait_sel = (int)G(UNI(a.gait.selected))[e];
         }
+        if constexpr (!P::kStatic) {
+            if (obs_only) {   // an env the reset of this tick touched is observed through its pre-reset quaternion (entity_manager.py:189-195)
+                term = live ? (int)G(UNI(a.terminated))[n] : 0;
+                trunc = live ? (int)G(UNI(a.truncated))[n] : 0;
+                const float* const stash = UNI(a.quat_stash);
+                if (stash && (needs & PN_QUAT) && (term | trunc)) q = ldg4(G(stash) + 4u * e);
+            }
+        }
         // a static program's contact-count terminations: the counts are taken HERE, so the contact rows are requested together with
         // the loads above instead of as a round trip of their own between two terms' statistics branches
         int pre_cnt[ws_term_rows<P>()] = {};
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 term_body(k, t, eval_termination_term(t, a, tr, (uint32_t)has_maxlen));
             }
         }
-        const bool done0 = live && (term | trunc);
+        const bool done0 = live && (term | trunc) && !obs_only;
         GF_WSTAMP(9);
         // ---- command.step then command.reset draws (values only; stores wait for the barrier) ------------------------------
 #pragma unroll
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
 
     if (wave == 0) {
         // ---- control: stores --------------------------------------------------------------------------------------------------
-        if (live) {
+        if (live && !obs_only) {
             G(UNI(a.terminated))[n_raw] = (uint8_t)term;
             G(UNI(a.truncated))[n_raw] = (uint8_t)trunc;
             uint8_t* const rd = UNI(a.roll_done);

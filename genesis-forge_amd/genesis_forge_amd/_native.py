@@ -269,6 +269,7 @@ class GfStatsPackArgs(C.Structure):
 
 GF_POST_MAX_CMD, GF_POST_MAX_OBS, GF_POST_MAX_GAIT = 2, 2, 1
 GF_POST_TERMINATION_DONE = 1   # GfPostRefs.flags
+GF_POST_OBSERVE_ONLY = 2
 
 
 class GfRolloutArgs(C.Structure):

@@ -34,6 +34,7 @@ through one of them (``reset([…])`` or ``resample_command([…])`` called by t
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Optional
 
 from . import _native as nat
@@ -105,6 +106,8 @@ class StepTrace:
                 plain.append(c)
         calls = plain
         self.py_marks = marks
+        self._term_call = next((c for c in calls if c[0] == "termination_step"), None)   # (its masks: inputs of a fused tail observation launch)
+        self._tail_refs = None
         self.patches: list[Callable] = []   # Python-side per-step work that has Python semantics (live ranges, log registration)
         self.native: list = []              # GfReplayPatch entries: every per-step descriptor field, applied by gf_replay_step
         self.native_op: list = []           # … and the index of the op each entry belongs to (-1: none, applied first)
@@ -332,7 +335,34 @@ class StepTrace:
             pr[5 + i] = t.data_ptr()   # (applied by the piece of the op list that follows: its table carries the pointer patches)
 
     # -- the Python tail of an env that overrides reset(), part by part ----------------------------------------------------
-    def _build_tail_segment(self, calls):
+    def _fuse_tail_obs(self, calls, reset_args):
+        """The observation launches of the tail as ONE launch of the fused kernel's observation waves (GF_POST_OBSERVE_ONLY: the
+        masks are inputs, nothing is reset) when the library takes the combination — up to two managers, their gathers behind.
+        Returns the replacement call list, or ``calls`` unchanged."""
+        term = self._term_call
+        obs = [c for c in calls if c[0] == "observe"]
+        if term is None or reset_args is None or not 1 <= len(obs) <= nat.GF_POST_MAX_OBS:
+            return calls
+        if self.adapter is not None:
+            # (a scene whose getters return new tensors every tick: the reset descriptor's scene pointers are refreshed only in steps
+            #  that reset an env, so in the others they would not match this tick's — the observation launches stay their own)
+            return calls
+        if os.environ.get("GF_NO_TAIL_FUSE", "0") == "1":
+            return calls
+        refs = nat.GfPostRefs()
+        refs.flags = nat.GF_POST_OBSERVE_ONLY
+        refs.termination, refs.reset = C.addressof(term[1]), C.addressof(reset_args)
+        refs.num_observe = len(obs)
+        for m, o in enumerate(obs):
+            refs.observe[m] = C.addressof(o[1])
+        if not self.backend.post_check(refs):
+            return calls
+        self._tail_refs = refs   # (kept alive with the recording)
+        first = next(k for k, c in enumerate(calls) if c[0] == "observe")
+        rest = [c for c in calls if c[0] != "observe"]
+        return rest[:first] + [("post_obs", refs, obs)] + rest[first:]
+
+    def _build_tail_segment(self, calls, reset_args=None):
         """The launches one part of the Python tail made in the ordinary step (the in-step reset of the done envs by the
         termination masks; the observations) as a patch table + op list of their own.  The user's reset() still runs — its code
         before and after ``super().reset(ids)`` sees exactly what it sees in an ordinary step — but what ``super().reset(ids)`` and
@@ -343,23 +373,32 @@ class StepTrace:
             return None
         # gathers behind all observation launches: two of them then share a launch (gf_run_ops)
         calls = [c for c in calls if c[0] != "history_unroll"] + [c for c in calls if c[0] == "history_unroll"]
+        described = [c[1] for c in calls]   # every descriptor a launch reads, fused or not
+        if reset_args is not None:
+            calls = self._fuse_tail_obs(calls, reset_args)
         saved = (self.native, self.patches, self.afters, self._cur_op)
         self.native, self.patches, self.afters = [], [], []
         try:
             ops = (nat.GfOp * len(calls))()
             P = nat.GfReplayPatch
             for k, (fn, args, owner) in enumerate(calls):
-                ops[k].phase, ops[k].args = nat.PHASE_OF_FN[fn], C.addressof(args)
                 self._cur_op = k
-                self._hooks(fn, args, owner)
-                if hasattr(args, "stats") and args.stats:
-                    self.native.append(P(nat.GF_PATCH_PARAM, 0, nat.field_addr(args, "stats"), None, None))
+                if fn == "post_obs":   # the fused observation launch: the hooks and patches are the member launches' own
+                    ops[k].phase, ops[k].args = nat.GF_OP_POST_PHYSICS, C.addressof(args)
+                    members = owner
+                else:
+                    ops[k].phase, ops[k].args = nat.PHASE_OF_FN[fn], C.addressof(args)
+                    members = [(fn, args, owner)]
+                for mfn, margs, mowner in members:
+                    self._hooks(mfn, margs, mowner)
+                    if hasattr(margs, "stats") and margs.stats:
+                        self.native.append(P(nat.GF_PATCH_PARAM, 0, nat.field_addr(margs, "stats"), None, None))
             if self.adapter is not None:
-                self.native.extend(self._scene_patches([c[1] for c in calls]))
+                self.native.extend(self._scene_patches(described))
             table = (nat.GfReplayPatch * max(1, len(self.native)))(*self.native)
             desc = nat.GfReplay(C.addressof(ops), len(calls), len(self.native), C.addressof(table), C.addressof(self.env._rng_c))
             return {"ops": ops, "table": table, "desc": desc, "patches": self.patches, "afters": [f for _, f in self.afters],
-                    "keep": [c[1] for c in calls]}
+                    "keep": [c[1] for c in calls] + described, "fused_obs": any(c[0] == "post_obs" for c in calls)}
         finally:
             self.native, self.patches, self.afters, self._cur_op = saved
 
@@ -384,7 +423,9 @@ class StepTrace:
             self._tail_tries = 1 << 30   # the tail stays a Python walk for the life of this recording
             return
         try:
-            segs = {part: self._build_tail_segment(tail_calls[part]) for part in ("reset", "obs")}
+            reset_args = next((c[1] for c in tail_calls["reset"] if c[0] == "masked_reset"), None)
+            segs = {"reset": self._build_tail_segment(tail_calls["reset"]),
+                    "obs": self._build_tail_segment(tail_calls["obs"], reset_args)}
         except Untraceable:
             segs = {"reset": None}
         if any(v is None for v in segs.values()):

@@ -749,8 +749,15 @@ int gf_gae(const GfGaeArgs* a, void* stream);                     /* returns and
  * them: a host-evaluated reward column (GF_R_EXTERNAL) has to be computed after the termination phase and before the reward
  * phase (managed_env.py:303-319: the callable may read this step's termination buffers), so the step is
  * termination launch -> the callables -> ONE launch for reward ... observation.  Any termination table is then acceptable,
- * including GF_T_EXTERNAL terms. */
-enum { GF_POST_TERMINATION_DONE = 1 };
+ * including GF_T_EXTERNAL terms.
+ * GF_POST_OBSERVE_ONLY: every phase of the step up to and including the reset has ALREADY run — the termination phase, the
+ * rewards, the command managers and the reset of the done envs (gf_masked_reset on `reset`, by mask or by the index list a user's
+ * `reset(envs_idx)` override took: managed_env.py:308-310) — and only the observation managers are left (managed_env.py:324).
+ * The launch reads `terminated` / `truncated` (an env reset in this tick is observed through `reset->quat_stash`, the stale-cache
+ * quirk of entity_manager.py:189-195) and runs the observation waves of the fused kernel for up to two managers as one launch;
+ * `reward`, the command and gait lists must be empty.  This is the observation part of a step whose reset goes through user
+ * code. */
+enum { GF_POST_TERMINATION_DONE = 1, GF_POST_OBSERVE_ONLY = 2 };
 typedef struct GfPostRefs {
     const GfTerminationArgs* termination;                 /* required */
     const GfRewardArgs* reward;                           /* may be NULL */

@@ -1163,6 +1163,12 @@ GFO_EXPORT int gfo_post_physics_check(const GfPostRefs* r) { return (r && r->ter
 GFO_EXPORT int gfo_post_physics_step(const GfPostRefs* r) {
     if (!r || !r->termination || !r->reset) return GF_E_NULL;
     int rc = GF_OK;
+    if (r->flags & GF_POST_OBSERVE_ONLY) {   /* everything up to the reset has run as calls of their own: the observations are left */
+        if (r->reward || r->num_command || r->num_gait) return GF_E_UNSUPPORTED;
+        for (int o = 0; o < r->num_observe; ++o)
+            if ((rc = gfo_observe(r->observe[o]))) return rc;
+        return GF_OK;
+    }
     /* GF_POST_TERMINATION_DONE: the termination phase already ran as a call of its own (Python-level terms between it and the
      * reward phase, managed_env.py:303-319) */
     if (!(r->flags & GF_POST_TERMINATION_DONE) && (rc = gfo_termination_step(r->termination))) return rc;

@@ -167,6 +167,7 @@ def _check_override(dev, n):
     tr = env._trace
     assert tr is not None and tr.tail_python, "an env that overrides reset() is recorded up to the reset; the user's reset() stays Python"
     assert sorted(tr.tail_seg) == ["obs", "reset"], "what super().reset(ids) and get_observations() launch replays natively, part by part"
+    assert tr.tail_seg["obs"]["fused_obs"], "both observation managers of the tail run as ONE launch of the fused kernel's observation waves (GF_POST_OBSERVE_ONLY)"
     assert (env.user_resets, env.user_reset_envs) == (e0.user_resets, e0.user_reset_envs) and env.user_resets > 0
     _same_runs(a, b)
 
