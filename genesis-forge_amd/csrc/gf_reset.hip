@@ -147,8 +147,8 @@ namespace gf {
 
 // ---- gf_done_compact: the ascending index list of the done envs --------------------------------------------------------------
 // A workgroup of 256 lanes owns 4 096 envs, a lane 16 consecutive mask bytes (one dwordx4 per mask when the rows are 16-byte
-// aligned).  Launch 1 leaves each block's count; launch 2 adds up the counts in front of its block (at most 256 of them at 1 M
-// envs), scans its lanes' counts (wave prefix by DPP-free shuffles + 4 wave totals through LDS) and writes the indices in order.
+// aligned).  Above 131 072 envs two launches: launch 1 leaves each block's count; launch 2 adds up the counts in front of its block (at most 256
+// of them at 1 M envs), scans its lanes' counts (wave prefix by DPP-free shuffles + 4 wave totals through LDS) and writes the indices in order.
 constexpr int kCompactBlock = 256, kCompactPerLane = 16, kCompactEnvs = kCompactBlock * kCompactPerLane;
 
 __device__ __forceinline__ uint32_t compact_bits(const GfCompactArgs& a, const int64_t first) {
@@ -226,6 +226,49 @@ __global__ __launch_bounds__(kCompactBlock) void compact_write_kernel(const GfCo
     if (blockIdx.x == (unsigned)num_blocks - 1 && threadIdx.x == kCompactBlock - 1) *a.count_out = off;   // the last lane of the last block ends at the total
 }
 
+// Up to kCompactSingle blocks (131 072 envs): ONE launch.  A block finds the count in front of it by counting the masks of the blocks
+// before it itself — at most 31 x 4 KiB of cache-resident bytes per block, read as 16-byte units by its 256 lanes — instead of
+// waiting for a launch that left per-block counts: a launch less on a path whose launches are all a few microseconds of latency.
+constexpr int kCompactSingle = 32;
+
+__global__ __launch_bounds__(kCompactBlock) void compact_single_kernel(const GfCompactArgs a, const int num_blocks) {
+    __shared__ int s_base, s_w[kCompactBlock / GF_WAVE];
+    const int64_t first = ((int64_t)blockIdx.x * kCompactBlock + threadIdx.x) * kCompactPerLane;
+    uint32_t bits = compact_bits(a, first);   // (requested first: the units in front need no result of it)
+    int part = 0;
+    const int units_before = (int)blockIdx.x * kCompactBlock;   // 16-env units in front of this block (all whole: N >= the block's first env)
+    for (int u = threadIdx.x; u < units_before; u += kCompactBlock) part += __builtin_popcount(compact_bits(a, (int64_t)u * kCompactPerLane));
+    const int wpart = (int)wave_sum((double)part);
+    if ((threadIdx.x & (GF_WAVE - 1)) == 0) s_w[threadIdx.x >> 6] = wpart;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < kCompactBlock / GF_WAVE; ++i) t += s_w[i];
+        s_base = t;
+    }
+    __syncthreads();
+    const int base = s_base;
+    const int mine = __builtin_popcount(bits);
+    const int lane = threadIdx.x & (GF_WAVE - 1);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < GF_WAVE; o <<= 1) {
+        const int up = __shfl_up(incl, o, GF_WAVE);
+        if (lane >= o) incl += up;
+    }
+    __syncthreads();   // (s_w is reused)
+    if (lane == GF_WAVE - 1) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int off = base + incl - mine;
+    for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) off += s_w[i];
+    while (bits) {
+        const int j = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        G(a.ids_out)[off++] = first + j;
+    }
+    if (blockIdx.x == (unsigned)num_blocks - 1 && threadIdx.x == kCompactBlock - 1) *a.count_out = off;
+}
+
 }  // namespace gf
 
 extern "C" __attribute__((visibility("default"))) int gf_done_compact(const GfCompactArgs* a, void* stream) {
@@ -239,8 +282,12 @@ extern "C" __attribute__((visibility("default"))) int gf_done_compact(const GfCo
     }
     const int blocks = (int)((a->num_envs + gf::kCompactEnvs - 1) / gf::kCompactEnvs);
     gf::PhaseScope scope(GF_PHASE_COMPACT, s);
-    gf::klaunch(gf::compact_count_kernel, dim3(blocks), dim3(gf::kCompactBlock), 0, s, *a);
-    gf::klaunch(gf::compact_write_kernel, dim3(blocks), dim3(gf::kCompactBlock), 0, s, *a, blocks);
+    if (blocks <= gf::kCompactSingle) {
+        gf::klaunch(gf::compact_single_kernel, dim3(blocks), dim3(gf::kCompactBlock), 0, s, *a, blocks);
+    } else {
+        gf::klaunch(gf::compact_count_kernel, dim3(blocks), dim3(gf::kCompactBlock), 0, s, *a);
+        gf::klaunch(gf::compact_write_kernel, dim3(blocks), dim3(gf::kCompactBlock), 0, s, *a, blocks);
+    }
     const int rc = gf::launch_status();
     if (rc != GF_OK || !a->wait) return rc;
     GF_HIP_CHECK(hipStreamSynchronize(s));

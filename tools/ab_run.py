@@ -22,9 +22,13 @@ def child(variant, config, steps):
         _native.lib_path = lambda: lib
     gs.set_device("cuda:0")
     name, _, size = config.partition("@")   # "go2_cmd@1048576": the config at another size
-    n, factory = tasks.BASELINE_CONFIGS[name]
-    n = int(size) if size else n
-    env = factory(n)
+    if name == "gait_override":   # the gait task with the example's reset() override (tools/bench_reset_override.py)
+        n = int(size) if size else 8192
+        env = tasks.Go2GaitTrainingCurriculumEnv(num_envs=n, scene_kwargs=dict(ang_noise=0.05, seed=1234, contact_prob=0.001, contact_force=40.0))
+    else:
+        n, factory = tasks.BASELINE_CONFIGS[name]
+        n = int(size) if size else n
+        env = factory(n)
     env.build(); env.seed(1); env.reset()
     d = env.action_space.shape[0]
     acts = [torch.randn(n, d, device="cuda") for _ in range(4)]
