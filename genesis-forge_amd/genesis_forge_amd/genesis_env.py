@@ -45,7 +45,7 @@ class EntityViews:
 
 class DoneIds:
     """The ascending index list of a step's done envs — what the reference gets from ``(terminated | truncated).nonzero()``
-    (managed_env.py:308-310) — through ``gf_done_compact``: two small launches write the list and leave the count in a pinned
+    (managed_env.py:308-310) — through ``gf_done_compact``: one small launch (two above 131 072 envs) writes the list and leaves the count in a pinned
     host word; the call itself waits for the stream (``wait``), so the one synchronisation of the step costs no second trip into
     the runtime.  torch's ``nonzero()`` costs an OR launch, a two-pass select, a device-to-host copy and an allocation for the
     same sync.

@@ -648,7 +648,7 @@ typedef struct GfGaeArgs {
  * (managed_env.py:308-310) and hands the list to `reset(ids)`; on the masked path nothing needs it — except code that takes
  * index lists by contract: Genesis' `envs_idx` setters (position_action_manager.py:455-464, mdp/reset.py:102-124), a user's
  * `reset(ids)` override, user-defined manager classes.  torch's `nonzero()` there is an OR launch, a two-pass select, a
- * device-to-host copy of the count and an allocation.  gf_done_compact: two small launches — per-block counts, then
+ * device-to-host copy of the count and an allocation.  gf_done_compact: one small launch up to 131 072 envs (a block counts the masks in front of it itself), two above — per-block counts, then
  * offsets + ordered writes — produce the ascending list in a caller-owned buffer and the count in a word the host reads after
  * synchronising the stream (pinned host memory).  Same order as nonzero(), so everything downstream is unchanged.
  * ---------------------------------------------------------------------------------------- */
