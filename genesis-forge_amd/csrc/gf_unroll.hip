@@ -7,7 +7,7 @@
 // load-batch → wait (for the loads AND the previous batch's stores: one vmcnt on gfx9) → store-batch run by the 12 waves per CU a
 // 64-env tile layout leaves — 3.4 TB/s on the gait task's 184 MB; history workgroups inside that launch (tried) write the same cache
 // lines as the tile workgroups from another XCD at another time and are slower still.  This copy depends on nothing but the ring:
-// 4 096-float chunks, 16-byte units aligned on `out` (rows of an odd-width frame are not 16-byte aligned, the array is), four units
+// 2 048-float chunks, 16-byte units aligned on `out` (rows of an odd-width frame are not 16-byte aligned, the array is), two units
 // per lane in flight, thousands of workgroups — tools/microbench_shift.hip puts the structure at 6.7 TB/s.
 // A unit that lies inside one frame is one dword-aligned 16-byte load; the ≤ 1 unit per frame that straddles a frame edge (O mod 4 ≠ 0)
 // is two of them and a select.  Algorithmic traffic: R 4·O·H + W 4·O·H bytes per env.
@@ -17,7 +17,7 @@
 namespace gf {
 
 constexpr int kUnrollBlock = 256;
-constexpr int kUnrollUnits = 4;   // 16-byte units per lane in flight
+constexpr int kUnrollUnits = 2;   // 16-byte units per lane in flight (2 / 4 / 8 measured on one box, whole gait step at 65 536 envs: 127.1 / 128.2 / 134.3 µs — profiles/r03_w_ab_unroll.jsonl)
 constexpr int kUnrollChunk = kUnrollBlock * kUnrollUnits * 4;   // floats per workgroup
 
 // Division by the two run-time widths (O·H per row, O per frame) as multiply-shift with magic numbers the HOST computes once per
