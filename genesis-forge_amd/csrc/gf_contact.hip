@@ -295,7 +295,20 @@ int contact_launch(const GfContactArgs* const* mgrs, int num, hipStream_t s) {
     if (E > kContactLdsBytes / per_env) E = kContactLdsBytes / per_env;
     if (E < 1) return GF_E_RANGE;  // more than ~2 000 contact slots per env
     // small problems: keep at least ~2 workgroups per CU busy rather than 64-env tiles on a quarter of the chip
+    const int e_max = E;
     while (E > 8 && ((int64_t)a0->num_envs + E - 1) / E < 512) E >>= 1;
+    // A block's rows of slot ids should start and end on cache-line boundaries (E·C·4 bytes a multiple of 128): a line shared by two
+    // blocks is fetched by both.  Take the largest such E that fits a block and still leaves 512 workgroups, unless it is much smaller
+    // than the choice above.  Measured over E on one box (profiles/r03_w_contact_e.txt, r03_w_contact_e_humanoid.txt): gait task
+    // (C = 60: multiples of 8) 19 → 16 at 65 536 envs and 9 → 16 at 8 192, whole step 136.4 → 133.5 and 36.7 → 35.5 µs; humanoid
+    // configs (C = 30: multiples of 16) 14 → 16, 24.5 → 24.1 and 48.0 → 44.4 µs — E = 16 is the minimum of every sweep.
+    if (C > 0) {
+        int q = 32, c = C;
+        while (q > 1 && (c & 1) == 0) { q >>= 1; c >>= 1; }   // q = 32 / gcd(C, 32)
+        int al = (e_max / q) * q;
+        while (al > q && ((int64_t)a0->num_envs + al - 1) / al < 512) al -= q;
+        if (al >= 1 && 4 * al >= 3 * E && ((int64_t)a0->num_envs + al - 1) / al >= 512) E = al;
+    }
     static const int forced_e = getenv("GF_CONTACT_E") ? atoi(getenv("GF_CONTACT_E")) : 0;   // experiments only
     if (forced_e > 0 && forced_e <= kContactLdsBytes / per_env) E = forced_e;
     k.envs_per_block = E;
