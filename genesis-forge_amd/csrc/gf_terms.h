@@ -238,6 +238,15 @@ __device__ __forceinline__ float term_value(const GfTerm& t, const Args& a, int6
     return v;
 }
 
+template <int OP, class Args>
+__device__ __forceinline__ float term_rows_then_value(const GfTerm& t, const Args& a, int64_t n) {
+    GfTerm tt = t;
+    tt.op = OP;   // (== t.op: the caller switched on it)
+    float rows[kTermRowRegs];
+    term_rows(tt, a, n, rows);
+    return term_value(tt, a, n, rows);
+}
+
 // what a reward term needs besides memory: the body-frame vectors (the quaternion rotation), the termination mask
 __host__ __device__ constexpr bool reward_op_body_frame(int op) {
     return op == GF_R_LIN_VEL_Z_L2 || op == GF_R_ANG_VEL_XY_L2 || op == GF_R_FLAT_ORIENTATION_L2 || op == GF_R_BODY_ACCEL_EXP ||
@@ -349,15 +358,14 @@ __device__ __forceinline__ float eval_reward_term(const GfTerm& t, const Args& a
             v = s;
         } break;
         case GF_R_EXTERNAL: v = G(a.ext[t.i[0]])[n]; break;
-        case GF_R_HAS_CONTACT:
-        case GF_R_CONTACT_FORCE:
-        case GF_R_FEET_SLIDE:
-        case GF_R_GAIT_PHASE:
-        case GF_R_FOOT_HEIGHT: {   // the memory-only terms: rows, then value (see term_rows)
-            float rows[kTermRowRegs];
-            term_rows(t, a, n, rows);
-            v = term_value(t, a, n, rows);
-        } break;
+        // the memory-only terms: rows, then value (see term_rows) — one case each, with the opcode a constant inside it: behind a
+        // run-time opcode the two halves are two switches, and the register block would have to stay live between them for every
+        // term at once (the table interpreter of the fused kernel went to scratch that way)
+        case GF_R_HAS_CONTACT: v = term_rows_then_value<GF_R_HAS_CONTACT>(t, a, n); break;
+        case GF_R_CONTACT_FORCE: v = term_rows_then_value<GF_R_CONTACT_FORCE>(t, a, n); break;
+        case GF_R_FEET_SLIDE: v = term_rows_then_value<GF_R_FEET_SLIDE>(t, a, n); break;
+        case GF_R_GAIT_PHASE: v = term_rows_then_value<GF_R_GAIT_PHASE>(t, a, n); break;
+        case GF_R_FOOT_HEIGHT: v = term_rows_then_value<GF_R_FOOT_HEIGHT>(t, a, n); break;
         default: break;
     }
     return v;

@@ -58,3 +58,63 @@ def test_no_gpu_means_loud_failure():
     a = nat.GfRotateArgs()
     with pytest.raises(nat.GfError, match="no ROCm device"):
         b.call("entity_rotate", a)
+
+
+def _kernel_resources(path):
+    """{mangled kernel name: (scratch bytes per lane, VGPRs)} of the gfx950 code objects embedded in a built library: the clang
+    offload bundles of its .hip_fatbin section, each code object's AMDGPU metadata note read with llvm-readelf."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    data = open(path, "rb").read()
+    out, pos = {}, 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            break
+        n, = struct.unpack_from("<Q", data, i + 24)
+        off = i + 32
+        for _ in range(n):
+            o, sz, tsz = struct.unpack_from("<QQQ", data, off)
+            triple = data[off + 24: off + 24 + tsz].decode()
+            off += 24 + tsz
+            if "gfx950" not in triple or not sz:
+                continue
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(data[i + o: i + o + sz])
+                f.flush()
+                txt = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+            for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", txt, re.S):
+                out[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+        pos = i + 24
+    return out
+
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def test_no_kernel_spills_to_scratch_and_the_fused_kernels_keep_their_occupancy():
+    """A kernel of this library that touches private memory is a regression (a register block kept live across a run-time switch put
+    the fused kernel's table interpreter there once: 10.9 -> 15.1 us at 65 536 envs before anything else noticed), and so is a fused
+    kernel whose registers cost it a workgroup per CU: 512 VGPRs per SIMD lane, one wave of each resident workgroup per SIMD."""
+    import pytest
+
+    if not os.path.exists(READELF):
+        pytest.skip("no llvm-readelf")
+    res = _kernel_resources(nat.lib_path())
+    assert len(res) >= 60, sorted(res)
+    spilled = {k: v for k, v in res.items() if v[0]}
+    assert not spilled, spilled
+
+    def vgprs(fragment):
+        hits = [v[1] for k, v in res.items() if fragment in k]
+        assert len(hits) == 1, (fragment, hits)
+        return hits[0]
+
+    assert vgprs("post_ws_kernelINS_6InterpILi3ELb0EEE") <= 128      # 12-DOF interpreter: four workgroups per CU
+    assert vgprs("post_ws_kernelINS_6InterpILi7ELb0EEE") <= 168      # 28-DOF interpreter: three
+    assert vgprs("post_ws_kernelINS_23ProgGo2CommandDirectionE") <= 84   # the benchmark's program: six
+    assert vgprs("post_ws_kernelINS_18ProgGo2GaitTrainerE") <= 100   # five
