@@ -8,6 +8,7 @@ fused launch, and the number of native ops one recorded step replays.
 """
 import argparse
 import json
+import gc
 import os
 import sys
 import time
@@ -69,6 +70,7 @@ def main():
         acts = [torch.randn(n, d, generator=g).to(gs.device) for _ in range(8)]
         for i in range(args.warmup):
             env.step(acts[i % 8])
+        gc.collect()   # (the previous config's env — gigabytes of tensors in reference cycles — is released here, not inside the timed loop)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
