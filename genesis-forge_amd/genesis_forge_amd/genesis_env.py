@@ -292,7 +292,7 @@ class GenesisEnv:
         if hit is not None and hit[0] == key:
             return hit[1]
         ids = self._done_ids_native(self.backend, mask, mask2)
-        self._done_ids_cache = (key, ids)
+        self._done_ids_cache = (key, ids, mask, mask2, None)
         return ids
 
     def invalidate_views(self) -> None:
@@ -364,6 +364,15 @@ class GenesisEnv:
 
     # -- reset -------------------------------------------------------------------------------------
     def _ids_to_mask(self, envs_idx) -> torch.Tensor:
+        hit = self._done_ids_cache
+        if hit is not None and envs_idx is hit[1] and hit[0][0] == self.step_count:   # (of THIS step: the masks are rewritten every step)
+            # the list this step's done_ids() compacted out of the termination masks, handed back (a user manager's reset(ids), a
+            # reset() override calling super().reset(ids)): its mask IS those masks — one OR per step at most, instead of a zeros +
+            # an index_put per manager that turns the list back into a mask for its masked launch
+            if hit[4] is None:
+                m1, m2 = hit[2], hit[3]
+                self._done_ids_cache = hit = hit[:4] + ((m1 if m2 is None else (m1 | m2)),)
+            return hit[4]
         mask = torch.zeros(self.num_envs, dtype=torch.bool, device=gs.device)
         if envs_idx is None:
             mask[:] = True

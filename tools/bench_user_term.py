@@ -89,6 +89,16 @@ def run(n, trace, steps=400):
         env.step(acts[i % 4])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps * 1e6
+    if os.environ.get("GF_PROFILE") == "1" and trace:   # where the host time of the recorded step goes
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(steps):
+            env.step(acts[i % 4])
+        pr.disable()
+        torch.cuda.synchronize()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
     tr = env._trace
     return dt, (tr is not None), (len(tr.splits) if tr else None), (tr.n_ops if tr else None)
 
