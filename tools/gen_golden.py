@@ -406,12 +406,19 @@ def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2,
 # ------------------------------------------------------------------------------------------------
 AT_SIZE = {"steps": 20, "episode_s": 0.3, "cmd_resample_s": 0.2, "contacts": False, "history": 2,
            "scene_kwargs": dict(ang_noise=0.35, lin_noise=0.05, seed=17, contact_prob=0.3, contact_force=30.0)}
-def run_reference_at_size(n):
-    """The reference's own ManagedEnvironment.step (managed_env.py:274-334) at n envs — in memory, no file."""
+def at_size_name(n, contacts):
+    return f"atsize_go2{'c' if contacts else ''}_{n}"
+
+
+def run_reference_at_size(n, contacts=None):
+    """The reference's own ManagedEnvironment.step (managed_env.py:274-334) at n envs — in memory, no file.  ``contacts``: with the
+    two ContactManagers of the contacts example (the reference's Taichi kernel source runs under the serial `ti` emulation of
+    tools/ref_stubs.py: ≈ 8 s per step at 4 096 envs, two minutes per step at 65 536 — so that variant exists at 4 096 envs only)."""
     global CMD_RESAMPLE_S
+    contacts = AT_SIZE["contacts"] if contacts is None else contacts
     keep, CMD_RESAMPLE_S = CMD_RESAMPLE_S, AT_SIZE["cmd_resample_s"]
     try:
-        return run_trajectory(f"atsize_go2_{n}", n=n, steps=AT_SIZE["steps"], contacts=AT_SIZE["contacts"], history=AT_SIZE["history"],
+        return run_trajectory(at_size_name(n, contacts), n=n, steps=AT_SIZE["steps"], contacts=contacts, history=AT_SIZE["history"],
                               scene_kwargs=AT_SIZE["scene_kwargs"], episode_s=AT_SIZE["episode_s"], save=False)
     finally:
         CMD_RESAMPLE_S = keep
@@ -420,13 +427,16 @@ def run_reference_at_size(n):
 def gen_at_size():
     """Compact, reference-derived fixtures for the GPU box (tests/helpers.py: compact_at_size says what they hold)."""
     import helpers
-    for n in (4096, 65536):
-        out = run_reference_at_size(n)
+    only = os.environ.get("GF_AT_SIZE_ONLY")   # e.g. "go2c_4096": regenerate one fixture
+    for n, contacts in ((4096, False), (65536, False), (4096, True)):
+        if only and at_size_name(n, contacts) != "atsize_" + only:
+            continue
+        out = run_reference_at_size(n, contacts)
         assert np.array_equal(out["actions"], helpers.at_size_actions(n, int(out["steps"]))), "the tests regenerate the actions from the same stream"
-        np.savez_compressed(os.path.join(GOLD, f"atsize_go2_{n}.npz"), **helpers.compact_at_size(out, n))
+        np.savez_compressed(os.path.join(GOLD, at_size_name(n, contacts) + ".npz"), **helpers.compact_at_size(out, n))
 
 
-def check_at_size(n):
+def check_at_size(n, contacts=False):
     """Container only: the reference itself at n envs against this package on the CPU oracle — the same actions, the same draws,
     every env of every step, compared in lockstep (nothing is stored: a 65 536-env trajectory is 0.5 GB)."""
     import helpers
@@ -434,14 +444,14 @@ def check_at_size(n):
     keep, CMD_RESAMPLE_S = CMD_RESAMPLE_S, AT_SIZE["cmd_resample_s"]
     try:
         torch.manual_seed(0)
-        ref_env = RefGo2Env(n, episode_s=AT_SIZE["episode_s"], scene_kwargs=AT_SIZE["scene_kwargs"], contacts=AT_SIZE["contacts"],
+        ref_env = RefGo2Env(n, episode_s=AT_SIZE["episode_s"], scene_kwargs=AT_SIZE["scene_kwargs"], contacts=contacts,
                             history=AT_SIZE["history"])
-        width = (48 + (4 if AT_SIZE["contacts"] else 0)) * (AT_SIZE["history"] or 1)
+        width = (48 + (4 if contacts else 0)) * (AT_SIZE["history"] or 1)
         draws = Draws(n, 3, width)
         install_contexts(ref_env, draws)
         draws.step = 0
         ref_env.build()
-        meta = dict(n=n, seed=SEED, contacts=int(AT_SIZE["contacts"]), history=AT_SIZE["history"] or 1, scene_kwargs=repr(AT_SIZE["scene_kwargs"]),
+        meta = dict(n=n, seed=SEED, contacts=int(contacts), history=AT_SIZE["history"] or 1, scene_kwargs=repr(AT_SIZE["scene_kwargs"]),
                     variant="cmd", episode_s=AT_SIZE["episode_s"], cmd_resample_s=AT_SIZE["cmd_resample_s"], obs=np.empty((0, width), dtype=np.float32))
         env, _n, seed, frame, _h = helpers._trajectory_env(meta)
     finally:
@@ -473,7 +483,7 @@ def check_at_size(n):
             assert abs(la[k] - lb[k]) <= 1e-5 + 1e-5 * abs(la[k]), f"log {k} at step {t}: {lb[k]} vs {la[k]}"
         dones += int(ra[2].sum() + ra[3].sum())
     assert dones > n // 10, f"only {dones} resets at {n} envs"
-    print(f"reference == package (oracle backend) at {n} envs x {AT_SIZE['steps']} steps, {dones} resets, every env compared")
+    print(f"reference == package (oracle backend) at {n} envs{' with contact managers' if contacts else ''} x {AT_SIZE['steps']} steps, {dones} resets, every env compared")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -953,7 +963,7 @@ if __name__ == "__main__":
         gen_at_size()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "check_at_size":
-        check_at_size(int(sys.argv[2]))
+        check_at_size(int(sys.argv[2]), contacts=len(sys.argv) > 3 and sys.argv[3] == "contacts")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "examples":
         import example_cases
