@@ -427,9 +427,11 @@ def run_reference_at_size(n, contacts=None):
 def gen_at_size():
     """Compact, reference-derived fixtures for the GPU box (tests/helpers.py: compact_at_size says what they hold)."""
     import helpers
-    only = os.environ.get("GF_AT_SIZE_ONLY")   # e.g. "go2c_4096": regenerate one fixture
-    for n, contacts in ((4096, False), (65536, False), (4096, True)):
-        if only and at_size_name(n, contacts) != "atsize_" + only:
+    # `at_size` regenerates the three fixtures that take minutes; `at_size go2c_65536` the contact-manager run at 65 536 envs (the
+    # serial Taichi emulation: ≈ 2 minutes per step, ≈ 45 minutes); `at_size <name>` any single one
+    only = sys.argv[2] if len(sys.argv) > 2 else os.environ.get("GF_AT_SIZE_ONLY")
+    for n, contacts in ((4096, False), (65536, False), (4096, True), (65536, True)):
+        if (only and at_size_name(n, contacts) != "atsize_" + only) or (not only and (n, contacts) == (65536, True)):
             continue
         out = run_reference_at_size(n, contacts)
         assert np.array_equal(out["actions"], helpers.at_size_actions(n, int(out["steps"]))), "the tests regenerate the actions from the same stream"

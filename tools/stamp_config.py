@@ -3,7 +3,7 @@
 `post_ws_kernel` (GF_WSTAMP in csrc/gf_post_ws.h), taken in a DIAGNOSTIC build of the library (-DGF_STAMPS, built into
 tools/_stamps/; no product build contains a stamp) while the env steps on the recorded path.
 
-    python tools/stamp_config.py build                    # here or on the GPU box: hipcc, ~1 min
+    python tools/stamp_config.py build                    # here or on the GPU box: hipcc, ~1 min (again after any change under csrc/ or include/)
     python tools/stamp_config.py run gait_8192 [steps]    # on the GPU box
 """
 import ctypes as C
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "genesis-forge_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_stamps")
 LIB = os.path.join(OUT, "libgf_step_stamps.so")
-NAMES = ["args staged", "pre-barrier done", "past barrier A", "role stores", "(unused)", "tile built", "past barrier B", "end"]
+NAMES = ["args staged", "pre-barrier done", "past barrier A", "role stores", "obs starts", "tile built", "past barrier B", "end"]
 
 
 def build():
