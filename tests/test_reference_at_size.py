@@ -10,8 +10,9 @@ behind the same host logic.  Two legs close the chain (missing #4):
 * everywhere: compact fixtures recorded from the same reference runs (``tools/gen_golden.py at_size``; per-step mask popcounts,
   f64 sums and sums of squares of reward / observation / command over ALL envs, integer sums of the episode counters, the logged
   scalars, and all outputs of a strided 64-env sample) against the oracle (CPU) and against the HIP kernels (``-m gpu``) at
-  4 096 and 65 536 envs — and at 4 096 envs WITH the contacts example's ContactManagers (``atsize_go2c_4096``: contact kernel,
-  air time, contact-force termination / rewards / observation at a size where the contact launch runs 256 workgroups).
+  4 096 and 65 536 envs — and at both sizes WITH the contacts example's ContactManagers (``atsize_go2c_*``: contact kernel, air time,
+  contact-force termination / rewards / observation; the 65 536-env reference run took 50 minutes of the serial Taichi emulation,
+  ``tools/gen_golden.py at_size go2c_65536``).
 """
 import os
 import subprocess
@@ -45,7 +46,7 @@ def test_reference_itself_equals_package_with_contact_managers(oracle_lib_path):
     assert "reference == package (oracle backend) at 1024 envs with contact managers" in p.stdout
 
 
-FIXTURES = ["atsize_go2_4096", "atsize_go2_65536", "atsize_go2c_4096"]   # (…c: with the contact managers)
+FIXTURES = ["atsize_go2_4096", "atsize_go2_65536", "atsize_go2c_4096", "atsize_go2c_65536"]   # (…c: with the contact managers)
 
 
 @pytest.mark.parametrize("name", FIXTURES)
