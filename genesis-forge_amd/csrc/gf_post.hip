@@ -562,12 +562,26 @@ static bool why_enabled() {
     } while (0)
 
 static int pack(const GfPostRefs* r, Packer& pk) {
-    if (!r || !r->termination || !r->reset) return GF_E_NULL;
+    if (!r || !r->termination) return GF_E_NULL;
+    // GF_POST_NO_RESET: termination … command / gait step, nothing behind them.  There is no reset to describe, so `reset` and the
+    // masked command / gait descriptors may be absent; the checks below then run against a stand-in that says "no section of the
+    // reset applies" (the seed / env offset every phase shares comes from the first stepped manager).
+    const bool no_reset = (r->flags & GF_POST_NO_RESET) != 0;
+    if (!no_reset && !r->reset) return GF_E_NULL;
     GfPostArgs& a = pk.a;
     const GfTerminationArgs& T = *r->termination;
-    const GfResetArgs& RS = *r->reset;
+    GfResetArgs none{};
+    if (no_reset && !r->reset) {
+        none.num_envs = T.num_envs; none.mask = T.terminated; none.mask2 = T.truncated;
+        none.num_dofs = r->reward ? r->reward->num_dofs : 0;
+        if (r->num_command > 0 && r->command_step[0]) { none.seed = r->command_step[0]->seed; none.env_offset = r->command_step[0]->env_offset; }
+        else if (r->num_gait > 0 && r->gait_step[0]) { none.seed = r->gait_step[0]->seed; none.env_offset = r->gait_step[0]->env_offset; }
+    }
+    const GfResetArgs& RS = r->reset ? *r->reset : none;
     const GfRewardArgs* RW = r->reward;
     const int N = T.num_envs;
+    UNSUP(no_reset && (r->num_observe != 0 || r->rollout || (r->flags & GF_POST_OBSERVE_ONLY)));
+    a.no_reset = no_reset ? 1 : 0;
     // GF_POST_OBSERVE_ONLY: the step's phases up to the reset have run as launches of their own; `reset` is the descriptor that reset
     // ran with (its masks, its stale-quaternion stash, the seed every phase shares) and nothing in it is applied again
     const bool obs_only = (r->flags & GF_POST_OBSERVE_ONLY) != 0;
@@ -594,16 +608,19 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     for (int c = 0; c < a.n_cmd; ++c) {
         const GfCommandArgs* s = r->command_step[c];
         const GfCommandArgs* m = r->command_reset[c];
-        UNSUP(!s || !m || s->mode != GF_CMD_STEP || m->mode != GF_CMD_MASKED || s->command != m->command || s->num_ranges != m->num_ranges);
-        UNSUP(s->num_envs != N || m->num_envs != N || s->num_ranges > kPostMaxRanges || s->draws || m->draws || s->resample_steps <= 0);
-        UNSUP(m->mask != T.terminated || m->mask2 != T.truncated || s->episode_length != T.episode_length);
-        UNSUP(s->seed != RS.seed || m->seed != RS.seed || s->env_offset != RS.env_offset || m->env_offset != RS.env_offset);
+        UNSUP(!s || (!m && !no_reset) || s->mode != GF_CMD_STEP);
+        UNSUP(s->num_envs != N || s->num_ranges > kPostMaxRanges || s->draws || s->resample_steps <= 0 || s->episode_length != T.episode_length);
+        UNSUP(s->seed != RS.seed || s->env_offset != RS.env_offset);
+        if (m) {
+            UNSUP(m->mode != GF_CMD_MASKED || s->command != m->command || s->num_ranges != m->num_ranges || m->num_envs != N || m->draws);
+            UNSUP(m->mask != T.terminated || m->mask2 != T.truncated || m->seed != RS.seed || m->env_offset != RS.env_offset);
+        }
         UNSUP(s->stats && a.stats && s->stats != a.stats);
         PostCmd& pc = a.cmds[c];
         pc.command = s->command; pc.width = s->num_ranges; pc.resample_steps = s->resample_steps;
-        pc.stream_step = s->stream; pc.stream_reset = m->stream;
+        pc.stream_step = s->stream; pc.stream_reset = m ? m->stream : 0;
         for (int j = 0; j < s->num_ranges; ++j) {
-            UNSUP(s->lo[j] != m->lo[j] || s->hi[j] != m->hi[j]);
+            UNSUP(m && (s->lo[j] != m->lo[j] || s->hi[j] != m->hi[j]));
             pc.lo[j] = s->lo[j]; pc.hi[j] = s->hi[j];
         }
         needs |= PN_EPLEN;
@@ -616,20 +633,24 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     if (a.n_gait) {
         const GfGaitArgs* gs = r->gait_step[0];
         const GfGaitArgs* gm = r->gait_reset[0];
-        UNSUP(!gs || !gm || gs->mode != GF_CMD_STEP || gm->mode != GF_CMD_MASKED || !gs->state || gs->state != gm->state || !gs->selected || gs->selected != gm->selected);
-        UNSUP(gs->num_envs != N || gm->num_envs != N || gs->draws || gm->draws || gs->resample_steps <= 0 || gs->num_gaits < 1 || gs->num_gaits > GF_MAX_GAITS);
-        UNSUP(gm->mask != T.terminated || gm->mask2 != T.truncated || gs->episode_length != T.episode_length);
-        UNSUP(gs->seed != RS.seed || gm->seed != RS.seed || gs->env_offset != RS.env_offset || gm->env_offset != RS.env_offset);
+        UNSUP(!gs || (!gm && !no_reset) || gs->mode != GF_CMD_STEP || !gs->state || !gs->selected);
+        UNSUP(gs->num_envs != N || gs->draws || gs->resample_steps <= 0 || gs->num_gaits < 1 || gs->num_gaits > GF_MAX_GAITS || gs->episode_length != T.episode_length);
+        UNSUP(gs->seed != RS.seed || gs->env_offset != RS.env_offset);
         UNSUP(gs->stats && a.stats && gs->stats != a.stats);
-        UNSUP(gs->wave_flags != gm->wave_flags || (gs->wave_flags != nullptr) != (r->gait_flags_next[0] != nullptr) || (gs->wave_flags && gs->wave_flags == r->gait_flags_next[0]));
+        UNSUP((gs->wave_flags != nullptr) != (r->gait_flags_next[0] != nullptr) || (gs->wave_flags && gs->wave_flags == r->gait_flags_next[0]));
         UNSUP(reinterpret_cast<uintptr_t>(gs->state) & 15u);
-        // both descriptors are filled from the same manager state (curriculum values are re-read per launch)
-        UNSUP(gs->num_gaits != gm->num_gaits || gs->fixed_clearance_mask != gm->fixed_clearance_mask || gs->dt != gm->dt || gs->two_pi != gm->two_pi);
-        UNSUP(memcmp(gs->cum_weight, gm->cum_weight, sizeof(gs->cum_weight)) != 0 || memcmp(gs->gait_offsets, gm->gait_offsets, sizeof(gs->gait_offsets)) != 0);
-        UNSUP(gs->clearance_lo != gm->clearance_lo || gs->clearance_hi != gm->clearance_hi || gs->period_lo != gm->period_lo || gs->period_hi != gm->period_hi);
+        if (gm) {
+            UNSUP(gm->mode != GF_CMD_MASKED || gs->state != gm->state || gs->selected != gm->selected || gm->num_envs != N || gm->draws);
+            UNSUP(gm->mask != T.terminated || gm->mask2 != T.truncated || gm->seed != RS.seed || gm->env_offset != RS.env_offset);
+            UNSUP(gs->wave_flags != gm->wave_flags);
+            // both descriptors are filled from the same manager state (curriculum values are re-read per launch)
+            UNSUP(gs->num_gaits != gm->num_gaits || gs->fixed_clearance_mask != gm->fixed_clearance_mask || gs->dt != gm->dt || gs->two_pi != gm->two_pi);
+            UNSUP(memcmp(gs->cum_weight, gm->cum_weight, sizeof(gs->cum_weight)) != 0 || memcmp(gs->gait_offsets, gm->gait_offsets, sizeof(gs->gait_offsets)) != 0);
+            UNSUP(gs->clearance_lo != gm->clearance_lo || gs->clearance_hi != gm->clearance_hi || gs->period_lo != gm->period_lo || gs->period_hi != gm->period_hi);
+        }
         PostGait& pg = a.gait;
         pg.state = gs->state; pg.selected = gs->selected; pg.flags_in = gs->wave_flags; pg.flags_out = r->gait_flags_next[0];
-        pg.stream_step = gs->stream; pg.stream_reset = gm->stream;
+        pg.stream_step = gs->stream; pg.stream_reset = gm ? gm->stream : 0;
         pg.resample_steps = gs->resample_steps; pg.num_gaits = gs->num_gaits; pg.fixed_clearance_mask = gs->fixed_clearance_mask;
         memcpy(pg.cum_weight, gs->cum_weight, sizeof(pg.cum_weight));
         memcpy(pg.gait_offsets, gs->gait_offsets, sizeof(pg.gait_offsets));
@@ -765,8 +786,8 @@ static int pack(const GfPostRefs* r, Packer& pk) {
         // reward-manager reset section must address the same buffers
         UNSUP(RS.episode_seconds && RS.episode_seconds != RW->episode_seconds);
         UNSUP(RS.episode_sums && RS.episode_sums != RW->episode_sums);
-        UNSUP(!RS.episode_seconds);  // the fused kernel always resets the seconds of done envs
-        UNSUP((RS.reward_logging != 0) != (a.logging != 0));
+        UNSUP(!no_reset && !RS.episode_seconds);  // the fused kernel always resets the seconds of done envs
+        UNSUP(!no_reset && (RS.reward_logging != 0) != (a.logging != 0));
         a.reward_rows = RS.num_reward_terms;
         a.reward_log_mask = RS.reward_log_mask;
         a.uncovered_rows = 0;
@@ -919,7 +940,7 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     }
 
     // everything the kernel dereferences must exist, be float4-aligned and agree on D
-    a.num_dofs = D;
+    a.num_dofs = D > 0 ? D : 4;   // (no phase of the launch reads a DOF row — possible in front of a reset that user code runs: one unused chunk)
     a.needs = needs;
     UNSUP((needs & PN_QUAT) && !a.quat);
     UNSUP((needs & PN_POS) && !a.pos);
@@ -1060,7 +1081,7 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     gf::PhaseScope scope(GF_PHASE_POST, s);
     bool any_ring = false;
     for (int m = 0; m < a.n_obs; ++m) any_ring = any_ring || a.obs[m].ring != 0;
-    const bool ws_only = a.n_gait || a.roll_obs || a.roll_reward || a.roll_done || any_ring || a.term_done || (a.num_dofs != 12 && a.num_dofs != 28);   // the one-wave variant has neither a gait manager nor rollout stores
+    const bool ws_only = a.n_gait || a.roll_obs || a.roll_reward || a.roll_done || any_ring || a.term_done || a.no_reset || (a.num_dofs != 12 && a.num_dofs != 28);   // the one-wave variant has neither a gait manager nor rollout stores
     if (gf::g_options[GF_OPT_POST_VARIANT] == 0 && !ws_only) {
         if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid, gf::kEnvBlock, lds, s, a);
         else GF_LAUNCH(scope, gf::post_kernel<3>, grid, gf::kEnvBlock, lds, s, a);

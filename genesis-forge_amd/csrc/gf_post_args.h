@@ -125,7 +125,7 @@ struct alignas(16) GfPostArgs {
     int32_t roll_obs_index;
     int32_t term_done;   // GF_POST_TERMINATION_DONE: the masks are inputs, the termination table is not evaluated
     int32_t obs_only;    // GF_POST_OBSERVE_ONLY: the masks are inputs and nothing is reset; the observation waves run (interpreter only)
-    int32_t _pad_obs_only;
+    int32_t no_reset;    // GF_POST_NO_RESET: termination … command / gait step only: no env is treated as done, nothing is observed
     const uint8_t* gait_wave_flags;   // == gait.flags_in when the reward terms reproduce the env-0 quirk (GF_R_GAIT_PHASE)
     PostGait gait;
     GfTerm tterms[kPostMaxTerm];

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 term_body(k, t, eval_termination_term(t, a, tr, (uint32_t)has_maxlen));
             }
         }
-        const bool done0 = live && (term | trunc) && !obs_only;
+        const bool done0 = live && (term | trunc) && !obs_only && !UNI(a.no_reset);   // (GF_POST_NO_RESET: the masks are written, no env is treated as done)
         GF_WSTAMP(9);
         // ---- command.step then command.reset draws (values only; stores wait for the barrier) ------------------------------
 #pragma unroll

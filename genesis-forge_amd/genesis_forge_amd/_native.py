@@ -270,6 +270,7 @@ class GfStatsPackArgs(C.Structure):
 GF_POST_MAX_CMD, GF_POST_MAX_OBS, GF_POST_MAX_GAIT = 2, 2, 1
 GF_POST_TERMINATION_DONE = 1   # GfPostRefs.flags
 GF_POST_OBSERVE_ONLY = 2
+GF_POST_NO_RESET = 4
 
 
 class GfRolloutArgs(C.Structure):

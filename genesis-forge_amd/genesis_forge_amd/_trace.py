@@ -494,6 +494,32 @@ class StepTrace:
         while j < len(fns) and fns[j] in ("command_step", "gait_step") and tail[j][1].mode == nat.GF_CMD_STEP:
             (steps if fns[j] == "command_step" else gsteps).append(tail[j])
             j += 1
+        if j == len(fns) and self.tail_python and not py and (steps or gsteps) and os.environ.get("GF_NO_TAIL_FUSE", "0") != "1":
+            # An env whose reset() is overridden: the recording ends in front of the reset (the user's reset(ids) and the observations
+            # are the Python tail).  Termination, rewards and the command / gait steps still make ONE launch — GF_POST_NO_RESET: the
+            # masks are written, no env is treated as done — instead of a one-wave phase chain.
+            if len(steps) > nat.GF_POST_MAX_CMD or len(gsteps) > nat.GF_POST_MAX_GAIT:
+                return None
+            refs.flags = nat.GF_POST_NO_RESET
+            refs.num_command, refs.num_gait = len(steps), len(gsteps)
+            for c, st in enumerate(steps):
+                refs.command_step[c] = C.addressof(st[1])
+            self._gait_swaps = []
+            P = nat.GfReplayPatch
+            reward_args = tail[1][1] if refs.reward else None
+            for g, st in enumerate(gsteps):
+                refs.gait_step[g] = C.addressof(st[1])
+                mgr = st[2]
+                refs.gait_flags_next[g] = mgr._wave_flags_next.data_ptr()
+                # the launch reads the bytes the previous step left and writes its own into the manager's OTHER buffer, as the full
+                # fused launch does; the masked gait launch of the tail then finds the manager's CURRENT buffer (the rotor has
+                # advanced) and updates the reset blocks' bytes in place
+                sw = [P(nat.GF_PATCH_ROTATE, 0, nat.field_addr(st[1], "wave_flags"), C.addressof(refs) + nat.GfPostRefs.gait_flags_next.offset + 8 * g,
+                        C.addressof(mgr._flags_rotor))]
+                if reward_args is not None and reward_args.gait_wave_flags:
+                    sw.append(P(nat.GF_PATCH_COPY, 0, nat.field_addr(reward_args, "gait_wave_flags"), None, nat.field_addr(st[1], "wave_flags")))
+                self._gait_swaps.extend(sw)
+            return refs if self.backend.post_check(refs) else None
         if j >= len(fns) or fns[j] != "masked_reset":
             return None
         refs.reset = C.addressof(tail[j][1])

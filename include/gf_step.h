@@ -756,8 +756,11 @@ int gf_gae(const GfGaeArgs* a, void* stream);                     /* returns and
  * The launch reads `terminated` / `truncated` (an env reset in this tick is observed through `reset->quat_stash`, the stale-cache
  * quirk of entity_manager.py:189-195) and runs the observation waves of the fused kernel for up to two managers as one launch;
  * `reward`, the command and gait lists must be empty.  This is the observation part of a step whose reset goes through user
- * code. */
-enum { GF_POST_TERMINATION_DONE = 1, GF_POST_OBSERVE_ONLY = 2 };
+ * code.
+ * GF_POST_NO_RESET: the counterpart for the FRONT of such a step — termination, rewards, command.step / gait.step as one launch,
+ * and nothing after them: no env is reset (the masks are written; the reset follows by index list through user code, then the
+ * observation-only launch), `reset`, `command_reset[]`, `gait_reset[]` may be NULL, `num_observe` must be 0. */
+enum { GF_POST_TERMINATION_DONE = 1, GF_POST_OBSERVE_ONLY = 2, GF_POST_NO_RESET = 4 };
 typedef struct GfPostRefs {
     const GfTerminationArgs* termination;                 /* required */
     const GfRewardArgs* reward;                           /* may be NULL */

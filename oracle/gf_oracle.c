@@ -1158,10 +1158,27 @@ GFO_EXPORT int gfo_gae(const GfGaeArgs* a) {
 }
 
 /* Host twin of gf_post_physics_step: BY DEFINITION the phases in the reference's order (managed_env.py:303-326). */
-GFO_EXPORT int gfo_post_physics_check(const GfPostRefs* r) { return (r && r->termination && r->reset) ? GF_OK : GF_E_NULL; }
+GFO_EXPORT int gfo_post_physics_check(const GfPostRefs* r) { return (r && r->termination && (r->reset || (r->flags & GF_POST_NO_RESET))) ? GF_OK : GF_E_NULL; }
 
 GFO_EXPORT int gfo_post_physics_step(const GfPostRefs* r) {
-    if (!r || !r->termination || !r->reset) return GF_E_NULL;
+    if (!r || !r->termination) return GF_E_NULL;
+    if (r->flags & GF_POST_NO_RESET) {   /* the front of a step whose reset goes through user code: nothing behind the step phases */
+        int rc0 = GF_OK;
+        if (r->num_observe || r->rollout || (r->flags & GF_POST_OBSERVE_ONLY)) return GF_E_UNSUPPORTED;
+        if (!(r->flags & GF_POST_TERMINATION_DONE) && (rc0 = gfo_termination_step(r->termination))) return rc0;
+        if (r->reward && (rc0 = gfo_reward_step(r->reward))) return rc0;
+        for (int c = 0; c < r->num_command; ++c)
+            if ((rc0 = gfo_command_step(r->command_step[c]))) return rc0;
+        for (int g = 0; g < r->num_gait; ++g)
+            if ((rc0 = gfo_gait_step(r->gait_step[g]))) return rc0;
+        for (int g = 0; g < r->num_gait; ++g)
+            if (r->gait_flags_next[g] && r->gait_step[g]->wave_flags) {
+                const int64_t blocks = ((int64_t)r->gait_step[g]->num_envs + 63) / 64;
+                memcpy(r->gait_flags_next[g], r->gait_step[g]->wave_flags, (size_t)blocks);
+            }
+        return GF_OK;
+    }
+    if (!r->reset) return GF_E_NULL;
     int rc = GF_OK;
     if (r->flags & GF_POST_OBSERVE_ONLY) {   /* everything up to the reset has run as calls of their own: the observations are left */
         if (r->reward || r->num_command || r->num_gait) return GF_E_UNSUPPORTED;

@@ -244,7 +244,11 @@ def test_user_overrides_limit_what_is_recorded(oracle_backend):
         for t, (x, y) in enumerate(zip(want, got)):
             assert torch.equal(x, y), f"{cls.__name__}: observation {t} differs from the plain env"
         if how == "tail":
-            assert env._trace is not None and env._trace.tail_python and env._trace.post_refs is None
+            # (recorded up to the reset: termination, rewards and the command step are ONE launch that resets nothing — GF_POST_NO_RESET)
+            assert env._trace is not None and env._trace.tail_python
+            from genesis_forge_amd import _native as nat
+
+            assert env._trace.post_refs is not None and env._trace.post_refs.flags == nat.GF_POST_NO_RESET and env._trace.post_refs.num_observe == 0
         elif how == "fused":
             assert env._trace is not None and not env._trace.tail_python and env._trace.post_refs is not None and env.seen == 6
         else:
