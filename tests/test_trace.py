@@ -885,3 +885,41 @@ def test_random_dof_variant_hip_equals_oracle(hip_backend, oracle_lib_path, seed
             assert abs(x[4][key] - y[4][key]) <= 1e-5 + 1e-5 * abs(y[4][key]), (t, key)
         resets += int(y[2].sum() + y[3].sum())
     assert resets > 0
+
+
+def test_split_fused_launch_flags_are_checked_by_the_library(oracle_backend):
+    """GF_POST_NO_RESET / GF_POST_OBSERVE_ONLY (the two ends of a step whose reset runs through user code): the descriptors a recorded
+    override env builds pass the HIP library's own validation (gf_post_physics_check packs them — host work, no GPU), and the
+    combinations the flags exclude are refused."""
+    import copy
+
+    import envs
+    from genesis_forge_amd import _native as nat
+
+    env = envs.Go2GaitTrainingCurriculumEnv(num_envs=70, max_episode_length_s=0.3, scene_kwargs=dict(ang_noise=0.35, seed=11, contact_prob=0.05))
+    env.build()
+    env.seed(3)
+    env.reset()
+    g = torch.Generator().manual_seed(1)
+    for _ in range(40):
+        env.step(torch.randn(70, 12, generator=g))
+    tr = env._trace
+    assert tr is not None and tr.tail_python and tr.post_refs is not None and tr.tail_seg.get("obs", {}).get("fused_obs")
+    hip = nat.HipBackend()   # loads the library; nothing is launched
+    front, back = tr.post_refs, tr._tail_refs
+    assert front.flags == nat.GF_POST_NO_RESET and not front.reset and front.num_observe == 0 and front.num_gait == 1
+    assert back.flags == nat.GF_POST_OBSERVE_ONLY and back.num_observe == 2 and not back.reward
+    assert hip.post_check(front) and hip.post_check(back)
+
+    def variant(refs, **kw):
+        r = nat.GfPostRefs.from_buffer_copy(refs)
+        for k, v in kw.items():
+            setattr(r, k, v)
+        return r
+
+    assert not hip.post_check(variant(front, flags=nat.GF_POST_NO_RESET | nat.GF_POST_OBSERVE_ONLY))
+    assert not hip.post_check(variant(front, flags=0))                      # without the flag the reset descriptor is required
+    assert not hip.post_check(variant(front, num_observe=1))                # nothing is observed in front of the reset
+    assert not hip.post_check(variant(back, reward=front.reward))           # the observation-only launch has no reward phase
+    assert not hip.post_check(variant(back, num_command=1))
+    assert not hip.post_check(variant(back, num_observe=0))
