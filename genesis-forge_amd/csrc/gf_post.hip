@@ -979,7 +979,7 @@ using gf::lds_ws_floats;
 // library only keeps the table; ids start at kDynBase.  Registration is rare and append-only (fixed-size table, the count is
 // published last), selection walks it on every launch of a config no built-in program matches.
 namespace {
-constexpr int kDynBase = 100, kDynMax = 64;
+constexpr int kDynBase = 100, kDynMax = 256;   // (programs registered per process)
 struct DynProgram {
     void* dl;
     char name[64];
