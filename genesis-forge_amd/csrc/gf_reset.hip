@@ -236,8 +236,37 @@ __global__ __launch_bounds__(kCompactBlock) void compact_single_kernel(const GfC
     const int64_t first = ((int64_t)blockIdx.x * kCompactBlock + threadIdx.x) * kCompactPerLane;
     uint32_t bits = compact_bits(a, first);   // (requested first: the units in front need no result of it)
     int part = 0;
-    const int units_before = (int)blockIdx.x * kCompactBlock;   // 16-env units in front of this block (all whole: N >= the block's first env)
-    for (int u = threadIdx.x; u < units_before; u += kCompactBlock) part += __builtin_popcount(compact_bits(a, (int64_t)u * kCompactPerLane));
+    // The masks in front of this block: whole blocks of kCompactBlock 16-env units, so every lane runs the same blockIdx.x passes —
+    // eight at a time, as plain 16-byte loads issued together (compact_bits() has a branch per call: one pass at a time was a memory
+    // round trip per block in front, 6 of the kernel's 11 µs at 65 536 envs).  Unaligned masks take the general path.
+    typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
+    auto nonzero_bytes = [](u32x4c w) __attribute__((always_inline)) {
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t x = w[k];
+            n += __builtin_popcount((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);   // one bit per non-zero byte
+        }
+        return n;
+    };
+    if (((reinterpret_cast<uintptr_t>(a.mask) | reinterpret_cast<uintptr_t>(a.mask2)) & 15u) == 0) {
+        const GF_GLOBAL u32x4c* m1 = reinterpret_cast<const GF_GLOBAL u32x4c*>(G(a.mask));
+        const GF_GLOBAL u32x4c* m2 = a.mask2 ? reinterpret_cast<const GF_GLOBAL u32x4c*>(G(a.mask2)) : nullptr;
+        constexpr int kBatch = 8;
+        for (int b0 = 0; b0 < (int)blockIdx.x; b0 += kBatch) {
+            u32x4c w[kBatch], w2[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int64_t u = (int64_t)(b0 + j < (int)blockIdx.x ? b0 + j : b0) * kCompactBlock + threadIdx.x;
+                w[j] = m1[u];
+                w2[j] = m2 ? m2[u] : u32x4c{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) part += b0 + j < (int)blockIdx.x ? nonzero_bytes(w[j] | w2[j]) : 0;
+        }
+    } else {
+        for (int b = 0; b < (int)blockIdx.x; ++b) part += __builtin_popcount(compact_bits(a, ((int64_t)b * kCompactBlock + threadIdx.x) * kCompactPerLane));
+    }
     const int wpart = (int)wave_sum((double)part);
     if ((threadIdx.x & (GF_WAVE - 1)) == 0) s_w[threadIdx.x >> 6] = wpart;
     __syncthreads();
