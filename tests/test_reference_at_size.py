@@ -39,11 +39,11 @@ def test_reference_itself_equals_package_at_size(n, oracle_lib_path):
 def test_reference_itself_equals_package_with_contact_managers(oracle_lib_path):
     """The same lockstep check with the contacts example's two ContactManagers (contact-force termination, feet-air-time and
     has-contact rewards, a contact-force observation item): the reference's Taichi kernel SOURCE runs under the serial emulation
-    of tools/ref_stubs.py, ≈ 2 ms per env and step — 1 024 envs (16 tiles) here, 4 096 in the fixture below."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden.py"), "check_at_size", "1024", "contacts"],
+    of tools/ref_stubs.py, ≈ 2 ms per env and step — 512 envs (8 tiles) here, 4 096 in the fixture below."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden.py"), "check_at_size", "512", "contacts"],
                        capture_output=True, text=True, timeout=900, env=dict(os.environ, GF_DEVICE="cpu"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    assert "reference == package (oracle backend) at 1024 envs with contact managers" in p.stdout
+    assert "reference == package (oracle backend) at 512 envs with contact managers" in p.stdout
 
 
 FIXTURES = ["atsize_go2_4096", "atsize_go2_65536", "atsize_go2c_4096", "atsize_go2c_65536"]   # (…c: with the contact managers)
