@@ -85,13 +85,17 @@ __device__ __forceinline__ void chain_observe(const ChainBArgs& a, float* tile) 
 
 __global__ __launch_bounds__(kObsBlock) void chain_b_kernel(const ChainBArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
-    const bool w0 = threadIdx.x < kEnvBlock;  // the per-env phases are one wave per 64 envs
-    if (w0) reset_body(a.reset);
-    __syncthreads();
-    if (w0) {
+    // The per-env phases are one wave per 64 envs each — and independent of each other (the masked command / gait launches read the
+    // termination masks and their own state, nothing the reset writes), so three waves run them side by side instead of one wave
+    // one after the other: the reset's path for a tile with a done env is a chain of ≈ 6 memory round trips by itself.
+    const int wave = (int)(threadIdx.x >> 6);
+    if (wave == 0) {
+        reset_body(a.reset);
+    } else if (wave == 1) {
 #pragma unroll
         for (int c = 0; c < kChainCmd; ++c)
             if (c < a.n_cmd) command_body(a.cmd[c]);
+    } else if (wave == 2) {
 #pragma unroll
         for (int g = 0; g < kChainGait; ++g)
             if (g < a.n_gait) gait_body(a.gait[g], ((a.gait_flags_all >> g) & 1) != 0);

@@ -12,7 +12,8 @@
 namespace gf {
 
 __device__ __forceinline__ void command_body(const GfCommandArgs& a) {
-    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
+    const int lane = (int)(threadIdx.x & (GF_WAVE - 1));   // (one wave per 64 envs: whichever wave of a wider workgroup runs the body)
+    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + lane;
     const bool live = n < a.num_envs;
     bool go = false;
     if (live) {
@@ -22,7 +23,7 @@ __device__ __forceinline__ void command_body(const GfCommandArgs& a) {
     }
     if (a.stats && a.mode == GF_CMD_STEP) {
         const unsigned long long m = __ballot(go);
-        if (m && threadIdx.x == 0) atomicAdd(&stats_shard(a.stats)->resample_count, popc64(m));
+        if (m && lane == 0) atomicAdd(&stats_shard(a.stats)->resample_count, popc64(m));
     }
     if (!go) return;
     const int R = a.num_ranges;

@@ -20,7 +20,8 @@ namespace gf {
 // `flags_all` (masked launches only): rewrite the swing / stance byte of EVERY block, not only of the blocks that hold a reset
 // env — the phase chains use it to keep the flags' only writer in a different launch from their reader (gf_chain.hip).
 __device__ __forceinline__ void gait_body(const GfGaitArgs& a, const bool flags_all = false) {
-    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
+    const int lane = (int)(threadIdx.x & (GF_WAVE - 1));   // (one wave per 64 envs: whichever wave of a wider workgroup runs the body)
+    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + lane;
     const bool live = n < a.num_envs;
     const int64_t m = live ? n : (int64_t)a.num_envs - 1;  // tail lanes shadow the last env and never store
     const bool step = a.mode == GF_CMD_STEP;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void gait_body(const GfGaitArgs& a, const bool flags_
 #pragma unroll
             for (int g = 0; g < GF_MAX_GAITS; ++g) {
                 const unsigned long long b = __ballot(live && sel == g);
-                if (b && threadIdx.x == 0) atomicAdd(&stats_shard(a.stats)->gait_count[g], popc64(b));
+                if (b && lane == 0) atomicAdd(&stats_shard(a.stats)->gait_count[g], popc64(b));
             }
         }
         // the periodic clock (:231-239), for every env
@@ -92,7 +93,7 @@ __device__ __forceinline__ void gait_body(const GfGaitArgs& a, const bool flags_
             if (__ballot(live && (fl & 1))) byte |= 1u << (2 * f);
             if (__ballot(live && (fl & 2))) byte |= 2u << (2 * f);
         }
-        if (threadIdx.x == 0) a.wave_flags[blockIdx.x] = (uint8_t)byte;
+        if (lane == 0) a.wave_flags[blockIdx.x] = (uint8_t)byte;
     }
     if (live && (step || go)) {
         typedef float f32x4v __attribute__((ext_vector_type(4)));

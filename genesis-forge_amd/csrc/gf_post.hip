@@ -1033,10 +1033,10 @@ extern "C" __attribute__((visibility("default"))) int gf_post_program_count(void
 #define GF_POST_PROGRAMS(X)                                                                                                \
     X(1, gf::ProgGo2CommandDirection) X(2, gf::ProgGo2Simple) X(3, gf::ProgGo2Contacts) X(4, gf::ProgGo2RoughTerrain) \
     X(5, gf::ProgBerkeleyHumanoid) X(6, gf::ProgGo2GaitTrainer) \
-    X(7, gf::ProgHumanoid28Stress)
+    X(7, gf::ProgHumanoid28Stress) X(8, gf::ProgGo2GaitTrainerFront) X(9, gf::ProgGo2GaitTrainerObs)
 
 static int select_program(const gf::GfPostArgs& a) {
-    if (gf::g_options[GF_OPT_POST_VARIANT] < 2 || a.obs_only) return 0;   // (the observation-only launch is the interpreter's)
+    if (gf::g_options[GF_OPT_POST_VARIANT] < 2) return 0;
 #define GF_MATCH(id, P) \
     if (gf::program_matches<P>(a)) return id;
     GF_POST_PROGRAMS(GF_MATCH)

@@ -185,6 +185,51 @@ struct ProgGo2GaitTrainer {
     static constexpr int n_gait = 1;
 };
 
+// examples/gait_trainer as shipped — with its reset() override (environment.py:347-352) the step is recorded in front of the reset: termination, rewards, command and gait step (GF_POST_NO_RESET) …
+struct ProgGo2GaitTrainerFront {
+    static constexpr bool kStatic = true;
+    static constexpr const char* name = "go2_gait_trainer_front";
+    static constexpr int DV = 3;
+    static constexpr int n_term = 3;
+    static constexpr TermSig term[3] = {{1, 1}, {2, 0}, {6, 0}};
+    static constexpr int n_rew = 9;
+    static constexpr RewSig rew[9] = {{18, 0, 1, 0}, {19, 0, 1, 0}, {3, 0, 0, 0}, {10, 0, 1, 0}, {11, 0, 1, 2}, {8, 0, 0, 0}, {5, 0, 0, 0}, {9, 0, 0, 0}, {14, 0, 2, 0}};
+    static constexpr int n_cmd = 1;
+    static constexpr int cmd_width[GF_POST_MAX_CMD] = {3, 0};
+    static constexpr int n_obs = 0;
+    static constexpr int obs_width[GF_POST_MAX_OBS] = {0, 0};
+    static constexpr int obs_history[GF_POST_MAX_OBS] = {0, 0};
+    static constexpr int obs_items[GF_POST_MAX_OBS] = {0, 0};
+    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {
+        {},
+        {}};
+    static constexpr int n_air = 0;
+    static constexpr int n_gait = 1;
+};
+
+// … and, behind the user's reset, the policy and critic observations (GF_POST_OBSERVE_ONLY); signatures from gf_post_physics_describe
+struct ProgGo2GaitTrainerObs {
+    static constexpr bool kStatic = true;
+    static constexpr const char* name = "go2_gait_trainer_obs";
+    static constexpr int DV = 3;
+    static constexpr int n_term = 0;
+    static constexpr TermSig term[1] = {};
+    static constexpr int n_rew = 0;
+    static constexpr RewSig rew[1] = {};
+    static constexpr int n_cmd = 0;
+    static constexpr int cmd_width[GF_POST_MAX_CMD] = {0, 0};
+    static constexpr int n_obs = 2;
+    static constexpr int obs_width[GF_POST_MAX_OBS] = {62, 16};
+    static constexpr int obs_history[GF_POST_MAX_OBS] = {5, 5};
+    static constexpr int obs_items[GF_POST_MAX_OBS] = {8, 2};
+    static constexpr ItemSig item[GF_POST_MAX_OBS][kPostMaxItems] = {
+        {{1, 14, 0, false, false}, {1, 3, 1, false, false}, {2, 3, 0, false, false}, {3, 3, 0, false, false}, {4, 3, 0, false, false}, {5, 12, 0, false, false}, {6, 12, 0, true, false}, {8, 12, 0, false, false}},
+        {{10, 4, 0, false, false}, {7, 12, 0, true, false}}};
+    static constexpr int n_air = 0;
+    static constexpr int n_gait = 0;
+    static constexpr bool term_done = true;   // the termination masks are inputs (Python-level terms ran behind a termination launch of its own)
+};
+
 // ---- matching -------------------------------------------------------------------------------------------------------------------
 // a recorded signature (registered with tools/register_program.py)
 struct ProgHumanoid28Stress {
@@ -216,7 +261,7 @@ inline size_t lds_ws_floats(int omax, int n_gait) {
 
 template <class P>
 bool program_matches(const GfPostArgs& a) {
-    if ((a.term_done != 0) != prog_term_done<P>::value || a.num_dofs != 4 * P::DV || a.num_term != P::n_term || a.num_rew != P::n_rew || a.n_cmd != P::n_cmd || a.n_obs != P::n_obs || a.n_air != P::n_air ||
+    if ((a.term_done != 0) != prog_term_done<P>::value || a.num_dofs != 4 * P::DV || a.num_term != P::n_term || (a.num_rew < 0 ? 0 : a.num_rew) != P::n_rew || a.n_cmd != P::n_cmd || a.n_obs != P::n_obs || a.n_air != P::n_air ||
         a.n_gait != P::n_gait)
         return false;
     for (int k = 0; k < P::n_term; ++k)

@@ -202,10 +202,9 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         n_term = UNI(a.num_term); n_rew = UNI(a.num_rew); n_cmd = UNI(a.n_cmd); n_obs = UNI(a.n_obs);
     }
     const uint64_t seed = UNI(a.seed);
-    // GF_POST_OBSERVE_ONLY (interpreter): everything up to the reset has run as launches of their own — the masks are inputs, no env
-    // is "done" as far as this launch is concerned, the observation waves do their part
-    bool obs_only = false;
-    if constexpr (!P::kStatic) obs_only = UNI(a.obs_only) != 0;
+    // GF_POST_OBSERVE_ONLY (a run-time argument of every program): everything up to the reset has run as launches of their own — the
+    // masks are inputs, no env is "done" as far as this launch is concerned, the observation waves do their part
+    const bool obs_only = UNI(a.obs_only) != 0;
     constexpr int R = DV;
     const uint32_t ro = e * (uint32_t)D;
     GfStepStats* const k_stats = UNI(a.stats);
@@ -307,13 +306,11 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             grow[8] = g2.x; grow[9] = g2.y; grow[10] = g2.z; grow[11] = g2.w; grow[12] = g3.x; grow[13] = g3.y; grow[14] = g3.z; grow[15] = g3.w;
             gait_sel = (int)G(UNI(a.gait.selected))[e];
         }
-        if constexpr (!P::kStatic) {
-            if (obs_only) {   // an env the reset of this tick touched is observed through its pre-reset quaternion (entity_manager.py:189-195)
-                term = live ? (int)G(UNI(a.terminated))[n] : 0;
-                trunc = live ? (int)G(UNI(a.truncated))[n] : 0;
-                const float* const stash = UNI(a.quat_stash);
-                if (stash && (needs & PN_QUAT) && (term | trunc)) q = ldg4(G(stash) + 4u * e);
-            }
+        if (obs_only) {   // an env the reset of this tick touched is observed through its pre-reset quaternion (entity_manager.py:189-195)
+            term = live ? (int)G(UNI(a.terminated))[n] : 0;
+            trunc = live ? (int)G(UNI(a.truncated))[n] : 0;
+            const float* const stash = UNI(a.quat_stash);
+            if (stash && (needs & PN_QUAT) && (term | trunc)) q = ldg4(G(stash) + 4u * e);
         }
         // a static program's contact-count terminations: the counts are taken HERE, so the contact rows are requested together with
         // the loads above instead of as a round trip of their own between two terms' statistics branches

@@ -16,7 +16,8 @@
 namespace gf {
 
 __device__ __forceinline__ void reset_body(const GfResetArgs& a) {
-    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + threadIdx.x;
+    const int lane = (int)(threadIdx.x & (GF_WAVE - 1));   // (one wave per 64 envs: whichever wave of a wider workgroup runs the body)
+    const int64_t n = (int64_t)blockIdx.x * kEnvBlock + lane;
     const bool live = n < a.num_envs;
     const bool go = live && (a.mask[n] || (a.mask2 && a.mask2[n]));
     const unsigned long long wave_go = __ballot(go);
@@ -24,7 +25,7 @@ __device__ __forceinline__ void reset_body(const GfResetArgs& a) {
     const int64_t N = a.num_envs;
     const int D = a.num_dofs;
 
-    if (a.stats && threadIdx.x == 0) atomicAdd(&stats_shard(a.stats)->reset_count, popc64(wave_go));
+    if (a.stats && lane == 0) atomicAdd(&stats_shard(a.stats)->reset_count, popc64(wave_go));
 
     // ---- RewardManager.reset: needs every lane for the wave reduction --------------------------
     if (a.episode_seconds) {
@@ -39,15 +40,15 @@ __device__ __forceinline__ void reset_body(const GfResetArgs& a) {
 #pragma unroll
                 for (int t = 0; t < GF_MAX_TERMS; ++t) sum[t] = (go && t < a.num_reward_terms) ? a.episode_sums[(int64_t)t * N + n] : 0.0f;
 #pragma unroll
-                for (int t = 0; t < GF_MAX_TERMS; ++t) s_sum[t][threadIdx.x & (kEnvBlock - 1)] = sum[t];
+                for (int t = 0; t < GF_MAX_TERMS; ++t) s_sum[t][lane] = sum[t];
             }
             for (int t = 0; t < a.num_reward_terms; ++t) {
                 float* v = a.episode_sums + (int64_t)t * N + (live ? n : 0);
                 if (a.reward_log_mask & (1u << t)) {
-                    const float per_sec = go ? (s_sum[t][threadIdx.x & (kEnvBlock - 1)] / secs) : 0.0f;  // value[envs_idx] /= episode_seconds
+                    const float per_sec = go ? (s_sum[t][lane] / secs) : 0.0f;  // value[envs_idx] /= episode_seconds
                     if (a.stats) {
                         const double s = wave_sum((double)per_sec);
-                        if (threadIdx.x == 0) unsafeAtomicAdd(&stats_shard(a.stats)->reward_episode_sum[t], s);  // native global_atomic_add_f64
+                        if (lane == 0) unsafeAtomicAdd(&stats_shard(a.stats)->reward_episode_sum[t], s);  // native global_atomic_add_f64
                     }
                 }
                 if (go) *v = 0.0f;

@@ -58,6 +58,7 @@ def parse(sig: str) -> dict:
     out = {"DV": int(g(r"DV = (\d+)").group(1)), "n_term": int(g(r"n_term = (\d+)").group(1)), "n_rew": int(g(r"n_rew = (-?\d+)").group(1)),
            "n_cmd": int(g(r"n_cmd = (\d+)").group(1)), "n_obs": int(g(r"n_obs = (\d+)").group(1)), "n_air": int(g(r"n_air = (\d+)").group(1)),
            "n_gait": int(g(r"n_gait = (\d+)").group(1))}
+    out["n_rew"] = max(0, out["n_rew"])   # (-1: no reward manager in the launch — as a program: no reward terms; the matcher agrees)
     out["term_done"] = g(r"term_done = 1") is not None
     out["term"] = g(r"term = (\{.*?\}); n_rew").group(1)
     out["rew"] = g(r"rew = (\{.*?\}); n_cmd").group(1)
