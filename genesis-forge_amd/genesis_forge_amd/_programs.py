@@ -293,8 +293,8 @@ def mode_for(env) -> str:
 class Pending:
     """An ``async`` compile in flight for one env."""
 
-    def __init__(self, env, sig: str, proc, so: str):
-        self.env, self.sig, self.proc, self.so = env, sig, proc, so
+    def __init__(self, env, sig: str, proc, so: str, slot: str = "_program_info"):
+        self.env, self.sig, self.proc, self.so, self.slot = env, sig, proc, so, slot
         self.countdown = 32
 
     def __del__(self):
@@ -323,22 +323,41 @@ class Pending:
             return False
         try:
             register(self.env.backend, finish_compile(self.proc))
-            self.env._program_info = {"signature": self.sig, "plugin": self.so, "compile_s": self.proc._gf_seconds, "mode": "async"}
+            setattr(self.env, self.slot, {"signature": self.sig, "plugin": self.so, "compile_s": self.proc._gf_seconds, "mode": "async"})
         except Exception as e:   # a failed compile must never take the run down: the interpreter is correct, just slower
-            self.env._program_info = {"signature": self.sig, "error": str(e), "mode": "async"}
+            setattr(self.env, self.slot, {"signature": self.sig, "error": str(e), "mode": "async"})
         return True
 
 
-def on_recorded(env) -> None:
-    """A step has just been recorded.  If its fused launch is the interpreter's, get the config its own program."""
+class PendingSet:
+    """The async compiles in flight for one env (its fused launch; the observation-only launch of a ``reset()``-override tail)."""
+
+    def __init__(self):
+        self.items: list = []
+
+    def add(self, p: "Pending") -> None:
+        self.items.append(p)
+
+    def poll(self) -> bool:
+        self.items = [p for p in self.items if not p.poll()]
+        return not self.items
+
+
+def on_recorded(env, refs=None) -> None:
+    """A step has just been recorded (``refs`` None: its fused launch) — or the tail of a ``reset()``-override env adopted, whose
+    observation managers run as one GF_POST_OBSERVE_ONLY launch (``refs``).  If that launch is the interpreter's, get it its own
+    program."""
     tr = env._trace
     backend = env.backend
-    if tr is None or tr.post_refs is None or not hasattr(backend, "post_describe") or not hasattr(backend, "register_program"):
+    slot = "_program_info" if refs is None else "_program_info_tail"
+    if refs is None:
+        refs = tr.post_refs if tr is not None else None
+    if refs is None or not hasattr(backend, "post_describe") or not hasattr(backend, "register_program"):
         return
     mode = mode_for(env)
     if mode == "off":
         return
-    sig = backend.post_describe(tr.post_refs)
+    sig = backend.post_describe(refs)
     if not sig.startswith("program 0 "):
         return   # a built-in program, or one registered earlier
     if hipcc() is None and not os.path.exists(plugin_paths(sig)[2]):
@@ -351,11 +370,13 @@ def on_recorded(env) -> None:
                 finish_compile(proc)
                 secs = proc._gf_seconds
             register(backend, so)
-            env._program_info = {"signature": sig, "plugin": so, "compile_s": secs, "mode": mode}
+            setattr(env, slot, {"signature": sig, "plugin": so, "compile_s": secs, "mode": mode})
         else:
-            env._program_pending = Pending(env, sig, proc, so)
+            if env._program_pending is None:
+                env._program_pending = PendingSet()
+            env._program_pending.add(Pending(env, sig, proc, so, slot))
     except Exception as e:
-        env._program_info = {"signature": sig, "error": str(e), "mode": mode}
+        setattr(env, slot, {"signature": sig, "error": str(e), "mode": mode})
 
 
 if __name__ == "__main__":   # python -m genesis_forge_amd._programs module:callable [num_envs]

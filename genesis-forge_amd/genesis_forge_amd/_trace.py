@@ -432,6 +432,10 @@ class StepTrace:
             self._tail_tries = 1 << 30   # a part that cannot be replayed natively (a Python-level observation item): stop trying
             return
         self.tail_seg = segs
+        if segs["obs"].get("fused_obs"):
+            from . import _programs
+
+            _programs.on_recorded(self.env, self._tail_refs)   # (a structure no built-in program matches gets its own: GF_JIT)
         mine = {C.addressof(c[1]) for part in ("reset", "obs") for c in tail_calls[part]}
         self.arg_set.update(mine)
         b = self.backend

@@ -81,6 +81,7 @@ class ManagedEnvironment(GenesisEnv):
         self._partition_cache = None
         self._program_pending = None   # a static program of this config being compiled in a child process (_programs.Pending)
         self._program_info: Optional[dict] = None   # what became of it: signature, plugin path, compile seconds (or the error)
+        self._program_info_tail: Optional[dict] = None   # the same for the observation-only launch of a reset()-override tail
         #: "off" / "sync" / "async": compile a static program of the fused post-physics kernel for this config's structure when no
         #: built-in one matches (None: by size, see _programs.mode_for; GF_JIT overrides)
         self.jit_programs: Optional[str] = None
