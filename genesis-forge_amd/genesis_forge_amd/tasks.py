@@ -521,4 +521,7 @@ BASELINE_CONFIGS = {
     # launch runs the program compiled for it at run time (genesis_forge_amd/_programs.py; GF_JIT) instead of the interpreter
     "go2_user": (65536, lambda n, **kw: bench_env(n, obs_noise=True, **kw)),
     "gait_8192": (8192, lambda n, **kw: Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.001), **kw)),
+    # the gait example AS SHIPPED: with its reset() override (curriculum hook, examples/gait_trainer/environment.py:347-352) — the reset
+    # runs through user code by index list; what is recorded around it: GF_POST_NO_RESET in front, GF_POST_OBSERVE_ONLY behind
+    "gait_override_8192": (8192, lambda n, **kw: Go2GaitTrainingCurriculumEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.001), **kw)),
 }

@@ -48,6 +48,7 @@ CASES = [
     ("humanoid28", 8192, "interp", 24, "interpreter"),        # … and the 28-DOF table interpreter every other 28-DOF config runs (GF_OPT_POST_VARIANT = 1)
     ("go2_cmd", 65536, "interp", 18, "interpreter"),          # … and the 12-DOF interpreter at the benchmark size
     ("go2_user", 65536, "jit", 20, "jit_"),                   # a structure the library was not built with, on its run-time compiled program
+    ("gait_override_8192", 8192, "short", 24, "go2_gait_trainer_front"),   # the gait example as shipped (reset() override): the two split launches
 ]
 
 
@@ -175,6 +176,8 @@ def _timed_workload(hip_backend, hip, cpu, name, n, variant, steps, program):
         assert tr.post_refs is not None, "the post-physics phases of this config run as the fused launch"
         what = hip_backend.post_describe(tr.post_refs)
         assert (f"({program}" if program.endswith("_") else f"({program})") in what.split(":")[0], what
+        if name == "gait_override_8192":
+            assert tr.tail_seg.get("obs", {}).get("fused_obs") and "(go2_gait_trainer_obs)" in hip_backend.post_describe(tr._tail_refs).split(":")[0]
     assert envs["cpu"]._trace is None
     if variant == "short" or (name == "go2_cmd" and n >= 4096):   # (rough terrain's 30-degree limit never fires at the bench noise level)
         assert resets > 0, "the trajectory must reset envs"
