@@ -191,6 +191,9 @@ class StepStats:
             self.ring = torch.zeros(_RING, STATS_BYTES, dtype=torch.uint8, device=self.device)
             self.vec_ring = torch.zeros(_RING, STATS_VECTOR_LEN, dtype=torch.float64, device=self.device)
             self.last_reset = torch.zeros(STATS_VECTOR_LEN, dtype=torch.float64, device=self.device)
+            # every slot's address, once (a recorded step asks for three or four of them: a data_ptr() call each otherwise)
+            self._ring_ptrs = [self.ring.data_ptr() + k * STATS_BYTES for k in range(_RING)]
+            self._vec_ptrs = [self.vec_ring.data_ptr() + k * STATS_VECTOR_LEN * 8 for k in range(_RING)]
             self.ring_pos = 0
             self._ring_prev = None      # slot written by the previous recorded step (not folded yet)
             self._ring_snaps = [None] * _RING
@@ -201,10 +204,10 @@ class StepStats:
             self._fold_slot = None
 
     def ring_ptr(self, slot: int) -> int:
-        return self.ring.data_ptr() + slot * STATS_BYTES
+        return self._ring_ptrs[slot]
 
     def vec_ptr(self, slot: int) -> int:
-        return self.vec_ring.data_ptr() + slot * STATS_VECTOR_LEN * 8
+        return self._vec_ptrs[slot]
 
     def ring_next(self):
         """(this step's slot pointer, slot pointer to zero, previous slot pointer or None, its vector row or None, snapshot)."""
@@ -218,9 +221,10 @@ class StepStats:
         self._ring_snaps[i] = weakref.ref(snap)  # weak: a log nobody kept is never copied out
         self._ring_prev = i
         self.ring_pos = (i + 1) % _RING
+        rp = self._ring_ptrs
         if prev is None:
-            return self.ring_ptr(i), self.ring_ptr(self.ring_pos), None, None, snap
-        return self.ring_ptr(i), self.ring_ptr(self.ring_pos), self.ring_ptr(prev), self.vec_ptr(prev), snap
+            return rp[i], rp[self.ring_pos], None, None, snap
+        return rp[i], rp[self.ring_pos], rp[prev], self._vec_ptrs[prev], snap
 
     def _fold_latest(self, backend) -> None:
         """The newest slot has not been folded by a following step yet: fold it explicitly (one tiny launch)."""
