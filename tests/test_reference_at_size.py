@@ -46,7 +46,8 @@ def test_reference_itself_equals_package_with_contact_managers(oracle_lib_path):
     assert "reference == package (oracle backend) at 512 envs with contact managers" in p.stdout
 
 
-FIXTURES = ["atsize_go2_4096", "atsize_go2_65536", "atsize_go2c_4096", "atsize_go2c_65536"]   # (…c: with the contact managers)
+FIXTURES = ["atsize_go2_4096", "atsize_go2_65536", "atsize_go2c_4096", "atsize_go2c_65536",   # (…c: with the contact managers)
+            "atsize_rough_16384"]   # BASELINE config 3's structure at its size: terrain spawn / height lookups, two ContactManagers
 
 
 @pytest.mark.parametrize("name", FIXTURES)

@@ -406,11 +406,11 @@ def run_trajectory(name, n, steps, contacts, history, scene_kwargs, episode_s=2,
 # ------------------------------------------------------------------------------------------------
 AT_SIZE = {"steps": 20, "episode_s": 0.3, "cmd_resample_s": 0.2, "contacts": False, "history": 2,
            "scene_kwargs": dict(ang_noise=0.35, lin_noise=0.05, seed=17, contact_prob=0.3, contact_force=30.0)}
-def at_size_name(n, contacts):
-    return f"atsize_go2{'c' if contacts else ''}_{n}"
+def at_size_name(n, contacts, variant="cmd"):
+    return f"atsize_rough_{n}" if variant == "rough" else f"atsize_go2{'c' if contacts else ''}_{n}"
 
 
-def run_reference_at_size(n, contacts=None):
+def run_reference_at_size(n, contacts=None, variant="cmd"):
     """The reference's own ManagedEnvironment.step (managed_env.py:274-334) at n envs — in memory, no file.  ``contacts``: with the
     two ContactManagers of the contacts example (the reference's Taichi kernel source runs under the serial `ti` emulation of
     tools/ref_stubs.py: ≈ 8 s per step at 4 096 envs, two minutes per step at 65 536 — so that variant exists at 4 096 envs only)."""
@@ -418,6 +418,9 @@ def run_reference_at_size(n, contacts=None):
     contacts = AT_SIZE["contacts"] if contacts is None else contacts
     keep, CMD_RESAMPLE_S = CMD_RESAMPLE_S, AT_SIZE["cmd_resample_s"]
     try:
+        if variant == "rough":   # BASELINE config 3's structure (terrain lookups, spawn on the terrain, out of bounds, two ContactManagers)
+            return run_trajectory(at_size_name(n, False, "rough"), n=n, steps=AT_SIZE["steps"], contacts=False, history=None, variant="rough",
+                                  scene_kwargs=AT_SIZE["scene_kwargs"], episode_s=AT_SIZE["episode_s"], save=False)
         return run_trajectory(at_size_name(n, contacts), n=n, steps=AT_SIZE["steps"], contacts=contacts, history=AT_SIZE["history"],
                               scene_kwargs=AT_SIZE["scene_kwargs"], episode_s=AT_SIZE["episode_s"], save=False)
     finally:
@@ -430,12 +433,14 @@ def gen_at_size():
     # `at_size` regenerates the three fixtures that take minutes; `at_size go2c_65536` the contact-manager run at 65 536 envs (the
     # serial Taichi emulation: ≈ 2 minutes per step, ≈ 45 minutes); `at_size <name>` any single one
     only = sys.argv[2] if len(sys.argv) > 2 else os.environ.get("GF_AT_SIZE_ONLY")
-    for n, contacts in ((4096, False), (65536, False), (4096, True), (65536, True)):
-        if (only and at_size_name(n, contacts) != "atsize_" + only) or (not only and (n, contacts) == (65536, True)):
+    # … `at_size rough_16384` BASELINE config 3's structure at its size (two ContactManagers under the emulation: ≈ 12 minutes)
+    for n, contacts, variant in ((4096, False, "cmd"), (65536, False, "cmd"), (4096, True, "cmd"), (65536, True, "cmd"), (16384, False, "rough")):
+        name = at_size_name(n, contacts, variant)
+        if (only and name != "atsize_" + only) or (not only and ((n, contacts) == (65536, True) or variant == "rough")):
             continue
-        out = run_reference_at_size(n, contacts)
+        out = run_reference_at_size(n, contacts, variant)
         assert np.array_equal(out["actions"], helpers.at_size_actions(n, int(out["steps"]))), "the tests regenerate the actions from the same stream"
-        np.savez_compressed(os.path.join(GOLD, at_size_name(n, contacts) + ".npz"), **helpers.compact_at_size(out, n))
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **helpers.compact_at_size(out, n))
 
 
 def check_at_size(n, contacts=False):
