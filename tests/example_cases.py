@@ -51,6 +51,15 @@ for _ex, _n, _steps in (("command_direction", 130, 56), ("rough_terrain", 130, 5
                                   events={5: "more_gaits", 6: "more_gaits", 7: "wider_ranges", 20: "more_gaits"} if _base["events"] else {})
 
 
+# … and BASELINE config 5's example at the size one rank of an 8-GPU strong-scaling run holds (8 192 envs = 128 tiles): the fixture is
+# COMPACT (helpers.compact_example: per-step sums, sums of squares and a strided 64-env sample of every recorded field; the actions are
+# regenerated from the generator's stream) — the full trajectory is 300 MB.  The reference run takes ≈ 10 minutes (three ContactManagers
+# through the serial Taichi emulation): `python tools/gen_golden.py examples gait_trainer_n8192`.
+CASES["gait_trainer_n8192"] = dict(CASES["gait_trainer"], example="gait_trainer", n=8192, steps=20, episode_s=0.3, compact=True,
+                                   resample={"velocity_command": 0.2, "gait_command_manager": 0.3},
+                                   events={5: "more_gaits", 6: "more_gaits", 7: "wider_ranges", 12: "more_gaits"})
+
+
 def example_of(key: str) -> str:
     """The reference example directory (and restated task config) a case runs."""
     return CASES[key].get("example", key)

@@ -189,6 +189,66 @@ def compare_example(fix, res, tol=FLOAT_TOL):
             assert abs(got[k] - want[k]) <= 1e-5 + 1e-5 * abs(want[k]), f"log {k} at step {t}: {got[k]} vs {want[k]}"
 
 
+_EX_SKIP = ("actions", "obs0", "log_keys", "log_values", "seed", "example", "logs")
+_EX_EXACT = ("terminated", "truncated", "episode_length", "max_episode_length", "gait_gait_selected")
+
+
+def example_actions(case):
+    """The action stream of tools/gen_golden.py run_example (a compact fixture does not store it)."""
+    rng = np.random.RandomState(7)
+    acts = []
+    for t in range(case["steps"]):
+        act = rng.standard_normal((case["n"], case["dofs"])).astype(np.float32)
+        if t == 5:
+            act[0, 0] = 1e9
+        acts.append(act)
+    return np.stack(acts)
+
+
+def compact_example(out, n):
+    """An example trajectory (every recorded field, [steps, n, …]) reduced to what travels: per step the sum over all envs (f64, or
+    int64 for masks / counters / indices), for floats the sum of squares, and every value of a strided 64-env sample."""
+    idx = at_size_sample(n)
+    c = {"n": np.int64(n), "compact": np.int64(1), "sample": idx, "obs0_sample": out["obs0"][idx], "obs0_sum": np.asarray(out["obs0"], dtype=np.float64).sum()}
+    for k, v in out.items():
+        if k in _EX_SKIP or not isinstance(v, np.ndarray):
+            continue
+        a = v.reshape(v.shape[0], n, -1)
+        if k in _EX_EXACT:
+            c[k + "_sum"] = a.astype(np.int64).sum(axis=(1, 2))
+        else:
+            d = a.astype(np.float64)
+            c[k + "_sum"], c[k + "_sumsq"] = d.sum(axis=(1, 2)), (d * d).sum(axis=(1, 2))
+        c[k + "_sample"] = a[:, idx]
+    for k in ("log_keys", "log_values", "seed", "example"):
+        if k in out:
+            c[k] = out[k]
+    return c
+
+
+def compare_compact_example(fix, got, logs, tol=FLOAT_TOL):
+    n = int(fix["n"])
+    np.testing.assert_allclose(got["obs0_sample"], fix["obs0_sample"], atol=tol, rtol=0)
+    fields = sorted(k[:-7] for k in fix.files if k.endswith("_sample") and k != "obs0_sample")
+    assert fields and all(f + "_sample" in got for f in fields), [f for f in fields if f + "_sample" not in got]
+    for k in fields:
+        if k in _EX_EXACT:
+            assert np.array_equal(got[k + "_sum"], fix[k + "_sum"]), f"{k}: per-step integer sum over all envs differs"
+            assert np.array_equal(got[k + "_sample"], fix[k + "_sample"]), f"{k}: sampled envs differ"
+        else:
+            np.testing.assert_allclose(got[k + "_sample"], fix[k + "_sample"], atol=tol, rtol=0, err_msg=f"{k}: sampled envs")
+            width = fix[k + "_sample"].shape[-1]
+            np.testing.assert_allclose(got[k + "_sum"], fix[k + "_sum"], atol=n * width * tol, rtol=1e-13, err_msg=f"{k}: sum over all envs")
+            scale = 2.0 * float(np.abs(fix[k + "_sample"]).max() + 1.0) * 4.0
+            np.testing.assert_allclose(got[k + "_sumsq"], fix[k + "_sumsq"], atol=n * width * tol * scale, rtol=1e-13, err_msg=f"{k}: sum of squares")
+    lkeys = [str(k) for k in fix["log_keys"]]
+    for t in range(len(logs)):
+        want = {k: fix["log_values"][t, j] for j, k in enumerate(lkeys) if not np.isnan(fix["log_values"][t, j])}
+        assert set(logs[t]) == set(want), f"log keys differ at step {t}: {sorted(logs[t])} vs {sorted(want)}"
+        for k in want:
+            assert abs(logs[t][k] - want[k]) <= 1e-5 + 1e-5 * abs(want[k]), f"log {k} at step {t}: {logs[t][k]} vs {want[k]}"
+
+
 # ----------------------------------------------------------------------------------------------------
 # The reference at the sizes that get timed (tools/gen_golden.py at_size; fixtures atsize_go2_<n>.npz)
 # ----------------------------------------------------------------------------------------------------

@@ -20,7 +20,8 @@ import torch
 import example_cases
 import helpers
 
-CASE_KEYS = list(example_cases.CASES)   # the six examples at n = 8 plus the multi-tile cases (<example>_n<envs>)
+CASE_KEYS = [k for k, c in example_cases.CASES.items() if not c.get("compact")]   # the six examples at n = 8 plus the multi-tile cases (<example>_n<envs>)
+COMPACT_KEYS = [k for k, c in example_cases.CASES.items() if c.get("compact")]     # … and at a timed size, as a compact fixture (helpers.compact_example)
 EXAMPLES = [k for k in CASE_KEYS if example_cases.example_of(k) == k]
 RESTATED = CASE_KEYS  # gait_trainer runs on the native GaitCommandManager
 REF_EXAMPLES = "/root/reference/examples"
@@ -99,6 +100,31 @@ def test_restated_config_hip(hip_backend, name):
     env = envs.make_example(example_cases.example_of(name), case)
     res = helpers.replay_example(fix, case, env, "cuda")
     helpers.compare_example(fix, res)
+
+
+def _compact_case(name, dev):
+    """The restated config at a timed size against the reference's own example file run at that size: per-step sums over all envs +
+    a strided 64-env sample of every recorded field (outputs, counters, commands, gait-manager state, logged scalars)."""
+    import envs
+
+    case = example_cases.CASES[name]
+    fix = helpers.load(f"traj_ex_{name}")
+    assert int(fix["compact"]) == 1 and int(fix["n"]) == case["n"]
+    env = envs.make_example(example_cases.example_of(name), case)
+    res = helpers.replay_example({"seed": fix["seed"], "actions": helpers.example_actions(case)}, case, env, dev)
+    logs = res.pop("logs")
+    helpers.compare_compact_example(fix, helpers.compact_example(res, case["n"]), logs)
+
+
+@pytest.mark.parametrize("name", COMPACT_KEYS)
+def test_restated_config_at_size_cpu_oracle(oracle_backend, name):
+    _compact_case(name, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", COMPACT_KEYS)
+def test_restated_config_at_size_hip(hip_backend, name):
+    _compact_case(name, "cuda")
 
 
 def _philox_run(name, dev, trace, n, steps=45):

@@ -953,7 +953,12 @@ def run_example(name):
                 log_arr[t, j] = d[k]
     out = {k: np.stack(v) for k, v in rec.items()}
     out.update(obs0=obs0.numpy().copy(), log_keys=np.array(keys), log_values=log_arr, seed=np.int64(SEED), example=np.array(name))
-    np.savez_compressed(os.path.join(GOLD, f"traj_ex_{name}.npz"), **out)
+    if case.get("compact"):   # (a size whose full trajectory would be hundreds of MB: sums + a strided sample, tests/helpers.py)
+        import helpers
+        assert np.array_equal(out["actions"], helpers.example_actions(case)), "the tests regenerate the actions from the same stream"
+        np.savez_compressed(os.path.join(GOLD, f"traj_ex_{name}.npz"), **helpers.compact_example(out, n))
+    else:
+        np.savez_compressed(os.path.join(GOLD, f"traj_ex_{name}.npz"), **out)
     print(f"traj_ex_{name}: steps", steps, "obs", out["obs"].shape[1:], "terminated", int(out["terminated"].sum()), "truncated",
           int(out["truncated"].sum()), "log keys", len(keys))
 
@@ -974,7 +979,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "examples":
         import example_cases
-        for ex in (sys.argv[2:] or example_cases.CASES):
+        for ex in (sys.argv[2:] or [k for k, c in example_cases.CASES.items() if not c.get("compact")]):   # (compact cases — minutes of reference time — by name)
             run_example(ex)
         sys.exit(0)
     gen_terrain()
