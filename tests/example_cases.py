@@ -58,6 +58,11 @@ for _ex, _n, _steps in (("command_direction", 130, 56), ("rough_terrain", 130, 5
 CASES["gait_trainer_n8192"] = dict(CASES["gait_trainer"], example="gait_trainer", n=8192, steps=20, episode_s=0.3, compact=True,
                                    resample={"velocity_command": 0.2, "gait_command_manager": 0.3},
                                    events={5: "more_gaits", 6: "more_gaits", 7: "wider_ranges", 12: "more_gaits"})
+# the headline config's example file at the headline size, and BASELINE config 4's at its size (compact fixtures as above)
+CASES["command_direction_n65536"] = dict(CASES["command_direction"], example="command_direction", n=65536, steps=20, episode_s=0.3, compact=True,
+                                         resample={"velocity_command": 0.2}, events={})
+CASES["berkeley_humanoid_n8192"] = dict(CASES["berkeley_humanoid"], example="berkeley_humanoid", n=8192, steps=20, episode_s=0.3, compact=True,
+                                        resample={"velocity_command": 0.2}, events={})
 
 
 def example_of(key: str) -> str:

@@ -123,8 +123,10 @@ def set_example_draws(env, seed, step, dev):
     env.set_draws(**d)
 
 
-def replay_example(fix, case, env, dev="cpu", user_gait_cls=None):
-    """Drive ``env`` (a task config of tests/example_cases.py, built here) with the fixture's actions and draws."""
+def replay_example(fix, case, env, dev="cpu", user_gait_cls=None, compact=False):
+    """Drive ``env`` (a task config of tests/example_cases.py, built here) with the fixture's actions and draws.  ``compact``: keep per
+    step only what a compact fixture holds (compact_example's sums and sample, computed on the device) — a full trajectory at a
+    timed size is hundreds of MB of host copies."""
     import example_cases
 
     seed, n = int(fix["seed"]), case["n"]
@@ -139,6 +141,7 @@ def replay_example(fix, case, env, dev="cpu", user_gait_cls=None):
     obs0, _ = env.reset()
     f = lambda t: t.detach().cpu().numpy().copy()
     out = {"obs0": f(obs0)}
+    sample_idx = torch.from_numpy(at_size_sample(n)).to(dev) if compact else None
     rec = {}
     logs = []
     for t in range(case["steps"]):
@@ -158,10 +161,25 @@ def replay_example(fix, case, env, dev="cpu", user_gait_cls=None):
         if g is not None:
             for fld in GAIT_FIELDS:
                 vals["gait_" + fld] = getattr(g, fld if fld != "gait_selected" else "_gait_selected")
-        for k, v in vals.items():
-            rec.setdefault(k, []).append(f(v))
+        if compact:
+            for k, v in vals.items():
+                a = v.reshape(n, -1)
+                if k in _EX_EXACT:
+                    rec.setdefault(k + "_sum", []).append(int(a.long().sum()))
+                else:
+                    d = a.double()
+                    rec.setdefault(k + "_sum", []).append(float(d.sum()))
+                    rec.setdefault(k + "_sumsq", []).append(float((d * d).sum()))
+                rec.setdefault(k + "_sample", []).append(f(a[sample_idx]))
+        else:
+            for k, v in vals.items():
+                rec.setdefault(k, []).append(f(v))
         logs.append({k: float(v) for k, v in extras["episode"].items()})
-    out.update({k: np.stack(v) for k, v in rec.items()})
+    if compact:
+        out = {"n": np.int64(n), "obs0_sample": out["obs0"][at_size_sample(n)], "obs0_sum": np.asarray(out["obs0"], dtype=np.float64).sum()}
+        out.update({k: (np.stack(v) if k.endswith("_sample") else np.asarray(v)) for k, v in rec.items()})
+    else:
+        out.update({k: np.stack(v) for k, v in rec.items()})
     out["logs"] = logs
     return out
 

@@ -29,12 +29,16 @@ def uniform(seed: int, stream: int, n_env: int, n_col: int) -> np.ndarray:
     groups = (n_col + 3) // 4
     out = np.empty((n_env, groups * 4), dtype=np.float32)
     grp = np.arange(groups, dtype=np.uint32)[None, :]
+    words = np.empty((min(n_env, 8192), groups, 4), dtype=np.uint32)   # one scratch block for every chunk (no per-chunk stack)
     for e0 in range(0, n_env, 8192):
-        env = np.arange(e0, min(e0 + 8192, n_env), dtype=np.uint32)[:, None]
+        m = min(8192, n_env - e0)
+        env = np.arange(e0, e0 + m, dtype=np.uint32)[:, None]
         x = philox4x32_10(env, grp, np.uint32(stream & 0xFFFFFFFF), np.uint32((stream >> 32) & 0xFFFFFFFF),
                           seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-        v = np.stack(x, axis=-1).reshape(env.shape[0], groups * 4)
-        out[e0:e0 + env.shape[0]] = (v >> np.uint32(8)).astype(np.float32) * np.float32(5.9604644775390625e-8)
+        w = words[:m]
+        for k in range(4):
+            w[:, :, k] = x[k]
+        out[e0:e0 + m] = (w.reshape(m, groups * 4) >> np.uint32(8)).astype(np.float32) * np.float32(5.9604644775390625e-8)
     return np.ascontiguousarray(out[:, :n_col])
 
 

@@ -111,9 +111,9 @@ def _compact_case(name, dev):
     fix = helpers.load(f"traj_ex_{name}")
     assert int(fix["compact"]) == 1 and int(fix["n"]) == case["n"]
     env = envs.make_example(example_cases.example_of(name), case)
-    res = helpers.replay_example({"seed": fix["seed"], "actions": helpers.example_actions(case)}, case, env, dev)
+    res = helpers.replay_example({"seed": fix["seed"], "actions": helpers.example_actions(case)}, case, env, dev, compact=True)
     logs = res.pop("logs")
-    helpers.compare_compact_example(fix, helpers.compact_example(res, case["n"]), logs)
+    helpers.compare_compact_example(fix, res, logs)
 
 
 @pytest.mark.parametrize("name", COMPACT_KEYS)
