@@ -869,6 +869,8 @@ static int pack(const GfPostRefs* r, Packer& pk) {
         PostObs& po = a.obs[m];
         po.obs = ob->obs; po.prev = (ob->history_len > 1 && !ob->history_ring) ? ob->prev_obs : nullptr; po.stream = ob->stream;
         po.ring = ob->history_ring;
+        // (the frame of an in-place ring is read back by the gather that follows: cached)
+        if (!po.ring && N * (int64_t)ob->obs_width * (ob->history_len > 0 ? ob->history_len : 1) * 4 >= kObsStreamBytes) a.obs_stream |= 1u << m;
         po.num_items = ob->num_items; po.width = ob->obs_width; po.history = ob->history_len;
         omax = ob->obs_width > omax ? ob->obs_width : omax;
         bool uses_entity = false;

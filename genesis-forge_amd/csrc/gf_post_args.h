@@ -74,6 +74,11 @@ struct PostObs {
     GfObsItem items[kPostMaxItems];
 };
 
+// An observation output of this size or more is streamed out with the non-temporal hint: nothing in the step reads it again, and the
+// policy that does finds 200 MB at 1 M envs in no cache either way; cached, it evicts the state the next launch reads (whole step at
+// 1 048 576 envs 229 -> 212 us with the hint; at 65 536 envs, 12.6 MB, no difference — profiles/r03_z_ab_nt.jsonl).
+constexpr int64_t kObsStreamBytes = (int64_t)64 << 20;
+
 struct alignas(16) GfPostArgs {
     int32_t num_envs, num_dofs, num_term, num_rew;
     uint32_t needs;
@@ -126,6 +131,7 @@ struct alignas(16) GfPostArgs {
     int32_t term_done;   // GF_POST_TERMINATION_DONE: the masks are inputs, the termination table is not evaluated
     int32_t obs_only;    // GF_POST_OBSERVE_ONLY: the masks are inputs and nothing is reset; the observation waves run (interpreter only)
     int32_t no_reset;    // GF_POST_NO_RESET: termination … command / gait step only: no env is treated as done, nothing is observed
+    uint32_t obs_stream;   // bit m: observation manager m's output is larger than the caches keep from step to step: non-temporal stores
     const uint8_t* gait_wave_flags;   // == gait.flags_in when the reward terms reproduce the env-0 quirk (GF_R_GAIT_PHASE)
     PostGait gait;
     GfTerm tterms[kPostMaxTerm];

@@ -945,6 +945,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             // history (H > 1): 16-byte units over the tile's contiguous [rows, O·H] run, whatever O is (gf_obs_hist.h) — the
             // gait task's 62-wide policy frame has no 16-byte aligned rows, the run has
             const bool flat = H > 1 && !ring && O >= 4 && (reinterpret_cast<uintptr_t>(ob_out) & 15u) == 0;
+            const bool nt = ((UNI(a.obs_stream) >> m) & 1u) != 0;   // kObsStreamBytes (gf_post_args.h)
             if (flat) {   // the pure history units went out above (hist_early); what touches the new frame comes from the tile
                 const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
                 write_mixed_units(out, prev, tile, S, rows, O, (int)OH, t, roll);
@@ -954,8 +955,14 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 int rw = t / o4, c4 = t - rw * o4;
                 for (int i = t; i < rows * o4; i += kWsBlock) {
                     const float* r = tile + rw * S + c4 * 4;
-                    reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OH)[c4] = f32x4{r[0], r[1], r[2], r[3]};
-                    if (roll) reinterpret_cast<GF_GLOBAL f32x4*>(roll + rw * OH)[c4] = f32x4{r[0], r[1], r[2], r[3]};
+                    const f32x4 v4{r[0], r[1], r[2], r[3]};
+                    if (nt) {
+                        __builtin_nontemporal_store(v4, reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OH) + c4);
+                        if (roll) __builtin_nontemporal_store(v4, reinterpret_cast<GF_GLOBAL f32x4*>(roll + rw * OH) + c4);
+                    } else {
+                        reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OH)[c4] = v4;
+                        if (roll) reinterpret_cast<GF_GLOBAL f32x4*>(roll + rw * OH)[c4] = v4;
+                    }
                     rw += qstep; c4 += rstep;
                     if (c4 >= o4) { c4 -= o4; ++rw; }
                 }

@@ -51,6 +51,23 @@ __device__ __forceinline__ int64_t rows_before(int64_t e, const UnrollConsts& c)
 // (whole units and edge halves) is issued before the one wait; a first version composed edge units from element loads AFTER the
 // stores, and since every wave meets an edge that put four more serialised round trips on every wave: 48 us instead of 25 for the
 // gait policy history at 65 536 envs (profiles/r02_m_unroll_edges.txt).
+// Streaming (`NT`): a gather whose ring + output are larger than the caches can hold from one step to the next (kStreamBytes) reads
+// and writes with the non-temporal hint — nothing of it is found again by the next launch anyway, and without the hint the 200 MB of
+// the gait policy history at 65 536 envs pushed every OTHER kernel's working set out of L2 / MALL each step: the whole gait step
+// went from 129.6 to 114.8 us with it, the same step at 8 192 envs (12 MB ring, re-read from cache every step) from 35.7 to 36.7
+// the other way — hence the size rule (profiles/r03_z_ab_nt.jsonl).
+constexpr int64_t kStreamBytes = (int64_t)64 << 20;
+template <bool NT, class T>
+__device__ __forceinline__ T stream_load(const GF_GLOBAL T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, class T>
+__device__ __forceinline__ void stream_store(GF_GLOBAL T* p, const T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <bool NT>
 __device__ __forceinline__ void unroll_chunk(const GfHistoryUnrollArgs& a, const UnrollConsts& uc, const unsigned block) {
     const UnrollMap map(uc, a.frame_width, a.history_len, a.ring_slot - 1);
     const int64_t total = a.num_envs * (int64_t)map.OH, units = total >> 2;
@@ -80,7 +97,7 @@ __device__ __forceinline__ void unroll_chunk(const GfHistoryUnrollArgs& a, const
         // unconditional, back to back.  A lane past the array reads `ring + 0` — 16 bytes that exist when a frame is at least a unit
         // wide; with narrower frames (`!wide`: the element path below does the loading) `ring + 0` may end less than 16 bytes before
         // the end of the tensor (O*H < 4, last row), so the wave-uniform base is the code object's zero pad then
-        v[k] = *reinterpret_cast<const GF_GLOBAL f32x4u*>(vbase + (!on || !wide ? 0 : (la >= 4 ? so : so + la - 4)));
+        v[k] = stream_load<NT>(reinterpret_cast<const GF_GLOBAL f32x4u*>(vbase + (!on || !wide ? 0 : (la >= 4 ? so : so + la - 4))));
         w[k] = f32x4u{0.f, 0.f, 0.f, 0.f};   // (not v[k]: a copy would wait for the load)
     }
     if (wide) {
@@ -88,7 +105,7 @@ __device__ __forceinline__ void unroll_chunk(const GfHistoryUnrollArgs& a, const
         for (int k = 0; k < kUnrollUnits; ++k)
             if (lead[k] < 4) {   // the unit's second frame: its first four floats
                 int cc;
-                w[k] = *reinterpret_cast<const GF_GLOBAL f32x4u*>(ring + map.src(at[k] + lead[k], cc));
+                w[k] = stream_load<NT>(reinterpret_cast<const GF_GLOBAL f32x4u*>(ring + map.src(at[k] + lead[k], cc)));
             }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), once
 #pragma unroll
@@ -99,8 +116,8 @@ __device__ __forceinline__ void unroll_chunk(const GfHistoryUnrollArgs& a, const
                 if (la == 1) r = f32x4a{v[k].w, w[k].x, w[k].y, w[k].z};
                 else if (la == 2) r = f32x4a{v[k].z, v[k].w, w[k].x, w[k].y};
                 else if (la == 3) r = f32x4a{v[k].y, v[k].z, v[k].w, w[k].x};
-                *reinterpret_cast<GF_GLOBAL f32x4a*>(out + at[k]) = r;
-                if (out2) *reinterpret_cast<GF_GLOBAL f32x4a*>(out2 + at[k]) = r;
+                stream_store<NT>(reinterpret_cast<GF_GLOBAL f32x4a*>(out + at[k]), r);
+                if (out2) stream_store<NT>(reinterpret_cast<GF_GLOBAL f32x4a*>(out2 + at[k]), r);
             }
     } else {   // frames narrower than a unit: element by element
 #pragma unroll
@@ -128,13 +145,15 @@ __device__ __forceinline__ void unroll_chunk(const GfHistoryUnrollArgs& a, const
     }
 }
 
-__global__ __launch_bounds__(kUnrollBlock) void history_unroll_kernel(const GfHistoryUnrollArgs a, const UnrollConsts uc) { unroll_chunk(a, uc, blockIdx.x); }
+template <bool NT>
+__global__ __launch_bounds__(kUnrollBlock) void history_unroll_kernel(const GfHistoryUnrollArgs a, const UnrollConsts uc) { unroll_chunk<NT>(a, uc, blockIdx.x); }
 
 // two managers (policy + critic of one env), one launch: workgroups [0, split) gather the first, the rest the second
+template <bool NT>
 __global__ __launch_bounds__(kUnrollBlock) void history_unroll2_kernel(const GfHistoryUnrollArgs a, const UnrollConsts ua, const GfHistoryUnrollArgs b,
                                                                         const UnrollConsts ub, const unsigned split) {
-    if (blockIdx.x < split) unroll_chunk(a, ua, blockIdx.x);
-    else unroll_chunk(b, ub, blockIdx.x - split);
+    if (blockIdx.x < split) unroll_chunk<NT>(a, ua, blockIdx.x);
+    else unroll_chunk<NT>(b, ub, blockIdx.x - split);
 }
 
 int unroll_prep(const GfHistoryUnrollArgs* a) {
@@ -162,6 +181,12 @@ static int64_t unroll_blocks(const GfHistoryUnrollArgs* a) {
     return (total + kUnrollChunk - 1) / kUnrollChunk;
 }
 
+// ring + output (+ second output) of the launch, in bytes, against kStreamBytes
+static bool unroll_streams(const GfHistoryUnrollArgs* a, const GfHistoryUnrollArgs* b) {
+    auto bytes = [](const GfHistoryUnrollArgs* x) { return x ? x->num_envs * (int64_t)x->frame_width * x->history_len * 4 * (x->out2 ? 3 : 2) : (int64_t)0; };
+    return bytes(a) + bytes(b) >= kStreamBytes;
+}
+
 // gf_run_ops: two consecutive gather ops share a launch.  Returns GF_OK or an error; *fused = 1 when both were launched.
 int unroll_pair(const GfHistoryUnrollArgs* a, const GfHistoryUnrollArgs* b, hipStream_t s, int* fused) {
     *fused = 0;
@@ -170,7 +195,8 @@ int unroll_pair(const GfHistoryUnrollArgs* a, const GfHistoryUnrollArgs* b, hipS
     if (unroll_prep(b) != GF_OK || a->num_envs == 0 || b->num_envs == 0 || g_prof.phase == GF_PHASE_UNROLL) return GF_OK;   // caller launches them one by one
     const int64_t na = unroll_blocks(a), nb = unroll_blocks(b);
     if (na + nb >= (int64_t)1 << 31) return GF_OK;
-    klaunch(history_unroll2_kernel, dim3((unsigned)(na + nb)), dim3(kUnrollBlock), 0, s, *a, unroll_consts(a), *b, unroll_consts(b), (unsigned)na);
+    if (unroll_streams(a, b)) klaunch(history_unroll2_kernel<true>, dim3((unsigned)(na + nb)), dim3(kUnrollBlock), 0, s, *a, unroll_consts(a), *b, unroll_consts(b), (unsigned)na);
+    else klaunch(history_unroll2_kernel<false>, dim3((unsigned)(na + nb)), dim3(kUnrollBlock), 0, s, *a, unroll_consts(a), *b, unroll_consts(b), (unsigned)na);
     *fused = 1;
     return launch_status();
 }
@@ -185,6 +211,7 @@ extern "C" __attribute__((visibility("default"))) int gf_history_unroll(const Gf
     if (blocks >= (int64_t)1 << 31) return GF_E_RANGE;
     hipStream_t s = (hipStream_t)stream;
     gf::PhaseScope scope(GF_PHASE_UNROLL, s);
-    GF_LAUNCH(scope, gf::history_unroll_kernel, (unsigned)blocks, gf::kUnrollBlock, 0, s, *a, gf::unroll_consts(a));
+    if (gf::unroll_streams(a, nullptr)) GF_LAUNCH(scope, gf::history_unroll_kernel<true>, (unsigned)blocks, gf::kUnrollBlock, 0, s, *a, gf::unroll_consts(a));
+    else GF_LAUNCH(scope, gf::history_unroll_kernel<false>, (unsigned)blocks, gf::kUnrollBlock, 0, s, *a, gf::unroll_consts(a));
     return gf::launch_status();
 }
