@@ -28,12 +28,25 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword
 // odd-width frame are not 16-byte aligned, the run is.  Units that touch a new-frame column wait for the LDS tile
 // (write_mixed_units).  A batch = kObsShift units per lane, loads first, stores later: the caller puts other work between
 // the two so the lane never sits on an empty queue.
+// `NT`: the non-temporal hint on the loads of the old history and the stores of the new tensor, for outputs no cache keeps from one
+// step to the next (kObsStreamBytes, gf_post_args.h)
+template <bool NT, class T>
+__device__ __forceinline__ T obs_stream_load(const GF_GLOBAL T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, class T>
+__device__ __forceinline__ void obs_stream_store(GF_GLOBAL T* p, const T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 struct HistBatch {
     f32x4u v[kObsShift];
     uint32_t pure;   // bit k: unit k of the batch is a pure history unit of this lane
 };
 // `stride` = lanes that share the run (the whole 256-thread workgroup, or the 192 lanes of the three waves that shift history while
 // the fourth folds rewards in the fused kernel)
+template <bool NT = false>
 __device__ __forceinline__ void hist_load(HistBatch& b, const GF_GLOBAL float* __restrict__ prev, int first, int units, int O, int OH, const FastDiv& dr,
                                           const int stride = kObsBlock) {
     b.pure = 0u;
@@ -47,19 +60,21 @@ __device__ __forceinline__ void hist_load(HistBatch& b, const GF_GLOBAL float* _
         const int e = uu << 2, row = dr.div(e), c = e - row * OH;
         const bool pure = u < units && c >= O && c + 3 < OH;
         b.pure |= pure ? 1u << k : 0u;
-        b.v[k] = *reinterpret_cast<const GF_GLOBAL f32x4u*>(prev + (pure ? e - O : 0));
+        b.v[k] = obs_stream_load<NT>(reinterpret_cast<const GF_GLOBAL f32x4u*>(prev + (pure ? e - O : 0)));
     }
 }
+template <bool NT = false>
 __device__ __forceinline__ void hist_store(const HistBatch& b, GF_GLOBAL float* out, int first, const int stride = kObsBlock, const bool wait = true) {
     if (wait) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), once: every load of the batch has landed, the stores below need no further waits
 #pragma unroll
     for (int k = 0; k < kObsShift; ++k)
-        if ((b.pure >> k) & 1u) *reinterpret_cast<GF_GLOBAL f32x4a*>(out + ((first + k * stride) << 2)) = f32x4a{b.v[k].x, b.v[k].y, b.v[k].z, b.v[k].w};
+        if ((b.pure >> k) & 1u) obs_stream_store<NT>(reinterpret_cast<GF_GLOBAL f32x4a*>(out + ((first + k * stride) << 2)), f32x4a{b.v[k].x, b.v[k].y, b.v[k].z, b.v[k].w});
 }
 
 // … and the units the history batches left: every unit with at least one new-frame column (frame from the LDS tile, the
 // history elements it shares a unit with from `prev`), plus the run's last rows·O·H mod 4 floats.
 // `out2` (optional, wave-uniform): a second destination with the same layout — the rollout-storage row of the RL library (§8f-5)
+template <bool NT = false>
 __device__ __forceinline__ void write_mixed_units(GF_GLOBAL float* __restrict__ out, const GF_GLOBAL float* __restrict__ prev, const float* tile, int S, int rows, int O,
                                                   int OH, int tid, GF_GLOBAL float* __restrict__ out2 = nullptr) {
     const int total = rows * OH, units = total >> 2;
@@ -94,11 +109,11 @@ __device__ __forceinline__ void write_mixed_units(GF_GLOBAL float* __restrict__ 
         }
 #pragma unroll
         for (int b = 0; b < kU; ++b)
-            if (at[b] >= 0) *reinterpret_cast<GF_GLOBAL f32x4a*>(out + at[b]) = v[b];
+            if (at[b] >= 0) obs_stream_store<NT>(reinterpret_cast<GF_GLOBAL f32x4a*>(out + at[b]), v[b]);
         if (out2) {
 #pragma unroll
             for (int b = 0; b < kU; ++b)
-                if (at[b] >= 0) *reinterpret_cast<GF_GLOBAL f32x4a*>(out2 + at[b]) = v[b];
+                if (at[b] >= 0) obs_stream_store<NT>(reinterpret_cast<GF_GLOBAL f32x4a*>(out2 + at[b]), v[b]);
         }
     }
     const int tail = total & 3;

@@ -833,10 +833,18 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         constexpr int kLanes = 3 * kEnvBlock;
         const int lid = (wave == 0 ? 0 : wave - 1) * kEnvBlock + lane;
         HistBatch hb;
-        for (int first = lid; first - lid < units; first += kObsShift * kLanes) {   // wave-uniform trip count
-            hist_load(hb, prev, first, units, O, (int)OH, dr, kLanes);
-            hist_store(hb, out, first, kLanes);
-            if (roll) hist_store(hb, roll, first, kLanes, false);
+        if ((UNI(a.obs_stream) >> m) & 1u) {   // kObsStreamBytes (gf_post_args.h)
+            for (int first = lid; first - lid < units; first += kObsShift * kLanes) {   // wave-uniform trip count
+                hist_load<true>(hb, prev, first, units, O, (int)OH, dr, kLanes);
+                hist_store<true>(hb, out, first, kLanes);
+                if (roll) hist_store<true>(hb, roll, first, kLanes, false);
+            }
+        } else {
+            for (int first = lid; first - lid < units; first += kObsShift * kLanes) {
+                hist_load(hb, prev, first, units, O, (int)OH, dr, kLanes);
+                hist_store(hb, out, first, kLanes);
+                if (roll) hist_store(hb, roll, first, kLanes, false);
+            }
         }
     };
     if constexpr (P::kStatic) {
@@ -948,7 +956,8 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             const bool nt = ((UNI(a.obs_stream) >> m) & 1u) != 0;   // kObsStreamBytes (gf_post_args.h)
             if (flat) {   // the pure history units went out above (hist_early); what touches the new frame comes from the tile
                 const GF_GLOBAL float* prev = G(ob_prev) + n0 * OH;
-                write_mixed_units(out, prev, tile, S, rows, O, (int)OH, t, roll);
+                if (nt) write_mixed_units<true>(out, prev, tile, S, rows, O, (int)OH, t, roll);
+                else write_mixed_units(out, prev, tile, S, rows, O, (int)OH, t, roll);
             } else if ((O & 3) == 0) {
                 const int o4 = O >> 2;
                 const int qstep = kWsBlock / o4, rstep = kWsBlock - qstep * o4;

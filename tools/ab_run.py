@@ -21,6 +21,9 @@ def child(variant, config, steps):
         lib = os.path.join(ROOT, "tools", "_ab", variant, "libgf_step.so")
         _native.lib_path = lambda: lib
     gs.set_device("cuda:0")
+    if os.environ.get("GF_OBS_OUTPUT"):   # "static" / "ring": another output contract than the default
+        from genesis_forge_amd.managers import ObservationManager
+        ObservationManager.default_output = os.environ["GF_OBS_OUTPUT"]
     name, _, size = config.partition("@")   # "go2_cmd@1048576": the config at another size
     if name == "gait_override":   # the gait task with the example's reset() override (tools/bench_reset_override.py)
         n = int(size) if size else 8192
