@@ -808,12 +808,13 @@ def _ring_run(dev, kind, output, n, steps=14):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["go2_hist", "gait"])
-def test_in_place_history_ring_hip(hip_backend, kind):
+@pytest.mark.parametrize("kind,n,steps", [("go2_hist", 1000, 14), ("gait", 1000, 14), ("gait", 65536 + 37, 7)])
+def test_in_place_history_ring_hip(hip_backend, kind, n, steps):
     """The in-place ring through the fused post-physics kernel (interpreter for the noisy Go2 config, the gait static program):
-    only the new frame is written; gathered newest first it equals the default output bit for bit."""
-    want, _ = _ring_run("cuda", kind, "static", 1000)
-    got, env = _ring_run("cuda", kind, "ring", 1000)
+    only the new frame is written; gathered newest first it equals the default output bit for bit.  At 65 573 envs the gait
+    policy history is 81 MB: the in-kernel shift of the static output runs with the streaming hint there (kObsStreamBytes)."""
+    want, _ = _ring_run("cuda", kind, "static", n, steps)
+    got, env = _ring_run("cuda", kind, "ring", n, steps)
     assert env._trace is not None and env._trace.post_refs is not None
     for t, (a, b) in enumerate(zip(want, got)):
         for k, (x, y) in enumerate(zip(a, b)):
