@@ -17,7 +17,10 @@
 namespace gf {
 
 constexpr int kUnrollBlock = 256;
-constexpr int kUnrollUnits = 2;   // 16-byte units per lane in flight (2 / 4 / 8 measured on one box, whole gait step at 65 536 envs: 127.1 / 128.2 / 134.3 µs — profiles/r03_w_ab_unroll.jsonl)
+#ifndef GF_UNROLL_UNITS   // (A/B builds: tools/ab_build.sh)
+#define GF_UNROLL_UNITS 2
+#endif
+constexpr int kUnrollUnits = GF_UNROLL_UNITS;   // 16-byte units per lane in flight (2 / 4 / 8 measured on one box, whole gait step at 65 536 envs: 127.1 / 128.2 / 134.3 µs — profiles/r03_w_ab_unroll.jsonl)
 constexpr int kUnrollChunk = kUnrollBlock * kUnrollUnits * 4;   // floats per workgroup
 
 // Division by the two run-time widths (O·H per row, O per frame) as multiply-shift with magic numbers the HOST computes once per
