@@ -58,8 +58,13 @@ __device__ __forceinline__ int64_t rows_before(int64_t e, const UnrollConsts& c)
 // and writes with the non-temporal hint — nothing of it is found again by the next launch anyway, and without the hint the 200 MB of
 // the gait policy history at 65 536 envs pushed every OTHER kernel's working set out of L2 / MALL each step: the whole gait step
 // went from 129.6 to 114.8 us with it, the same step at 8 192 envs (12 MB ring, re-read from cache every step) from 35.7 to 36.7
-// the other way — hence the size rule (profiles/r03_z_ab_nt.jsonl).
-constexpr int64_t kStreamBytes = (int64_t)64 << 20;
+// the other way — hence the size rule (profiles/r03_z_ab_nt.jsonl; the threshold at 16 MB or 0 instead: 51 MB of gather at 16 384 envs
+// 45.3 -> 47.1 us, 38 MB at 12 288 envs 40.1 -> 41.6, r03_z_ab_gather_units_threshold.jsonl — which also re-checks the units per lane
+// with the hint on: 1 / 2 / 4 / 8 = 112.7 / 112.5 / 114.8 / 119.1 us).
+#ifndef GF_STREAM_MB   // (A/B builds)
+#define GF_STREAM_MB 64
+#endif
+constexpr int64_t kStreamBytes = (int64_t)GF_STREAM_MB << 20;
 template <bool NT, class T>
 __device__ __forceinline__ T stream_load(const GF_GLOBAL T* p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
