@@ -134,13 +134,13 @@ def test_compiled_program_equals_oracle_hip(hip_backend, oracle_lib_path, signat
     if signatures[seed].startswith("program 0 "):
         assert info["program"] is not None and "plugin" in info["program"], info["program"]
         now = hip_backend.post_describe(info["post_refs"])
-        assert re.match(r"program 1\d\d \(jit_", now), now[:60]
+        assert re.match(r"program [1-3]\d\d \(jit_", now), now[:60]
     tr = info["env"]._trace
     if tr is not None and tr.tail_seg.get("obs", {}).get("fused_obs"):
         # a reset() override: the observation-only launch of the tail has a structure of its own — and a program of its own
         tail = info["env"]._program_info_tail
         assert tail is not None and "plugin" in tail, tail
-        assert re.match(r"program 1\d\d \(jit_", hip_backend.post_describe(tr._tail_refs))
+        assert re.match(r"program [1-3]\d\d \(jit_", hip_backend.post_describe(tr._tail_refs))
     monkeypatch.setenv("GF_JIT", "off")
     gs.set_device("cpu")
     nat.set_backend(OracleBackend(oracle_lib_path))
