@@ -141,26 +141,50 @@ __device__ __forceinline__ void synth_link_one(const GfSynthSceneArgs& a, const 
 
 // Sampled contact of slot c of env n (flat index k = n·C + c): 32 B of output per lane, coalesced.  The second Philox block only
 // feeds the z force of an ACTIVE slot; an empty slot's outputs are constants, so it is skipped for waves without an active slot.
+// foot_link_mask != 0 selects the walking model (gf_step.h, GfSynthSceneArgs): the k-th foot owns slot k and touches the ground in
+// the stance half of a 20-tick trot cycle; the ground sits on side a or side b of a contact at random.
 __device__ __forceinline__ void synth_contact_one(const GfSynthSceneArgs& a, const int64_t k, const uint32_t genv, const int c, const float p0, const float p1) {
     const int NL = a.num_scene_links;
     const uint32_t col = (uint32_t)(8 + 8 * c);
     // columns col..col+3 share one Philox block, col+4 starts the next
     const U4 r0 = philox4x32_10(genv, col >> 2, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
     const float u_act = u24_to_unit(r0.x), u_link = u24_to_unit(r0.y);
-    const bool active = u_act < a.contact_prob;
+    const uint32_t feet = a.foot_link_mask;
+    bool active = u_act < a.contact_prob;
+    int lb = 1 + (int)(u_link * (float)(NL - 1));
+    bool robot_on_a = false;
+    if (feet) {
+        const int n_feet = __builtin_popcount(feet);
+        if (c < n_feet) {
+            uint32_t m = feet;
+            for (int j = 0; j < c; ++j) m &= m - 1u;
+            lb = __builtin_ctz(m);
+            const uint32_t ph = ((uint32_t)a.tick + genv * 7u) % 20u;
+            const bool pair_a = ((c ^ (c >> 1)) & 1) == 0;
+            const bool stance = pair_a ? ph < 10u : ph >= 10u;
+            const float p = stance ? fminf(1.8f * a.foot_contact_prob, 1.0f) : 0.2f * a.foot_contact_prob;
+            active = u_act < p;
+            robot_on_a = u_link < 0.5f;
+        } else {
+            const int kk = (int)(u_link * (float)(2 * (NL - 1)));
+            lb = 1 + (kk >> 1);
+            robot_on_a = (kk & 1) != 0;
+        }
+    }
     float fz = 0.0f;
     if (active) {
         const U4 r1 = philox4x32_10(genv, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
         fz = u24_to_unit(r1.x);
     }
     const float fx = u24_to_unit(r0.z) * 2.0f - 1.0f, fy = u24_to_unit(r0.w) * 2.0f - 1.0f;
-    int lb = 1 + (int)(u_link * (float)(NL - 1));
     if (lb > NL - 1) lb = NL - 1;
-    a.link_a_out[k] = active ? 0 : -1;
-    a.link_b_out[k] = active ? lb : -1;
-    a.contact_force_out[k * 3 + 0] = active ? fx * a.contact_force * 0.25f : 0.0f;
-    a.contact_force_out[k * 3 + 1] = active ? fy * a.contact_force * 0.25f : 0.0f;
-    a.contact_force_out[k * 3 + 2] = active ? fz * a.contact_force : 0.0f;
+    // the stored force is the force on link_b: with the robot link on side a it is the reaction
+    const float sx = fx * a.contact_force * 0.25f, sy = fy * a.contact_force * 0.25f, sz = fz * a.contact_force;
+    a.link_a_out[k] = active ? (robot_on_a ? lb : 0) : -1;
+    a.link_b_out[k] = active ? (robot_on_a ? 0 : lb) : -1;
+    a.contact_force_out[k * 3 + 0] = active ? (robot_on_a ? -sx : sx) : 0.0f;
+    a.contact_force_out[k * 3 + 1] = active ? (robot_on_a ? -sy : sy) : 0.0f;
+    a.contact_force_out[k * 3 + 2] = active ? (robot_on_a ? -sz : sz) : 0.0f;
     a.contact_pos_out[k * 3 + 0] = active ? p0 + fx * 0.2f : 0.0f;
     a.contact_pos_out[k * 3 + 1] = active ? p1 + fy * 0.2f : 0.0f;
     a.contact_pos_out[k * 3 + 2] = 0.0f;

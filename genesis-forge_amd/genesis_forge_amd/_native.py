@@ -212,11 +212,11 @@ class GfRotateArgs(C.Structure):
 class GfSynthSceneArgs(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_dofs", C.c_int32), ("num_contacts", C.c_int32), ("num_scene_links", C.c_int32),
                 ("dt", C.c_float), ("joint_rate", C.c_float), ("ang_noise", C.c_float), ("lin_noise", C.c_float),
-                ("height_target", C.c_float), ("contact_prob", C.c_float), ("contact_force", C.c_float), ("_padf", C.c_float),
+                ("height_target", C.c_float), ("contact_prob", C.c_float), ("contact_force", C.c_float), ("foot_contact_prob", C.c_float),
                 ("targets", P), ("pos", P), ("quat", P), ("lin_vel", P), ("ang_vel", P), ("dof_pos", P), ("dof_vel", P),
                 ("contact_force_out", P), ("contact_pos_out", P), ("link_a_out", P), ("link_b_out", P),
                 ("links_quat_out", P), ("links_vel_out", P), ("links_pos_out", P), ("seed", C.c_uint64), ("tick", C.c_uint64),
-                ("env_offset", C.c_uint32), ("_pad2", C.c_uint32)]
+                ("env_offset", C.c_uint32), ("foot_link_mask", C.c_uint32)]
 
 
 class GfOp(C.Structure):

@@ -395,7 +395,7 @@ class SyntheticScene:
 
     def __init__(self, dt: float = 0.02, substeps: int = 2, max_collision_pairs: int = 0, seed: int = 1234,
                  joint_rate: float = 10.0, ang_noise: float = 0.05, lin_noise: float = 0.05, height_target: Optional[float] = None,
-                 contact_prob: float = 0.15, contact_force: float = 40.0, **_ignored):
+                 contact_prob: float = 0.15, contact_force: float = 40.0, foot_links=None, foot_contact_prob: float = 0.5, **_ignored):
         self.dt = dt
         self.substeps = substeps
         self.n_contacts = int(max_collision_pairs)
@@ -403,6 +403,11 @@ class SyntheticScene:
         self.joint_rate, self.ang_noise, self.lin_noise = joint_rate, ang_noise, lin_noise
         self.height_target = height_target
         self.contact_prob, self.contact_force_scale = contact_prob, contact_force
+        # walking contact model (GfSynthSceneArgs.foot_link_mask): `foot_links` = regular expressions over the robot's link names;
+        # the matching links touch the ground in a trot pattern, `contact_prob` is then the density of the other (body) contacts
+        self.foot_links = [foot_links] if isinstance(foot_links, str) else list(foot_links or [])
+        self.foot_contact_prob = foot_contact_prob
+        self._foot_mask = 0
         self.entities: list = []
         self.robot: Optional[SyntheticEntity] = None
         self._n_links = 0
@@ -458,6 +463,17 @@ class SyntheticScene:
         self.links_pos_all = torch.zeros(n_envs, max(self._n_links, 1), 3, device=dev)
         import numpy as _np
         self.envs_offset = _np.zeros((n_envs, 3), dtype=_np.float32)  # gs.Scene.envs_offset (viewer placement; velocity_command.py:244)
+        if self.foot_links and self.robot is not None:
+            import re
+            for l in self.robot.links:
+                if any(re.fullmatch(pat, l.name) for pat in self.foot_links):
+                    if l.idx >= 32:
+                        raise ValueError("foot_links: scene link index beyond the 32-bit foot mask")
+                    self._foot_mask |= 1 << l.idx
+            if not self._foot_mask:
+                raise ValueError(f"foot_links {self.foot_links} match no link of the robot")
+            if bin(self._foot_mask).count("1") > self.n_contacts:
+                raise ValueError("foot_links: more feet than contact slots (max_collision_pairs)")
         self.is_built = True
 
     # -- solver surface -------------------------------------------------------------------------------
@@ -477,6 +493,7 @@ class SyntheticScene:
         a.dt, a.joint_rate, a.ang_noise, a.lin_noise = self.dt, self.joint_rate, self.ang_noise, self.lin_noise
         a.height_target = r.init_pos[2] if self.height_target is None else self.height_target
         a.contact_prob, a.contact_force = self.contact_prob, self.contact_force_scale
+        a.foot_contact_prob, a.foot_link_mask = self.foot_contact_prob, self._foot_mask
         a.targets = r._targets.data_ptr()
         a.pos, a.quat, a.lin_vel, a.ang_vel = r.pos.data_ptr(), r.quat.data_ptr(), r.lin_vel.data_ptr(), r.ang_vel.data_ptr()
         a.dof_pos, a.dof_vel = r.dof_pos.data_ptr(), r.dof_vel.data_ptr()

@@ -491,12 +491,20 @@ class Go2RoughTerrainEnv(ManagedEnvironment):
 # ----------------------------------------------------------------------------------------------------------------------------
 # The workloads that get TIMED (bench.py: "go2_cmd"; tools/bench_configs.py: all of them).  tests/test_bench_parity.py walks the
 # same table and compares every one of them with the oracle at the size it is timed at.
-# Stand-in physics settings: small attitude noise (about 0.2 % of the envs fall over per step) and, where a config terminates
-# on body / torso contact, a contact density that resets 0.3-0.5 % of the envs per step (episodes of a few hundred steps) - a
-# scene that reset several per cent of its envs every step would time the reset path, not the step.
+# Stand-in physics settings: small attitude noise (about 0.2 % of the envs fall over per step; SURVEY.md §8d's input spec would
+# reset 2-8 % per step, which times the reset path rather than the step) and, for the configs with ContactManagers, the WALKING
+# contact model of the synthetic scene (GfSynthSceneArgs.foot_link_mask): the links the config's foot ContactManager tracks touch
+# the ground in a trot pattern — two to four feet of a quadruped (one or two of a biped) per tick, the ground on either side of the
+# contact pair, so the Taichi kernel's matching branches (managers/contact/kernel.py:47-78), the air-time bookkeeping and
+# feet_air_time (mdp/rewards.py:431-469) do real work every step — while body contacts (base / torso / thigh / calf) stay rare
+# enough that the configs that terminate on them reset 0.3-0.5 % of the envs per step (episodes of a few hundred steps).
 # ----------------------------------------------------------------------------------------------------------------------------
 _SC = dict(ang_noise=0.05, seed=1234)
 _CON = dict(_SC, contact_prob=0.15, contact_force=40.0)
+
+
+def _walk(foot_links, body_prob, **kw):
+    return dict(_SC, contact_force=40.0, foot_links=foot_links, foot_contact_prob=0.5, contact_prob=body_prob, **kw)
 
 
 def bench_env(num_envs: int, **kw):
@@ -509,19 +517,19 @@ BASELINE_CONFIGS = {
     "simple": (4096, lambda n, **kw: Go2SimpleEnv(num_envs=n, scene_kwargs=dict(_SC), **kw)),
     "go2_cmd": (4096, lambda n, **kw: bench_env(n, **kw)),
     "go2_cmd_65536": (65536, lambda n, **kw: bench_env(n, **kw)),
-    "contacts": (4096, lambda n, **kw: Go2ContactsEnv(num_envs=n, scene_kwargs=dict(_CON), **kw)),
+    "contacts": (4096, lambda n, **kw: Go2ContactsEnv(num_envs=n, scene_kwargs=_walk(".*_calf", 0.01), **kw)),
     "rough_terrain": (16384, lambda n, **kw: Go2RoughTerrainEnv(num_envs=n, height_reward=False,
-                                                               scene_kwargs=dict(_CON, max_collision_pairs=30), **kw)),
-    "humanoid": (8192, lambda n, **kw: BerkeleyHumanoidEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.002, max_collision_pairs=30), **kw)),
+                                                               scene_kwargs=_walk(".*_calf", 0.01, max_collision_pairs=30), **kw)),
+    "humanoid": (8192, lambda n, **kw: BerkeleyHumanoidEnv(num_envs=n, scene_kwargs=_walk(".*_faa", 0.002, max_collision_pairs=30), **kw)),
     # BASELINE config 4 as stated ("~28-DOF"): the same kind of manager stack over a synthetic 28-joint humanoid (the reference's
     # berkeley_humanoid example, "humanoid" above, has 12 actuated joints)
     "humanoid28": (8192, lambda n, **kw: HumanoidGaitLikeEnv(num_envs=n, dofs=28, **kw)),
-    "gait": (65536, lambda n, **kw: Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.001), **kw)),
+    "gait": (65536, lambda n, **kw: Go2GaitTrainingEnv(num_envs=n, scene_kwargs=_walk(".*_foot", 0.001), **kw)),
     # a USER's config: the Go2 task with observation noise — a structure none of the library's built-in programs has, so its fused
     # launch runs the program compiled for it at run time (genesis_forge_amd/_programs.py; GF_JIT) instead of the interpreter
     "go2_user": (65536, lambda n, **kw: bench_env(n, obs_noise=True, **kw)),
-    "gait_8192": (8192, lambda n, **kw: Go2GaitTrainingEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.001), **kw)),
+    "gait_8192": (8192, lambda n, **kw: Go2GaitTrainingEnv(num_envs=n, scene_kwargs=_walk(".*_foot", 0.001), **kw)),
     # the gait example AS SHIPPED: with its reset() override (curriculum hook, examples/gait_trainer/environment.py:347-352) — the reset
     # runs through user code by index list; what is recorded around it: GF_POST_NO_RESET in front, GF_POST_OBSERVE_ONLY behind
-    "gait_override_8192": (8192, lambda n, **kw: Go2GaitTrainingCurriculumEnv(num_envs=n, scene_kwargs=dict(_CON, contact_prob=0.001), **kw)),
+    "gait_override_8192": (8192, lambda n, **kw: Go2GaitTrainingCurriculumEnv(num_envs=n, scene_kwargs=_walk(".*_foot", 0.001), **kw)),
 }

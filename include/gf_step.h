@@ -544,9 +544,9 @@ typedef struct GfSynthSceneArgs {
     float ang_noise;          /* rad/s per tick */
     float lin_noise;          /* m/s per tick */
     float height_target;
-    float contact_prob;       /* per slot */
+    float contact_prob;       /* per slot (walking model: per BODY slot) */
     float contact_force;      /* force scale */
-    float _padf;
+    float foot_contact_prob;  /* walking model (foot_link_mask != 0): mean per-tick probability that a foot touches the ground */
     const float* targets;     /* [N,D] PD targets written by phase A */
     float* pos;               /* [N,3] in/out */
     float* quat;              /* [N,4] in/out */
@@ -564,7 +564,16 @@ typedef struct GfSynthSceneArgs {
     uint64_t seed;
     uint64_t tick;
     uint32_t env_offset;      /* global index of local env 0 */
-    uint32_t _pad2;
+    /* Walking contact model.  0: every slot is an independent (ground, random robot link) contact with probability contact_prob.
+     * Otherwise bit l marks scene link l (< 32) as a FOOT: the k-th foot owns slot k — its contact with the ground, made with
+     * probability min(1, 1.8 p) while the foot is in the stance half of a 20-tick trot cycle (diagonal pairs alternate, the
+     * cycle offset differs per env) and 0.2 p in the swing half, p = foot_contact_prob: two to four feet of a quadruped on the
+     * ground every tick, as the reference's foot ContactManager / feet_air_time / the Taichi kernel's matching branch expect
+     * (examples/gait_trainer/environment.py:140-153, mdp/rewards.py:431-469, managers/contact/kernel.py:47-78).  The remaining
+     * slots are body contacts as before (probability contact_prob, any robot link).  Every contact puts the ground on side a or
+     * side b at random (force stored as the force on link_b, so it is negated when the robot link is link_a): both branches of
+     * kernel.py:74-78 run. */
+    uint32_t foot_link_mask;
 } GfSynthSceneArgs;
 
 /* ------------------------------------------------------------------------------------------

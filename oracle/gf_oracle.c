@@ -1060,15 +1060,38 @@ GFO_EXPORT int gfo_synth_scene_step(const GfSynthSceneArgs* a) {
                 const float fx = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 2) * 2.0f - 1.0f;
                 const float fy = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 3) * 2.0f - 1.0f;
                 const float fz = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 4);
-                const int active = u_act < a->contact_prob;
+                int active = u_act < a->contact_prob;
                 const int64_t k = n * C + c;
                 int32_t lb = 1 + (int32_t)(u_link * (float)(NL - 1));
+                int robot_on_a = 0;
+                if (a->foot_link_mask) {   /* walking model (gf_step.h, GfSynthSceneArgs.foot_link_mask) */
+                    const uint32_t feet = a->foot_link_mask, genv = (uint32_t)n + a->env_offset;
+                    int n_feet = 0;
+                    for (uint32_t m = feet; m; m &= m - 1u) ++n_feet;
+                    if (c < n_feet) {
+                        uint32_t m = feet;
+                        for (int64_t j = 0; j < c; ++j) m &= m - 1u;
+                        lb = 0;
+                        while (!((m >> lb) & 1u)) ++lb;
+                        const uint32_t ph = ((uint32_t)a->tick + genv * 7u) % 20u;
+                        const int pair_a = (((int)c ^ ((int)c >> 1)) & 1) == 0;
+                        const int stance = pair_a ? ph < 10u : ph >= 10u;
+                        const float pr = stance ? fminf(1.8f * a->foot_contact_prob, 1.0f) : 0.2f * a->foot_contact_prob;
+                        active = u_act < pr;
+                        robot_on_a = u_link < 0.5f;
+                    } else {
+                        const int32_t kk = (int32_t)(u_link * (float)(2 * (NL - 1)));
+                        lb = 1 + (kk >> 1);
+                        robot_on_a = (kk & 1) != 0;
+                    }
+                }
                 if (lb > (int32_t)NL - 1) lb = (int32_t)NL - 1;
-                a->link_a_out[k] = active ? 0 : -1;
-                a->link_b_out[k] = active ? lb : -1;
-                a->contact_force_out[k * 3 + 0] = active ? fx * a->contact_force * 0.25f : 0.0f;
-                a->contact_force_out[k * 3 + 1] = active ? fy * a->contact_force * 0.25f : 0.0f;
-                a->contact_force_out[k * 3 + 2] = active ? fz * a->contact_force : 0.0f;
+                const float sx = fx * a->contact_force * 0.25f, sy = fy * a->contact_force * 0.25f, sz = fz * a->contact_force;
+                a->link_a_out[k] = active ? (robot_on_a ? lb : 0) : -1;
+                a->link_b_out[k] = active ? (robot_on_a ? 0 : lb) : -1;
+                a->contact_force_out[k * 3 + 0] = active ? (robot_on_a ? -sx : sx) : 0.0f;
+                a->contact_force_out[k * 3 + 1] = active ? (robot_on_a ? -sy : sy) : 0.0f;
+                a->contact_force_out[k * 3 + 2] = active ? (robot_on_a ? -sz : sz) : 0.0f;
                 a->contact_pos_out[k * 3 + 0] = active ? p[0] + fx * 0.2f : 0.0f;
                 a->contact_pos_out[k * 3 + 1] = active ? p[1] + fy * 0.2f : 0.0f;
                 a->contact_pos_out[k * 3 + 2] = 0.0f;
