@@ -1,15 +1,17 @@
 // gf_api.hip — library-level entry points: version, error strings, stats clear, opt-in
 // HIP-event profiling around the kernel of one phase (used by bench.py for roofline.achieved).
+#include <cstdlib>
 #include <vector>
 
 #include "gf_launch.h"
 
 namespace gf {
-int g_options[GF_OPT_COUNT] = {2, 0, 0, 1};
+int g_options[GF_OPT_COUNT] = {2, 0, 0, 1, getenv("GF_NO_CONTACT_FOLD") ? 0 : 1};
 Profiler g_prof;
 thread_local LaunchSink g_sink;
 bool contact_compatible(const GfContactArgs* x, const GfContactArgs* y);          // gf_contact.hip
 int contact_launch(const GfContactArgs* const* mgrs, int num, hipStream_t s);
+int post_step(const GfPostRefs* r, const GfContactArgs* const* mgrs, int num_mgr, hipStream_t s);   // gf_post.hip
 int chain_a_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc, DeferredFlags* deferred);   // gf_chain.hip
 int chain_b_try(const GfOp* ops, int i, int num_ops, hipStream_t s, int* rc, DeferredFlags* deferred);
 int gait_launch(const GfGaitArgs* a, hipStream_t s, bool flags_all);                                      // gf_gait.hip
@@ -261,6 +263,12 @@ GF_EXPORT int gf_run_ops(const GfOp* ops, int num_ops, void* stream, int* failed
                     if (!gf::contact_compatible(run[0], nx) || links + nx->num_targets > 64) break;
                     links += nx->num_targets;
                     run[cnt++] = nx;
+                }
+                // … and when the fused post-physics launch follows them, its first phase (the same 64-env tiles, one launch less)
+                if (run[0] && i + cnt < num_ops && ops[i + cnt].phase == GF_OP_POST_PHYSICS && ops[i + cnt].args) {
+                    rc = gf::post_step((const GfPostRefs*)ops[i + cnt].args, run, cnt, s);
+                    if (rc == GF_OK) { i += cnt; break; }
+                    if (rc != GF_E_UNSUPPORTED) { i += cnt; break; }   // (a real failure belongs to the post-physics op)
                 }
                 rc = gf::contact_launch(run, cnt, s);
                 if (rc == GF_OK) i += cnt - 1;

@@ -966,6 +966,80 @@ static int pack(const GfPostRefs* r, Packer& pk) {
     return GF_OK;
 }
 
+
+// ---- the scene's ContactManagers in front of the other phases, in the same launch (GfPostArgs.cfold) ------------------------------
+int validate_contact(const GfContactArgs* a);                                   // gf_contact.hip
+bool contact_compatible(const GfContactArgs* x, const GfContactArgs* y);
+ContactMgrL contact_mgr_image(const GfContactArgs* a);
+
+// GF_OK: pk.a.cfold describes the managers and the launch runs their step first; GF_E_UNSUPPORTED: the caller launches the contact
+// kernel itself (more than 32 tracked links / 16 with-filter links / 255 scene links, slot rows that do not fit the tile's LDS,
+// a statistics block other than the step's, an observation-only launch, GF_OPT_FOLD_CONTACT = 0).
+static int fold_contacts(Packer& pk, const GfContactArgs* const* mgrs, int num) {
+    GfPostArgs& a = pk.a;
+    UNSUP(!g_options[GF_OPT_FOLD_CONTACT] || g_options[GF_OPT_POST_VARIANT] == 0);
+    UNSUP(num < 1 || num > kFoldMaxMgr || a.obs_only);
+    PostContact& f = a.cfold;
+    int total = 0;
+    for (int m = 0; m < num; ++m) {
+        const GfContactArgs* c = mgrs[m];
+        const int rc = validate_contact(c);
+        if (rc) return rc;
+        UNSUP(m > 0 && !contact_compatible(mgrs[0], c));
+        UNSUP(c->num_envs != a.num_envs || c->num_contacts < 1 || c->num_scene_links > 255);
+        UNSUP(total + c->num_targets > kFoldMaxTargets || c->num_with > kFoldMaxWith);
+        UNSUP(c->stats && c->stats != a.stats);
+        const ContactMgrL l = contact_mgr_image(c);
+        PostContactMgr& o = f.m[m];
+        o.contacts = l.contacts; o.contact_positions = l.contact_positions; o.position_counts = l.position_counts;
+        o.link_vel_out = l.link_vel_out; o.link_pos_out = l.link_pos_out;
+        o.last_air_time = l.last_air_time; o.current_air_time = l.current_air_time;
+        o.last_contact_time = l.last_contact_time; o.current_contact_time = l.current_contact_time;
+        o.air_time_threshold = l.air_time_threshold;
+        o.num_targets = (uint8_t)l.num_targets; o.num_with = (uint8_t)l.num_with;
+        o.has_with_filter = l.has_with_filter ? 1 : 0; o.track_air_time = l.track_air_time ? 1 : 0;
+        for (int w = 0; w < c->num_with; ++w) {
+            UNSUP(c->with_link_ids[w] < 0 || c->with_link_ids[w] > 254);
+            o.with_ids[w] = (uint8_t)c->with_link_ids[w];
+        }
+        for (int t = 0; t < c->num_targets; ++t) {
+            UNSUP(c->target_link_ids[t] < 0 || c->target_link_ids[t] > 254);
+            f.target_ids[total] = (uint8_t)c->target_link_ids[t];
+            f.mgr_of[total] = (uint8_t)m;
+            f.local_of[total] = (uint8_t)t;
+            ++total;
+        }
+    }
+    const GfContactArgs* c0 = mgrs[0];
+    UNSUP(fold_lds_bytes(c0->num_contacts) + sizeof(GfPostArgs) > 60 * 1024);
+    // Measured (profiles/r04_i_configs_fold*.jsonl, one box, GF_NO_CONTACT_FOLD A/B): the fold takes 1.6-3.4 us off a step whenever the
+    // tile's tracked links are at most three passes of the 256 lanes (contacts, rough terrain, humanoid: 4 / 9 / 3 links) and 9 us off
+    // the gait task (13 links, four passes) at 65 536 envs — but ADDS 1.7 us to the gait task at 8 192 envs, where 128 tiles of 64
+    // envs occupy half of the chip and a launch of its own spreads the same pairs over 512 small workgroups.  GF_OPT_FOLD_CONTACT = 2
+    // folds regardless.
+    UNSUP(g_options[GF_OPT_FOLD_CONTACT] != 2 && (total * kEnvBlock + kWsBlock - 1) / kWsBlock >= 4 && a.num_envs < 16384);
+    f.force = c0->force; f.position = c0->position; f.links_quat = c0->links_quat; f.links_vel = c0->links_vel; f.links_pos = c0->links_pos;
+    f.link_a = c0->link_a; f.link_b = c0->link_b;
+    f.num_contacts = c0->num_contacts; f.num_scene_links = c0->num_scene_links; f.num_mgr = num; f.total_targets = total;
+    f.dt = c0->dt;
+    return GF_OK;
+}
+
+static int post_launch(const GfPostArgs& a, hipStream_t s);
+bool post_program_folds(const GfPostArgs& a);   // the kernel this descriptor selects carries the contact phase
+
+int post_step(const GfPostRefs* r, const GfContactArgs* const* mgrs, int num_mgr, hipStream_t s) {
+    Packer pk;
+    int rc = pack(r, pk);
+    if (rc) return rc;
+    if (num_mgr > 0) {
+        UNSUP(!post_program_folds(pk.a));
+        rc = fold_contacts(pk, mgrs, num_mgr);
+        if (rc) return rc;
+    }
+    return post_launch(pk.a, s);
+}
+
 }  // namespace gf
 
 extern "C" __attribute__((visibility("default"))) int gf_post_physics_check(const GfPostRefs* r) {
@@ -988,6 +1062,7 @@ struct DynProgram {
     int (*matches)(const gf::GfPostArgs*);
     const void* kernel;
     size_t (*lds_bytes)(int, int);
+    bool folds;   // gfp_folds(): the plugin's kernel carries the contact phase (ws_prog_folds<P>)
 };
 DynProgram g_dyn[kDynMax];
 std::atomic<int> g_dyn_count{0};
@@ -1024,6 +1099,8 @@ extern "C" __attribute__((visibility("default"))) int gf_post_program_register(c
     d.matches = mt;
     d.kernel = kn();
     d.lds_bytes = ld;
+    auto fo = (int (*)(void))dlsym(dl, "gfp_folds");
+    d.folds = fo && fo() != 0;
     g_dyn_count.store(n + 1);
     if (id_out) *id_out = kDynBase + n;
     return GF_OK;
@@ -1049,6 +1126,16 @@ static int select_program(const gf::GfPostArgs& a) {
     return 0;
 }
 
+bool gf::post_program_folds(const gf::GfPostArgs& a) {
+    const int id = select_program(a);
+    if (id >= kDynBase) return g_dyn[id - kDynBase].folds;
+#define GF_FOLDS(pid, P) \
+    if (id == pid) return gf::ws_prog_folds<P>();
+    GF_POST_PROGRAMS(GF_FOLDS)
+#undef GF_FOLDS
+    return true;   // the table interpreter
+}
+
 extern "C" __attribute__((visibility("default"))) int gf_post_physics_describe(const GfPostRefs* r, char* buf, int cap) {
     gf::Packer pk;
     const int rc = gf::pack(r, pk);
@@ -1066,19 +1153,21 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_describe(c
     return GF_OK;
 }
 
-extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const GfPostRefs* r, void* stream) {
-    gf::Packer pk;
-    const int rc = gf::pack(r, pk);
-    if (rc) return rc;
+int gf::post_launch(const gf::GfPostArgs& packed, hipStream_t s) {
 #ifdef GF_STAMPS
-    pk.a.stamps = gf_debug_stamps;
-    pk.a.stamp_block = (uint32_t)(pk.a.num_envs / 64 / 2);
+    gf::GfPostArgs stamped = packed;
+    stamped.stamps = gf_debug_stamps;
+    stamped.stamp_block = (uint32_t)(packed.num_envs / 64 / 2);
+    const gf::GfPostArgs& a = stamped;
+#else
+    const gf::GfPostArgs& a = packed;
 #endif
-    const gf::GfPostArgs& a = pk.a;
     int omax = 0;
     for (int m = 0; m < a.n_obs; ++m) omax = a.obs[m].width > omax ? a.obs[m].width : omax;
     const size_t lds = sizeof(gf::GfPostArgs) + ((size_t)(gf::kPostMaxReward + gf::kPostAuxRows) * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock) * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
+    // a folded contact phase stages the tile's slot ids in the LDS the later phases use (behind the interpreter's descriptor copy)
+    const size_t fold_lds = a.cfold.num_mgr > 0 ? gf::fold_lds_bytes(a.cfold.num_contacts) : 0;
+    auto with_fold = [&](size_t bytes, bool interp) { const size_t need = fold_lds ? fold_lds + (interp ? sizeof(gf::GfPostArgs) : 0) : 0; return bytes > need ? bytes : need; };
     const unsigned grid = gf::env_grid(a.num_envs);
     gf::PhaseScope scope(GF_PHASE_POST, s);
     bool any_ring = false;
@@ -1090,7 +1179,7 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
     } else if (const int prog = select_program(a); prog >= kDynBase) {
         // a program compiled at run time: the plugin's kernel handle, launched like any other (launch sink, dispatch events)
         const DynProgram& d = g_dyn[prog - kDynBase];
-        const size_t lds_dyn = d.lds_bytes(omax, a.n_gait);
+        const size_t lds_dyn = with_fold(d.lds_bytes(omax, a.n_gait), false);
         void* kargs[1] = {const_cast<gf::GfPostArgs*>(&a)};
         if (scope.active()) {
             scope.use_dispatch_events();
@@ -1100,14 +1189,14 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
         }
     } else if (prog) {
 #define GF_RUN(id, P) \
-        if (prog == id) GF_LAUNCH(scope, gf::post_ws_kernel<P>, grid, gf::kWsBlock, lds_ws_floats<P>(omax, a.n_gait) * sizeof(float), s, a);
+        if (prog == id) GF_LAUNCH(scope, gf::post_ws_kernel<P>, grid, gf::kWsBlock, with_fold(lds_ws_floats<P>(omax, a.n_gait) * sizeof(float), false), s, a);
         GF_POST_PROGRAMS(GF_RUN)
 #undef GF_RUN
     } else {
 #define GF_RUN_INTERP_T(DV_, T_)                                                                                              \
         do {                                                                                                                  \
             using Var = gf::Interp<DV_, T_>;                                                                                  \
-            const size_t lds_var = sizeof(gf::GfPostArgs) + lds_ws_floats<Var>(omax, a.n_gait) * sizeof(float);               \
+            const size_t lds_var = with_fold(sizeof(gf::GfPostArgs) + lds_ws_floats<Var>(omax, a.n_gait) * sizeof(float), true); \
             GF_LAUNCH(scope, gf::post_ws_kernel<Var>, grid, gf::kWsBlock, lds_var, s, a);                                     \
         } while (0)
 #define GF_RUN_INTERP(DV_) \
@@ -1128,4 +1217,14 @@ extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const
 #undef GF_RUN_INTERP
     }
     return gf::launch_status();
+}
+
+extern "C" __attribute__((visibility("default"))) int gf_post_physics_step(const GfPostRefs* r, void* stream) {
+    return gf::post_step(r, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int gf_post_physics_step_contacts(const GfPostRefs* r, const GfContactArgs* const* contacts, int num_contacts,
+                                                                                   void* stream) {
+    if (num_contacts < 0 || (num_contacts > 0 && !contacts)) return GF_E_NULL;
+    return gf::post_step(r, contacts, num_contacts, (hipStream_t)stream);
 }

@@ -4,6 +4,7 @@
 
 #include "gf_launch.h"
 #include "gf_terms.h"
+#include "gf_contact_tile.h"
 
 // Diagnostic build only (tools/stamp_post.hip, -DGF_STAMPS): lane 0 of one workgroup records the 100 MHz wall
 // clock at the phase boundaries into a buffer of its own; no product build contains a stamp.
@@ -79,6 +80,37 @@ struct PostObs {
 // 1 048 576 envs 229 -> 212 us with the hint; at 65 536 envs, 12.6 MB, no difference — profiles/r03_z_ab_nt.jsonl).
 constexpr int64_t kObsStreamBytes = (int64_t)64 << 20;
 
+// The scene's ContactManagers stepped IN FRONT of the other phases by the same launch (SURVEY.md §8f-1 ∘ §8f-2;
+// managed_env.py:294-326 runs contact.step, termination, reward … back to back per env, contact_manager.py:384-477): a compact
+// image of up to four GfContactArgs over the same scene arrays.  num_mgr == 0: the contact phase ran as a launch of its own (or the
+// config has no ContactManager).  Link ids travel as bytes (a scene with more than 255 links keeps the stand-alone launch).
+constexpr int kFoldMaxMgr = 4;
+constexpr int kFoldMaxTargets = 32;   // tracked links over all folded managers
+constexpr int kFoldMaxWith = 16;      // with-filter links per manager
+struct PostContactMgr {
+    float *contacts, *contact_positions, *position_counts, *link_vel_out, *link_pos_out;
+    float *last_air_time, *current_air_time, *last_contact_time, *current_contact_time;
+    float air_time_threshold;
+    uint8_t num_targets, num_with, has_with_filter, track_air_time;
+    uint8_t with_ids[kFoldMaxWith];
+};
+static_assert(sizeof(PostContactMgr) == 96 && offsetof(PostContactMgr, air_time_threshold) == 72, "the kernel reads this image word by word");
+struct PostContact {
+    const float *force, *position, *links_quat, *links_vel, *links_pos;
+    const int32_t *link_a, *link_b;
+    int32_t num_contacts, num_scene_links, num_mgr, total_targets;
+    float dt;
+    int32_t _pad;
+    uint8_t target_ids[kFoldMaxTargets], mgr_of[kFoldMaxTargets], local_of[kFoldMaxTargets];
+    PostContactMgr m[kFoldMaxMgr];
+};
+// LDS of the contact phase, in 32-bit words: the tables the lanes index (manager images, tracked-link table, with-filter lists),
+// then the tile's slot ids and occupancy masks (gf_contact_tile.h).  It aliases the LDS of the phases behind it.
+constexpr int kFoldTableWords = kFoldMaxMgr * kContactMgrWords + kFoldMaxTargets + kFoldMaxTargets / 2 + kFoldMaxMgr * GF_MAX_LINK_IDS;
+static_assert(kFoldTableWords % 4 == 0, "the slot-id rows behind the tables are read and written as 16-byte units");
+// (+ one scratch row per wave: the target of the contact phase's cache warm-up requests)
+__host__ __device__ constexpr size_t fold_lds_bytes(int C) { return (size_t)(kFoldTableWords + contact_lds_ints(kEnvBlock, C) + 4 * kEnvBlock) * 4; }
+
 struct alignas(16) GfPostArgs {
     int32_t num_envs, num_dofs, num_term, num_rew;
     uint32_t needs;
@@ -138,6 +170,7 @@ struct alignas(16) GfPostArgs {
     GfTerm rterms[kPostMaxReward];
     PostCmd cmds[GF_POST_MAX_CMD];
     PostObs obs[GF_POST_MAX_OBS];
+    PostContact cfold;
 #ifdef GF_STAMPS
     unsigned long long* stamps;
     uint32_t stamp_block;

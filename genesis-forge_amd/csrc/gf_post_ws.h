@@ -153,6 +153,25 @@ __host__ __device__ constexpr bool ws_obs_has(int op) {
     return false;
 }
 static_assert(kPostAuxRows >= 4 * 8, "aux rows cover 32 DOF");
+// Can this kernel run the scene's ContactManagers as its first phase (GfPostArgs.cfold)?  The interpreter always can; a static program
+// only when its structure reads a ContactManager's buffers — the phase costs registers (88), and a program that never sees contacts
+// (the benchmark's: 79) keeps its occupancy.  A config whose contact buffers only Python reads keeps the stand-alone contact launch.
+__host__ __device__ constexpr bool reward_op_reads_contacts(int op) {
+    return op == GF_R_HAS_CONTACT || op == GF_R_CONTACT_FORCE || op == GF_R_FEET_AIR_TIME || op == GF_R_FEET_SLIDE || op == GF_R_GAIT_PHASE || op == GF_R_FOOT_HEIGHT;
+}
+template <class P>
+__host__ __device__ constexpr bool ws_prog_folds() {
+    if constexpr (P::kStatic) {
+        if (P::n_air > 0) return true;
+        for (int k = 0; k < P::n_term; ++k)
+            if (term_op_counts_contacts(P::term[k].op)) return true;
+        for (int k = 0; k < P::n_rew; ++k)
+            if (reward_op_reads_contacts(P::rew[k].op)) return true;
+        return ws_obs_has<P>(GF_O_CONTACT_FORCE_NORM);
+    } else {
+        return true;
+    }
+}
 
 template <class P>
 __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg) {
@@ -221,6 +240,98 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
         if constexpr (P::kStatic) cm.width = P::cmd_width[c];
         return cm;
     };
+
+    // ---- contact phase: every ContactManager of the scene for this tile, in front of the phases that read their buffers -----------
+    // (contact_manager.py:384-477, kernel.py:35-90 → gf_contact_tile.h; until round 4 a launch of its own.)  All four waves run it:
+    // one lane per (env, tracked link), the tile's slot ids staged in LDS — the region the later phases use is free until then.  The
+    // managers' public buffers are written to memory as before (they are API); the workgroup barrier behind the phase makes them
+    // visible to this workgroup's waves (one CU, one L1), which read them back as L2 hits instead of as a dependent launch's loads.
+    if constexpr (ws_prog_folds<P>()) {
+        int fold_mgr = 0;
+        if constexpr (P::kStatic) fold_mgr = karg.cfold.num_mgr;
+        else fold_mgr = UNI(a.cfold.num_mgr);
+        if (fold_mgr > 0) {
+            int32_t* const cw = reinterpret_cast<int32_t*>(xch);
+            int32_t* const t_mgr = cw;                                               // [kFoldMaxMgr][kContactMgrWords]
+            int32_t* const t_target = t_mgr + kFoldMaxMgr * kContactMgrWords;        // [kFoldMaxTargets]
+            uint16_t* const t_meta = reinterpret_cast<uint16_t*>(t_target + kFoldMaxTargets);   // [kFoldMaxTargets]
+            int32_t* const t_with = t_target + kFoldMaxTargets + kFoldMaxTargets / 2; // [kFoldMaxMgr][GF_MAX_LINK_IDS]
+            int32_t* const ids = cw + kFoldTableWords;
+            // a word of the compact image at a lane-dependent offset (scalar loads at constant offsets plus per-lane selects were
+            // measured slower: 5.5 vs 4.1 us to the end of the slot-id stage at 8 192 envs, profiles/r04_h_stamps.txt)
+            auto cf_word = [&](int byte_off) GF_INLINE_LAMBDA -> uint32_t {
+                if constexpr (P::kStatic)
+                    return *(const __attribute__((address_space(4))) uint32_t*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                                               offsetof(GfPostArgs, cfold) + byte_off);
+                else
+                    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + offsetof(GfPostArgs, cfold) + byte_off);
+            };
+            const int tid = (int)threadIdx.x;
+            const int T = UNI(a.cfold.total_targets), C = UNI(a.cfold.num_contacts);
+            if (tid < fold_mgr) {   // this manager's image (ContactMgrL) and with-filter list
+                const int base = (int)offsetof(PostContact, m) + tid * (int)sizeof(PostContactMgr);
+                int32_t* img = t_mgr + tid * kContactMgrWords;
+                const uint32_t packed = cf_word(base + 76);
+                img[0] = (int32_t)(packed & 0xffu); img[1] = (int32_t)((packed >> 8) & 0xffu);
+                img[2] = (int32_t)((packed >> 16) & 0xffu); img[3] = (int32_t)(packed >> 24);
+                img[4] = (int32_t)cf_word(base + 72); img[5] = 0;
+#pragma unroll
+                for (int w = 0; w < 18; ++w) img[6 + w] = (int32_t)cf_word(base + 4 * w);
+#pragma unroll
+                for (int w = 0; w < kFoldMaxWith / 4; ++w) {
+                    const uint32_t b4 = cf_word(base + 80 + 4 * w);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t_with[tid * GF_MAX_LINK_IDS + 4 * w + j] = (int32_t)((b4 >> (8 * j)) & 0xffu);
+                }
+            }
+            if (tid < T) {
+                const int sh = 8 * (tid & 3), wd = tid & ~3;
+                t_target[tid] = (int32_t)((cf_word((int)offsetof(PostContact, target_ids) + wd) >> sh) & 0xffu);
+                t_meta[tid] = (uint16_t)(((cf_word((int)offsetof(PostContact, mgr_of) + wd) >> sh) & 0xffu) |
+                                         (((cf_word((int)offsetof(PostContact, local_of) + wd) >> sh) & 0xffu) << 8));
+            }
+            {   // While the contact phase runs its own chain of round trips, the rows the roles below will request are pulled towards this CU:
+                // one LDS-DMA dword per lane and array (no register, no wait; the first dword of the env's row — rows are at most a
+                // cache line long, so every line of the tile's block is touched) into a scratch row nobody reads.  The roles' real
+                // loads then hit the L1 / L2 instead of starting a round trip to memory behind the phase.
+                float* const pf = reinterpret_cast<float*>(ids + contact_lds_ints(kEnvBlock, C)) + wave * kEnvBlock;
+                auto warm = [&](const bool on, const float* base, const uint32_t off) GF_INLINE_LAMBDA {
+                    __builtin_amdgcn_global_load_lds(gsel(on, base, off), pf, 4, 0, 0);
+                };
+                if (wave == 0) {
+                    warm((needs & PN_QUAT) != 0, UNI(a.quat), 4u * e);
+                    warm((needs & PN_POS) != 0, UNI(a.pos), 3u * e);
+                    warm((needs & PN_LIN) != 0, UNI(a.lin_vel), 3u * e);
+                    warm((needs & PN_ANG) != 0, UNI(a.ang_vel), 3u * e);
+                    warm((needs & PN_EPLEN) != 0, reinterpret_cast<const float*>(UNI(a.episode_length)), e);
+                    warm((needs & PN_MAXLEN) != 0, reinterpret_cast<const float*>(UNI(a.max_episode_length)), e);
+                    if (has_gait) warm(true, UNI(a.gait.state), (uint32_t)GF_GAIT_ROW * e);
+                } else if (wave == 1) {
+                    warm((needs & PN_DOFDEV) != 0, UNI(a.dof_pos), ro);
+                    warm((needs & PN_ACTRATE) != 0, UNI(a.env_actions), ro);
+                    warm((needs & PN_ACTRATE) != 0, UNI(a.env_last_actions), ro);
+                    warm(has_reward && UNI(a.episode_seconds) != nullptr, UNI(a.episode_seconds), e);
+                } else if (wave == 2) {
+                    warm((needs & PN_DOFPOS) != 0, UNI(a.dof_pos), ro);
+                    warm((needs & PN_DOFVEL) != 0, UNI(a.dof_vel), ro);
+                } else {
+                    warm((needs & PN_TARGETS) != 0, UNI(a.targets), ro);
+                    warm((needs & PN_ACTIONS) != 0, UNI(a.env_actions), ro);
+                    warm(UNI(a.dof_force) != nullptr, UNI(a.dof_force), ro);
+                }
+            }
+            const ContactScene sc{UNI(a.cfold.force), UNI(a.cfold.position), UNI(a.cfold.links_quat), UNI(a.cfold.links_vel), UNI(a.cfold.links_pos),
+                                  UNI(a.cfold.link_a), UNI(a.cfold.link_b), C, UNI(a.cfold.num_scene_links), T, UNI(a.cfold.dt)};
+            const ContactLds cl = contact_lds_carve(ids, kEnvBlock, C, reinterpret_cast<const ContactMgrL*>(t_mgr), t_target, t_meta, t_with);
+            const int envs_here = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
+            const int flag_mask = contact_tile(sc, cl, kEnvBlock, n0, envs_here, tid, kWsBlock, [&](int i) GF_INLINE_LAMBDA { (void)i; GF_WSTAMP(12 + i); });   // (its first barrier covers the tables)
+            if (shard) {   // non-finite force sanitised: the warning flag of contact_manager.py:399-403 (every folded manager counts into the step's block)
+                const unsigned long long b = __ballot(flag_mask != 0);
+                if (b && lane == 0) atomicOr(&shard->contact_flags, 1);
+            }
+            __syncthreads();   // the managers' buffers are visible to the tile's waves; the LDS is free for the phases below
+        }
+    }
 
     // ---- state that lives across the barrier, per role -------------------------------------------------------------
     // The roles are branches of ONE function, so to the register allocator a value that wave 0 carries across the barrier and a value

@@ -152,7 +152,8 @@ __device__ __forceinline__ void synth_contact_one(const GfSynthSceneArgs& a, con
     const uint32_t feet = a.foot_link_mask;
     bool active = u_act < a.contact_prob;
     int lb = 1 + (int)(u_link * (float)(NL - 1));
-    bool robot_on_a = false;
+    bool robot_on_a = false, foot_slot = false;
+    float fz = 0.0f;
     if (feet) {
         const int n_feet = __builtin_popcount(feet);
         if (c < n_feet) {
@@ -165,14 +166,17 @@ __device__ __forceinline__ void synth_contact_one(const GfSynthSceneArgs& a, con
             const float p = stance ? fminf(1.8f * a.foot_contact_prob, 1.0f) : 0.2f * a.foot_contact_prob;
             active = u_act < p;
             robot_on_a = u_link < 0.5f;
+            // a foot slot takes its normal force from the same draw as its side (both halves of [0, 1) map onto [0, 1), exactly):
+            // every wave holds foot slots, so a second Philox block for them would be paid by every lane of every wave
+            fz = robot_on_a ? u_link * 2.0f : u_link * 2.0f - 1.0f;
+            foot_slot = true;
         } else {
             const int kk = (int)(u_link * (float)(2 * (NL - 1)));
             lb = 1 + (kk >> 1);
             robot_on_a = (kk & 1) != 0;
         }
     }
-    float fz = 0.0f;
-    if (active) {
+    if (active && !foot_slot) {
         const U4 r1 = philox4x32_10(genv, (col >> 2) + 1, (uint32_t)a.tick, (uint32_t)(a.tick >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
         fz = u24_to_unit(r1.x);
     }

@@ -13,7 +13,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-GF_ABI_VERSION = 6
+GF_ABI_VERSION = 7
 GF_MAX_TERMS = 24
 GF_MAX_TERM_TERMS = 16
 GF_MAX_OBS_ITEMS = 24
@@ -88,6 +88,7 @@ GF_ROT_PROJ_GRAVITY, GF_ROT_LIN_VEL, GF_ROT_ANG_VEL = 0, 1, 2
 GF_OPT_PROFILE_STRIDE = 1  # gf_set_option: stamp every k-th launch of the profiled phase
 GF_OPT_CHAIN = 3           # gf_set_option: 1 (default) = fold runs of per-env phases of a recorded step into phase-chain launches
 GF_OPT_GRAPH = 2           # gf_set_option: 1 = recorded steps replay as one hipGraphLaunch; 0 (default: measured faster) = plain launches
+GF_OPT_FOLD_CONTACT = 4    # gf_set_option: 1 (default) = the contact ops in front of a fused post-physics op run as that launch's first phase
 GF_OPT_POST_VARIANT = 0  # gf_set_option: 0 = interpreter, one wave per tile; 1 = interpreter, four waves; 2 = + static programs (default)
 
 GF_ERRORS = {-1: "GF_E_NULL", -2: "GF_E_RANGE", -3: "GF_E_OPCODE", -4: "GF_E_SLOT", -5: "GF_E_UNSUPPORTED"}

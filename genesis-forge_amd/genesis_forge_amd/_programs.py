@@ -39,7 +39,7 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 _HEADERS = ("gf_post_args.h", "gf_post_ws.h", "gf_post_programs.h", "gf_terms.h", "gf_device.h", "gf_obs_hist.h", "gf_prefetch.h",
-            "gf_launch.h")
+            "gf_launch.h", "gf_contact_tile.h")
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-fvisibility=hidden", "-Wno-unused-value"]
 
 
@@ -123,6 +123,7 @@ GFP_EXPORT const char* gfp_name(void) {{ return gf::ProgJit::name; }}
 GFP_EXPORT int gfp_matches(const gf::GfPostArgs* a) {{ return gf::program_matches<gf::ProgJit>(*a) ? 1 : 0; }}
 GFP_EXPORT const void* gfp_kernel(void) {{ return (const void*)&gf::post_ws_kernel<gf::ProgJit>; }}
 GFP_EXPORT size_t gfp_lds_bytes(int omax, int n_gait) {{ return gf::lds_ws_floats<gf::ProgJit>(omax, n_gait) * sizeof(float); }}
+GFP_EXPORT int gfp_folds(void) {{ return gf::ws_prog_folds<gf::ProgJit>() ? 1 : 0; }}
 '''
 
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 6
+#define GF_ABI_VERSION 7
 
 #define GF_MAX_TERMS 24          /* reward terms per manager          */
 #define GF_MAX_TERM_TERMS 16     /* termination terms per manager     */
@@ -567,7 +567,7 @@ typedef struct GfSynthSceneArgs {
     /* Walking contact model.  0: every slot is an independent (ground, random robot link) contact with probability contact_prob.
      * Otherwise bit l marks scene link l (< 32) as a FOOT: the k-th foot owns slot k — its contact with the ground, made with
      * probability min(1, 1.8 p) while the foot is in the stance half of a 20-tick trot cycle (diagonal pairs alternate, the
-     * cycle offset differs per env) and 0.2 p in the swing half, p = foot_contact_prob: two to four feet of a quadruped on the
+     * cycle offset differs per env) and 0.2 p in the swing half, p = foot_contact_prob (its normal force comes from the draw that picks the side): two to four feet of a quadruped on the
      * ground every tick, as the reference's foot ContactManager / feet_air_time / the Taichi kernel's matching branch expect
      * (examples/gait_trainer/environment.py:140-153, mdp/rewards.py:431-469, managers/contact/kernel.py:47-78).  The remaining
      * slots are body contacts as before (probability contact_prob, any robot link).  Every contact puts the ground on side a or
@@ -710,7 +710,10 @@ int gf_abi_version(void);
  * envs, 27.8 vs 24 µs at 65 536; gait config 107 vs 94 µs at 8 192 (profiles/r01_l_graph_vs_plain.jsonl). */
 /* GF_OPT_CHAIN (default 1): gf_run_ops folds runs of per-env phases the fused post-physics kernel does not cover into phase
  * chains — termination → reward → command.step…, and reset → command.reset… → observe… — one launch each (csrc/gf_chain.hip). */
-enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_GRAPH = 2, GF_OPT_CHAIN = 3, GF_OPT_COUNT = 4 };
+/* GF_OPT_FOLD_CONTACT (default 1): gf_run_ops hands the contact_step ops in front of a fused post-physics op to that launch
+ * (gf_post_physics_step_contacts) instead of launching the contact kernel itself — unless that measured slower (more than 12 tracked
+ * links below 16 384 envs); 0 keeps the two launches (A/B, tests), 2 folds whenever it is possible. */
+enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_GRAPH = 2, GF_OPT_CHAIN = 3, GF_OPT_FOLD_CONTACT = 4, GF_OPT_COUNT = 5 };
 int gf_set_option(int option, int value);
 int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView, 17 GfPostRefs, 18 GfRolloutArgs, 19 GfHistoryUnrollArgs, 20 GfRolloutPolicyArgs, 21 GfGaeArgs, 22 GfCompactArgs): binding self-check */
 const char* gf_build_info(void);
@@ -797,6 +800,16 @@ typedef struct GfPostRefs {
 
 int gf_post_physics_check(const GfPostRefs* r);               /* GF_OK if gf_post_physics_step can fuse this combination */
 int gf_post_physics_step(const GfPostRefs* r, void* stream);  /* replaces managed_env.py:303-326 in one launch */
+/* The same launch with the scene's ContactManagers stepped IN FRONT of the other phases (SURVEY.md §8f-1 ∘ §8f-2): the reference runs
+ * contact.step, termination, reward … back to back per env (managed_env.py:294-326, managers/contact/contact_manager.py:384-477,
+ * managers/contact/kernel.py:35-90), and the fused launch works on the same 64-env tiles and reads what the contact step just
+ * wrote — so `contacts[0 .. num_contacts)` (up to four GfContactArgs over the same scene arrays: what gf_contact_step takes, one
+ * per manager) run as the first phase of the launch: slot ids staged in the tile's LDS, one lane per (env, tracked link), the
+ * managers' public buffers written as gf_contact_step writes them, a workgroup barrier, then termination … observation.  By
+ * construction the results are those of gf_contact_step per manager followed by gf_post_physics_step.  GF_E_UNSUPPORTED when the
+ * managers cannot be folded (more than 32 tracked links or 16 with-filter links, link ids above 254, slot rows beyond the tile's
+ * LDS, a statistics block other than the step's, GF_POST_OBSERVE_ONLY): the caller runs gf_contact_step itself. */
+int gf_post_physics_step_contacts(const GfPostRefs* r, const GfContactArgs* const* contacts, int num_contacts, void* stream);
 /* Writes "program <id> (<name>): <structure signature>" for this combination into buf: which kernel
  * gf_post_physics_step would launch (id 0 = table interpreter, >0 = a static program compiled for exactly this
  * structure) and the signature in the notation of csrc/gf_post_programs.h.  Host-only, no GPU needed. */

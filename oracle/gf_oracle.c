@@ -1059,7 +1059,7 @@ GFO_EXPORT int gfo_synth_scene_step(const GfSynthSceneArgs* a) {
                 const float u_link = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 1);
                 const float fx = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 2) * 2.0f - 1.0f;
                 const float fy = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 3) * 2.0f - 1.0f;
-                const float fz = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 4);
+                float fz = philox_uniform(a->seed, a->tick, (uint32_t)n + a->env_offset, col + 4);
                 int active = u_act < a->contact_prob;
                 const int64_t k = n * C + c;
                 int32_t lb = 1 + (int32_t)(u_link * (float)(NL - 1));
@@ -1079,6 +1079,7 @@ GFO_EXPORT int gfo_synth_scene_step(const GfSynthSceneArgs* a) {
                         const float pr = stance ? fminf(1.8f * a->foot_contact_prob, 1.0f) : 0.2f * a->foot_contact_prob;
                         active = u_act < pr;
                         robot_on_a = u_link < 0.5f;
+                        fz = robot_on_a ? u_link * 2.0f : u_link * 2.0f - 1.0f;   /* (the side's draw, stretched back onto [0, 1): exact) */
                     } else {
                         const int32_t kk = (int32_t)(u_link * (float)(2 * (NL - 1)));
                         lb = 1 + (kk >> 1);
@@ -1286,6 +1287,17 @@ GFO_EXPORT int gfo_stats_last_reset(const double* rows, int num_rows, double* ds
             break;
         }
     return GF_OK;
+}
+
+/* host twin of gf_post_physics_step_contacts: by definition the managers' steps, then the post-physics phases, in sequence
+ * (managed_env.py:294-326) */
+GFO_EXPORT int gfo_post_physics_step_contacts(const GfPostRefs* r, const GfContactArgs* const* contacts, int num_contacts) {
+    if (num_contacts < 0 || (num_contacts > 0 && !contacts)) return GF_E_NULL;
+    for (int m = 0; m < num_contacts; ++m) {
+        const int rc = gfo_contact_step(contacts[m]);
+        if (rc != GF_OK) return rc;
+    }
+    return gfo_post_physics_step(r);
 }
 
 /* host twin of gf_run_ops (the recorded-step replay), so the trace/replay host logic is testable on CPU */

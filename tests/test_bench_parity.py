@@ -183,6 +183,63 @@ def _timed_workload(hip_backend, hip, cpu, name, n, variant, steps, program):
         assert resets > 0, "the trajectory must reset envs"
 
 
+FOLD_CASES = [  # (fold = 2: "whenever possible" — the default leaves the gait task below 16 384 envs on two launches, measured faster)
+    ("contacts", 4096), ("rough_terrain", 1000), ("rough_terrain", 16384), ("humanoid", 130), ("humanoid", 8192), ("gait", 8192), ("gait", 65536),
+              ("gait_override_8192", 8192), ("humanoid28", 1000), ("humanoid28-interp", 257)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n", FOLD_CASES, ids=[f"{c[0]}-{c[1]}" for c in FOLD_CASES])
+def test_contact_phase_folded_into_the_post_launch_equals_a_launch_of_its_own(hip_backend, name, n):
+    """SURVEY.md §8f-1 ∘ §8f-2: gf_run_ops hands the contact ops in front of the fused post-physics op to that launch
+    (gf_post_physics_step_contacts; managed_env.py:294-326 runs the phases back to back per env).  Same inputs, GF_OPT_FOLD_CONTACT
+    on / off: every output and every manager buffer bit for bit, and in the folded run the contact kernel is never launched."""
+    from genesis_forge_amd import _native as nat
+
+    interp = name.endswith("-interp")
+    cfg = name.split("-")[0]
+    runs = {}
+    for fold in (2, 0):
+        hip_backend.set_option(nat.GF_OPT_FOLD_CONTACT, fold)
+        if interp:
+            hip_backend.set_option(nat.GF_OPT_POST_VARIANT, 1)
+        try:
+            env = _make(cfg, n, "short")
+            env.build()
+            for m in env.managers["command"]:
+                m.resample_time_sec = 0.1 if m is env.managers["command"][0] else 0.14
+            env.seed(99)
+            env.reset()
+            d = env.action_space.shape[0]
+            g = torch.Generator().manual_seed(5)
+            rows = []
+            for t in range(30):
+                if t == 6:   # the step is recorded by now: count the contact launches of the replayed steps
+                    assert env._trace is not None
+                    hip_backend.profile_begin(nat.GF_PHASE_CONTACT, 64)
+                act = torch.randn(n, d, generator=g).to("cuda:0")
+                ex, cl, log = _state(env, env.step(act))
+                extra = {}
+                for i, m in enumerate(env.managers["contact"]):
+                    extra[f"pos{i}"] = m.contact_positions
+                    for nm in ("link_vel", "link_pos"):
+                        if getattr(m, "_has_" + nm, False):
+                            extra[f"{nm}{i}"] = getattr(m, nm)
+                rows.append(({k: v.clone() for k, v in {**ex, **cl, **extra}.items()}, log))
+            _ms, samples = hip_backend.profile_end()
+            runs[fold] = (rows, samples)
+        finally:
+            hip_backend.set_option(nat.GF_OPT_FOLD_CONTACT, 0 if os.environ.get("GF_NO_CONTACT_FOLD") else 1)
+            hip_backend.set_option(nat.GF_OPT_POST_VARIANT, 2)
+    assert runs[2][1] == 0, "folded: the recorded step launches no contact kernel"
+    assert runs[0][1] == 24, "a launch of its own per step when the fold is switched off"
+    for t, ((a, la), (b, lb)) in enumerate(zip(runs[2][0], runs[0][0])):
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), f"{k} differs at step {t}"
+        assert la == lb, t
+
+
 def test_every_timed_config_has_a_parity_case():
     """`configs_untested` is empty: every entry of the table bench.py / tools/bench_configs.py time has a case at its size."""
     from genesis_forge_amd.tasks import BASELINE_CONFIGS

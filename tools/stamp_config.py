@@ -62,14 +62,14 @@ def run(config, steps):
         env.step(acts[i % 4])
     assert env._trace is not None, "not recorded"
     C.c_void_p.in_dll(lib, "gf_debug_stamps").value = stamps.data_ptr()
-    acc = torch.zeros(4, 12, dtype=torch.float64)
+    acc = torch.zeros(4, 16, dtype=torch.float64)
     for i in range(steps):
         env.step(acts[i % 4])
         torch.cuda.synchronize()
         h = stamps.cpu()
         t0 = min(int(h[64 + 16 * w + 1]) for w in range(4))
         for w in range(4):
-            for k in range(1, 12):
+            for k in range(1, 16):
                 acc[w, k] += (int(h[64 + 16 * w + k]) - t0) / 100.0
     acc /= steps
     print(f"{config}: {n} envs, fused={env._trace.post_refs is not None}, mean of {steps} launches, us since the first wave had its args (middle workgroup)")
@@ -79,6 +79,9 @@ def run(config, steps):
     print("  inside the pre-barrier block — wave 0: terminations evaluated | command draws | gait manager;  wave 1: rows reduced | (behind the barrier) fold starts | fold done;  wave 2: rows requested")
     for w in (0, 1, 2):
         print(f"  wave {w}: " + " ".join(f"{float(acc[w, k]):17.2f}" for k in range(9, 12 if w < 2 else 10)))
+    print("  folded contact phase (0 when the launch has none): slot ids + masks in LDS | prefix done | contributions in LDS | links done")
+    for w in range(4):
+        print(f"  wave {w}: " + " ".join(f"{float(acc[w, k]):17.2f}" for k in range(12, 16)))
 
 
 if __name__ == "__main__":
