@@ -309,6 +309,28 @@ def main():
     run_rank(args)
 
 
+def pin_rank() -> dict:
+    """Give this rank its own share of the host cores (``os.sched_setaffinity``, from inside the rank): below ~16 k envs a step is
+    host-bound (17 us at 4 096 envs), so N unpinned Python hosts on one box would migrate over each other's cores.  The cores this
+    process may run on are split into LOCAL_WORLD_SIZE contiguous shares; ``GF_PIN=0`` leaves the affinity alone.  Returns what was
+    done, for the per-rank entry of the JSON line."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:   # not Linux
+        return {"pinned": False, "cpus": None, "why": "no sched_getaffinity"}
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    if os.environ.get("GF_PIN", "1") == "0" or local_world <= 1 or len(avail) < 2 * local_world:
+        return {"pinned": False, "cpus": len(avail), "why": "GF_PIN=0" if os.environ.get("GF_PIN", "1") == "0" else "one rank, or fewer than two cores per rank"}
+    share = len(avail) // local_world
+    mine = avail[(local % local_world) * share:(local % local_world + 1) * share]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError as e:
+        return {"pinned": False, "cpus": len(avail), "why": repr(e)}
+    return {"pinned": True, "cpus": len(mine), "first": mine[0], "last": mine[-1]}
+
+
 def run_rank(args):
     # stdout carries exactly ONE line, the JSON result of rank 0.  Libraries write there too (RCCL prints a five-line version banner
     # on rank 0 when the first communicator is created; gloo a connection note), so the descriptor is kept aside and fd 1 points at
@@ -316,6 +338,7 @@ def run_rank(args):
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
+    affinity = pin_rank()   # BEFORE anything touches the GPU (and never through taskset / numactl: under a profiler that is a forbidden exec)
 
     import torch
     import torch.distributed as dist
@@ -362,13 +385,14 @@ def run_rank(args):
         N, global_envs = args.num_envs, args.num_envs * world
     env = make_env(N, args.config)
     D = env.action_space.shape[0]
-    gfd.attach(env, global_num_envs=global_envs, reduce_every=args.reduce_every, force=dist_on)
+    gfd.attach(env, global_num_envs=global_envs, reduce_every=args.reduce_every, force=dist_on, lockstep_reads=True)   # (every rank reads the same logs)
     env.seed(1234)          # one seed for all ranks: Philox is keyed by the GLOBAL env id, so shards draw different numbers
     env.reset()
     g = torch.Generator().manual_seed(1234 + rank)
     acts = [torch.randn(N, D, generator=g).to(gs.device) for _ in range(8)]
 
     local_times: list = []
+    host_times: list = []   # the step loop's own time, before the final synchronize: what the HOST spends per batch
 
     def barrier():
         sync()
@@ -384,10 +408,12 @@ def run_rank(args):
             t0 = time.perf_counter()
             for i in range(steps):
                 e.step(a[i % len(a)])
+            host_dt = time.perf_counter() - t0
             sync()
             dt = time.perf_counter() - t0
             barrier()
             local_times.append(dt)   # this rank's own clock, before the max over ranks (reported per rank)
+            host_times.append(host_dt / steps)
             if dist_on:
                 t = torch.tensor([dt], device=gs.device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -427,7 +453,8 @@ def run_rank(args):
     batch = statistics.median(times)
     # what each rank ran on and measured by its own clock: makes the one line checkable against the launcher's view of the node
     mine = {"rank": rank, "device": ("cpu (rehearsal)" if rehearsal else torch.cuda.get_device_name(gs.device)), "device_index": (None if rehearsal else gs.device.index),
-            "num_envs": N, "env_offset": env.env_offset, "batch_ms_median": statistics.median(local_times) * 1e3, "batch_ms_max": max(local_times) * 1e3}
+            "num_envs": N, "env_offset": env.env_offset, "batch_ms_median": statistics.median(local_times) * 1e3, "batch_ms_max": max(local_times) * 1e3,
+            "host_us_per_step": statistics.median(host_times) * 1e6, "affinity": affinity}
     per_rank = [mine]
     if dist_on:
         per_rank = [None] * dist.get_world_size()
@@ -467,6 +494,8 @@ def run_rank(args):
                        "dofs": D, "reward_terms": T, "termination_terms": len(env.managers["termination"].term_cfg), "command_managers": len(env.managers["command"]),
                        "obs_width": int(env.observation_space.shape[0]), "scene": "synthetic (gf_synth_scene_step)", "parallelism": f"env-shard x{world}",
                        "stats_allreduce_every_steps": (args.reduce_every if dist_on else None), "dist_backend": (dist_backend if dist_on else None),
+                       # dmabuf IPC for RCCL across processes on this driver: launch.spawn_ranks sets 0 unless the environment says otherwise
+                       "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "setup_steps_before_warmup": PRIMING_STEPS, "fused_post_physics": fused, "observation_output": OBS_OUTPUT,
                        "launches_per_step": env._trace.n_ops if env._trace is not None else None},
             "timing": {"batches": len(times), "timed_s": sum(times), "batch_ms_median": batch * 1e3, "batch_ms_min": min(times) * 1e3,

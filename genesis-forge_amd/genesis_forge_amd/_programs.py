@@ -21,11 +21,14 @@ program is there.
 
 Policy (``GF_JIT``): ``off``; ``sync`` — compile when the step is recorded, blocking; ``async`` — compile in a child process,
 register when it is done (polled every 32 steps), the interpreter runs meanwhile.  Default: ``async`` from 16 384 envs on
-(below that a step is host-bound and the kernel's 2–3 µs do not show), ``off`` otherwise.  Missing ``hipcc`` = ``off``.
+(below that a step is host-bound and the kernel's 2–3 µs do not show), ``off`` otherwise, and ``off`` under a profiler
+(``LD_PRELOAD`` / ``ROCP*`` / ``HSA_TOOLS*`` in the environment; the child compiler never inherits those).  Missing ``hipcc`` = ``off``.
+Plugins are keyed by signature, kernel headers, flags and ``hipcc --version``.
 """
 from __future__ import annotations
 
 import hashlib
+import itertools
 import os
 import re
 import shutil
@@ -44,7 +47,30 @@ _FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared
 
 
 def cache_dir() -> str:
-    return os.environ.get("GF_PROGRAM_CACHE") or os.path.join(PKG_DIR, "programs")
+    """``GF_PROGRAM_CACHE``, else ``<package>/../programs``; when that tree is not writable (an installed, read-only package) a
+    per-user directory."""
+    d = os.environ.get("GF_PROGRAM_CACHE")
+    if d:
+        return d
+    d = os.path.join(PKG_DIR, "programs")
+    probe = d if os.path.isdir(d) else PKG_DIR
+    if os.access(probe, os.W_OK):
+        return d
+    return os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "genesis_forge_amd", "programs")
+
+
+# What a profiler / tool injects into a process: the child compiler must not inherit it.  Under ``rocprofv3 --pmc`` the preloaded
+# library initialises the GPU inside hipcc, which then execs clang / lld — an exec from a GPU-initialised process.
+_TOOL_ENV_PREFIXES = ("ROCP", "ROCPROFILER", "ROCTRACER", "HSA_TOOLS", "RPD_")
+_TOOL_ENV_NAMES = ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE", "ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIB")
+
+
+def under_profiler() -> bool:
+    return any(k in os.environ for k in _TOOL_ENV_NAMES) or any(k.startswith(_TOOL_ENV_PREFIXES) for k in os.environ)
+
+
+def compiler_env() -> dict:
+    return {k: v for k, v in os.environ.items() if k not in _TOOL_ENV_NAMES and not k.startswith(_TOOL_ENV_PREFIXES)}
 
 
 def hipcc() -> Optional[str]:
@@ -127,9 +153,28 @@ GFP_EXPORT int gfp_folds(void) {{ return gf::ws_prog_folds<gf::ProgJit>() ? 1 : 
 '''
 
 
+_COMPILER_ID: Optional[str] = None
+
+
+def compiler_id() -> str:
+    """``hipcc --version`` (one call per process): a plugin built by another ROCm release is not the one this library expects."""
+    global _COMPILER_ID
+    if _COMPILER_ID is None:
+        cc = hipcc()
+        out = ""
+        if cc is not None:
+            try:
+                out = subprocess.run([cc, "--version"], capture_output=True, text=True, timeout=60, env=compiler_env()).stdout
+            except Exception:
+                out = ""
+        _COMPILER_ID = hashlib.sha1(out.encode()).hexdigest()[:12] if out else "no-compiler"
+    return _COMPILER_ID
+
+
 def _build_tag() -> str:
-    """What a plugin was built against: the kernel headers and the compiler flags (8 hex digits, first part of its file name)."""
-    return hashlib.sha1((_headers_digest() + "|" + " ".join(_FLAGS)).encode()).hexdigest()[:8]
+    """What a plugin was built against: the kernel headers, the compiler flags and the compiler's version (8 hex digits, first part
+    of its file name)."""
+    return hashlib.sha1((_headers_digest() + "|" + " ".join(_FLAGS) + "|" + compiler_id()).encode()).hexdigest()[:8]
 
 
 def plugin_key(sig: str) -> str:
@@ -137,13 +182,25 @@ def plugin_key(sig: str) -> str:
     return _build_tag() + hashlib.sha1(body.encode()).hexdigest()[:12]
 
 
+_STALE_SECONDS = 24 * 3600.0
+_compile_counter = itertools.count()
+
+
 def _sweep_stale(directory: str) -> None:
-    """Plugins built against other kernel headers can never be loaded again (their name no longer comes up): remove them."""
+    """Plugins built against other kernel headers can never be loaded again by THIS checkout (their name no longer comes up): remove
+    the ones nobody has touched for a day — another checkout or another rank sharing the cache may be compiling or about to load a
+    younger one."""
     tag = _build_tag()
+    now = time.time()
     try:
         for name in os.listdir(directory):
-            if name.startswith("gfp_") and not name.startswith("gfp_" + tag) and name.endswith((".so", ".hip")):
-                os.unlink(os.path.join(directory, name))
+            if name.startswith("gfp_") and not name.startswith("gfp_" + tag) and (name.endswith((".so", ".hip", ".lock")) or ".tmp" in name):
+                path = os.path.join(directory, name)
+                try:
+                    if now - os.path.getmtime(path) > _STALE_SECONDS:
+                        os.unlink(path)
+                except OSError:
+                    pass
     except OSError:
         pass
 
@@ -168,17 +225,33 @@ def start_compile(sig: str):
         raise RuntimeError("hipcc not found: static programs cannot be compiled at run time")
     os.makedirs(os.path.dirname(src), exist_ok=True)
     _sweep_stale(os.path.dirname(src))
-    with open(src, "w") as fh:
-        fh.write(plugin_source(sig, key))
-    tmp = f"{so}.{os.getpid()}.tmp"
-    proc = subprocess.Popen(compile_command(src, tmp), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
-    proc._gf_tmp, proc._gf_so, proc._gf_t0 = tmp, so, time.perf_counter()
+    # Several ranks record the same step at the same time and share the cache: every process compiles from a source file of its OWN
+    # (pid in the name, renamed into place: nobody ever reads a half-written file) into a plugin of its own, and the finished plugin
+    # is moved into place atomically — whoever finishes last wins with identical bytes.
+    text = plugin_source(sig, key)
+    uid = f"{os.getpid()}_{next(_compile_counter)}"
+    my_src = f"{src}.{uid}.tmp.hip"
+    with open(my_src, "w") as fh:
+        fh.write(text)
+    try:
+        if not os.path.exists(src):
+            shutil.copyfile(my_src, src + f".{uid}.tmp.cp")
+            os.replace(src + f".{uid}.tmp.cp", src)   # (kept for inspection: the source a cached plugin was built from)
+    except OSError:
+        pass
+    tmp = f"{so}.{uid}.tmp"
+    proc = subprocess.Popen(compile_command(my_src, tmp), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=compiler_env())
+    proc._gf_tmp, proc._gf_so, proc._gf_t0, proc._gf_src = tmp, so, time.perf_counter(), my_src
     return so, proc
 
 
 def finish_compile(proc) -> str:
     """Wait for a compile started by ``start_compile``; the finished plugin is moved into place atomically."""
     _out, err = proc.communicate()
+    try:
+        os.unlink(proc._gf_src)
+    except (OSError, AttributeError):
+        pass
     if proc.returncode != 0:
         try:
             os.unlink(proc._gf_tmp)
@@ -287,7 +360,9 @@ def precompile(make_env, num_envs: int = 64) -> Optional[dict]:
 def mode_for(env) -> str:
     m = os.environ.get("GF_JIT")
     if m is None:
-        m = getattr(env, "jit_programs", None) or ("async" if env.num_envs >= 16384 else "off")
+        # (a run under a profiler compiles nothing by itself: set GF_JIT explicitly — the child compiler then runs with the tool's
+        # variables scrubbed — or precompile the config's program beforehand)
+        m = getattr(env, "jit_programs", None) or ("async" if env.num_envs >= 16384 and not under_profiler() else "off")
     return m if m in ("off", "sync", "async") else "off"
 
 
@@ -306,6 +381,12 @@ class Pending:
                 proc.kill()
                 proc.wait(timeout=5)
             except Exception:
+                pass
+        my_src = getattr(proc, "_gf_src", None)
+        if my_src and os.path.exists(my_src) and (proc is None or proc.poll() is not None):
+            try:
+                os.unlink(my_src)
+            except OSError:
                 pass
         tmp = getattr(proc, "_gf_tmp", None)
         if tmp and os.path.exists(tmp) and (proc is None or proc.returncode != 0 or not os.path.exists(getattr(proc, "_gf_so", ""))):

@@ -98,6 +98,12 @@ class SceneAdapter:
         self._pushes: dict = {}     # name -> callable(ids) registered by the reset sections of this tick's reset descriptor
         self._hold = None           # the previous epoch's tensors: kept until the next one so no launch outlives its inputs
         self.fetches = 0            # getter calls made (tests count them)
+        self.fetches_last_tick = 0  # getter calls of the last replayed tick (== len(plan): one call per getter and tick)
+        #: None = not checked yet; True = the simulator's envs_idx setters behave as the masked reset assumes (verify_setters);
+        #: False = they do not: resets go by index list through the managers' reference-style reset(ids), with a warning
+        self.setters_verified: Optional[bool] = None
+        self.setter_report: list = []
+        self._push_checked = False
 
     # -- snapshot ---------------------------------------------------------------------------------------------------------
     def invalidate(self) -> None:
@@ -135,8 +141,54 @@ class SceneAdapter:
             order.append(key)
             out.append(t)
         self.fetches += len(plan)
+        self.fetches_last_tick = len(plan)
         self._cache, self.order = cache, order
         return out
+
+    # -- the documented assumption, checked against the simulator at hand ------------------------------------------------------------
+    def verify_setters(self, entity, dofs_idx=None, env_id: int = 0, tol: float = 1e-6) -> bool:
+        """The masked reset on an adapter scene writes the done envs' post-reset rows into the tick's snapshot and brings the
+        simulator up to date through its ``envs_idx`` setters (``push``); the observation of the same tick then reads the SNAPSHOT.
+        That is only right if, after ``set_pos / set_quat / set_dofs_position``, the simulator's getters return what was set — and
+        zero velocities where ``zero_velocity`` asked for it (mdp/reset.py:102-124, position_action_manager.py:455-464,
+        entity_manager.py:189-195).  Checked once, on one env, right before the first full reset (which overwrites the probe): set a
+        pose / joint row through the setters, read it back through the getters, compare, restore.  Returns False (and fills
+        ``setter_report``) when the simulator behaves differently; the env then resets by index list the reference's way."""
+        ids = torch.tensor([int(env_id)], device=entity.get_pos().device, dtype=torch.long)
+        report = []
+
+        def close(name, got, want):
+            got, want = got.detach().float().cpu().reshape(-1), want.detach().float().cpu().reshape(-1)
+            if got.shape != want.shape or not torch.allclose(got, want, atol=tol, rtol=0):
+                report.append(f"{name}: read back {got.tolist()} after setting {want.tolist()}")
+
+        try:
+            pos0, quat0 = entity.get_pos().clone(), entity.get_quat().clone()
+            probe_p = pos0[ids] + torch.tensor([[0.125, -0.25, 0.0625]], device=pos0.device, dtype=pos0.dtype)
+            entity.set_pos(probe_p, envs_idx=ids, zero_velocity=True)
+            close("set_pos -> get_pos", entity.get_pos()[ids], probe_p)
+            close("set_pos(zero_velocity=True) -> get_vel", entity.get_vel()[ids], torch.zeros(1, 3))
+            close("set_pos(zero_velocity=True) -> get_ang", entity.get_ang()[ids], torch.zeros(1, 3))
+            probe_q = torch.tensor([[0.8, 0.0, 0.6, 0.0]], device=quat0.device, dtype=quat0.dtype)
+            entity.set_quat(probe_q, envs_idx=ids, zero_velocity=True)
+            close("set_quat -> get_quat", entity.get_quat()[ids], probe_q)
+            close("set_quat leaves get_pos alone", entity.get_pos()[ids], probe_p)
+            if dofs_idx is not None:
+                idx = [int(i) for i in dofs_idx]
+                d0 = entity.get_dofs_position(idx).clone()
+                probe_d = d0[ids] + 0.03125
+                entity.set_dofs_position(position=probe_d, dofs_idx_local=idx, envs_idx=ids)
+                close("set_dofs_position -> get_dofs_position", entity.get_dofs_position(idx)[ids], probe_d)
+                close("set_dofs_position -> get_dofs_velocity", entity.get_dofs_velocity(idx)[ids], torch.zeros(1, len(idx)))
+                entity.set_dofs_position(position=d0[ids], dofs_idx_local=idx, envs_idx=ids)
+            entity.set_pos(pos0[ids], envs_idx=ids, zero_velocity=True)
+            entity.set_quat(quat0[ids], envs_idx=ids, zero_velocity=True)
+        except Exception as e:   # a simulator without one of the calls: nothing to rely on
+            report.append(f"{type(e).__name__}: {e}")
+        self.setter_report = report
+        self.setters_verified = not report
+        self.invalidate()
+        return self.setters_verified
 
     # -- typed fetchers ----------------------------------------------------------------------------------------------------
     def base(self, entity, what: str) -> torch.Tensor:
@@ -206,6 +258,34 @@ class SceneAdapter:
         ids = self.env.done_ids(mask, mask2)   # (a view of the env's index buffer: the setters gather with it right away)
         if ids.numel() > 0:
             self.push(ids)
+            if not self._push_checked:
+                self._push_checked = True
+                self.verify_push(ids)
+
+    def verify_push(self, ids: torch.Tensor, tol: float = 1e-6) -> bool:
+        """The second half of the setter check, on the first in-step reset (the probe before the first full reset sees a scene at
+        rest, where "velocities are zeroed" cannot fail): the rows the masked reset wrote into the snapshot for the done envs must be
+        what the simulator's getters return now that the setters have run.  A mismatch switches the env to index-list resets."""
+        import warnings
+
+        report = []
+        ids = ids.clone()
+        for key, t in list(self._cache.items()):
+            if key[0] not in ("base", "dofs"):
+                continue
+            fresh = self._fetch[key]()
+            self.fetches += 1
+            a, b = fresh[ids].detach().float().cpu(), t[ids].detach().float().cpu()
+            if a.shape != b.shape or not torch.allclose(a, b, atol=tol, rtol=0):
+                report.append(f"{key[0]} {key[2]}: the simulator holds values the masked reset did not write (max |d| = {float((a - b).abs().max()):.3g})")
+        if report:
+            self.setter_report = report
+            self.setters_verified = False
+            warnings.warn("genesis_forge_amd: after the envs_idx setters the simulator does not hold the reset rows the masked reset assumed ("
+                          + "; ".join(report) + ") - scene-side resets fall back to the index-list path", RuntimeWarning)
+            self.env._partition_cache = None
+            self.env.invalidate_trace()
+        return not report
 
     # -- pointer attribution for a recorded step ---------------------------------------------------------------------------
     def attribute(self, descriptors: list, plan: list, skip: set) -> tuple:

@@ -360,6 +360,20 @@ class StepStats:
         for k in range(n):
             self._grp_work[i + k] = None
 
+    #: reduce_every > 1: may a log read close an open batch by itself?  That is a COLLECTIVE, so it is only safe when every rank reads
+    #: the same steps (``distributed.attach(..., lockstep_reads=True)``: training loops that log on every rank, curricula, bench.py).
+    #: The default refuses instead of hanging a run whose rank 0 alone reads a fresh log.
+    lockstep_reads = False
+
+    def _early_close(self, what: str) -> None:
+        if not self.lockstep_reads:
+            raise RuntimeError(
+                f"{what} is a collective with reduce_every = {self.reduce_every}: every rank would have to do it at the same step, and a "
+                "rank-local read (a rank-0-only logger) would wait for the other ranks forever.  Read steps older than reduce_every, call "
+                "env.stats.flush_reduce() on EVERY rank first, attach with lockstep_reads=True if all ranks read the same steps, or keep "
+                "reduce_every = 1 (rank-local reads)")
+        self.flush_reduce()
+
     def flush_reduce(self) -> None:
         """Close the open batch now (COLLECTIVE: every rank must call it at the same step): the newest pending step has not been
         followed by another recorded step yet, so its shards are folded explicitly, then every pending row is all-reduced."""
@@ -392,7 +406,7 @@ class StepStats:
         is still open the batch is closed first (a collective — the documented cost of reading a fresh step with K > 1);
         whether that happens depends only on WHICH step is read, never on what else happens to be alive on this rank."""
         if want is not None and want in self._grp_open:
-            self.flush_reduce()
+            self._early_close("reading the log of a step whose statistics batch is still open")
         seen = []
         for w in self._grp_work:
             if w is not None and w is not True and not any(w is x for x in seen):
@@ -407,7 +421,8 @@ class StepStats:
     def _group_last_reset(self) -> Optional["HostStats"]:
         """Batched group ring: global statistics of the most recent recorded step that reset at least one env (COLLECTIVE when a
         batch is open — curricula read this on every rank at the same step)."""
-        self.flush_reduce()
+        if getattr(self, "_grp_open", None):
+            self._early_close("reading the last episode means while a statistics batch is open")
         seen = []
         for w in self._grp_work:
             if w is not None and w is not True and not any(w is x for x in seen):

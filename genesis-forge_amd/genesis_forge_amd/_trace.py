@@ -91,6 +91,12 @@ class StepTrace:
         #: run in Python in the middle of the replay, the snapshot's addresses reach the descriptors as call parameters
         self.adapter = env._adapter
         self.scene_plan: list = []
+        self._scene_shapes: list = []     # the plan's tensor shapes in the recorded steps (checked every replayed tick)
+        self._null_stub = None
+        if env._adapter is not None:
+            import torch
+            from . import gs
+            self._null_stub = torch.zeros(16, dtype=torch.int32, device=gs.device)
         self._images = images
         self.tail_python = tail_python
         self.tail_seg: dict = {}   # "reset" / "obs" → native segment of the Python tail (see _build_tail_segment)
@@ -293,6 +299,7 @@ class StepTrace:
             raise Untraceable("the scene snapshot of this tick does not extend the recorded fetch plan")
         if len(plan) > len(self.scene_plan):
             self.scene_plan = plan
+            self._scene_shapes = [tuple(ad.peek(key).shape) for key, _f in plan]
             params = (C.c_void_p * (5 + len(plan)))()
             for i in range(self.n_params):
                 params[i] = self.params[i]
@@ -331,8 +338,29 @@ class StepTrace:
         env.robot.control_dofs_position(am._actions, am.dofs_idx)
         env.scene.step()
         pr = self.params
+        shapes = self._scene_shapes
         for i, t in enumerate(self.adapter.refetch(self.scene_plan)):
-            pr[5 + i] = t.data_ptr()   # (applied by the piece of the op list that follows: its table carries the pointer patches)
+            # (applied by the piece of the op list that follows: its table carries the pointer patches.  An EMPTY tensor — a tick
+            #  without a single contact — has no address; no kernel reads through it either: any non-null value will do)
+            pr[5 + i] = t.data_ptr() or self._null_stub.data_ptr()
+            if i < len(shapes) and tuple(t.shape) != shapes[i]:
+                self._scene_shape_changed(i, t)
+
+    def _scene_shape_changed(self, i: int, t) -> None:
+        """A tensor of the fetch plan came back with another shape than in the recorded steps.  Genesis pads the collider's contact
+        arrays to the current tick's contact count (contact_manager.py:391-426 takes its sizes from the fresh tensors every step), so
+        for those the scalar fields of the recorded ContactManager descriptors follow; anything else is not a step this recording
+        describes."""
+        key = self.scene_plan[i][0]
+        old = self._scene_shapes[i]
+        if key and key[0] == "contacts" and t.dim() == len(old) and tuple(t.shape)[:1] == old[:1]:
+            c = int(t.shape[1]) if t.dim() > 1 else 0
+            for a in getattr(self, "_contact_args", []):
+                a.num_contacts = c
+            self._scene_shapes[i] = tuple(t.shape)
+            return
+        raise RuntimeError(f"recorded step: the scene's {key} changed shape from {old} to {tuple(t.shape)} between ticks; "
+                           "call env.invalidate_trace() after changing the scene")
 
     # -- the Python tail of an env that overrides reset(), part by part ----------------------------------------------------
     def _fuse_tail_obs(self, calls, reset_args):
@@ -625,7 +653,10 @@ class StepTrace:
             self.native.extend(native)
             self.afters.append((self._cur_op, owner._trace_after))
         elif fn == "contact_step":
-            pass
+            # (an adapter scene re-checks the contact arrays' shapes every replayed tick: _scene_pre)
+            if not hasattr(self, "_contact_args"):
+                self._contact_args = []
+            self._contact_args.append(args)
         elif fn == "rollout_write":
             pol = next(m for m in env.managers["observation"] if m.name == owner.obs_name)
             fused = self.post_refs is not None and bool(self.post_refs.rollout)

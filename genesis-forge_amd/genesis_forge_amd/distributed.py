@@ -40,7 +40,7 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int]:
     return rank, world
 
 
-def attach(env, group=None, global_num_envs: Optional[int] = None, reduce_every: int = 1, force: bool = False) -> None:
+def attach(env, group=None, global_num_envs: Optional[int] = None, reduce_every: int = 1, force: bool = False, lockstep_reads: bool = False) -> None:
     """Make ``env``'s logging statistics global: sums over the ranks of ``group`` (default group if None).
     ``env.num_envs`` stays the local shard size; ``env.global_num_envs`` is the denominator of fractions.
 
@@ -59,7 +59,9 @@ def attach(env, group=None, global_num_envs: Optional[int] = None, reduce_every:
     With K > 1 the batches are tied to the recorded step: anything that invalidates it (``invalidate_trace``: a mutated weight /
     param / range, ``reset([ids])`` or ``resample_command`` between steps, a re-seed) closes the open batch with a collective
     and must therefore happen on every rank at the same step, as must reading the log of a step whose batch is still open.
-    K > 1 is for lock-step training loops only; it stays opt-in until RCCL scaling has been measured on a real node."""
+    K > 1 is for lock-step training loops only; it stays opt-in until RCCL scaling has been measured on a real node.
+    ``lockstep_reads`` (K > 1): the caller promises that every rank reads the same steps' logs, so a read may close an open batch by
+    itself; without it such a read RAISES (a rank-0-only logger would otherwise wait for the other ranks forever)."""
     if reduce_every < 1 or reduce_every > 32 or 64 % reduce_every != 0:
         raise ValueError("reduce_every must divide 64 and be at most 32")
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
@@ -67,6 +69,7 @@ def attach(env, group=None, global_num_envs: Optional[int] = None, reduce_every:
         return   # (``force``: take the collective path even in a group of one — how the RCCL calls are exercised on a one-GPU box)
     env.stats.group = group if group is not None else dist.group.WORLD
     env.stats.reduce_every = reduce_every
+    env.stats.lockstep_reads = bool(lockstep_reads)
     if global_num_envs is None:
         n = torch.tensor([env.num_envs], dtype=torch.int64, device=env.stats.device)
         dist.all_reduce(n, group=group)

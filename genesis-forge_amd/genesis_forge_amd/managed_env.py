@@ -377,6 +377,24 @@ class ManagedEnvironment(GenesisEnv):
                         m.reset(ids)
         self.invalidate_views()
 
+    def _verify_adapter_setters(self) -> None:
+        """Before the first full reset on a scene with Genesis' public surface only: does the simulator behave as the masked reset
+        assumes (SceneAdapter.verify_setters)?  If not, the scene-side reset sections are not fused: every manager with one resets
+        by index list, as in the reference (mdp/reset.py:102-124, position_action_manager.py:455-464)."""
+        import warnings
+
+        ad = self._adapter
+        am = self.managers["action"]
+        robot = getattr(self, "robot", None)
+        if robot is None or not all(hasattr(robot, k) for k in ("set_pos", "set_quat", "get_pos", "get_quat")):
+            ad.setters_verified = True   # nothing the masked reset would write through
+            return
+        ok = ad.verify_setters(robot, getattr(am, "dofs_idx", None) if am is not None else None)
+        self._partition_cache = None
+        if not ok:
+            warnings.warn("genesis_forge_amd: the simulator's envs_idx setters do not read back what the masked reset assumes ("
+                          + "; ".join(ad.setter_report) + ") - scene-side resets fall back to the index-list path", RuntimeWarning)
+
     def reset(self, env_ids: list[int] | None = None):
         """Reset one or more environments and every registered manager (managed_env.py:336-371)."""
         outside = not self._in_step
@@ -402,6 +420,8 @@ class ManagedEnvironment(GenesisEnv):
             self.stats.clear(self.backend)
             if self._adapter is not None:
                 self._adapter.invalidate()   # between steps the simulator may have been edited: read it afresh
+                if env_ids is None and self._adapter.setters_verified is None:
+                    self._verify_adapter_setters()
         mask = self._ids_to_mask(env_ids)
         ids = env_ids if env_ids is not None else torch.arange(self.num_envs, device=gs.device)
         self._reset_with_mask(mask, None, ids=ids)

@@ -333,7 +333,8 @@ class PositionActionManager(BaseActionManager):
         self.env.robot.set_dofs_position(position=position, dofs_idx_local=self.dofs_idx, envs_idx=envs_idx)
 
     def _can_fuse_reset(self) -> bool:
-        return hasattr(self.env.robot, "gf_masked_dofs") or self.env._adapter is not None
+        ad = self.env._adapter
+        return hasattr(self.env.robot, "gf_masked_dofs") or (ad is not None and ad.setters_verified is not False)
 
     def _fill_reset(self, a: nat.GfResetArgs) -> None:
         """Scene-side section of the fused reset: dof_pos <- default (+noise), dof_vel <- 0.  PD gains are

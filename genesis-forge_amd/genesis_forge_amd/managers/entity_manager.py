@@ -127,7 +127,8 @@ class EntityManager(BaseManager):
     def _can_fuse_reset(self) -> bool:
         """True when the scene has masked setters and the on_reset entry is a fixed-pose ``mdp.reset.position`` or a
         ``mdp.reset.randomize_terrain_position`` whose arguments are static (see its ``gf_spawn``)."""
-        if not hasattr(self.entity, "gf_masked_base") and self.env._adapter is None:
+        ad = self.env._adapter
+        if not hasattr(self.entity, "gf_masked_base") and (ad is None or ad.setters_verified is False):
             return False
         from ..mdp import reset as reset_mdp
         items = list(self.on_reset.values())

@@ -40,7 +40,7 @@ def run_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_every=1
         env.config = config
     env.build()
     env.seed(5)
-    gfd.attach(env, reduce_every=reduce_every)
+    gfd.attach(env, reduce_every=reduce_every, lockstep_reads=True)   # (every rank reads the same steps' logs)
     assert env.env_offset == start and env.global_num_envs == n_global
     env.reset()
     g = torch.Generator().manual_seed(0)
@@ -83,7 +83,7 @@ def run_probe_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_e
                                  scene_kwargs=dict(ang_noise=0.0, seed=3))
     env.build()
     env.seed(5)
-    gfd.attach(env, reduce_every=reduce_every)
+    gfd.attach(env, reduce_every=reduce_every, lockstep_reads=True)
     env.reset()
     g = torch.Generator().manual_seed(0)
     out, resets = {}, []
@@ -98,3 +98,40 @@ def run_probe_shard(rank, world, port, out_dir, n_global, steps, sizes, reduce_e
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_rank0_reader(rank, world, port, out_dir, reduce_every):
+    """A rank-0-only logger with K > 1: rank 0 reads a fresh step's log, rank 1 never does.  Without ``lockstep_reads`` the read must
+    RAISE on rank 0 (closing the open batch is a collective the other rank never enters); the run then goes on."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from genesis_forge_amd import _native as nat
+    from genesis_forge_amd import distributed as gfd
+    from genesis_forge_amd import gs
+    from oracle_backend import OracleBackend
+    from envs import Go2CommandDirectionEnv
+
+    gs.set_device("cpu")
+    nat.set_backend(OracleBackend(os.path.join(ROOT, "oracle", "libgf_oracle.so")))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    env = Go2CommandDirectionEnv(num_envs=33 + 4 * rank, max_episode_length_s=1, cmd_resample_s=0.3, scene_kwargs=dict(ang_noise=0.3, seed=3))
+    env.build()
+    env.seed(5)
+    gfd.attach(env, reduce_every=reduce_every)
+    env.reset()
+    g = torch.Generator().manual_seed(rank)
+    raised, old_ok = False, False
+    logs = []
+    for t in range(3 * reduce_every + 5):
+        _o, _r, _te, _tr, ex = env.step(torch.randn(env.num_envs, 12, generator=g))
+        logs.append(ex["episode"])
+        if rank == 0 and t == reduce_every + 2 and env._trace is not None:
+            try:
+                dict(ex["episode"])
+            except RuntimeError as e:
+                raised = "collective" in str(e)
+        if rank == 0 and t == 3 * reduce_every + 4:
+            dict(logs[t - 2 * reduce_every - 2])   # a step whose batch closed long ago: rank-local, no collective
+            old_ok = True
+    torch.save({"raised": raised, "old_ok": old_ok, "traced": env._trace is not None}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()

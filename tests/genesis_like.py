@@ -133,10 +133,10 @@ class GenesisLikeEntity:
         self._set("zero_all_dofs_velocity"); self._e.zero_all_dofs_velocity(envs_idx)
 
     def set_pos(self, pos, envs_idx=None, zero_velocity: bool = True):
-        self._set("set_pos"); self._e.set_pos(pos, envs_idx, zero_velocity)
+        self._set("set_pos"); self._e.set_pos(pos, envs_idx, zero_velocity and not self._scene.sloppy_setters)
 
     def set_quat(self, quat, envs_idx=None, zero_velocity: bool = True):
-        self._set("set_quat"); self._e.set_quat(quat, envs_idx, zero_velocity)
+        self._set("set_quat"); self._e.set_quat(quat, envs_idx, zero_velocity and not self._scene.sloppy_setters)
 
 
 class _Collider:
@@ -146,8 +146,21 @@ class _Collider:
     def get_contacts(self, as_tensor: bool = True, to_torch: bool = True):
         sc, sim = self._scene, self._scene._sim
         sc.calls["get_contacts"] += 1
-        return {"force": sc._hand_out(None, sim.contact_force.clone()), "position": sc._hand_out(None, sim.contact_pos.clone()),
-                "link_a": sc._hand_out(None, sim.link_a.clone()), "link_b": sc._hand_out(None, sim.link_b.clone())}
+        force, pos, la, lb = sim.contact_force, sim.contact_pos, sim.link_a, sim.link_b
+        if sc.trim_contacts and la.shape[1] > 0:
+            # Genesis' collider: an env's contacts sit at the front of its row and the arrays are padded to the tick's LARGEST contact
+            # count — their second dimension changes from tick to tick (contact_manager.py:391-426 sizes everything from the fresh
+            # tensors).  Compaction keeps the slot order, so every per-link sum adds the same values in the same order.
+            active = (la >= 0) | (lb >= 0)
+            order = torch.argsort((~active).to(torch.int8), dim=1, stable=True)
+            cmax = int(active.sum(1).max())
+            sc.contact_counts.append(cmax)
+            idx = order[:, :cmax]
+            force = torch.gather(force, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+            pos = torch.gather(pos, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+            la, lb = torch.gather(la, 1, idx), torch.gather(lb, 1, idx)
+        return {"force": sc._hand_out(None, force.clone()), "position": sc._hand_out(None, pos.clone()),
+                "link_a": sc._hand_out(None, la.clone()), "link_b": sc._hand_out(None, lb.clone())}
 
 
 class _RigidSolver:
@@ -163,8 +176,11 @@ class GenesisLikeScene:
     """``gs.Scene`` look-alike (same constructor keywords as the synthetic scene, which it drives in private)."""
 
     poison = True
+    sloppy_setters = False  # True: set_pos / set_quat IGNORE zero_velocity — a simulator the masked reset's assumption does not hold for
+    trim_contacts = False   # True: get_contacts() pads to the tick's largest contact count, as Genesis does (the shape varies per tick)
 
     def __init__(self, **kw):
+        self.contact_counts: list = []
         self._sim = _synth.SyntheticScene(**kw)
         self.dt = self._sim.dt
         self.substeps = self._sim.substeps

@@ -33,6 +33,32 @@ def test_gpus_2_self_launch_weak():
     assert out["config"]["parallelism"] == "env-shard x2" and out["config"]["dist_backend"] == "gloo"
     assert out["value"] > 0 and abs(out["value"] - 192 * 6 / (out["ms_per_step"] * 6e-3)) < 1e-6 * out["value"]
     assert out["timing"]["batches"] >= 1 and out["timing"]["timed_s"] >= 0.3
+    # every rank pins itself to its own share of the host cores (from inside the rank) and reports it, with the host's
+    # own time per step; the IPC mode RCCL needs on this driver is reported and comes from the environment when that sets it
+    ranks = out["ranks"]
+    assert all(r["host_us_per_step"] > 0 for r in ranks)
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 4:
+        assert all(r["affinity"]["pinned"] and r["affinity"]["cpus"] == ncpu // 2 for r in ranks)
+        assert ranks[0]["affinity"]["last"] < ranks[1]["affinity"]["first"], "disjoint core sets"
+    assert out["config"]["hsa_enable_ipc_mode_legacy"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("config,global_envs", [("gait", 140), ("humanoid", 132)])
+def test_gpus_2_strong_scaling_with_a_collective_per_step(config, global_envs):
+    """--scaling strong --config gait|humanoid with --reduce-every 1: the K = 1 path (one all-reduce of one statistics row per step,
+    rank-local log reads) next to the K = 32 default of the other cases; GF_PIN=0 leaves the affinity alone."""
+    os.environ["GF_PIN"] = "0"
+    try:
+        out = _bench("--gpus", "2", "--steps", "5", "--warmup", "2", "--scaling", "strong", "--global-envs", str(global_envs), "--config", config,
+                     "--reduce-every", "1", "--no-cpu-baseline")
+    finally:
+        del os.environ["GF_PIN"]
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["workload"] == config
+    assert out["config"]["stats_allreduce_every_steps"] == 1 and out["config"]["global_num_envs"] == global_envs
+    assert [r["num_envs"] for r in out["ranks"]] == [global_envs // 2] * 2 and not any(r["affinity"]["pinned"] for r in out["ranks"])
+    assert out["value"] > 0
 
 
 @pytest.mark.timeout(300)

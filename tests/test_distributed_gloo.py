@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from _dist_worker import run_probe_shard, run_shard
+from _dist_worker import run_probe_shard, run_rank0_reader, run_shard
 
 
 def _free_port():
@@ -96,6 +96,23 @@ def test_last_episode_means_survive_ring_recycling(oracle_lib_path, reduce_every
                 assert abs(log[k] - v) <= 1e-6 + 1e-6 * abs(v), (t, k, log[k], v)
             for k, v in want_means.items():
                 assert (means[k] != means[k] and v != v) or abs(means[k] - v) <= 1e-6 + 1e-6 * abs(v), (t, k, means[k], v)   # (nan: a zero-weight term, as in the reference)
+
+
+@pytest.mark.timeout(300)
+def test_rank_local_read_of_an_open_batch_raises_instead_of_hanging(oracle_lib_path):
+    """with K > 1 a rank-0-only logger that reads a fresh step's log would enter a collective alone.  Unless the caller
+    promised lock-step reads (``attach(lockstep_reads=True)``) the read raises; logs of closed batches stay readable rank-locally."""
+    with tempfile.TemporaryDirectory() as d:
+        ctx = mp.get_context("spawn")
+        port = _free_port()
+        procs = [ctx.Process(target=run_rank0_reader, args=(r, 2, port, d, 8)) for r in range(2)]
+        for q in procs:
+            q.start()
+        for q in procs:
+            q.join(200)
+            assert q.exitcode == 0, "a rank hung or died"
+        r0 = torch.load(os.path.join(d, "rank0.pt"))
+    assert r0["traced"] and r0["raised"] and r0["old_ok"]
 
 
 def test_shard_partition():

@@ -105,6 +105,65 @@ def test_recorded_step_on_genesis_like_scene_cpu(oracle_backend, name):
         assert tr.tail_python and sorted(tr.tail_seg) == ["obs", "reset"]
 
 
+@pytest.mark.parametrize("name", ["gait", "rough_terrain", "humanoid"])
+def test_contact_arrays_that_change_shape_every_tick_cpu(oracle_backend, name):
+    """Genesis pads the collider's contact arrays to the CURRENT tick's contact count, so their shape varies from
+    tick to tick; a recorded step re-patched only the pointers and ran the kernel with the recorded step's slot count.  With the
+    double trimming its arrays the same way (poisoned stale tensors included), the recorded step must still equal the synthetic run."""
+    _varying_contacts(name, "cpu")
+
+
+def _varying_contacts(name, dev):
+    a, _ = run(name, dev, None, False)
+    GenesisLikeScene.trim_contacts = True
+    try:
+        b, env = run(name, dev, GenesisLikeScene, True)
+    finally:
+        GenesisLikeScene.trim_contacts = False
+    same(a, b)
+    assert env._trace is not None, env._untraceable
+    counts = env.scene.contact_counts
+    assert len(set(counts)) > 2, f"the contact arrays should change shape from tick to tick: {sorted(set(counts))}"
+
+
+def test_setter_assumption_is_checked_against_the_simulator(oracle_backend):
+    """"after set_pos / set_quat / set_dofs_position the getters return what was set, velocities zeroed" was a comment
+    (_scene_adapter.py).  It is now a run-time check before the first full reset: one env is probed through the
+    setters and read back through the getters.  On the double it holds; on a variant whose setters ignore ``zero_velocity`` the env
+    warns, takes the scene-side resets off the masked path (index lists, the reference's reset(ids)) and — recorded or ordinary —
+    observes what the SIMULATOR holds (non-zero base velocities of a just-reset env), not what the masked reset would have assumed."""
+    import warnings
+
+    _, env = run("go2_plain", "cpu", GenesisLikeScene, True, steps=12)
+    ad = env._adapter
+    assert ad.setters_verified is True and ad.setter_report == []
+    assert env.managers["action"]._can_fuse_reset() and all(m._can_fuse_reset() for m in env.managers["entity"])
+    assert ad.fetches_last_tick == len(env._trace.scene_plan) > 0   # one call per getter of the plan in a replayed tick
+
+    GenesisLikeScene.sloppy_setters = True
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            rec, env_r = run("go2_plain", "cpu", GenesisLikeScene, True, steps=40)
+        assert any("envs_idx setters" in str(x.message) and "base vel" in str(x.message) for x in w), [str(x.message) for x in w]
+        assert env_r._adapter.setters_verified is False
+        assert not any(m._can_fuse_reset() for m in env_r.managers["entity"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ordi, env_o = run("go2_plain", "cpu", GenesisLikeScene, False, steps=40)
+        same(rec, ordi)
+        # a just-reset env keeps its base velocity on this simulator, and the observation shows it (go2_plain: obs[3:6] = ang vel, [6:9] = lin vel)
+        seen = 0
+        for xs, _log in rec:
+            obs, term, trunc = xs[0], xs[2], xs[3]
+            done = term | trunc
+            if done.any():
+                seen += int((obs[done][:, 3:9].abs().sum(1) > 0).sum())
+        assert seen > 0
+    finally:
+        GenesisLikeScene.sloppy_setters = False
+
+
 def test_one_getter_call_per_tick_and_one_index_list(oracle_backend, monkeypatch):
     """A replayed step on the double: control_dofs_position + scene.step() once, every getter of the plan once, setters only on
     steps that reset an env, and exactly one index-list compaction (gf_done_compact + sync: what the envs_idx setters need, where the
@@ -195,6 +254,12 @@ def test_random_configs_on_genesis_like_scene_cpu(oracle_backend, seed):
     got, info = _fuzz_on(GenesisLikeScene, seed, "cpu", trace=True)
     assert info["recorded"], info["env"]._untraceable
     fz._compare(got, want, 0, f"seed {seed} on the Genesis-shaped double")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gait", "humanoid"])
+def test_contact_arrays_that_change_shape_every_tick_hip(hip_backend, name):
+    _varying_contacts(name, "cuda")
 
 
 @pytest.mark.gpu

@@ -150,3 +150,48 @@ def test_compiled_program_equals_oracle_hip(hip_backend, oracle_lib_path, signat
         nat.set_backend(None)
         gs.set_device("cuda:0")
     fz._compare(hip, ref, FLOAT_TOL, f"seed {seed} compiled program")
+
+
+def test_child_compiler_never_inherits_a_profilers_environment(monkeypatch):
+    """under ``rocprofv3 --pmc`` LD_PRELOAD and the ROCP_* tool variables would reach hipcc, whose preloaded library
+    initialises the GPU before it execs clang — a forbidden exec on this pool.  The child env is scrubbed and the default policy is
+    ``off`` while such variables are present."""
+    from genesis_forge_amd import _programs
+
+    class _E:
+        num_envs, jit_programs = 65536, None
+
+    monkeypatch.delenv("GF_JIT", raising=False)
+    for k in list(os.environ):
+        if k in _programs._TOOL_ENV_NAMES or k.startswith(_programs._TOOL_ENV_PREFIXES):
+            monkeypatch.delenv(k)
+    assert _programs.mode_for(_E()) == "async" and not _programs.under_profiler()
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "x")
+    monkeypatch.setenv("ROCPROFILER_PC_SAMPLING", "1")
+    monkeypatch.setenv("HSA_TOOLS_LIB", "y")
+    assert _programs.under_profiler() and _programs.mode_for(_E()) == "off"
+    env = _programs.compiler_env()
+    assert not {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_PC_SAMPLING", "HSA_TOOLS_LIB"} & set(env)
+    assert env.get("PATH") == os.environ.get("PATH")
+    monkeypatch.setenv("GF_JIT", "sync")   # an explicit choice stands (the child is scrubbed either way)
+    assert _programs.mode_for(_E()) == "sync"
+
+
+def test_concurrent_compiles_of_one_program_share_the_cache(tmp_path, monkeypatch):
+    """ranks that record the same step at the same time compile from sources of their own and move the finished plugin
+    into place atomically — no process ever reads a file another one is writing."""
+    from genesis_forge_amd import _programs
+
+    if _programs.hipcc() is None:
+        pytest.skip("no hipcc")
+    monkeypatch.setenv("GF_PROGRAM_CACHE", str(tmp_path))
+    sig = ("program 0 (interpreter): DV = 3; n_term = 1; term = {{1, 1}}; n_rew = 1; rew = {{9, 0, 0, 0}}; n_cmd = 0; cmd_width = {}; n_obs = 1;"
+           " obs[0]: width 12 history 1 items {{8, 12, 0, false, false}}; n_air = 0; n_gait = 0")
+    so1, p1 = _programs.start_compile(sig)
+    so2, p2 = _programs.start_compile(sig)   # the plugin is not there yet: a second compile starts, as in another rank
+    assert so1 == so2 and p1 is not None and p2 is not None and p1._gf_src != p2._gf_src and p1._gf_tmp != p2._gf_tmp
+    assert _programs.finish_compile(p1) == so1 and _programs.finish_compile(p2) == so1
+    assert os.path.exists(so1) and not os.path.exists(p1._gf_src) and not os.path.exists(p2._gf_src)
+    assert [n for n in os.listdir(tmp_path) if ".tmp" in n] == []
+    assert _programs.start_compile(sig) == (so1, None)   # cache hit

@@ -26,7 +26,7 @@ def _run(reduce_every, steps=70):
     env = tasks.Go2CommandDirectionEnv(num_envs=1000, max_episode_length_s=0.4, cmd_resample_s=0.2, contacts=True, scene_kwargs=dict(ang_noise=0.3, seed=3))
     env.build()
     if reduce_every:
-        gfd.attach(env, reduce_every=reduce_every, force=True)
+        gfd.attach(env, reduce_every=reduce_every, force=True, lockstep_reads=True)
         assert env.stats.group is not None
     env.seed(5)
     env.reset()

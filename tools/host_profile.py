@@ -23,7 +23,7 @@ if os.environ.get("GF_DIST_FORCE") == "1":   # the process-group path with one r
     from genesis_forge_amd import distributed as gfd
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29632")
     dist.init_process_group("nccl", rank=0, world_size=1)
-    gfd.attach(env, reduce_every=int(os.environ.get("GF_REDUCE_EVERY", "32")), force=True)
+    gfd.attach(env, reduce_every=int(os.environ.get("GF_REDUCE_EVERY", "32")), force=True, lockstep_reads=True)
 env.seed(1); env.reset()
 d = env.action_space.shape[0]
 acts = [torch.randn(n, d, device=gs.device) for _ in range(8)]
