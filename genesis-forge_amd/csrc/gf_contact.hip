@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
     }
     const ContactScene sc{a.force, a.position, a.links_quat, a.links_vel, a.links_pos, a.link_a, a.link_b, C, a.num_scene_links, T, a.dt};
     const ContactLds l = contact_lds_carve(lds_raw, E, C, reinterpret_cast<const ContactMgrL*>(&s_mgr[0][0]), s_target, s_meta, &s_with[0][0]);
-    const int flag_mask = contact_tile(sc, l, E, n0, envs_here, (int)threadIdx.x, (int)blockDim.x);   // (its first barrier covers the tables)
+    const int flag_mask = contact_tile<1, 1>(sc, l, E, n0, envs_here, (int)threadIdx.x, (int)blockDim.x);   // (its first barrier covers the tables)
     // non-finite force seen: one flag per manager (contact_manager.py:399-403 prints a warning)
     for (int m = 0; m < a.num_mgr; ++m) {
         if (!a.m[m].stats) continue;

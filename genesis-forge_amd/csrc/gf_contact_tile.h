@@ -83,11 +83,12 @@ struct ContactNoStamp { __device__ __forceinline__ void operator()(int) const {}
 // runs afterwards as ~12 launches is done by the same lane while the summed force is in registers.
 // Lanes are LINK-major within a pass: nthreads / E links of every env per pass (the fused launch's 64-env tile: four — the feet
 // of a quadruped are one pass, so the matches of a walking robot cost ONE dependent round trip per tile, and the passes over body
-// links, which rarely touch anything, only scan LDS and store); the air-time state of the first four passes is requested up front.
+// links, which rarely touch anything, only scan LDS and store); the air-time state of the first kAirAhead passes is requested up
+// front, a lane's slot-id requests go out U units at a time (the stand-alone launch sizes its workgroups for ONE pass and one unit).
 // Every thread of the workgroup calls this (it synchronises the workgroup twice); the caller's tables must be written before the
 // call (its first barrier publishes them).  Returns a bit per manager: this lane sanitised a non-finite force for it
 // (contact_manager.py:399-403 prints a warning).
-template <class Stamp = ContactNoStamp>
+template <int kAirAhead = 4, int U = 4, class Stamp = ContactNoStamp>
 __device__ __forceinline__ int contact_tile(const ContactScene& a, const ContactLds& l, const int E, const int64_t n0, const int envs_here, const int tid,
                                             const int nthreads, Stamp&& stamp = Stamp()) {
     const int C = a.C, T = a.T;
@@ -104,7 +105,6 @@ __device__ __forceinline__ int contact_tile(const ContactScene& a, const Contact
     for (int i = tid; i < envs_here * MW; i += nthreads) smask[i] = 0u;
     __syncthreads();
     // ---- requests that depend on nothing: the air-time state of the first kAirAhead passes ---------------------------------------------
-    constexpr int kAirAhead = 4;
     float air_pre[kAirAhead], con_pre[kAirAhead];
 #pragma unroll
     for (int p = 0; p < kAirAhead; ++p) {
@@ -135,7 +135,6 @@ __device__ __forceinline__ int contact_tile(const ContactScene& a, const Contact
         const bool vec = ((n0 * C) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.link_a) | reinterpret_cast<uintptr_t>(a.link_b)) & 15u) == 0;
         const int slots4 = vec ? (slots >> 2) : 0;
         // (all of a lane's requests first — a 64-env tile of 60 slots is four units per lane and array: one round trip, not four)
-        constexpr int U = 4;
         for (int b4 = 0; b4 < slots4; b4 += U * nthreads) {
             i32x4 va[U], vb[U];
 #pragma unroll

@@ -290,7 +290,9 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                 t_meta[tid] = (uint16_t)(((cf_word((int)offsetof(PostContact, mgr_of) + wd) >> sh) & 0xffu) |
                                          (((cf_word((int)offsetof(PostContact, local_of) + wd) >> sh) & 0xffu) << 8));
             }
-            {   // While the contact phase runs its own chain of round trips, the rows the roles below will request are pulled towards this CU:
+            if (N <= 16384) {   // (small launches only: with every workgroup of 65 536 envs resident the requested lines do not survive in the 4 MB L2 of an
+                                // XCD until the roles ask for them — PMC reads of the gait task's launch 166 MB with the warm-up, profiles/r04_k_pmc_cfg.md)
+                // While the contact phase runs its own chain of round trips, the rows the roles below will request are pulled towards this CU:
                 // one LDS-DMA dword per lane and array (no register, no wait; the first dword of the env's row — rows are at most a
                 // cache line long, so every line of the tile's block is touched) into a scratch row nobody reads.  The roles' real
                 // loads then hit the L1 / L2 instead of starting a round trip to memory behind the phase.
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                                   UNI(a.cfold.link_a), UNI(a.cfold.link_b), C, UNI(a.cfold.num_scene_links), T, UNI(a.cfold.dt)};
             const ContactLds cl = contact_lds_carve(ids, kEnvBlock, C, reinterpret_cast<const ContactMgrL*>(t_mgr), t_target, t_meta, t_with);
             const int envs_here = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
-            const int flag_mask = contact_tile(sc, cl, kEnvBlock, n0, envs_here, tid, kWsBlock, [&](int i) GF_INLINE_LAMBDA { (void)i; GF_WSTAMP(12 + i); });   // (its first barrier covers the tables)
+            const int flag_mask = contact_tile<4, 4>(sc, cl, kEnvBlock, n0, envs_here, tid, kWsBlock, [&](int i) GF_INLINE_LAMBDA { (void)i; GF_WSTAMP(12 + i); });   // (its first barrier covers the tables)
             if (shard) {   // non-finite force sanitised: the warning flag of contact_manager.py:399-403 (every folded manager counts into the step's block)
                 const unsigned long long b = __ballot(flag_mask != 0);
                 if (b && lane == 0) atomicOr(&shard->contact_flags, 1);
