@@ -477,6 +477,8 @@ class HipBackend(Backend):
         self.lib.gf_stats_last_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         self.lib.gf_post_physics_check.restype = C.c_int
         self.lib.gf_post_physics_check.argtypes = [C.POINTER(GfPostRefs)]
+        self.lib.gf_post_physics_step_contacts.restype = C.c_int
+        self.lib.gf_post_physics_step_contacts.argtypes = [C.POINTER(GfPostRefs), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
         self.lib.gf_post_physics_describe.restype = C.c_int
         self.lib.gf_post_physics_describe.argtypes = [C.POINTER(GfPostRefs), C.c_char_p, C.c_int]
         self.lib.gf_post_program_register.restype = C.c_int
@@ -543,6 +545,12 @@ class HipBackend(Backend):
 
     def post_check(self, refs) -> bool:
         return self.lib.gf_post_physics_check(C.byref(refs)) == 0
+
+    def post_step_contacts(self, refs, contact_args: list) -> int:
+        """gf_post_physics_step_contacts: the fused post-physics launch with these ContactManagers' step as its first phase.  Returns the
+        status (0, or GF_E_UNSUPPORTED = -5 when the managers cannot be folded) — raw, for callers that fall back themselves."""
+        arr = (C.c_void_p * max(1, len(contact_args)))(*[C.addressof(a) for a in contact_args])
+        return self.lib.gf_post_physics_step_contacts(C.byref(refs), arr, len(contact_args), self._stream())
 
     def post_describe(self, refs) -> str:
         buf = C.create_string_buffer(4096)

@@ -112,3 +112,63 @@ def test_folded_launch_equals_separate_launches(hip_backend):
                 for got, want in zip((cm.last_air_time, cm.current_air_time, cm.last_contact_time, cm.current_contact_time), air):
                     assert torch.equal(got, want)
         _check(env, fix, t)
+
+
+@pytest.mark.gpu
+def test_contact_step_as_first_phase_of_the_fused_launch_raw_abi(hip_backend):
+    """gf_post_physics_step_contacts through the raw ABI on the reference-recorded contact arrays: link ids on both sides, empty slots,
+    NaN / Inf forces, a with-filter on another entity and one on own links, air time — the three managers run as the first phase of a
+    fused post-physics launch (of an unrelated Go2 env of the same size: any fusable step will do) and must leave exactly what three
+    gf_contact_step launches leave, which is what the reference left (fixture)."""
+    import envs
+    from genesis_forge_amd import _native as nat
+
+    fix0 = helpers.load("contact_kernel")
+    n = int(fix0["n"])
+    env, fix = _env(n, int(fix0["C"]), "cuda")
+    host = envs.Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=1, cmd_resample_s=0.3, contacts=True, scene_kwargs=dict(ang_noise=0.3, seed=3))
+    host.build(); host.seed(3); host.reset()
+    g = torch.Generator().manual_seed(0)
+    for _ in range(6):
+        host.step(torch.randn(n, 12, generator=g).to("cuda"))
+    refs = host._trace.post_refs
+    assert refs is not None
+    hip_backend.set_option(nat.GF_OPT_FOLD_CONTACT, 2)
+    try:
+        for t in range(int(fix["steps"])):
+            _load_step(env, fix, t, "cuda")
+            air_before = [[x.clone() for x in (cm.last_air_time, cm.current_air_time, cm.last_contact_time, cm.current_contact_time)]
+                          if cm.last_air_time is not None else None for cm in env.cms]
+            for cm in env.cms:
+                cm.step()
+            separate = [(cm.contacts.clone(), cm.contact_positions.clone(), cm._contact_position_counts.clone(),
+                         [x.clone() for x in (cm.last_air_time, cm.current_air_time, cm.last_contact_time, cm.current_contact_time)]
+                         if cm.last_air_time is not None else None) for cm in env.cms]
+            for cm, before in zip(env.cms, air_before):   # rewind the air-time state, poison the outputs
+                cm.contacts.fill_(float("nan")); cm.contact_positions.fill_(float("nan")); cm._contact_position_counts.fill_(-1.0)
+                if before is not None:
+                    for dst, src in zip((cm.last_air_time, cm.current_air_time, cm.last_contact_time, cm.current_contact_time), before):
+                        dst.copy_(src)
+            descs = []
+            for cm in env.cms:
+                a = nat.GfContactArgs()
+                C.memmove(C.addressof(a), C.addressof(cm._args), C.sizeof(a))
+                a.stats = None   # (the managers of another env: no statistics block of the host env's step)
+                descs.append(a)
+            rc = hip_backend.post_step_contacts(refs, descs)
+            assert rc == 0, f"not folded: {nat.GF_ERRORS.get(rc, rc)}"
+            torch.cuda.synchronize()
+            for cm, (f, p, c, air) in zip(env.cms, separate):
+                assert torch.equal(cm.contacts, f) and torch.equal(cm.contact_positions, p) and torch.equal(cm._contact_position_counts, c)
+                if air is not None:
+                    for got, want in zip((cm.last_air_time, cm.current_air_time, cm.last_contact_time, cm.current_contact_time), air):
+                        assert torch.equal(got, want)
+            _check(env, fix, t)
+        # what cannot be folded is refused, nothing launched: a descriptor over another number of envs
+        bad = nat.GfContactArgs()
+        C.memmove(C.addressof(bad), C.addressof(env.cms[0]._args), C.sizeof(bad))
+        bad.num_envs = n + 1
+        bad.stats = None
+        assert hip_backend.post_step_contacts(refs, [bad]) == -5
+    finally:
+        hip_backend.set_option(nat.GF_OPT_FOLD_CONTACT, 1)
