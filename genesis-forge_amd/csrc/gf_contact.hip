@@ -41,6 +41,8 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
     const int64_t n0 = (int64_t)blockIdx.x * E;
     const int envs_here = (int)((int64_t)a.num_envs - n0 < E ? (int64_t)a.num_envs - n0 : E);
     const auto* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    const ContactScene sc{a.force, a.position, a.links_quat, a.links_vel, a.links_pos, a.link_a, a.link_b, C, a.num_scene_links, T, a.dt};
+    const ContactIdsPending<1> pend = contact_ids_request<1>(sc, n0, envs_here, (int)threadIdx.x, (int)blockDim.x);   // (in flight while the tables below arrive)
     // The kernel is a chain of memory round trips at the env counts of a real run (a few hundred workgroups), so the tables a
     // lane indexes with its own (env, tracked link) are staged once per workgroup — vector loads from the kernel-argument segment
     for (int i = threadIdx.x; i < kContactMaxMgr * kContactMgrWords; i += blockDim.x) {
@@ -57,9 +59,8 @@ __global__ __launch_bounds__(kContactBlock) void contact_kernel(const ContactMul
         (&s_with[0][0])[i] = *(const __attribute__((address_space(4))) int32_t*)(kp + offsetof(ContactMultiArgs, m) + (size_t)m * sizeof(ContactMgr) +
                                                                                  offsetof(ContactMgr, with_link_ids) + 4 * w);
     }
-    const ContactScene sc{a.force, a.position, a.links_quat, a.links_vel, a.links_pos, a.link_a, a.link_b, C, a.num_scene_links, T, a.dt};
     const ContactLds l = contact_lds_carve(lds_raw, E, C, reinterpret_cast<const ContactMgrL*>(&s_mgr[0][0]), s_target, s_meta, &s_with[0][0]);
-    const int flag_mask = contact_tile<1, 1>(sc, l, E, n0, envs_here, (int)threadIdx.x, (int)blockDim.x);   // (its first barrier covers the tables)
+    const int flag_mask = contact_tile<1, 1>(sc, l, E, n0, envs_here, (int)threadIdx.x, (int)blockDim.x, pend);   // (its first barrier covers the tables)
     // non-finite force seen: one flag per manager (contact_manager.py:399-403 prints a warning)
     for (int m = 0; m < a.num_mgr; ++m) {
         if (!a.m[m].stats) continue;

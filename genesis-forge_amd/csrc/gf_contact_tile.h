@@ -72,6 +72,31 @@ struct FastDivC {
 
 struct ContactNoStamp { __device__ __forceinline__ void operator()(int) const {} };
 
+// The first U units (four slot ids per lane and array) of a workgroup's slot-id rows, REQUESTED: the caller asks for them before it
+// stages its tables (those come from the kernel-argument segment with vector loads of their own), so the two round trips are one.
+template <int U>
+struct ContactIdsPending {
+    i32x4 va[U], vb[U];
+    bool vec;
+};
+template <int U>
+__device__ __forceinline__ ContactIdsPending<U> contact_ids_request(const ContactScene& a, const int64_t n0, const int envs_here, const int tid, const int nthreads) {
+    ContactIdsPending<U> p;
+    const int C = a.C;
+    const GF_GLOBAL int32_t* ga = G(a.link_a) + n0 * C;
+    const GF_GLOBAL int32_t* gb = G(a.link_b) + n0 * C;
+    // four ids per lane and array (dwordx4: 1 KiB per wave instruction) when the block's rows start 16-byte aligned
+    p.vec = C > 0 && ((n0 * C) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.link_a) | reinterpret_cast<uintptr_t>(a.link_b)) & 15u) == 0;
+    const int slots4 = p.vec ? ((envs_here * C) >> 2) : 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i4 = u * nthreads + tid;
+        p.va[u] = i32x4{-1, -1, -1, -1}; p.vb[u] = p.va[u];
+        if (i4 < slots4) { p.va[u] = reinterpret_cast<const GF_GLOBAL i32x4*>(ga)[i4]; p.vb[u] = reinterpret_cast<const GF_GLOBAL i32x4*>(gb)[i4]; }
+    }
+    return p;
+}
+
 // ContactManager.step for the E (<= 64, <= nthreads) envs [n0, n0 + envs_here) of a workgroup.
 // (1) Their link_a / link_b rows (E·C ints each, contiguous in memory) are staged into LDS as packed pairs with flat coalesced
 // loads — every slot id is read from HBM exactly once, whatever the number of managers and tracked links, all of a lane's requests
@@ -90,7 +115,7 @@ struct ContactNoStamp { __device__ __forceinline__ void operator()(int) const {}
 // (contact_manager.py:399-403 prints a warning).
 template <int kAirAhead = 4, int U = 4, class Stamp = ContactNoStamp>
 __device__ __forceinline__ int contact_tile(const ContactScene& a, const ContactLds& l, const int E, const int64_t n0, const int envs_here, const int tid,
-                                            const int nthreads, Stamp&& stamp = Stamp()) {
+                                            const int nthreads, const ContactIdsPending<U>& pend, Stamp&& stamp = Stamp()) {
     const int C = a.C, T = a.T;
     const int MW = (C + 31) >> 5;  // 32-bit words of one env's "slot holds a contact" mask
     const int slots = envs_here * C;
@@ -131,17 +156,20 @@ __device__ __forceinline__ int contact_tile(const ContactScene& a, const Contact
             }
         };
         auto pack = [](int la, int lb) GF_CONTACT_INLINE { return ((uint32_t)la & 0xffffu) | ((uint32_t)lb << 16); };
-        // four ids per lane and array (dwordx4: 1 KiB per wave instruction) when the block's rows start 16-byte aligned
-        const bool vec = ((n0 * C) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.link_a) | reinterpret_cast<uintptr_t>(a.link_b)) & 15u) == 0;
+        // the first U units per lane were requested by the caller (contact_ids_request) before it staged its tables; any further
+        // ones — more than U·nthreads units: beyond a 64-env tile of 64 slots — are requested here, U at a time
+        const bool vec = pend.vec;
         const int slots4 = vec ? (slots >> 2) : 0;
-        // (all of a lane's requests first — a 64-env tile of 60 slots is four units per lane and array: one round trip, not four)
         for (int b4 = 0; b4 < slots4; b4 += U * nthreads) {
             i32x4 va[U], vb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i4 = b4 + u * nthreads + tid;
-                va[u] = i32x4{-1, -1, -1, -1}; vb[u] = va[u];
-                if (i4 < slots4) { va[u] = reinterpret_cast<const GF_GLOBAL i32x4*>(ga)[i4]; vb[u] = reinterpret_cast<const GF_GLOBAL i32x4*>(gb)[i4]; }
+                va[u] = pend.va[u]; vb[u] = pend.vb[u];
+                if (b4 > 0) {
+                    va[u] = i32x4{-1, -1, -1, -1}; vb[u] = va[u];
+                    if (i4 < slots4) { va[u] = reinterpret_cast<const GF_GLOBAL i32x4*>(ga)[i4]; vb[u] = reinterpret_cast<const GF_GLOBAL i32x4*>(gb)[i4]; }
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

@@ -162,6 +162,7 @@ __host__ __device__ constexpr bool reward_op_reads_contacts(int op) {
 template <class P>
 __host__ __device__ constexpr bool ws_prog_folds() {
     if constexpr (P::kStatic) {
+        if (P::n_term == 0 && P::n_rew == 0 && P::n_cmd == 0 && P::n_gait == 0) return false;   // an observation-only launch (GF_POST_OBSERVE_ONLY) never folds
         if (P::n_air > 0) return true;
         for (int k = 0; k < P::n_term; ++k)
             if (term_op_counts_contacts(P::term[k].op)) return true;
@@ -268,6 +269,12 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             };
             const int tid = (int)threadIdx.x;
             const int T = UNI(a.cfold.total_targets), C = UNI(a.cfold.num_contacts);
+            const int envs_here = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
+            const ContactScene sc{UNI(a.cfold.force), UNI(a.cfold.position), UNI(a.cfold.links_quat), UNI(a.cfold.links_vel), UNI(a.cfold.links_pos),
+                                  UNI(a.cfold.link_a), UNI(a.cfold.link_b), C, UNI(a.cfold.num_scene_links), T, UNI(a.cfold.dt)};
+            // the tile's slot ids are requested FIRST: they depend on nothing, and the table rows below are vector loads from the
+            // kernel-argument segment — a cold round trip the slot ids now share instead of following
+            const ContactIdsPending<4> pend = contact_ids_request<4>(sc, n0, envs_here, tid, kWsBlock);
             if (tid < fold_mgr) {   // this manager's image (ContactMgrL) and with-filter list
                 const int base = (int)offsetof(PostContact, m) + tid * (int)sizeof(PostContactMgr);
                 int32_t* img = t_mgr + tid * kContactMgrWords;
@@ -322,11 +329,8 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                     warm(UNI(a.dof_force) != nullptr, UNI(a.dof_force), ro);
                 }
             }
-            const ContactScene sc{UNI(a.cfold.force), UNI(a.cfold.position), UNI(a.cfold.links_quat), UNI(a.cfold.links_vel), UNI(a.cfold.links_pos),
-                                  UNI(a.cfold.link_a), UNI(a.cfold.link_b), C, UNI(a.cfold.num_scene_links), T, UNI(a.cfold.dt)};
             const ContactLds cl = contact_lds_carve(ids, kEnvBlock, C, reinterpret_cast<const ContactMgrL*>(t_mgr), t_target, t_meta, t_with);
-            const int envs_here = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
-            const int flag_mask = contact_tile<4, 4>(sc, cl, kEnvBlock, n0, envs_here, tid, kWsBlock, [&](int i) GF_INLINE_LAMBDA { (void)i; GF_WSTAMP(12 + i); });   // (its first barrier covers the tables)
+            const int flag_mask = contact_tile<4, 4>(sc, cl, kEnvBlock, n0, envs_here, tid, kWsBlock, pend, [&](int i) GF_INLINE_LAMBDA { (void)i; GF_WSTAMP(12 + i); });   // (its first barrier covers the tables)
             if (shard) {   // non-finite force sanitised: the warning flag of contact_manager.py:399-403 (every folded manager counts into the step's block)
                 const unsigned long long b = __ballot(flag_mask != 0);
                 if (b && lane == 0) atomicOr(&shard->contact_flags, 1);
