@@ -1012,12 +1012,16 @@ static int fold_contacts(Packer& pk, const GfContactArgs* const* mgrs, int num) 
     }
     const GfContactArgs* c0 = mgrs[0];
     UNSUP(fold_lds_bytes(c0->num_contacts) + sizeof(GfPostArgs) > 60 * 1024);
-    // Measured (profiles/r04_i_configs_fold*.jsonl, one box, GF_NO_CONTACT_FOLD A/B): the fold takes 1.6-3.4 us off a step whenever the
-    // tile's tracked links are at most three passes of the 256 lanes (contacts, rough terrain, humanoid: 4 / 9 / 3 links) and 9 us off
-    // the gait task (13 links, four passes) at 65 536 envs — but ADDS 1.7 us to the gait task at 8 192 envs, where 128 tiles of 64
-    // envs occupy half of the chip and a launch of its own spreads the same pairs over 512 small workgroups.  GF_OPT_FOLD_CONTACT = 2
-    // folds regardless.
-    UNSUP(g_options[GF_OPT_FOLD_CONTACT] != 2 && (total * kEnvBlock + kWsBlock - 1) / kWsBlock >= 4 && a.num_envs < 16384);
+    // Measured on one box with the fold as shipped and switched off (tools/scaling_table.sh, profiles/r04_t_scaling.jsonl; us per step):
+    //   one pass of the tile's 256 lanes (up to 4 tracked links: humanoid 3, contacts 4)  8 192 … 1 024 envs: 24.7 / 23.1 / 22.8 / 22.6 vs 26.6 / 26.6 / 25.3 / 25.0
+    //   three passes (rough terrain, 9 links)   16 384 / 8 192 / 4 096 / 2 048 envs: 32.0 / 27.4 / 25.1 / 25.1 vs 31.6 / 25.5 / 25.8 / 25.2
+    //   four passes (gait task, 13 links)       65 536 / 32 768 / 16 384 / 8 192 envs: 118.2 / 73.4 / 51.0 / 39.9 vs 125.5 / 77.2 / 50.3 / 39.3
+    // A tile that needs several passes pays them one after the other on ONE CU, where a launch of its own spreads the same pairs over
+    // four times as many small workgroups: below these sizes (128-256 tiles on 256 CUs) that costs more than the launch it saves.
+    // GF_OPT_FOLD_CONTACT = 2 folds regardless.
+    const int passes = (total * kEnvBlock + kWsBlock - 1) / kWsBlock;
+    const int min_envs = passes >= 4 ? 32768 : (passes >= 2 ? 16384 : 0);
+    UNSUP(g_options[GF_OPT_FOLD_CONTACT] != 2 && a.num_envs < min_envs);
     f.force = c0->force; f.position = c0->position; f.links_quat = c0->links_quat; f.links_vel = c0->links_vel; f.links_pos = c0->links_pos;
     f.link_a = c0->link_a; f.link_b = c0->link_b;
     f.num_contacts = c0->num_contacts; f.num_scene_links = c0->num_scene_links; f.num_mgr = num; f.total_targets = total;

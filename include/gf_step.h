@@ -711,8 +711,8 @@ int gf_abi_version(void);
 /* GF_OPT_CHAIN (default 1): gf_run_ops folds runs of per-env phases the fused post-physics kernel does not cover into phase
  * chains — termination → reward → command.step…, and reset → command.reset… → observe… — one launch each (csrc/gf_chain.hip). */
 /* GF_OPT_FOLD_CONTACT (default 1): gf_run_ops hands the contact_step ops in front of a fused post-physics op to that launch
- * (gf_post_physics_step_contacts) instead of launching the contact kernel itself — unless that measured slower (more than 12 tracked
- * links below 16 384 envs); 0 keeps the two launches (A/B, tests), 2 folds whenever it is possible. */
+ * (gf_post_physics_step_contacts) instead of launching the contact kernel itself — unless that measured slower (more than 4 tracked
+ * links below 16 384 envs, more than 12 below 32 768); 0 keeps the two launches (A/B, tests), 2 folds whenever it is possible. */
 enum { GF_OPT_POST_VARIANT = 0, GF_OPT_PROFILE_STRIDE = 1, GF_OPT_GRAPH = 2, GF_OPT_CHAIN = 3, GF_OPT_FOLD_CONTACT = 4, GF_OPT_COUNT = 5 };
 int gf_set_option(int option, int value);
 int gf_sizeof(int which);   /* sizeof of the ABI structs (0 = GfStepStats … 11 = GfObsItem, 12 GfTerrainView, 13 GfTerrainHeightArgs, 14 GfGaitArgs, 15 GfContactView, 16 GfCommandView, 17 GfPostRefs, 18 GfRolloutArgs, 19 GfHistoryUnrollArgs, 20 GfRolloutPolicyArgs, 21 GfGaeArgs, 22 GfCompactArgs): binding self-check */

@@ -183,7 +183,7 @@ def _timed_workload(hip_backend, hip, cpu, name, n, variant, steps, program):
         assert resets > 0, "the trajectory must reset envs"
 
 
-FOLD_CASES = [  # (fold = 2: "whenever possible" — the default leaves the gait task below 16 384 envs on two launches, measured faster)
+FOLD_CASES = [  # (fold = 2: "whenever possible" — the default keeps multi-pass tiles of small launches on two launches, measured faster)
     ("contacts", 4096), ("rough_terrain", 1000), ("rough_terrain", 16384), ("humanoid", 130), ("humanoid", 8192), ("gait", 8192), ("gait", 65536),
               ("gait_override_8192", 8192), ("humanoid28", 1000), ("humanoid28-interp", 257)]
 
