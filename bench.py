@@ -309,26 +309,84 @@ def main():
     run_rank(args)
 
 
+def _cpulist(text: str) -> list:
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes() -> list:
+    """NUMA node of every GPU of this box, in KFD topology order (the order HIP enumerates devices in), read from sysfs — no HIP call:
+    /sys/class/kfd/kfd/topology/nodes/<n>/properties (simd_count > 0: a GPU; drm_render_minor) →
+    /sys/class/drm/renderD<minor>/device/numa_node.  [] when the box does not say."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    out = []
+    try:
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(line.split()[:2] for line in open(os.path.join(base, n, "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+            node = -1
+            try:
+                node = int(open(f"/sys/class/drm/renderD{minor}/device/numa_node").read())
+            except (OSError, ValueError):
+                pass
+            out.append(node)
+    except (OSError, ValueError):
+        return []
+    return out
+
+
+def pin_plan(local: int, local_world: int, avail: list, gpu_nodes: list, node_cpus: dict) -> list:
+    """The cores rank `local` of `local_world` runs on.  When the box says which NUMA node every rank's GPU hangs off, the ranks whose
+    GPUs share a node split THAT node's cores (of the ones this process may use) among themselves, in rank order; otherwise — or when a
+    node's share would be empty — the available cores are split into `local_world` contiguous shares."""
+    share = len(avail) // local_world
+    flat = avail[local * share:(local + 1) * share]
+    if len(gpu_nodes) < local_world or gpu_nodes[local] < 0:
+        return flat
+    node = gpu_nodes[local]
+    peers = [r for r in range(local_world) if gpu_nodes[r] == node]
+    cpus = [c for c in node_cpus.get(node, []) if c in set(avail)]
+    per = len(cpus) // len(peers)
+    if per < 1:
+        return flat
+    k = peers.index(local)
+    return cpus[k * per:(k + 1) * per]
+
+
 def pin_rank() -> dict:
     """Give this rank its own share of the host cores (``os.sched_setaffinity``, from inside the rank): below ~16 k envs a step is
-    host-bound (17 us at 4 096 envs), so N unpinned Python hosts on one box would migrate over each other's cores.  The cores this
-    process may run on are split into LOCAL_WORLD_SIZE contiguous shares; ``GF_PIN=0`` leaves the affinity alone.  Returns what was
-    done, for the per-rank entry of the JSON line."""
+    host-bound (17 us at 4 096 envs), so N unpinned Python hosts on one box would migrate over each other's cores.  The share is
+    NUMA-local to the rank's GPU when sysfs says where the GPUs are (``pin_plan``); ``GF_PIN=0`` leaves the affinity alone.  Returns
+    what was done, for the per-rank entry of the JSON line."""
     try:
         avail = sorted(os.sched_getaffinity(0))
     except AttributeError:   # not Linux
         return {"pinned": False, "cpus": None, "why": "no sched_getaffinity"}
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))) % max(1, local_world)
     if os.environ.get("GF_PIN", "1") == "0" or local_world <= 1 or len(avail) < 2 * local_world:
         return {"pinned": False, "cpus": len(avail), "why": "GF_PIN=0" if os.environ.get("GF_PIN", "1") == "0" else "one rank, or fewer than two cores per rank"}
-    share = len(avail) // local_world
-    mine = avail[(local % local_world) * share:(local % local_world + 1) * share]
+    nodes = gpu_numa_nodes()
+    node_cpus = {}
+    for n in set(x for x in nodes if x >= 0):
+        try:
+            node_cpus[n] = _cpulist(open(f"/sys/devices/system/node/node{n}/cpulist").read())
+        except OSError:
+            pass
+    mine = pin_plan(local, local_world, avail, nodes, node_cpus)
     try:
         os.sched_setaffinity(0, mine)
     except OSError as e:
         return {"pinned": False, "cpus": len(avail), "why": repr(e)}
-    return {"pinned": True, "cpus": len(mine), "first": mine[0], "last": mine[-1]}
+    return {"pinned": True, "cpus": len(mine), "first": mine[0], "last": mine[-1],
+            "numa_node": (nodes[local] if len(nodes) >= local_world and nodes[local] >= 0 and mine and mine[0] in node_cpus.get(nodes[local], []) else None)}
 
 
 def run_rank(args):
@@ -460,6 +518,8 @@ def run_rank(args):
         per_rank = [None] * dist.get_world_size()
         dist.all_gather_object(per_rank, mine)
     _ = dict(env.extras["episode"])   # keep the logging path honest: read one step's global statistics (on every rank)
+    tm_ = env.managers["termination"]
+    reset_frac = float((tm_._terminated_buf | tm_._truncated_buf).float().mean()) if tm_ is not None else 0.0   # (after the timed region)
 
     fused = env._trace is not None and env._trace.post_refs is not None
     rm = env.managers["reward"]
@@ -496,6 +556,9 @@ def run_rank(args):
                        "stats_allreduce_every_steps": (args.reduce_every if dist_on else None), "dist_backend": (dist_backend if dist_on else None),
                        # dmabuf IPC for RCCL across processes on this driver: launch.spawn_ranks sets 0 unless the environment says otherwise
                        "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                       # SURVEY.md 8d's input spec would reset 2-8 % of the envs per step; the stand-in physics is set to about 0.2 % (episodes of a
+                       # few hundred steps: the step, not the reset path, is what is timed) - the measured fraction of the last timed step:
+                       "resets_last_step_frac": reset_frac,
                        "setup_steps_before_warmup": PRIMING_STEPS, "fused_post_physics": fused, "observation_output": OBS_OUTPUT,
                        "launches_per_step": env._trace.n_ops if env._trace is not None else None},
             "timing": {"batches": len(times), "timed_s": sum(times), "batch_ms_median": batch * 1e3, "batch_ms_min": min(times) * 1e3,

@@ -105,3 +105,24 @@ def test_spawn_ranks_propagates_failure_and_environment(tmp_path):
     assert rc == 3
     for r in range(3):
         assert (tmp_path / f"r{r}").read_text() == f"{r} {r} 3 127.0.0.1"
+
+
+def test_rank_pinning_plan_is_numa_local_when_the_box_says_so():
+    """bench.py:pin_plan — on an 8-GPU node (two sockets, SMT siblings numbered behind the physical cores) a contiguous split would give
+    ranks 2 and 3 the other socket's cores and make ranks 0 and 4 SMT siblings; with the GPUs' NUMA nodes from sysfs the ranks of a socket
+    split that socket's cores.  Without the information (or with an unusable node) it is the contiguous split."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    avail = list(range(256))
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    gpu_nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    plans = [bench.pin_plan(r, 8, avail, gpu_nodes, node_cpus) for r in range(8)]
+    assert all(len(p) == 32 for p in plans) and len(set(c for p in plans for c in p)) == 256   # disjoint, everything used
+    assert all(set(plans[r]) <= set(node_cpus[0]) for r in range(4)) and all(set(plans[r]) <= set(node_cpus[1]) for r in range(4, 8))
+    assert [bench.pin_plan(r, 8, avail, [], {}) for r in range(8)] == [list(range(32 * r, 32 * r + 32)) for r in range(8)]
+    assert bench.pin_plan(3, 8, avail, [0, 0, 0, -1, 1, 1, 1, 1], node_cpus) == list(range(96, 128))   # this rank's GPU unknown: its flat share
+    assert bench.pin_plan(1, 2, list(range(8)), [5, 5], {5: [100, 101]}) == [4, 5, 6, 7]              # the node's cores are not ours to use
+    assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
