@@ -701,7 +701,12 @@ class StepTrace:
                     while done < len(self.afters) and self.afters[done][0] < first:
                         self.afters[done][1]()
                         done += 1
-                    pre()
+                    # (launches the user code makes itself — a user manager's `super().step()` — count into THIS step's statistics slot)
+                    env.stats.ptr_override = cur
+                    try:
+                        pre()
+                    finally:
+                        env.stats.ptr_override = None
                 if count or desc.num_patches:
                     self.backend.replay_step(desc, aptr, pr, self.n_params)
         elif self.graph is not None and self.backend.graph_enabled:
@@ -777,10 +782,17 @@ def traceable(env, tail_python: bool = False) -> bool:
     # Overrides that produce the step's native outputs themselves (action, termination, reward, observation managers) are not
     # something a recording can stand in for.
     between = set(map(id, env.managers["entity"] + env.managers["contact"] + env.managers["command"]))
+    # Round 4: the step() of a user TerminationManager / RewardManager class as well — `super().step()` + torch on the manager's buffers
+    # is user code at the place of its phase; the launches it makes itself are its own (pointed at the step's statistics slot by the
+    # replay) and the native phases behind it read the manager's buffers as they find them.  (A reset() override of these two stays out:
+    # their reset is a section of the masked reset.)
+    phase_step = set(map(id, [m for m in (tm, rm) if m is not None]))
     for m in env._all_managers() + env.managers["terrain"]:
         for meth in ("step", "reset", "get_observations", "_perform_observation", "handle_actions"):
             if hasattr(m, meth) and not _most_derived_is_ours(m, meth):
                 if id(m) in between and meth in ("step", "reset"):
+                    continue
+                if id(m) in phase_step and meth == "step":
                     continue
                 return False
     if tm._dirty or tm._program.slots.volatile:

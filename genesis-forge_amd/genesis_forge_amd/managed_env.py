@@ -253,11 +253,11 @@ class ManagedEnvironment(GenesisEnv):
         truncated, terminated = self._truncated_buf, self._terminated_buf
         tm = self.managers["termination"]
         if tm is not None:
-            terminated, truncated = tm.step()
+            terminated, truncated = self._manager_step(tm)
 
         rewards = self._reward_buf
         if self.managers["reward"] is not None:
-            rewards = self.managers["reward"].step()
+            rewards = self._manager_step(self.managers["reward"])
 
         for m in self.managers["command"]:
             self._manager_step(m)
@@ -281,11 +281,10 @@ class ManagedEnvironment(GenesisEnv):
         (the recording keeps its place and calls it again there; launches it makes itself belong to it, not to the recording)."""
         rec = self.backend.tracer
         if rec is None or _most_derived_is_ours(m, "step"):
-            m.step()
-            return
+            return m.step()
         from .managers._program import call_untraced
         rec.python(m.step)
-        call_untraced(self, m.step)
+        return call_untraced(self, m.step)
 
     def _indexed_reset(self, indexed: list, mask: torch.Tensor, mask2: Optional[torch.Tensor]) -> None:
         """``reset(ids)`` of the managers that need an index list (user-defined classes, Python on_reset entries), for the done

@@ -135,7 +135,25 @@ def make_fuzz_env(seed: int):
                 rcfg["user_height"] = {"weight": 0.3, "fn": lambda env: torch.tanh(env.robot.get_pos()[:, 2])}
             if self.user_manager:
                 rcfg["in_phase"] = {"weight": 0.2, "fn": lambda env: torch.cos(6.2831853 * self.clock.phase)}
-            self.reward_manager = RewardManager(self, logging_enabled=pick(0.85), cfg=rcfg)
+            # user-defined RewardManager / TerminationManager CLASSES (their own step() around the library's, torch on the manager's
+            # buffers): python phases of a recorded step (round 4).  A random stream of their own, as for the user command manager.
+            rnd_cls = random.Random(77000 + seed)
+            self.user_reward_cls, self.user_term_cls = rnd_cls.random() < 0.2, rnd_cls.random() < 0.2
+            floor, grace = -round(rnd_cls.uniform(0.05, 0.5), 3), rnd_cls.choice([1, 2, 4])
+
+            class CappedRewards(RewardManager):
+                def step(s):
+                    r = super().step()
+                    r.clamp_(min=floor)
+                    return r
+
+            class GracefulTerminations(TerminationManager):
+                def step(s):
+                    te, tr = super().step()
+                    te &= s.env.episode_length > grace
+                    return te, tr
+
+            self.reward_manager = (CappedRewards if self.user_reward_cls else RewardManager)(self, logging_enabled=pick(0.85), cfg=rcfg)
 
             tcfg = {"timeout": {"fn": terminations.timeout, "time_out": True}}
             if pick(0.8):
@@ -156,7 +174,7 @@ def make_fuzz_env(seed: int):
             if pick(0.15):  # a user-level termination term (evaluated in front of the termination op)
                 self.has_user_term = True
                 tcfg["user_far"] = {"fn": lambda env: env.robot.get_pos()[:, :2].abs().sum(dim=1) > 0.35}
-            self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg=tcfg)
+            self.termination_manager = (GracefulTerminations if self.user_term_cls else TerminationManager)(self, logging_enabled=True, term_cfg=tcfg)
 
             items = {
                 "velocity_cmd": lambda: {"fn": vc.observation},
@@ -234,7 +252,7 @@ def _run(seed, dev, steps=STEPS):
     info = {"n": n, "recorded": env._trace is not None, "fused": bool(env._trace is not None and env._trace.post_refs is not None),
             "program": env._program_info, "post_refs": env._trace.post_refs if env._trace is not None else None, "env": env,
             "user_term": env.has_user_term, "user_obs": env.has_user_obs, "third_obs": env.third_obs, "overrides_reset": env.overrides_reset,
-            "user_manager": env.user_manager}
+            "user_manager": env.user_manager or env.user_reward_cls or env.user_term_cls}
     return out, info
 
 

@@ -317,6 +317,76 @@ def test_user_manager_class_is_replayed_between_native_phases(oracle_backend):
     assert counts_a == counts_b and counts_a[0] == 50 and counts_a[1] > 10, (counts_a, counts_b)
 
 
+def _user_term_reward_env(which):
+    """User-defined TerminationManager / RewardManager CLASSES with a step() of their own around the library's (`super().step()`, then
+    torch on the manager's buffers) — managers that produce the step's native outputs themselves."""
+    from genesis_forge_amd.managers import RewardManager, TerminationManager
+
+    class CappedRewards(RewardManager):
+        steps = 0
+
+        def step(self):
+            type(self).steps += 1
+            r = super().step()
+            r.clamp_(min=-0.5)           # in place on the manager's buffer: what the env returns and what a rollout storage copies
+            return r
+
+    class GracefulTerminations(TerminationManager):
+        steps = 0
+
+        def step(self):
+            type(self).steps += 1
+            te, tr = super().step()
+            te &= self.env.episode_length > 2    # a grace period applied to EVERY termination, in place on the manager's mask
+            return te, tr
+
+    class Env(Go2CommandDirectionEnv):
+        def config(self):
+            super().config()
+            if "reward" in which:
+                rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in self.reward_manager.cfg.items()}
+                self.managers["reward"] = None
+                self.reward_manager = CappedRewards(self, logging_enabled=True, cfg=rc)
+            if "termination" in which:
+                tc = {k: {"fn": v.fn, "params": dict(v.params), "time_out": v.time_out} for k, v in self.termination_manager.term_cfg.items()}
+                self.managers["termination"] = None
+                self.termination_manager = GracefulTerminations(self, logging_enabled=True, term_cfg=tc)
+
+    return Env, CappedRewards, GracefulTerminations
+
+
+@pytest.mark.parametrize("which", ["reward", "termination", "reward+termination"])
+def test_user_reward_and_termination_manager_classes_are_python_phases_of_a_recorded_step(oracle_backend, which):
+    """Round 4 (the part of it that pays): a user RewardManager / TerminationManager class with its own step() used to
+    keep the env on the 127 us ordinary step for good.  Its step() is now user code BETWEEN native pieces of a recorded step, like a
+    user command manager's: it runs where the ordinary step calls it, as often, with the launches it makes itself pointed at the
+    step's statistics slot; the phases on either side run as phase chains.  Bit-identical to the ordinary step, logs included."""
+    Env, R, T = _user_term_reward_env(which)
+    R.steps = T.steps = 0
+    a, _ = _run("cpu", False, cls=Env)
+    counts_a = (R.steps, T.steps)
+    R.steps = T.steps = 0
+    before = oracle_backend.replays
+    b, env = _run("cpu", True, cls=Env)
+    _same(a, b)
+    tr = env._trace
+    assert tr is not None, f"not recorded: {env._untraceable}"
+    assert len(tr.py_marks) == which.count("+") + 1 and tr.post_refs is None
+    assert oracle_backend.replays - before >= 40
+    assert (R.steps, T.steps) == counts_a and sum(counts_a) == 50 * (which.count("+") + 1)
+    assert any("Terminations / " in k for row in b for k in row[4]) and any("Rewards / " in k for row in b for k in row[4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["reward+termination"])
+def test_user_reward_and_termination_manager_classes_recorded_hip(hip_backend, which):
+    Env, _R, _T = _user_term_reward_env(which)
+    a, _ = _run("cuda", False, n=1000, cls=Env)
+    b, env = _run("cuda", True, n=1000, cls=Env)
+    assert env._trace is not None and len(env._trace.py_marks) == 2
+    _same(a, b)
+
+
 @pytest.mark.gpu
 def test_user_manager_class_recorded_hip(hip_backend):
     Env, _Clock = _user_manager_env()

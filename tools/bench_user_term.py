@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Step time of a config with one user-level (Python) term — a reward lambda (default) or an observation item (`obs`): recorded step
 (cut around the call) vs phase by phase — or (`manager`) a user-defined CommandManager CLASS with its own step() / reset(), a reward
-term and an observation item reading it (the shape of the reference's examples/gait_trainer/gait_command_manager.py).
-    python tools/bench_user_term.py [num_envs] [reward|obs|manager]"""
+term and an observation item reading it (the shape of the reference's examples/gait_trainer/gait_command_manager.py) — or (`classes`)
+user-defined RewardManager and TerminationManager CLASSES whose step() wraps the library's (round 4: python phases of a recorded step).
+    python tools/bench_user_term.py [num_envs] [reward|obs|manager|classes]"""
 import os
 import sys
 import time
@@ -75,6 +76,30 @@ def run(n, trace, steps=400):
             oc["clock"] = {"fn": lambda env: torch.stack([torch.sin(6.2831853 * env.clock.phase), env.clock.phase], dim=-1)}
             env.managers["observation"].remove(om)
             env.observation_manager = ObservationManager(env, cfg=oc)
+
+    if KIND == "classes":
+        from genesis_forge_amd.managers import RewardManager, TerminationManager
+
+        class CappedRewards(RewardManager):
+            def step(self):
+                r = super().step()
+                r.clamp_(min=-0.5)
+                return r
+
+        class GracefulTerminations(TerminationManager):
+            def step(self):
+                te, tr = super().step()
+                te &= self.env.episode_length > 2
+                return te, tr
+
+        def config():   # noqa: F811
+            orig()
+            rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in env.reward_manager.cfg.items()}
+            env.managers["reward"] = None
+            env.reward_manager = CappedRewards(env, logging_enabled=True, cfg=rc)
+            tc = {k: {"fn": v.fn, "params": dict(v.params), "time_out": v.time_out} for k, v in env.termination_manager.term_cfg.items()}
+            env.managers["termination"] = None
+            env.termination_manager = GracefulTerminations(env, logging_enabled=True, term_cfg=tc)
 
     env.config = config
     env.build()
