@@ -98,6 +98,8 @@ class StepTrace:
             from . import gs
             self._null_stub = torch.zeros(16, dtype=torch.int32, device=gs.device)
         self._images = images
+        from .managed_env import ManagedEnvironment
+        self._env_obs_python = not tail_python and type(env).get_observations is not ManagedEnvironment.get_observations
         self.tail_python = tail_python
         self.tail_seg: dict = {}   # "reset" / "obs" → native segment of the Python tail (see _build_tail_segment)
         self.backend = env.backend
@@ -132,7 +134,7 @@ class StepTrace:
         first_post0 = self._post_start(calls)
         # (user code in the middle of the post-physics phases — a user manager's step() between reward and reset — keeps them off
         # the single fused launch: the phases on either side of it run as phase chains, gf_run_ops)
-        marks_in_post = any(at > first_post0 for at, _ in marks)
+        marks_in_post = any(first_post0 < at < len(calls) for at, _ in marks)   # (user code BEHIND the last launch leaves the fused launch alone)
         self.post_refs = self._fuse_post(calls) if env.fuse_post_physics and not marks_in_post else None
         if self.post_refs is None:
             self._gait_swaps = []
@@ -753,6 +755,8 @@ class StepTrace:
         env._finish_step_light(snap)
         extras = env._extras
         obs = extras["observations"].get("policy") if len(env.managers["observation"]) > 0 else obs_tail
+        if self._env_obs_python:
+            obs = env._step_obs   # what the env's own get_observations() returned (a python phase behind the last launch)
         return obs, rm._reward_buf if rm is not None else env._reward_buf, tm._terminated_buf, tm._truncated_buf, extras
 
 
@@ -768,8 +772,8 @@ def traceable(env, tail_python: bool = False) -> bool:
         return False
     if tail_python and env.stats.group is not None:
         return False  # the per-step pack / all-reduce of a process group closes the statistics before the Python tail adds to them
-    if type(env).get_observations is not ManagedEnvironment.get_observations:
-        return False
+    # (a get_observations() override of the env is user code BEHIND the step's native phases: the recording keeps its place and calls
+    #  it again there — ManagedEnvironment._user_get_observations; round 4)
     if not getattr(env.scene, "gf_static_buffers", False) and env._adapter is None:
         return False
     if env._draws:
@@ -787,12 +791,19 @@ def traceable(env, tail_python: bool = False) -> bool:
     # replay) and the native phases behind it read the manager's buffers as they find them.  (A reset() override of these two stays out:
     # their reset is a section of the masked reset.)
     phase_step = set(map(id, [m for m in (tm, rm) if m is not None]))
+    # … and the get_observations() / _perform_observation() of a user ObservationManager class: user code at the manager's place
+    # among the observations (ManagedEnvironment._observe_all), the manager simply is not part of the recording.
+    phase_obs = set(map(id, env.managers["observation"]))
+    user_obs = set()
     for m in env._all_managers() + env.managers["terrain"]:
         for meth in ("step", "reset", "get_observations", "_perform_observation", "handle_actions"):
             if hasattr(m, meth) and not _most_derived_is_ours(m, meth):
                 if id(m) in between and meth in ("step", "reset"):
                     continue
                 if id(m) in phase_step and meth == "step":
+                    continue
+                if id(m) in phase_obs and meth in ("get_observations", "_perform_observation"):
+                    user_obs.add(id(m))
                     continue
                 return False
     if tm._dirty or tm._program.slots.volatile:
@@ -808,7 +819,7 @@ def traceable(env, tail_python: bool = False) -> bool:
     if tail_python:
         return True  # reset and observations run phase by phase unless StepTrace._tail_native_ok() lets their launches be replayed
     for om in env.managers["observation"]:
-        if not om._traceable():
+        if id(om) not in user_obs and not om._traceable():
             return False
     for em in env.managers["entity"]:
         if not em.enabled or not em._can_fuse_reset():

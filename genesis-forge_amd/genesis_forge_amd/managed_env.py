@@ -22,6 +22,7 @@ import os
 from typing import Any, Optional
 
 import torch
+from functools import partial
 
 from . import _native as nat
 from . import _trace
@@ -267,7 +268,14 @@ class ManagedEnvironment(GenesisEnv):
                 self.backend.tracer.cut_tail()  # a user reset(): the rest of the step stays Python in the recorded step
             self._reset_done(terminated, truncated)
 
-        obs = self.get_observations()
+        rec = self.backend.tracer
+        if rec is not None and not rec.tail_python and type(self).get_observations is not ManagedEnvironment.get_observations:
+            from .managers._program import call_untraced
+            rec.python(self._user_get_observations)
+            call_untraced(self, self._user_get_observations)
+            obs = self._step_obs
+        else:
+            obs = self.get_observations()
         ro = getattr(self, "_rollout", None)
         if ro is not None and tm is not None:
             # the RL library's rollout rows (learner.RolloutStorage): written from the manager-owned buffers of this step
@@ -456,11 +464,28 @@ class ManagedEnvironment(GenesisEnv):
                     rec.part = None
         return super().get_observations()
 
+    def _observe_one(self, m):
+        obs = m.get_observations()
+        self.extras["observations"][m.name] = obs
+        return obs
+
     def _observe_all(self):
         policy_obs = None
+        rec = self.backend.tracer if self._in_step else None
         for m in self.managers["observation"]:
-            obs = m.get_observations()
-            self.extras["observations"][m.name] = obs
+            if rec is not None and not (_most_derived_is_ours(m, "get_observations") and _most_derived_is_ours(m, "_perform_observation")):
+                # a user-defined ObservationManager class: its get_observations() is user code at this place of the step (the recording
+                # keeps the place and calls it again there; the launch it makes itself belongs to it)
+                from .managers._program import call_untraced
+                fn = partial(self._observe_one, m)
+                rec.python(fn)
+                obs = call_untraced(self, fn)
+            else:
+                obs = self._observe_one(m)
             if m.name == "policy":
                 policy_obs = obs
         return policy_obs
+
+    def _user_get_observations(self) -> None:
+        """An env whose get_observations() is overridden: the whole call is user code behind the step's native phases."""
+        self._step_obs = self.get_observations()

@@ -211,7 +211,8 @@ def test_user_overrides_limit_what_is_recorded(oracle_backend):
     """A reset() override is honoured by index list: the step is recorded only up to the reset (the rest stays Python).
     A step() override that wraps `super().step()` is code around the step, like the training loop's: the step inside is recorded and
     fused all the same, and a manager call the override makes between steps drops the recording like one the script makes.
-    A get_observations() override is code INSIDE the step: never recorded."""
+    A get_observations() override is user code BEHIND the step's native phases (round 4): the step is recorded and fused without the
+    observations, the override runs where the ordinary step calls it."""
     class ResetEnv(Go2CommandDirectionEnv):
         def reset(self, env_ids=None):
             return super().reset(env_ids)
@@ -235,7 +236,7 @@ def test_user_overrides_limit_what_is_recorded(oracle_backend):
     g = torch.Generator().manual_seed(0)
     acts = [torch.randn(8, 12, generator=g) for _ in range(6)]
     want = [ref.step(a)[0].clone() for a in acts]
-    for cls, how in ((ResetEnv, "tail"), (StepEnv, "fused"), (ObsEnv, None)):
+    for cls, how in ((ResetEnv, "tail"), (StepEnv, "fused"), (ObsEnv, "obs")):
         env = cls(num_envs=8, scene_kwargs=dict(seed=3))
         env.build()
         env.seed(5)
@@ -252,7 +253,8 @@ def test_user_overrides_limit_what_is_recorded(oracle_backend):
         elif how == "fused":
             assert env._trace is not None and not env._trace.tail_python and env._trace.post_refs is not None and env.seen == 6
         else:
-            assert env._trace is None
+            tr = env._trace
+            assert tr is not None and len(tr.py_marks) == 1 and tr.post_refs is not None and tr.post_refs.num_observe == 0
 
 
 def _user_manager_env():
@@ -375,6 +377,67 @@ def test_user_reward_and_termination_manager_classes_are_python_phases_of_a_reco
     assert oracle_backend.replays - before >= 40
     assert (R.steps, T.steps) == counts_a and sum(counts_a) == 50 * (which.count("+") + 1)
     assert any("Terminations / " in k for row in b for k in row[4]) and any("Rewards / " in k for row in b for k in row[4])
+
+
+def _user_obs_env(which):
+    """A user-defined ObservationManager CLASS whose get_observations() post-processes the library's, and / or an env whose own
+    get_observations() does (normalisation, clipping — the usual reasons)."""
+    from genesis_forge_amd.managers import ObservationManager
+
+    class ClippedObs(ObservationManager):
+        calls = 0
+
+        def get_observations(self):
+            type(self).calls += 1
+            return super().get_observations().clamp(-3.0, 3.0)
+
+    class Env(Go2CommandDirectionEnv):
+        env_calls = 0
+
+        def config(self):
+            super().config()
+            if "manager" in which:
+                om = self.observation_manager
+                oc = {k: {"fn": v.fn, "params": dict(v.params), "scale": v.scale, "noise": v.noise} for k, v in om.cfg.items()}
+                self.managers["observation"].remove(om)
+                self.observation_manager = ClippedObs(self, cfg=oc, history_len=2)
+
+        if "env" in which:
+            def get_observations(self):
+                type(self).env_calls += 1
+                o = super().get_observations()
+                return None if o is None else o * 0.5
+
+    return Env, ClippedObs
+
+
+@pytest.mark.parametrize("which", ["manager", "env", "manager+env"])
+def test_user_observation_code_is_a_python_phase_behind_the_fused_launch(oracle_backend, which):
+    """Round 4: a user ObservationManager class (its own get_observations()) and an env-level get_observations() override no longer keep
+    the env on the ordinary step: termination ... reset stay ONE fused launch (without that manager's observation) and the user's code
+    runs behind it, where the ordinary step calls it, as often.  Bit-identical to the ordinary step."""
+    Env, Obs = _user_obs_env(which)
+    Obs.calls = Env.env_calls = 0
+    a, _ = _run("cpu", False, cls=Env)
+    counts_a = (Obs.calls, Env.env_calls)
+    Obs.calls = Env.env_calls = 0
+    before = oracle_backend.replays
+    b, env = _run("cpu", True, cls=Env)
+    _same(a, b)
+    tr = env._trace
+    assert tr is not None, f"not recorded: {env._untraceable}"
+    assert tr.post_refs is not None and tr.post_refs.num_observe == 0 and len(tr.py_marks) == 1
+    assert oracle_backend.replays - before >= 40
+    assert (Obs.calls, Env.env_calls) == counts_a and sum(counts_a) >= 50
+
+
+@pytest.mark.gpu
+def test_user_observation_code_recorded_hip(hip_backend):
+    Env, _Obs = _user_obs_env("manager+env")
+    a, _ = _run("cuda", False, n=1000, cls=Env)
+    b, env = _run("cuda", True, n=1000, cls=Env)
+    assert env._trace is not None and env._trace.post_refs is not None
+    _same(a, b)
 
 
 @pytest.mark.gpu

@@ -3,7 +3,7 @@
 (cut around the call) vs phase by phase — or (`manager`) a user-defined CommandManager CLASS with its own step() / reset(), a reward
 term and an observation item reading it (the shape of the reference's examples/gait_trainer/gait_command_manager.py) — or (`classes`)
 user-defined RewardManager and TerminationManager CLASSES whose step() wraps the library's (round 4: python phases of a recorded step).
-    python tools/bench_user_term.py [num_envs] [reward|obs|manager|classes]"""
+    python tools/bench_user_term.py [num_envs] [reward|obs|manager|classes|obsclass]"""
 import os
 import sys
 import time
@@ -25,7 +25,13 @@ def run(n, trace, steps=400):
     else:
         os.environ["GF_NO_TRACE"] = "1"
 
-    env = Go2CommandDirectionEnv(num_envs=n, scene_kwargs=dict(ang_noise=0.05, seed=1))
+    env_cls = Go2CommandDirectionEnv
+    if KIND == "obsclass":
+        class env_cls(Go2CommandDirectionEnv):   # an env-level get_observations() override
+            def get_observations(self):
+                o = super().get_observations()
+                return None if o is None else o * 0.5
+    env = env_cls(num_envs=n, scene_kwargs=dict(ang_noise=0.05, seed=1))
     cfg_add = {"user_height": {"weight": 0.3, "fn": lambda env: torch.tanh(env.robot.get_pos()[:, 2])}}
     orig = env.config
 
@@ -100,6 +106,21 @@ def run(n, trace, steps=400):
             tc = {k: {"fn": v.fn, "params": dict(v.params), "time_out": v.time_out} for k, v in env.termination_manager.term_cfg.items()}
             env.managers["termination"] = None
             env.termination_manager = GracefulTerminations(env, logging_enabled=True, term_cfg=tc)
+
+    if KIND == "obsclass":   # a user ObservationManager class + an env-level get_observations() override (round 4: python phases behind the fused launch)
+        from genesis_forge_amd.managers import ObservationManager
+
+        class ClippedObs(ObservationManager):
+            def get_observations(self):
+                return super().get_observations().clamp(-3.0, 3.0)
+
+        def config():   # noqa: F811
+            orig()
+            om = env.observation_manager
+            oc = {k: {"fn": v.fn, "params": dict(v.params), "scale": v.scale, "noise": v.noise} for k, v in om.cfg.items()}
+            env.managers["observation"].remove(om)
+            env.observation_manager = ClippedObs(env, cfg=oc)
+
 
     env.config = config
     env.build()
