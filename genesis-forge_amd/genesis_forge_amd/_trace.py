@@ -99,7 +99,9 @@ class StepTrace:
             self._null_stub = torch.zeros(16, dtype=torch.int32, device=gs.device)
         self._images = images
         from .managed_env import ManagedEnvironment
-        self._env_obs_python = not tail_python and type(env).get_observations is not ManagedEnvironment.get_observations
+        env_obs = type(env).get_observations is not ManagedEnvironment.get_observations
+        self._env_obs_python = env_obs and not tail_python
+        self._env_obs_tail = env_obs and tail_python   # (with a reset() override too: the Python tail calls it, the step returns ITS value)
         self.tail_python = tail_python
         self.tail_seg: dict = {}   # "reset" / "obs" → native segment of the Python tail (see _build_tail_segment)
         self.backend = env.backend
@@ -143,12 +145,16 @@ class StepTrace:
         self.post_split = self.post_refs is not None and bool(self.post_refs.flags & nat.GF_POST_TERMINATION_DONE)
         mark_i = 0
         post_index = -1   # final index of the fused launch's op
+        scene_pre_at = None
         for idx, (fn, args, owner) in enumerate(calls):
             k_before = k
             while mark_i < len(marks) and marks[mark_i][0] <= idx:   # user code that ran before this call: a split in front of its op
                 assert idx <= first_post or self.post_refs is None
                 self.splits.append((k - 1, marks[mark_i][1]))
                 mark_i += 1
+            if scene_pre_at is not None:   # (behind the step() of a user-defined action manager class, which sends the targets itself)
+                self.splits.append((scene_pre_at, self._scene_pre))
+                scene_pre_at = None
             if idx < first_post:
                 self.ops[k].phase = nat.PHASE_OF_FN[fn]
                 self.ops[k].args = C.addressof(args)
@@ -174,13 +180,17 @@ class StepTrace:
             self._hooks(fn, args, owner)
             self.native_op.extend([self._cur_op] * (len(self.native) - len(self.native_op)))
             if fn == "action_step" and self.adapter is not None:
-                self.splits.append((self._cur_op + 1, self._scene_pre))   # control_dofs_position → scene.step() → state fetch
+                if owner is not None:
+                    self.splits.append((self._cur_op + 1, self._scene_pre))   # control_dofs_position → scene.step() → state fetch
+                else:
+                    scene_pre_at = self._cur_op + 1
             pre = owner._trace_pre(args) if hasattr(owner, "_trace_pre") else None
             if pre is not None:
                 assert idx < first_post + (2 if self.post_split else 0) or idx in self._late, "a phase with Python-level terms cannot be part of the fused launch"
                 self.splits.append((self._cur_op, pre))
         for _at, f in marks[mark_i:]:   # user code behind the last launch
             self.splits.append((k - 1, f))
+        assert scene_pre_at is None
         self.native.extend(self._gait_swaps)   # after the gait managers' own patches (those refill the descriptors)
         post_at = next((i - 1 for i in range(k) if self.ops[i].phase == nat.GF_OP_POST_PHYSICS), -1)
         self.native_op.extend([post_at] * (len(self.native) - len(self.native_op)))   # (they serve the fused launch)
@@ -337,7 +347,8 @@ class StepTrace:
         """What the ordinary step does between the action phase and the first post-physics phase (managed_env.py:290-292,
         position_action_manager.py:417), then the snapshot: each getter of the plan once, the new addresses into the descriptors."""
         env, am = self.env, self.action_owner
-        env.robot.control_dofs_position(am._actions, am.dofs_idx)
+        if am is not None:   # (a user-defined action manager class has sent its targets itself: its step() ran just before)
+            env.robot.control_dofs_position(am._actions, am.dofs_idx)
         env.scene.step()
         pr = self.params
         shapes = self._scene_shapes
@@ -621,7 +632,8 @@ class StepTrace:
         if fn == "action_step":
             self.action_owner = owner
             self.native.append(P(nat.GF_PATCH_ACTIONS, 0, nat.field_addr(args, "actions_in"), None, None))
-            if not owner._quiet_action_errors:
+            # (owner None: the env's bookkeeping launch in front of a user-defined action manager class, whose own step() is a python phase)
+            if owner is not None and not owner._quiet_action_errors:
                 self.afters.append((self._cur_op, owner._watch_flags))
         elif fn == "synth_scene_step":
             self.native.append(P(nat.GF_PATCH_COUNTER, 0, nat.field_addr(args, "tick"), None, C.addressof(owner._tick_c)))
@@ -671,7 +683,10 @@ class StepTrace:
     def replay(self, actions):
         env = self.env
         env._begin_step_light()
-        self.action_owner._raw_actions = actions
+        if self.action_owner is not None:
+            self.action_owner._raw_actions = actions
+        else:
+            env._step_actions = actions
         for p in self.patches:
             p(actions)
         snap = None
@@ -757,6 +772,8 @@ class StepTrace:
         obs = extras["observations"].get("policy") if len(env.managers["observation"]) > 0 else obs_tail
         if self._env_obs_python:
             obs = env._step_obs   # what the env's own get_observations() returned (a python phase behind the last launch)
+        elif self._env_obs_tail:
+            obs = obs_tail
         return obs, rm._reward_buf if rm is not None else env._reward_buf, tm._terminated_buf, tm._truncated_buf, extras
 
 
@@ -795,12 +812,19 @@ def traceable(env, tail_python: bool = False) -> bool:
     # among the observations (ManagedEnvironment._observe_all), the manager simply is not part of the recording.
     phase_obs = set(map(id, env.managers["observation"]))
     user_obs = set()
+    # … and the step() / handle_actions() of a user action manager class (the reference's extension point,
+    # position_action_manager.py:389-392): the env's bookkeeping launch takes the action kernel's place in the recording (it keeps the
+    # statistics ring), the user's code — `super().step(...)` launch included — follows it as a python phase (on a Genesis-shaped scene
+    # in front of StepTrace._scene_pre, which then leaves sending the targets to it).
+    phase_act = {id(am)}
     for m in env._all_managers() + env.managers["terrain"]:
         for meth in ("step", "reset", "get_observations", "_perform_observation", "handle_actions"):
             if hasattr(m, meth) and not _most_derived_is_ours(m, meth):
                 if id(m) in between and meth in ("step", "reset"):
                     continue
                 if id(m) in phase_step and meth == "step":
+                    continue
+                if id(m) in phase_act and meth in ("step", "handle_actions"):
                     continue
                 if id(m) in phase_obs and meth in ("get_observations", "_perform_observation"):
                     user_obs.add(id(m))

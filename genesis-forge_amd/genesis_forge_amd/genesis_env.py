@@ -346,7 +346,9 @@ class GenesisEnv:
             self._bk_consts = (one, zero, torch.full((D,), -torch.inf, device=gs.device), torch.full((D,), torch.inf, device=gs.device),
                                torch.empty_like(self._actions))
         one, zero, lo, hi, scratch = self._bk_consts
-        a = nat.GfActionArgs()
+        a = self.__dict__.get("_bk_args")   # (one descriptor for the env's life: a recorded step patches it in place)
+        if a is None:
+            a = self._bk_args = nat.GfActionArgs()
         a.num_envs, a.num_dofs, a.mode, a.check_finite = self.num_envs, D, nat.GF_ACTION_POSITION, 0
         a.actions_in = actions.data_ptr()
         a.scale, a.offset, a.clip_lo, a.clip_hi = one.data_ptr(), zero.data_ptr(), lo.data_ptr(), hi.data_ptr()

@@ -237,12 +237,21 @@ class ManagedEnvironment(GenesisEnv):
 
         # A: actions (+ env bookkeeping) and the simulation step
         am = self.managers["action"]
-        if am is not None and isinstance(am, PositionActionManager) and type(am).step is PositionActionManager.step:
+        if am is not None and isinstance(am, PositionActionManager) and type(am).step is PositionActionManager.step and not am._user_handler():
             am.step(actions, _fuse_env=True)
         else:
+            # a user-defined action manager class (its own step() / handle_actions()): the env's bookkeeping as a launch of its own,
+            # then the user's code — while the step is being recorded, as user code between native phases (_manager_step)
             self._bookkeep(actions)
             if am is not None:
-                am.step(actions)
+                rec = self.backend.tracer
+                if rec is not None and isinstance(am, PositionActionManager):
+                    from .managers._program import call_untraced
+                    self._step_actions = actions
+                    rec.python(self._user_action_step)
+                    call_untraced(self, self._user_action_step)
+                else:
+                    am.step(actions)
         self.scene.step()
         self.scene_stepped()
 
@@ -283,6 +292,10 @@ class ManagedEnvironment(GenesisEnv):
             ro.write(pol._last_out if pol is not None else obs, rewards, terminated, truncated)
         self._end_step()
         return obs, rewards, terminated, truncated, self.extras
+
+    def _user_action_step(self) -> None:
+        """``step(actions)`` of a user-defined action manager class with this step's actions (a recorded step calls it at its place)."""
+        self.managers["action"].step(self._step_actions)
 
     def _manager_step(self, m) -> None:
         """``m.step()`` — for a user-defined manager class while the step is being recorded: as user code between native phases
@@ -472,8 +485,11 @@ class ManagedEnvironment(GenesisEnv):
     def _observe_all(self):
         policy_obs = None
         rec = self.backend.tracer if self._in_step else None
-        for m in self.managers["observation"]:
-            if rec is not None and not (_most_derived_is_ours(m, "get_observations") and _most_derived_is_ours(m, "_perform_observation")):
+        # (user-defined ObservationManager classes observe LAST, recorded or not: their code then sits behind the step's last native
+        #  launch instead of between two observation phases, and the fused launch keeps the library managers — fuzz seed 310)
+        ours = lambda m: _most_derived_is_ours(m, "get_observations") and _most_derived_is_ours(m, "_perform_observation")
+        for m in sorted(self.managers["observation"], key=lambda m: not ours(m)):
+            if rec is not None and not ours(m):
                 # a user-defined ObservationManager class: its get_observations() is user code at this place of the step (the recording
                 # keeps the place and calls it again there; the launch it makes itself belongs to it)
                 from .managers._program import call_untraced

@@ -260,6 +260,23 @@ class PositionActionManager(BaseActionManager):
         GenesisEnv.step's bookkeeping (genesis_env.py:196-203)."""
         if not self.enabled:
             return
+        if self._user_handler():
+            # a subclass overrides handle_actions() — the reference's extension point ("Override this function if you want to change
+            # the action handling logic", position_action_manager.py:385-392): step() = keep the raw actions, hand them to it
+            if actions.dtype != torch.float32 or not actions.is_contiguous():
+                actions = actions.to(torch.float32).contiguous()
+            self._raw_actions = actions
+            out = self.handle_actions(actions)
+            if out is not None and out is not self._actions:
+                self._actions.copy_(out)   # (the manager's target buffer is persistent: descriptors and the scene address it)
+            return self._actions
+        return self._process(actions, _fuse_env)
+
+    def _user_handler(self) -> bool:
+        return type(self).handle_actions is not PositionActionManager.handle_actions
+
+    def _process(self, actions: torch.Tensor, _fuse_env: bool = False) -> torch.Tensor:
+        """The native Phase A launch: scale / offset / clip (or the joint-limit map), NaN / Inf flags, targets to the actuators."""
         env = self.env
         if actions.dtype != torch.float32 or not actions.is_contiguous():
             actions = actions.to(torch.float32).contiguous()
@@ -287,8 +304,9 @@ class PositionActionManager(BaseActionManager):
         return self._actions
 
     def handle_actions(self, actions: torch.Tensor) -> torch.Tensor:
-        """Kept for API compatibility: processes ``actions`` through Phase A and returns the targets."""
-        return self.step(actions)
+        """position_action_manager.py:389-419: actions → position targets, sent to the actuators.  A subclass that overrides it is
+        called by step() with the raw actions, and reaches this one (the native launch) through ``super().handle_actions(...)``."""
+        return self._process(actions, False)
 
     def _watch_flags(self):
         """The reference prints on NaN/Inf actions after two blocking ``.any()`` calls per step

@@ -305,8 +305,8 @@ class Go2CommandDirectionEnv(ManagedEnvironment):
             joint_names, default_pos = GO2_JOINTS, GO2_DEFAULT_POS
         else:
             joint_names, default_pos = [".*"], {".*": 0.1}
-        self.action_manager = PositionActionManager(self, joint_names=joint_names, default_pos=default_pos,
-                                                    scale=0.25, use_default_offset=True, pd_kp=20, pd_kv=0.5)
+        self.action_manager = getattr(self, "action_cls", PositionActionManager)(   # (tests plug a user-defined action manager class in)
+            self, joint_names=joint_names, default_pos=default_pos, scale=0.25, use_default_offset=True, pd_kp=20, pd_kv=0.5)
         self.velocity_command = VelocityCommandManager(
             self, range={"lin_vel_x": [-1.0, 1.0], "lin_vel_y": [-1.0, 1.0], "ang_vel_z": [-1.0, 1.0]}, standing_probability=0.02,
             resample_time_sec=self._cmd_resample_s)

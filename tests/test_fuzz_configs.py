@@ -61,7 +61,30 @@ def make_fuzz_env(seed: int):
             em = self.robot_manager = EntityManager(self, entity_attr="robot", on_reset={
                 "position": {"fn": reset.position, "params": {"position": [0.0, 0.0, uni(0.3, 0.45)], "quat": [1.0, 0.0, 0.0, 0.0],
                                                               "zero_velocity": pick(0.7)}}})
-            am = self.action_manager = PositionActionManager(
+            # user-defined ACTION manager classes (handle_actions() — the reference's extension point — or step() overridden), user
+            # ObservationManager classes and env-level get_observations() overrides: python phases of a recorded step (round 4).  A
+            # random stream of their own: the other draws of a seed are what they were before these existed.
+            rnd_usr = random.Random(55000 + seed)
+            self.user_action_cls = rnd_usr.choice([None] * 17 + ["handle_actions", "handle_actions", "step"])
+            self.user_obs_cls = rnd_usr.random() < 0.12
+            gain = rnd_usr.choice([0.5, 0.8])
+
+            class SmoothedActions(PositionActionManager):
+                def handle_actions(s, actions):
+                    prev = getattr(s, "_lp", None)
+                    s._lp = actions.clone() if prev is None else gain * prev + (1.0 - gain) * actions
+                    return super().handle_actions(s._lp)
+
+            class ScaledActions(PositionActionManager):
+                def step(s, actions):
+                    return super().step(actions * gain)
+
+            class ClippedObs(ObservationManager):
+                def get_observations(s):
+                    return super().get_observations().clamp(-2.0, 2.0)
+
+            action_cls = {None: PositionActionManager, "handle_actions": SmoothedActions, "step": ScaledActions}[self.user_action_cls]
+            am = self.action_manager = action_cls(
                 self, joint_names=GO2_JOINTS, default_pos=GO2_DEFAULT_POS, scale=rnd.choice([0.25, 0.5, 1.0]),
                 clip=rnd.choice([None, (-100.0, 100.0), (-1.5, 1.5)]), use_default_offset=pick(0.8), pd_kp=20, pd_kv=0.5)
             vc = self.velocity_command = VelocityCommandManager(
@@ -206,8 +229,8 @@ def make_fuzz_env(seed: int):
                 return cfg
 
             h = rnd.choice([None, None, 2, 3, 5])
-            self.observation_manager = ObservationManager(self, name="policy", cfg=obs_cfg(2), history_len=h, noise=0.02 if pick(0.15) else None,
-                                                          **out_mode(h))
+            self.observation_manager = (ClippedObs if self.user_obs_cls else ObservationManager)(
+                self, name="policy", cfg=obs_cfg(2), history_len=h, noise=0.02 if pick(0.15) else None, **out_mode(h))
             self.third_obs = False
             if pick(0.35):
                 h = rnd.choice([None, 4])
@@ -217,6 +240,11 @@ def make_fuzz_env(seed: int):
                     h = rnd.choice([None, 2])
                     ObservationManager(self, name="extra", cfg=obs_cfg(1), history_len=h, **out_mode(h))
 
+    if random.Random(56000 + seed).random() < 0.1:   # an env-level get_observations() override (normalisation, clipping)
+        def get_observations(self):
+            o = ManagedEnvironment.get_observations(self)
+            return None if o is None else o * 0.5
+        FuzzEnv.get_observations = get_observations
     FuzzEnv.overrides_reset = pick(0.2)
     if FuzzEnv.overrides_reset:  # a user reset(): honoured by index list; the step is recorded up to the reset only
         FuzzEnv.reset = lambda self, envs_idx=None: ManagedEnvironment.reset(self, envs_idx)
@@ -337,6 +365,9 @@ def test_random_config_recorded_equals_phase_by_phase_cpu(oracle_backend, seed):
         del os.environ["GF_NO_TRACE"]
     assert info["recorded"] and not info2["recorded"]
     _compare(fast, slow, 0, f"seed {seed} {info}")
+    if not info["overrides_reset"] and os.environ.get("GF_NO_FUSE", "0") != "1":
+        # (the structure check of the GPU test, here without a GPU: only user code BETWEEN post-physics phases keeps them off one launch)
+        assert info["fused"] == (not info["user_manager"]), {k: v for k, v in info.items() if k not in ("env", "post_refs")}
 
 
 def test_fuzz_configs_build_on_cpu(oracle_backend):

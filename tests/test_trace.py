@@ -431,6 +431,84 @@ def test_user_observation_code_is_a_python_phase_behind_the_fused_launch(oracle_
     assert (Obs.calls, Env.env_calls) == counts_a and sum(counts_a) >= 50
 
 
+def _user_action_env(which):
+    """A user-defined action manager CLASS: `handle_actions()` overridden (the reference's documented extension point,
+    position_action_manager.py:389-392 — here a first-order low-pass on the incoming actions in front of the library's processing) or
+    `step()` wrapped (targets post-processed)."""
+    from genesis_forge_amd.managers import PositionActionManager
+
+    class SmoothedActions(PositionActionManager):
+        calls = 0
+
+        def handle_actions(self, actions):
+            type(self).calls += 1
+            prev = getattr(self, "_lp", None)
+            self._lp = actions.clone() if prev is None else 0.7 * prev + 0.3 * actions
+            return super().handle_actions(self._lp)
+
+    class HalvedTargets(PositionActionManager):
+        calls = 0
+
+        def step(self, actions):
+            type(self).calls += 1
+            return super().step(actions * 0.5)
+
+    Cls = SmoothedActions if which == "handle_actions" else HalvedTargets
+
+    class Env(Go2CommandDirectionEnv):
+        action_cls = Cls
+
+    return Env, Cls
+
+
+@pytest.mark.parametrize("which", ["handle_actions", "step"])
+def test_user_action_manager_class_is_a_python_phase_of_a_recorded_step(oracle_backend, which):
+    """A user action manager class no longer keeps the env on the ordinary step: the env's bookkeeping launch takes the action kernel's
+    place in the recording, the user's step() / handle_actions() follows it as user code (its own `super()` launch included), and the
+    rest of the step is the fused launch as ever.  `handle_actions()` is honoured at all (it is what the reference's step() calls)."""
+    Env, Cls = _user_action_env(which)
+    Cls.calls = 0
+    a, env_a = _run("cpu", False, cls=Env)
+    calls_a = Cls.calls
+    assert calls_a >= 50
+    plain, _ = _run("cpu", False)
+    assert not torch.equal(a[-1][0], plain[-1][0]), "the user's action code has no effect on the step"
+    Cls.calls = 0
+    before = oracle_backend.replays
+    b, env = _run("cpu", True, cls=Env)
+    _same(a, b)
+    tr = env._trace
+    assert tr is not None, f"not recorded: {env._untraceable}"
+    assert tr.post_refs is not None and len(tr.py_marks) == 1 and tr.action_owner is None
+    assert oracle_backend.replays - before >= 40 and Cls.calls == calls_a
+
+
+@pytest.mark.gpu
+def test_user_action_manager_class_recorded_hip(hip_backend):
+    Env, _Cls = _user_action_env("handle_actions")
+    a, _ = _run("cuda", False, n=1000, cls=Env)
+    b, env = _run("cuda", True, n=1000, cls=Env)
+    assert env._trace is not None and env._trace.post_refs is not None and env._trace.action_owner is None
+    _same(a, b)
+
+
+def test_env_get_observations_override_next_to_a_reset_override(oracle_backend):
+    """Both overridden: the recorded step ends in front of the reset, the Python tail calls the user's get_observations() — and the
+    step returns ITS value, not the policy manager's (fuzz seed 216)."""
+    class Env(Go2CommandDirectionEnv):
+        def reset(self, env_ids=None):
+            return super().reset(env_ids)
+
+        def get_observations(self):
+            o = super().get_observations()
+            return None if o is None else o * 0.5
+
+    a, _ = _run("cpu", False, cls=Env)
+    b, env = _run("cpu", True, cls=Env)
+    assert env._trace is not None and env._trace.tail_python
+    _same(a, b)
+
+
 @pytest.mark.gpu
 def test_user_observation_code_recorded_hip(hip_backend):
     Env, _Obs = _user_obs_env("manager+env")

@@ -3,7 +3,8 @@
 (cut around the call) vs phase by phase — or (`manager`) a user-defined CommandManager CLASS with its own step() / reset(), a reward
 term and an observation item reading it (the shape of the reference's examples/gait_trainer/gait_command_manager.py) — or (`classes`)
 user-defined RewardManager and TerminationManager CLASSES whose step() wraps the library's (round 4: python phases of a recorded step).
-    python tools/bench_user_term.py [num_envs] [reward|obs|manager|classes|obsclass]"""
+or (`action`) a user-defined ACTION manager class overriding handle_actions(), the reference's extension point.
+    python tools/bench_user_term.py [num_envs] [reward|obs|manager|classes|obsclass|action]"""
 import os
 import sys
 import time
@@ -31,6 +32,17 @@ def run(n, trace, steps=400):
             def get_observations(self):
                 o = super().get_observations()
                 return None if o is None else o * 0.5
+    if KIND == "action":   # a low-pass on the incoming actions in front of the library's processing
+        from genesis_forge_amd.managers import PositionActionManager
+
+        class SmoothedActions(PositionActionManager):
+            def handle_actions(self, actions):
+                prev = getattr(self, "_lp", None)
+                self._lp = actions.clone() if prev is None else torch.lerp(actions, prev, 0.7)
+                return super().handle_actions(self._lp)
+
+        class env_cls(Go2CommandDirectionEnv):   # noqa: F811
+            action_cls = SmoothedActions
     env = env_cls(num_envs=n, scene_kwargs=dict(ang_noise=0.05, seed=1))
     cfg_add = {"user_height": {"weight": 0.3, "fn": lambda env: torch.tanh(env.robot.get_pos()[:, 2])}}
     orig = env.config
