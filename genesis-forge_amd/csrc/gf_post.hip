@@ -1171,15 +1171,19 @@ int gf::post_launch(const gf::GfPostArgs& packed, hipStream_t s) {
     const size_t lds = sizeof(gf::GfPostArgs) + ((size_t)(gf::kPostMaxReward + gf::kPostAuxRows) * gf::kEnvBlock + (size_t)(omax + 1) * gf::kEnvBlock) * sizeof(float);
     // a folded contact phase stages the tile's slot ids in the LDS the later phases use (behind the interpreter's descriptor copy)
     const size_t fold_lds = a.cfold.num_mgr > 0 ? gf::fold_lds_bytes(a.cfold.num_contacts) : 0;
-    auto with_fold = [&](size_t bytes, bool interp) { const size_t need = fold_lds ? fold_lds + (interp ? sizeof(gf::GfPostArgs) : 0) : 0; return bytes > need ? bytes : need; };
-    const unsigned grid = gf::env_grid(a.num_envs);
+    auto with_fold = [&](size_t bytes, bool interp) {
+        const size_t need = fold_lds ? fold_lds + (interp ? sizeof(gf::GfPostArgs) : 0) : 0;
+        return (bytes > need ? bytes : need) + (size_t)gf::kWsTilesLdsFloats * sizeof(float);
+    };
+    const unsigned grid1 = gf::env_grid(a.num_envs);
     gf::PhaseScope scope(GF_PHASE_POST, s);
     bool any_ring = false;
     for (int m = 0; m < a.n_obs; ++m) any_ring = any_ring || a.obs[m].ring != 0;
     const bool ws_only = a.n_gait || a.roll_obs || a.roll_reward || a.roll_done || any_ring || a.term_done || a.no_reset || (a.num_dofs != 12 && a.num_dofs != 28);   // the one-wave variant has neither a gait manager nor rollout stores
+    const unsigned grid = grid1;
     if (gf::g_options[GF_OPT_POST_VARIANT] == 0 && !ws_only) {
-        if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid, gf::kEnvBlock, lds, s, a);
-        else GF_LAUNCH(scope, gf::post_kernel<3>, grid, gf::kEnvBlock, lds, s, a);
+        if (a.num_dofs == 28) GF_LAUNCH(scope, gf::post_kernel<7>, grid1, gf::kEnvBlock, lds, s, a);
+        else GF_LAUNCH(scope, gf::post_kernel<3>, grid1, gf::kEnvBlock, lds, s, a);
     } else if (const int prog = select_program(a); prog >= kDynBase) {
         // a program compiled at run time: the plugin's kernel handle, launched like any other (launch sink, dispatch events)
         const DynProgram& d = g_dyn[prog - kDynBase];
@@ -1187,9 +1191,9 @@ int gf::post_launch(const gf::GfPostArgs& packed, hipStream_t s) {
         void* kargs[1] = {const_cast<gf::GfPostArgs*>(&a)};
         if (scope.active()) {
             scope.use_dispatch_events();
-            (void)hipExtLaunchKernel(d.kernel, dim3(grid), dim3(gf::kWsBlock), kargs, lds_dyn, s, scope.start(), scope.stop(), 0);
+            (void)hipExtLaunchKernel(d.kernel, dim3(grid1), dim3(gf::kWsBlock), kargs, lds_dyn, s, scope.start(), scope.stop(), 0);
         } else {
-            gf::sink_launch(d.kernel, dim3(grid), dim3(gf::kWsBlock), lds_dyn, s, kargs);
+            gf::sink_launch(d.kernel, dim3(grid1), dim3(gf::kWsBlock), lds_dyn, s, kargs);
         }
     } else if (prog) {
 #define GF_RUN(id, P) \

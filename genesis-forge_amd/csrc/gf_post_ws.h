@@ -174,6 +174,11 @@ __host__ __device__ constexpr bool ws_prog_folds() {
     }
 }
 
+#ifndef GF_WS_AHEAD
+#define GF_WS_AHEAD 0
+#endif
+constexpr int kWsTilesLdsFloats = GF_WS_AHEAD > 0 ? 4 * kEnvBlock : 0;   // (experiment: one scratch row per wave, the target of the look-ahead requests)
+
 template <class P>
 __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg) {
     constexpr int DV = P::DV;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     bool has_gait = false;
     if constexpr (P::kStatic) has_gait = P::n_gait > 0;
     else has_gait = UNI(a.n_gait) > 0;
-    float* xch = lds + kArgVec * 4;                          // [x_fields][64]
+    float* xch = lds + kArgVec * 4 + kWsTilesLdsFloats;      // [x_fields][64]
     // a static program knows how many reward rows it has and every variant knows its DOF chunks: the LDS a workgroup asks for decides
     // how many of them a CU holds (Go2 programs: 30 KB → 22.5 KB, five → seven workgroups per CU, what their 72 VGPRs allow)
     constexpr int kSumRows = ws_sum_rows<P>(), kAuxRows = ws_aux_rows<P>();
@@ -204,7 +209,8 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     GF_WSTAMP(1);
     const int lane = threadIdx.x & (GF_WAVE - 1);
     const int64_t N = UNI(a.num_envs);
-    const int64_t n0 = (int64_t)blockIdx.x * kEnvBlock;
+    const int64_t tile_id = blockIdx.x;
+    const int64_t n0 = tile_id * kEnvBlock;
     const int64_t n_raw = n0 + lane;
     const bool live = n_raw < N;
     const int64_t n = live ? n_raw : N - 1;
@@ -234,6 +240,43 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
     float* const k_reward = UNI(a.reward);
     const bool has_reward = n_rew >= 0 && k_reward != nullptr;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#if GF_WS_AHEAD > 0
+    {   // EXPERIMENT (tools/ab_build.sh -DGF_WS_AHEAD=K): the rows of the tile K workgroups ahead — same XCD when K % 8 == 0 —
+        // are pulled towards the caches while this tile works: one LDS-DMA dword per lane and array (every line of that tile's block is
+        // touched), no register, no wait.  (A loop over two tiles per workgroup, the other form of the pipeline, makes the compiler hoist the
+        // descriptor's scalar loads out of the loop: SGPRs spill into VGPR lanes, 77 -> 137 VGPRs — not measurable as a pipeline.)
+        const int64_t next_id = tile_id + GF_WS_AHEAD;
+        if (next_id < (N + kEnvBlock - 1) / kEnvBlock) {
+            const int64_t n2 = next_id * kEnvBlock + lane;
+            const uint32_t e2 = (uint32_t)(n2 < N ? n2 : N - 1), ro2 = e2 * (uint32_t)D;
+            float* const pf = lds + kArgVec * 4 + wave * kEnvBlock;
+            auto warm = [&](const bool on, const float* base, const uint32_t off) GF_INLINE_LAMBDA {
+                __builtin_amdgcn_global_load_lds(gsel(on, base, off), pf, 4, 0, 0);
+            };
+            if (wave == 0) {
+                warm((needs & PN_QUAT) != 0, UNI(a.quat), 4u * e2);
+                warm((needs & PN_POS) != 0, UNI(a.pos), 3u * e2);
+                warm((needs & PN_LIN) != 0, UNI(a.lin_vel), 3u * e2);
+                warm((needs & PN_ANG) != 0, UNI(a.ang_vel), 3u * e2);
+                warm((needs & PN_EPLEN) != 0, reinterpret_cast<const float*>(UNI(a.episode_length)), e2);
+                warm((needs & PN_MAXLEN) != 0, reinterpret_cast<const float*>(UNI(a.max_episode_length)), e2);
+                if (has_gait) warm(true, UNI(a.gait.state), (uint32_t)GF_GAIT_ROW * e2);
+            } else if (wave == 1) {
+                warm((needs & PN_DOFDEV) != 0, UNI(a.dof_pos), ro2);
+                warm((needs & PN_ACTRATE) != 0, UNI(a.env_actions), ro2);
+                warm((needs & PN_ACTRATE) != 0, UNI(a.env_last_actions), ro2);
+                warm(has_reward && UNI(a.episode_seconds) != nullptr, UNI(a.episode_seconds), e2);
+            } else if (wave == 2) {
+                warm((needs & PN_DOFPOS) != 0, UNI(a.dof_pos), ro2);
+                warm((needs & PN_DOFVEL) != 0, UNI(a.dof_vel), ro2);
+            } else {
+                warm((needs & PN_TARGETS) != 0, UNI(a.targets), ro2);
+                warm((needs & PN_ACTIONS) != 0, UNI(a.env_actions), ro2);
+                warm(UNI(a.dof_force) != nullptr, UNI(a.dof_force), ro2);
+            }
+        }
+    }
+#endif
 
     // the command managers' table rows; a static program knows the widths
     auto cmd_row = [&](int c) GF_INLINE_LAMBDA {
@@ -771,7 +814,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                     if (__ballot(live && (fl & 1))) byte |= 1u << (2 * f);
                     if (__ballot(live && (fl & 2))) byte |= 2u << (2 * f);
                 }
-                if (lane == 0) G(fout)[blockIdx.x] = (uint8_t)byte;
+                if (lane == 0) G(fout)[tile_id] = (uint8_t)byte;
             }
         }
         if (done) {
