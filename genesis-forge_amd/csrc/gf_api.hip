@@ -6,7 +6,8 @@
 #include "gf_launch.h"
 
 namespace gf {
-int g_options[GF_OPT_COUNT] = {2, 0, 0, 1, getenv("GF_NO_CONTACT_FOLD") ? 0 : 1};
+// (GF_NO_CONTACT_FOLD / GF_FORCE_CONTACT_FOLD: the measurement switches of tools/scaling_table.sh — never / always, against the size policy)
+int g_options[GF_OPT_COUNT] = {2, 0, 0, 1, getenv("GF_NO_CONTACT_FOLD") ? 0 : (getenv("GF_FORCE_CONTACT_FOLD") ? 2 : 1)};
 Profiler g_prof;
 thread_local LaunchSink g_sink;
 bool contact_compatible(const GfContactArgs* x, const GfContactArgs* y);          // gf_contact.hip

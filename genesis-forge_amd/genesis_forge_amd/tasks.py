@@ -2,6 +2,7 @@
 (examples/*/environment.py: same managers, cfg dicts, weights; pinned to the reference by tests/test_examples.py) plus two
 stress configs — and ``BASELINE_CONFIGS``, the table of workloads bench.py, tools/bench_configs.py and the parity tests at
 the timed sizes (tests/test_bench_parity.py) share."""
+import os
 import torch
 
 from genesis_forge_amd import ManagedEnvironment
@@ -504,6 +505,8 @@ _CON = dict(_SC, contact_prob=0.15, contact_force=40.0)
 
 
 def _walk(foot_links, body_prob, **kw):
+    if os.environ.get("GF_SPARSE_CONTACTS") == "1":   # round 3's near-empty contact tables (0.03-0.06 contacts per env and step), for comparison only
+        return dict(_SC, contact_force=40.0, contact_prob=body_prob, **kw)
     return dict(_SC, contact_force=40.0, foot_links=foot_links, foot_contact_prob=0.5, contact_prob=body_prob, **kw)
 
 

@@ -251,6 +251,49 @@ def make_fuzz_env(seed: int):
     return FuzzEnv()
 
 
+def _mutations(env, seed):
+    """Live edits of a running env's config (a curriculum: config_item.py:31-44, command ranges edited in place), drawn per seed from a
+    stream of their own: [(step, callable)].  Every edit must reach the very next step — recorded or not — and drop / refresh what a
+    recorded step froze; about half of the seeds get one to three."""
+    r = random.Random(57000 + seed)
+    if r.random() < 0.5:
+        return []
+    out = []
+    for _ in range(r.randint(1, 3)):
+        at = r.randint(3, 24)
+        kind = r.choice(["reward_weight", "reward_weight", "reward_param", "term_param", "range", "resample", "obs_scale", "zero_weight"])
+        rm, tm, vc = env.reward_manager, env.termination_manager, env.velocity_command
+        if kind in ("reward_weight", "zero_weight"):
+            name = r.choice(sorted(rm.cfg))
+            w = 0.0 if kind == "zero_weight" else round(r.uniform(-2.0, 2.0), 3)
+            out.append((at, lambda name=name, w=w: setattr(rm.cfg[name], "weight", w)))
+        elif kind == "reward_param":
+            cands = [(n, k) for n in sorted(rm.cfg) for k, v in rm.cfg[n].params.items() if isinstance(v, float)]
+            if cands:
+                n, k = r.choice(cands)
+                f = round(r.uniform(0.7, 1.3), 3)
+                out.append((at, lambda n=n, k=k, f=f: rm.cfg[n].params.__setitem__(k, rm.cfg[n].params[k] * f)))
+        elif kind == "term_param":
+            cands = [(n, k) for n in sorted(tm.term_cfg) for k, v in tm.term_cfg[n].params.items() if isinstance(v, float)]
+            if cands:
+                n, k = r.choice(cands)
+                f = round(r.uniform(0.7, 1.3), 3)
+                out.append((at, lambda n=n, k=k, f=f: tm.term_cfg[n].params.__setitem__(k, tm.term_cfg[n].params[k] * f)))
+        elif kind == "range":
+            hi = round(r.uniform(0.3, 2.5), 3)
+            out.append((at, lambda hi=hi: vc.range["lin_vel_x"].__setitem__(1, hi)))   # in place: no setter involved
+        elif kind == "resample":
+            sec = round(r.uniform(0.1, 0.6), 3)
+            out.append((at, lambda sec=sec: setattr(vc, "resample_time_sec", sec)))
+        else:
+            om = env.observation_manager
+            cands = sorted(k for k in om.cfg if k != "user_xy")
+            name = r.choice(cands)
+            sc = r.choice([0.1, 0.5, 2.0])
+            out.append((at, lambda name=name, sc=sc: setattr(om.cfg[name], "scale", sc)))
+    return out
+
+
 def _run(seed, dev, steps=STEPS):
     env = make_fuzz_env(seed)
     env.build()
@@ -260,7 +303,11 @@ def _run(seed, dev, steps=STEPS):
     g = torch.Generator().manual_seed(seed)
     f = lambda t: t.detach().cpu().clone()
     out = [({"obs": f(obs)}, {})]
+    edits = _mutations(env, seed)
     for t in range(steps):
+        for at, edit in edits:
+            if at == t:
+                edit()
         act = torch.randn(n, 12, generator=g)
         obs, rew, term, trunc, extras = env.step(act.to(dev))
         state = {"obs": obs, "reward": rew, "terminated": term, "truncated": trunc, "command": env.velocity_command.command,
