@@ -253,6 +253,40 @@ def test_rl_library_wrappers_over_the_recorded_step(oracle_backend):
             assert rew.shape == (33, 1) and term.shape == (33, 1) and trunc.shape == (33, 1)
 
 
+def test_rsl_rl_3_wrapper_returns_observation_groups_as_a_tensordict(oracle_backend, monkeypatch):
+    """With rsl-rl-lib >= 3 the wrapper hands out the env's observation groups as a TensorDict and get_observations() returns the
+    observations only (rsl_rl.py:24-34, 66-119).  Neither package is in this image: the version probe and a minimal ``tensordict``
+    module are stood in."""
+    import sys
+    import types
+    from importlib import metadata
+
+    from genesis_forge_amd.wrappers import RslRlWrapper
+
+    class TensorDict(dict):
+        def __init__(self, data, batch_size=None, device=None):
+            super().__init__(data)
+            self.batch_size, self.device = batch_size, device
+
+    monkeypatch.setitem(sys.modules, "tensordict", types.SimpleNamespace(TensorDict=TensorDict))
+    real = metadata.version
+    monkeypatch.setattr(metadata, "version", lambda name: "3.1.0" if name == "rsl-rl-lib" else real(name))
+    env = Go2CommandDirectionEnv(num_envs=9, scene_kwargs=dict(seed=4))
+    w = RslRlWrapper(env)
+    assert w.rsl3 and str(w.device) == "cpu"
+    w.build()
+    obs, extras = w.reset()
+    assert isinstance(obs, TensorDict) and set(obs) >= {"policy"} and obs["policy"].shape[0] == 9
+    got = w.get_observations()
+    assert isinstance(got, TensorDict) and torch.equal(got["policy"], obs["policy"])
+    obs2, rew, dones, extras = w.step(torch.zeros(9, 12))
+    assert isinstance(obs2, TensorDict) and "critic" in obs2 and torch.equal(obs2["critic"], obs2["policy"])
+    assert dones.dtype == torch.bool and torch.equal(extras["time_outs"], env.termination_manager._truncated_buf)
+    monkeypatch.setattr(metadata, "version", lambda name: "2.3.1" if name == "rsl-rl-lib" else real(name))
+    w2 = RslRlWrapper(env)
+    assert not w2.rsl3 and isinstance(w2.get_observations(), tuple) and isinstance(w2.step(torch.zeros(9, 12))[0], torch.Tensor)
+
+
 def test_external_command_controller(oracle_backend):
     """use_external_controller (command_manager.py:176-207): the controller's tensor IS the command — in the observation, in the
     tracking rewards — nothing is resampled, and such a step is never recorded (the tensor is the controller's to replace)."""
