@@ -110,7 +110,8 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
 
     const int64_t OH = (int64_t)O * H;
     const bool ring = a.history_ring != 0;   // in-place ring: only the new frame is written, into its slot
-    GF_GLOBAL float* out = G(a.obs) + n0 * OH + (ring ? (int64_t)(a.history_ring - 1) * O : 0);
+    const int64_t OS = (ring && a.ring_slots) ? (int64_t)O * a.ring_slots : OH;   // env stride of `out` (a ring with more slots than frames)
+    GF_GLOBAL float* out = G(a.obs) + n0 * OS + (ring ? (int64_t)(a.history_ring - 1) * O : 0);
     const GF_GLOBAL float* prev = (H > 1 && !ring) ? G(a.prev_obs) + n0 * OH : nullptr;
     // 16-byte units over the tile's contiguous run (see HistBatch); otherwise (a frame narrower than 4, an output that is not
     // 16-byte aligned) element by element
@@ -297,7 +298,7 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
         for (int i = tid; i < rows * o4; i += kObsBlock) {
             const int row = d4.div(i), c4 = i - row * o4;
             const float* r = tile + row * S + c4 * 4;
-            reinterpret_cast<GF_GLOBAL f32x4a*>(out + row * OH)[c4] = f32x4a{r[0], r[1], r[2], r[3]};
+            reinterpret_cast<GF_GLOBAL f32x4a*>(out + row * OS)[c4] = f32x4a{r[0], r[1], r[2], r[3]};
         }
     } else if (V == 2) {
         const int o2 = O >> 1;
@@ -305,13 +306,13 @@ __device__ __forceinline__ void observe_body(const int V, const GfObservationArg
         for (int i = tid; i < rows * o2; i += kObsBlock) {
             const int row = d2.div(i), c2 = i - row * o2;
             const float* r = tile + row * S + c2 * 2;
-            reinterpret_cast<GF_GLOBAL f32x2a*>(out + row * OH)[c2] = f32x2a{r[0], r[1]};
+            reinterpret_cast<GF_GLOBAL f32x2a*>(out + row * OS)[c2] = f32x2a{r[0], r[1]};
         }
     } else {
         const FastDiv d1(O);
         for (int i = tid; i < rows * O; i += kObsBlock) {
             const int row = d1.div(i), cc = i - row * O;
-            out[row * OH + cc] = tile[row * S + cc];
+            out[row * OS + cc] = tile[row * S + cc];
         }
     }
 }
@@ -333,8 +334,9 @@ namespace gf {
 int observe_prep(const GfObservationArgs* a, uint32_t* needs_out, int* vec_out) {
     if (!a || !a->obs) return GF_E_NULL;
     if (a->num_items <= 0 || a->num_items > GF_MAX_OBS_ITEMS || a->num_envs < 0) return GF_E_RANGE;
-    if (a->history_len < 1 || a->history_ring < 0 || a->history_ring > a->history_len) return GF_E_RANGE;
     const bool ring = a->history_ring != 0;
+    if (a->ring_slots && (!ring || (int64_t)a->ring_slots < a->history_len)) return GF_E_RANGE;
+    if (a->history_len < 1 || a->history_ring < 0 || (int64_t)a->history_ring > (a->ring_slots ? (int64_t)a->ring_slots : (int64_t)a->history_len)) return GF_E_RANGE;
     if (a->history_len > 1 && !ring && (!a->prev_obs || a->prev_obs == a->obs)) return GF_E_NULL;
     const int O = a->obs_width, D = a->num_dofs;
     if (O <= 0 || O >= GF_MAX_OBS_WIDTH) return GF_E_RANGE;

@@ -862,13 +862,15 @@ static int pack(const GfPostRefs* r, Packer& pk) {
         const GfObservationArgs* ob = r->observe[m];
         UNSUP(!ob || ob->num_envs != N || ob->num_items > kPostMaxItems || ob->noise_draws || !ob->obs);
         UNSUP(ob->seed != RS.seed || ob->env_offset != RS.env_offset);
-        UNSUP(ob->history_ring < 0 || ob->history_ring > ob->history_len);
+        UNSUP(ob->history_ring < 0 || (int64_t)ob->history_ring > (ob->ring_slots ? (int64_t)ob->ring_slots : (int64_t)ob->history_len));
         UNSUP(ob->history_len > 1 && !ob->history_ring && !ob->prev_obs);
         UNSUP((reinterpret_cast<uintptr_t>(ob->obs) & 15u) || (ob->prev_obs && (reinterpret_cast<uintptr_t>(ob->prev_obs) & 15u)));
         GfEntityView cur{a.pos, a.quat, a.lin_vel, a.ang_vel};
         PostObs& po = a.obs[m];
         po.obs = ob->obs; po.prev = (ob->history_len > 1 && !ob->history_ring) ? ob->prev_obs : nullptr; po.stream = ob->stream;
         po.ring = ob->history_ring;
+        po.ring_slots = (int32_t)ob->ring_slots;
+        UNSUP(ob->ring_slots && (!ob->history_ring || (int64_t)ob->ring_slots < ob->history_len || (int64_t)ob->history_ring > (int64_t)ob->ring_slots));
         // (the frame of an in-place ring is read back by the gather that follows: cached)
         if (!po.ring && N * (int64_t)ob->obs_width * (ob->history_len > 0 ? ob->history_len : 1) * 4 >= kObsStreamBytes) a.obs_stream |= 1u << m;
         po.num_items = ob->num_items; po.width = ob->obs_width; po.history = ob->history_len;

@@ -72,6 +72,8 @@ struct PostObs {
     int32_t width;
     int32_t history;
     int32_t ring;      // GfObservationArgs.history_ring: 0 = shift, k+1 = in-place ring, the new frame goes to slot k
+    int32_t ring_slots;   // GfObservationArgs.ring_slots: 0 = the ring has `history` slots; S = `obs` is [N, S, O] (a window buffer)
+    int32_t _pad;
     GfObsItem items[kPostMaxItems];
 };
 

@@ -1106,7 +1106,9 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             const int rows = (int)((N - n0) < kEnvBlock ? (N - n0) : kEnvBlock);
             const int64_t OH = (int64_t)O * H;
             const int ring = UNI(ob.ring);   // in-place history ring: only the new frame is written, into its slot
-            GF_GLOBAL float* out = G(ob_out) + n0 * OH + (ring ? (int64_t)(ring - 1) * O : 0);
+            const int ring_slots = UNI(ob.ring_slots);
+            const int64_t OS = (ring && ring_slots) ? (int64_t)O * ring_slots : OH;   // env stride of `out` (a ring with more slots than frames)
+            GF_GLOBAL float* out = G(ob_out) + n0 * OS + (ring ? (int64_t)(ring - 1) * O : 0);
             float* const roll_base = UNI(a.roll_obs);
             GF_GLOBAL float* roll = (roll_base && UNI(a.roll_obs_index) == m) ? G(roll_base) + n0 * OH : nullptr;   // observations[t+1] of the rollout storage
             const int t = threadIdx.x;
@@ -1126,10 +1128,10 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
                     const float* r = tile + rw * S + c4 * 4;
                     const f32x4 v4{r[0], r[1], r[2], r[3]};
                     if (nt) {
-                        __builtin_nontemporal_store(v4, reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OH) + c4);
+                        __builtin_nontemporal_store(v4, reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OS) + c4);
                         if (roll) __builtin_nontemporal_store(v4, reinterpret_cast<GF_GLOBAL f32x4*>(roll + rw * OH) + c4);
                     } else {
-                        reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OH)[c4] = v4;
+                        reinterpret_cast<GF_GLOBAL f32x4*>(out + rw * OS)[c4] = v4;
                         if (roll) reinterpret_cast<GF_GLOBAL f32x4*>(roll + rw * OH)[c4] = v4;
                     }
                     rw += qstep; c4 += rstep;
@@ -1148,7 +1150,7 @@ __global__ __launch_bounds__(kWsBlock) void post_ws_kernel(const GfPostArgs karg
             } else {
                 for (int i = t; i < rows * O; i += kWsBlock) {
                     const int rw = i / O, cc = i - rw * O;
-                    out[rw * OH + cc] = tile[rw * S + cc];
+                    out[rw * OS + cc] = tile[rw * S + cc];
                     if (roll) roll[rw * OH + cc] = tile[rw * S + cc];
                 }
                 if (H > 1 && !ring) {

@@ -203,7 +203,7 @@ class GfObservationArgs(C.Structure):
                 ("dof_pos", P), ("dof_vel", P), ("dof_force", P), ("targets", P), ("env_actions", P),
                 ("contact", GfContactView * GF_MAX_CONTACT_VIEWS), ("command", GfCommandView * GF_MAX_COMMAND_VIEWS),
                 ("ext", P * GF_MAX_EXT), ("noise_draws", P), ("seed", C.c_uint64), ("stream", C.c_uint64),
-                ("env_offset", C.c_uint32), ("_pad2", C.c_uint32), ("stale_quat", P), ("stale_mask", P), ("stale_mask2", P), ("prev_obs", P), ("obs", P), ("items", GfObsItem * GF_MAX_OBS_ITEMS)]
+                ("env_offset", C.c_uint32), ("ring_slots", C.c_uint32), ("stale_quat", P), ("stale_mask", P), ("stale_mask2", P), ("prev_obs", P), ("obs", P), ("items", GfObsItem * GF_MAX_OBS_ITEMS)]
 
 
 class GfRotateArgs(C.Structure):

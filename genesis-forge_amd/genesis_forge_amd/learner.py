@@ -45,6 +45,9 @@ class RolloutStorage:
         if om is None:
             raise ValueError(f"no ObservationManager named '{obs_name}'")
         self._om = om
+        if getattr(om, "output", None) == "window" and om._history_len > 1:
+            raise ValueError("RolloutStorage copies contiguous observation rows: an ObservationManager with output='window' hands out a "
+                             "strided view — use output='fresh' / 'static' for the manager the storage follows")
         self.obs_width = int(om.observation_space.shape[0])
         self.observations = torch.zeros((self.num_steps + 1, n, self.obs_width), device=gs.device, dtype=torch.float32)
         self.rewards = torch.zeros((self.num_steps, n), device=gs.device, dtype=torch.float32)

@@ -32,6 +32,14 @@ a call writes only the new frame into frame slot ``history_head`` and returns th
 traffic per env instead of the ``(2H-1)*O`` a newest-first concatenation costs (gait task: 20 MB instead of 182 MB per step at
 65 536 envs).  The frames are the reference's, their ORDER is by slot: newest first is ``history_order()`` (slots from
 ``history_head`` upwards, wrapping); ``ordered(obs)`` gathers a tensor into the reference's layout for consumers that need it.
+``output="window"`` (``history_len > 1`` only; round 4) gives the reference's LAYOUT at the ring's cost: the history lives in ONE
+persistent ``[N, S + H - 1, O]`` buffer (``S = H + window_slack`` slots are cycled through, downwards; the last ``H - 1`` slots mirror
+the first ``H - 1`` so that a window never wraps), a call writes only the new frame and returns ``H`` consecutive slots of it as an
+``[N, H*O]`` strided VIEW — newest frame first, exactly the reference's concatenation, no gather and no copy (``O`` floats per env and
+call, plus ``2(H-1)·O / S`` for the mirror copy once per cycle; rows are contiguous, the row stride is ``(S + H - 1)·O``, which
+``torch.nn.functional.linear`` and ``copy_`` take as they are).  The contract: a returned tensor stays intact for ``window_slack + 1``
+further observations of this manager (default ``H + 1``: enough for an RL loop that stores ``obs_t`` after ``step t + 1``, as rsl_rl's
+does), then its oldest frames are overwritten; it is read-only for the caller.
 """
 from __future__ import annotations
 
@@ -75,6 +83,8 @@ class ObservationManager(BaseManager):
     #: how a history of H > 1 frames becomes the [N, H*O] tensor in the "fresh" / "static" modes: "shift", "unroll" or "auto"
     default_history = os.environ.get("GF_OBS_HISTORY", "auto")
     static_slots = _OBS_RING
+    #: output="window": further observations a returned tensor survives, minus one (None: history_len)
+    window_slack: Optional[int] = None
 
     """Generates an observation tensor from a dict of items (ctor as observation_manager.py:134-156)."""
 
@@ -83,8 +93,8 @@ class ObservationManager(BaseManager):
         super().__init__(env, "observation")
         self._name = name
         self._output = output if output is not None else type(self).default_output
-        if self._output not in ("fresh", "static", "ring"):
-            raise ValueError("output must be 'fresh', 'static' or 'ring'")
+        if self._output not in ("fresh", "static", "ring", "window"):
+            raise ValueError("output must be 'fresh', 'static', 'ring' or 'window'")
         self._history_mode = history if history is not None else type(self).default_history
         if self._history_mode not in ("auto", "shift", "unroll"):
             raise ValueError("history must be 'auto', 'shift' or 'unroll'")
@@ -95,6 +105,10 @@ class ObservationManager(BaseManager):
         self._fresh_ptr = 0
         self._unrolled = False       # history kept as a ring + gather launch (module docstring: ``history=``); set by _refresh_modes()
         self._direct_fresh = False   # output="fresh" without history: the launch writes straight into the caller's new tensor
+        self._window = False         # output="window" with a history: the returned tensor is a strided view of _win
+        self._win: Optional[torch.Tensor] = None    # [N, (S + H - 1) * O]
+        self._win_view: Optional[torch.Tensor] = None
+        self._win_cycle = self._win_slots = 0       # S (slots cycled through), S + H - 1 (slots per env incl. the mirror tail)
 
         self.noise = noise
         self._observation_size = 1
@@ -126,13 +140,13 @@ class ObservationManager(BaseManager):
 
     @property
     def output(self) -> str:
-        """"fresh", "static" or "ring" (module docstring).  Assigning it drops a recorded step: the step's patch table is per mode."""
+        """"fresh", "static", "ring" or "window" (module docstring).  Assigning it drops a recorded step: the step's patch table is per mode."""
         return self._output
 
     @output.setter
     def output(self, value: str) -> None:
-        if value not in ("fresh", "static", "ring"):
-            raise ValueError("output must be 'fresh', 'static' or 'ring'")
+        if value not in ("fresh", "static", "ring", "window"):
+            raise ValueError("output must be 'fresh', 'static', 'ring' or 'window'")
         if value != self._output:
             self._output = value
             self._refresh_modes()
@@ -172,6 +186,7 @@ class ObservationManager(BaseManager):
             self._rotor.slot[i] = b.data_ptr()
         self._ring_clock.calls, self._ring_clock.length = 0, self._history_len
         self._ring = None
+        self._win = self._win_view = None
         self._fresh_pool = []
         self._dirty = True
         self._refresh_modes()
@@ -180,8 +195,18 @@ class ObservationManager(BaseManager):
         """The two per-mode flags the step's hot path reads (plain attributes: a property costs the host ~0.25 µs per read and a
         recorded step reads them seven times)."""
         built = bool(self._bufs)
-        self._direct_fresh = built and self._output == "fresh" and self._history_len == 1
-        on = built and self._history_len > 1 and self._output != "ring" and (
+        H = self._history_len
+        # (a window over a history of one frame is that frame: the plain fresh tensor)
+        self._direct_fresh = built and self._output in ("fresh", "window") and H == 1
+        self._window = built and self._output == "window" and H > 1
+        if self._window and self._win is None:
+            slack = H if self.window_slack is None else max(1, int(self.window_slack))
+            self._win_cycle, self._win_slots = H + slack, 2 * H + slack - 1
+            self._win = torch.zeros((self.env.num_envs, self._win_slots * self._frame), device=gs.device, dtype=gs.tc_float)   # zero history, as the reference's
+            self._ring_clock.calls = 0
+        if built:
+            self._ring_clock.length = self._win_cycle if self._window else H
+        on = built and H > 1 and self._output not in ("ring", "window") and (
             self._history_mode == "unroll" or (self._history_mode == "auto" and self._output == "fresh"))
         self._unrolled = on
         if on and self._ring is None:
@@ -308,6 +333,23 @@ class ObservationManager(BaseManager):
         per call; history kept as a ring: the gather's destination), or it is a copy — or the persistent slot itself (static)."""
         return out.clone() if self._output == "fresh" and not self._unrolled and not self._direct_fresh else out
 
+    # -- history window (output="window") ----------------------------------------------------------------------------
+    def _window_at(self, slot: int) -> torch.Tensor:
+        """H consecutive frame slots from ``slot`` on, as the reference's [N, H*O] newest-first tensor (a strided view)."""
+        O = self._frame
+        return torch.as_strided(self._win, (self._win.shape[0], self._history_len * O), (self._win_slots * O, 1), slot * O)
+
+    def _mirror_tail(self) -> None:
+        """The slot walk wraps from 0 to S - 1: the newest H - 1 frames (slots 0 … H-2) are copied behind slot S - 1, so that the
+        windows of the next H - 1 calls are consecutive slots too.  One strided copy per cycle."""
+        H, S = self._history_len, self._win_cycle
+        w = self._win.view(self._win.shape[0], self._win_slots, self._frame)
+        w[:, S:S + H - 1].copy_(w[:, :H - 1])
+
+    def _window_slot(self, calls: int) -> int:
+        S = self._win_cycle
+        return (S - calls % S) % S
+
     def _take_fresh(self) -> torch.Tensor:
         """A tensor nobody else holds.  Observations come out of blocks of 3 … 32 rows (≈ 16 MB; from 64 MB per observation on:
         one allocation per call): ONE ``torch.empty`` and ONE ``unbind`` per block, the rows' addresses computed — per step the host
@@ -375,6 +417,17 @@ class ObservationManager(BaseManager):
         return obs.view(n, H, O)[:, self.history_order(), :].reshape(n, H * O)
 
     def _rotate_ring(self, a) -> torch.Tensor:
+        if self._window:
+            ck = self._ring_clock
+            slot = self._window_slot(ck.calls)
+            if ck.calls and slot == self._win_cycle - 1:
+                self._mirror_tail()
+            a.history_ring, a.ring_slots = slot + 1, self._win_slots
+            ck.calls += 1
+            a.prev_obs, a.obs = None, self._win.data_ptr()
+            self._win_view = self._window_at(slot)
+            return self._win_view
+        a.ring_slots = 0
         if self._in_place or self._unrolled:
             H, ck = self._history_len, self._ring_clock
             a.history_ring = (H - ck.calls % H) % H + 1
@@ -396,6 +449,8 @@ class ObservationManager(BaseManager):
         return out
 
     def _current_out(self) -> torch.Tensor:
+        if self._window:
+            return self._win_view
         if self._unrolled or self._direct_fresh:
             return self._unroll_out
         return self._bufs[0] if self._in_place else self._bufs[self._rotor.cur]
@@ -434,6 +489,9 @@ class ObservationManager(BaseManager):
             args.prev_obs, args.obs = None, self._ring.data_ptr()
             out.append(P(nat.GF_PATCH_RING_SLOT, 0, nat.field_addr(args, "history_ring"), nat.field_addr(self._unroll_args, "ring_slot"),
                          C.addressof(self._ring_clock)))
+        elif self._window:   # the slot walks down a cycle of S slots (the clock's length); the view follows in _trace_after
+            args.prev_obs, args.obs, args.ring_slots = None, self._win.data_ptr(), self._win_slots
+            out.append(P(nat.GF_PATCH_RING_SLOT, 0, nat.field_addr(args, "history_ring"), None, C.addressof(self._ring_clock)))
         elif self._in_place:
             args.prev_obs, args.obs = None, self._bufs[0].data_ptr()
             out.append(P(nat.GF_PATCH_RING_SLOT, 0, nat.field_addr(args, "history_ring"), None, C.addressof(self._ring_clock)))
@@ -447,6 +505,13 @@ class ObservationManager(BaseManager):
 
     def _trace_fresh_patch(self, args):
         """Recorded step, output="fresh" without history: a Python patch that points the launch at this step's new tensor."""
+        if self._window:
+            # … output="window": the mirror copy of the step whose slot wraps (enqueued in front of the step's launches)
+            def mirror(_actions, self=self, ck=self._ring_clock):
+                if ck.calls and ck.calls % ck.length == 1:
+                    self._mirror_tail()
+
+            return mirror
         if not self._direct_fresh:
             return None
 
@@ -467,6 +532,8 @@ class ObservationManager(BaseManager):
 
     def _trace_after(self) -> None:
         """Recorded step, after the launches have been enqueued: publish this step's observation (a fresh copy by default)."""
+        if self._window:   # (the native patch has advanced the clock: the frame of this step sits in the slot of call `calls - 1`)
+            self._win_view = self._window_at(self._window_slot(self._ring_clock.calls - 1))
         out = self._bufs[self._rotor.cur] if self._unrolled and self._output == "static" else self._current_out()
         self._unroll_out = out if self._unrolled or self._direct_fresh else self._unroll_out
         self._last_out = out

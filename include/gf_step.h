@@ -484,7 +484,11 @@ typedef struct GfObservationArgs {
     uint64_t seed;
     uint64_t stream;
     uint32_t env_offset;      /* global index of local env 0 */
-    uint32_t _pad2;
+    uint32_t ring_slots;      /* history_ring != 0 only.  0: the ring has history_len frame slots (`obs` = [N, H, O]).  S >= history_len: `obs` is
+                                 [N, S, O] — the env stride is S·O floats — and history_ring - 1 < S.  With more slots than frames the host can
+                                 hand out H consecutive slots as a newest-first WINDOW of the buffer (a strided view, no gather): it walks the
+                                 slot downwards and mirrors the newest H-1 frames behind slot S' when the walk wraps
+                                 (ObservationManager output="window").  (This word was padding before: 0 = the old behaviour.) */
     /* The reference's EntityManager caches base_quat at entity.step() and does not refresh it after the reset
      * that follows in the same tick (entity_manager.py:163-167,189-195): body-frame items of envs that were just
      * reset are rotated by their PRE-reset quaternion.  stale_quat (written by gf_masked_reset.quat_stash) supplies

@@ -881,9 +881,11 @@ GFO_EXPORT int gfo_masked_reset(const GfResetArgs* a) {
 GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
     if (!a || !a->obs) return GF_E_NULL;
     if (a->num_items <= 0 || a->num_items > GF_MAX_OBS_ITEMS) return GF_E_RANGE;
-    if (a->history_ring < 0 || a->history_ring > a->history_len) return GF_E_RANGE;
+    if (a->ring_slots && (!a->history_ring || (int64_t)a->ring_slots < a->history_len)) return GF_E_RANGE;
+    if (a->history_ring < 0 || (int64_t)a->history_ring > (a->ring_slots ? (int64_t)a->ring_slots : (int64_t)a->history_len)) return GF_E_RANGE;
     if (a->history_len < 1 || (a->history_len > 1 && !a->history_ring && !a->prev_obs)) return a->history_len < 1 ? GF_E_RANGE : GF_E_NULL;
     const int64_t N = a->num_envs, D = a->num_dofs, O = a->obs_width, H = a->history_len;
+    const int64_t env_stride = (a->history_ring && a->ring_slots) ? O * (int64_t)a->ring_slots : O * H;   /* a ring with more slots than frames (gf_step.h) */
     const int64_t frame_off = a->history_ring ? (int64_t)(a->history_ring - 1) * O : 0;   /* in-place ring: only this slot is written */
     if (O <= 0 || O >= GF_MAX_OBS_WIDTH) return GF_E_RANGE;
     int64_t wsum = 0;
@@ -935,7 +937,7 @@ GFO_EXPORT int gfo_observe(const GfObservationArgs* a) {
     if (need_lin && !a->entity.lin_vel) return GF_E_NULL;
     if (need_ang && !a->entity.ang_vel) return GF_E_NULL;
     for (int64_t n = 0; n < N; ++n) {
-        float* row = a->obs + n * O * H + frame_off;
+        float* row = a->obs + n * env_stride + frame_off;
         int64_t col = 0;
         /* entity_manager.py:189-195: quaternion cached before the reset of this tick */
         GfEntityView ent = a->entity;

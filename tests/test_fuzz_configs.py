@@ -40,10 +40,15 @@ def make_fuzz_env(seed: int):
     rnd_out = random.Random(77000 + seed)   # output / history modes of the observation managers (a stream of its own: the configs of the
     #                                         seeds above are what they were before the modes were drawn)
 
+    rnd_win = random.Random(58000 + seed)   # output="window" (round 4), again a stream of its own
+
     def out_mode(history):
         if not history or history < 2:
             return dict(output=rnd_out.choice(["fresh", "fresh", "static"]))
-        return dict(output=rnd_out.choice(["fresh", "fresh", "static", "static", "ring"]), history=rnd_out.choice(["auto", "auto", "shift", "unroll"]))
+        mode = dict(output=rnd_out.choice(["fresh", "fresh", "static", "static", "ring"]), history=rnd_out.choice(["auto", "auto", "shift", "unroll"]))
+        if rnd_win.random() < 0.25:
+            mode = dict(output="window")
+        return mode
 
     n = rnd.choice([1, 63, 64, 65, 130, 257, 1000])
     pick = lambda p: rnd.random() < p

@@ -122,6 +122,80 @@ def test_observe_hip_equals_oracle(hip_backend, oracle_lib_path, seed):
         assert np.array_equal(a[:, 1:], p[:, :-1])
 
 
+def _run_ring_slots(case, dev, backend, slots, calls):
+    """A ring with more slots than frames (GfObservationArgs.ring_slots): `obs` is [N, slots, O], a call writes ONLY frame slot
+    history_ring - 1 — every other float of the buffer must keep its value."""
+    from genesis_forge_amd import _native as nat
+
+    n, D, O, H = case["n"], case["D"], case["O"], case["H"]
+    g = torch.Generator().manual_seed(case["seed"])
+    mk = lambda *shape: torch.randn(*shape, generator=g).to(dev)
+    dof_pos, raw, cmd, ext = mk(n, D), mk(n, D), mk(n, 3), mk(n, max(1, O))
+    a = nat.GfObservationArgs()
+    a.num_envs, a.num_dofs, a.obs_width, a.history_len, a.ring_slots = n, D, O, H, slots
+    a.dof_pos, a.env_actions = dof_pos.data_ptr(), raw.data_ptr()
+    a.command[1].command, a.command[1].width, a.command[1].stride = cmd.data_ptr(), 3, 0
+    a.ext[0] = ext.data_ptr()
+    a.seed, a.stream, a.env_offset = 77, 5, 1000
+    col, k = 0, 0
+    for op, i0, w in ((nat.GF_O_DOF_POS, 0, D), (nat.GF_O_COMMAND, 1, 3), (nat.GF_O_RAW_ACTIONS, 0, D)):
+        if col + w <= O:
+            a.items[k].op, a.items[k].i0, a.items[k].width, a.items[k].scale, a.items[k].noise = op, i0, w, (0.5 if k == 1 else 1.0), (0.02 if k == 2 else 0.0)
+            col += w; k += 1
+    if col < O:
+        ext_t = mk(n, O - col)
+        a.ext[0] = ext_t.data_ptr()
+        a.items[k].op, a.items[k].i0, a.items[k].width, a.items[k].scale = nat.GF_O_EXTERNAL, 0, O - col, 1.0
+        k += 1
+    a.num_items = k
+    buf = torch.arange(n * slots * O, dtype=torch.float32).reshape(n, slots * O).to(dev)   # recognisable content everywhere
+    a.obs = buf.data_ptr()
+    res = []
+    for c in range(calls):
+        a.history_ring = (slots - 1 - (c * 3) % slots) + 1
+        a.stream = 5 + c
+        dof_pos.add_(1.0)
+        backend.call("observe", a)
+        res.append((a.history_ring - 1, buf.cpu().clone()))
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,O,H,slots", [(0, 62, 5, 14), (1, 16, 5, 14), (2, 45, 3, 8), (3, 3, 2, 5), (4, 130, 2, 2), (5, 64, 4, 11)])
+def test_observe_ring_with_more_slots_than_frames_hip_equals_oracle(hip_backend, oracle_lib_path, seed, O, H, slots):
+    from oracle_backend import OracleBackend
+
+    case = dict(n=[200, 65, 64, 130, 5, 257][seed], D=12, O=O, H=H, seed=seed)
+    got = _run_ring_slots(case, "cuda", hip_backend, slots, calls=5)
+    torch.cuda.synchronize()
+    want = _run_ring_slots(case, "cpu", OracleBackend(oracle_lib_path), slots, calls=5)
+    before = torch.arange(case["n"] * slots * O, dtype=torch.float32).reshape(case["n"], slots, O)
+    for c, ((slot, a), (_s, b)) in enumerate(zip(got, want)):
+        a3, b3 = a.reshape(case["n"], slots, O), b.reshape(case["n"], slots, O)
+        np.testing.assert_allclose(a3.numpy(), b3.numpy(), atol=1e-6, rtol=0, err_msg=f"call {c}")
+        untouched = [s for s in range(slots) if s != slot]
+        assert torch.equal(a3[:, untouched], before[:, untouched]), f"call {c} wrote outside frame slot {slot}"
+        assert not torch.equal(a3[:, slot], before[:, slot])
+        before = a3.clone()
+
+
+def test_ring_slots_refusals(oracle_backend):
+    """ring_slots without a ring, fewer slots than frames, a slot beyond the buffer: GF_E_RANGE on both sides of the boundary
+    (the HIP side's check is observe_prep, host code: tests/test_error_codes.py runs it without a GPU through gf_observe_check)."""
+    from genesis_forge_amd import _native as nat
+
+    a = nat.GfObservationArgs()
+    buf, src = torch.zeros(4, 40), torch.zeros(4, 12)
+    a.num_envs, a.num_dofs, a.obs_width, a.history_len, a.num_items = 4, 12, 4, 3, 1
+    a.ext[0], a.obs = src.data_ptr(), buf.data_ptr()
+    a.items[0].op, a.items[0].i0, a.items[0].width, a.items[0].scale = nat.GF_O_EXTERNAL, 0, 4, 1.0
+    lib = oracle_backend.lib
+    for ring, slots, rc in ((1, 10, 0), (10, 10, 0), (11, 10, -2), (0, 10, -2), (1, 2, -2), (3, 0, 0), (4, 0, -2)):
+        a.history_ring, a.ring_slots = ring, slots
+        a.prev_obs = None
+        assert lib.gfo_observe(C.byref(a)) == rc, (ring, slots)
+
+
 def test_observe_cases_cover_the_widths():
     cases = [_case(s) for s in SEEDS]
     assert {c["O"] % 4 for c in cases} == {0, 1, 2, 3}

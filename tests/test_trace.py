@@ -1044,6 +1044,82 @@ def test_in_place_history_ring_stand_alone_kernel_hip(hip_backend, monkeypatch):
             assert torch.equal(x, y), f"output {k} differs at step {t}"
 
 
+def _window_check(dev, kind, n, steps, trace=True, slack=None):
+    """output="window" against the default output, step by step: equal values in the reference's layout, a strided VIEW of one
+    persistent buffer, intact for window_slack + 1 further observations."""
+    from genesis_forge_amd.managers import ObservationManager
+
+    old_slack = ObservationManager.window_slack
+    ObservationManager.window_slack = slack
+    try:
+        want, _ = _ring_run(dev, kind, "fresh", n, steps)
+        from genesis_forge_amd import tasks
+
+        old = ObservationManager.default_output
+        ObservationManager.default_output = "window"
+        try:
+            if kind == "gait":
+                env = tasks.Go2GaitTrainingEnv(num_envs=n, max_episode_length_s=0.4, scene_kwargs=dict(ang_noise=0.3, seed=3, contact_prob=0.05))
+            else:
+                env = Go2CommandDirectionEnv(num_envs=n, max_episode_length_s=0.4, cmd_resample_s=0.2, history=3, contacts=True, obs_noise=True,
+                                             scene_kwargs=dict(ang_noise=0.3, seed=3))
+            env.trace_enabled = trace
+            env.build()
+        finally:
+            ObservationManager.default_output = old
+    finally:
+        ObservationManager.window_slack = old_slack
+    env.seed(9)
+    env.reset()
+    g = torch.Generator().manual_seed(1)
+    d = env.action_space.shape[0]
+    held = []   # (step, manager index, the tensor the step returned, a copy of it)
+    oms = env.managers["observation"]
+    for t in range(steps):
+        obs, rew, te, tr, ex = env.step(torch.randn(n, d, generator=g).to(dev))
+        for k, m in enumerate(oms):
+            o = ex["observations"][m.name]
+            H, O = m._history_len, m._frame
+            assert o.shape == (n, H * O) and o.stride() == (m._win_slots * O, 1) and o.untyped_storage().data_ptr() == m._win.untyped_storage().data_ptr()
+            assert torch.equal(o.cpu(), want[t][k]), f"manager {k}: window differs from the fresh output at step {t}"
+            held.append((t, k, o, o.cpu().clone()))
+        assert torch.equal(obs, ex["observations"]["policy"]) and torch.equal(rew.cpu(), want[t][len(oms)])
+        for t0, k, o, copy in held:   # every tensor handed out up to window_slack + 1 observations ago is still what it was
+            if t - t0 <= oms[k]._win_cycle - oms[k]._history_len:
+                assert torch.equal(o.cpu(), copy), f"the observation of step {t0} (manager {k}) changed after {t - t0} further steps"
+    m = oms[0]
+    t0, k, o, copy = next(h for h in held if h[1] == 0 and steps - 1 - h[0] > m._win_cycle)
+    assert not torch.equal(o.cpu(), copy), "an observation older than the window's slack is expected to have been overwritten"
+    return env
+
+
+@pytest.mark.parametrize("trace", [True, False])
+def test_history_window_output_cpu(oracle_backend, trace):
+    env = _window_check("cpu", "go2_hist", 70, 24, trace=trace)
+    assert (env._trace is not None) == trace
+    env = _window_check("cpu", "gait", 70, 30, trace=trace, slack=2)
+    assert (env._trace is not None) == trace
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,steps", [("go2_hist", 1000, 24), ("gait", 1000, 36), ("gait", 65536 + 37, 14)])
+def test_history_window_output_hip(hip_backend, kind, n, steps):
+    """The window through the fused post-physics kernel (interpreter for the noisy Go2 config, the gait static program — its structure
+    is unchanged: the buffer's extra slots are a stride, GfObservationArgs.ring_slots)."""
+    env = _window_check("cuda", kind, n, steps)
+    assert env._trace is not None and env._trace.post_refs is not None
+    if kind == "gait":
+        text = hip_backend.post_describe(env._trace.post_refs)
+        assert text.startswith("program") and "interpreter" not in text.split("\n")[0] and "gait" in text.split("\n")[0], text.split("\n")[0]
+
+
+@pytest.mark.gpu
+def test_history_window_stand_alone_kernel_hip(hip_backend, monkeypatch):
+    monkeypatch.setenv("GF_NO_TRACE", "1")
+    env = _window_check("cuda", "gait", 130, 30)
+    assert env._trace is None
+
+
 def _run_dof_variant(dev, seed, trace):
     """The Go2 command stack over a synthetic D-joint robot with drawn D, env count, history, noise and episode / resample periods."""
     import random
