@@ -396,7 +396,10 @@ def run_rank(args):
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    affinity = pin_rank()   # BEFORE anything touches the GPU (and never through taskset / numactl: under a profiler that is a forbidden exec)
+    try:
+        affinity = pin_rank()   # BEFORE anything touches the GPU (and never through taskset / numactl: under a profiler that is a forbidden exec)
+    except Exception as e:      # (pinning is an optimisation: an unexpected sysfs layout on a node nobody has seen must not stop the run)
+        affinity = {"pinned": False, "cpus": None, "why": repr(e)}
 
     import torch
     import torch.distributed as dist

@@ -1114,9 +1114,9 @@ def test_history_window_output_hip(hip_backend, kind, n, steps):
 
 
 @pytest.mark.gpu
-def test_history_window_stand_alone_kernel_hip(hip_backend, monkeypatch):
-    monkeypatch.setenv("GF_NO_TRACE", "1")
-    env = _window_check("cuda", "gait", 130, 30)
+def test_history_window_stand_alone_kernel_hip(hip_backend):
+    """… and through the stand-alone observation kernel (no recording: every phase its own launch)."""
+    env = _window_check("cuda", "gait", 130, 30, trace=False)
     assert env._trace is None
 
 

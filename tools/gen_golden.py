@@ -754,6 +754,36 @@ CONTACT_CASES = [  # ContactManager ctor kwargs of the contact-kernel fixture (t
 ]
 
 
+def check_ti_parallel(n=4096, C=9, T=5, NL=14):
+    """The chunked execution of the Taichi kernel's emulation (tools/ref_stubs.py: ti_kernel, env chunks in forked workers) against the
+    serial one on the same arbitrary contact arrays (both sides of a pair, NaN / Inf forces, a with-filter): bit for bit."""
+    from genesis_forge.managers.contact.kernel import kernel_get_contact_forces
+
+    rng = np.random.RandomState(5)
+    la = rng.randint(-1, NL, (n, C)).astype(np.int32)
+    lb = rng.randint(0, NL, (n, C)).astype(np.int32)
+    f = (10.0 * rng.standard_normal((n, C, 3))).astype(np.float32)
+    f[3, 1, 0], f[77, 2, 1], f[n - 1, 0, 2] = np.nan, np.inf, -np.inf
+    pos = rng.standard_normal((n, C, 3)).astype(np.float32)
+    q = rng.standard_normal((n, NL, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    targets, withs = torch.tensor([2, 5, 6, 9, 13], dtype=torch.int32)[:T], torch.tensor([0, 3], dtype=torch.int32)
+    res = {}
+    for jobs in ("1", "8"):
+        os.environ["GF_TI_JOBS"] = jobs
+        for filt in (0, 1):
+            out_f, out_p, cnt = torch.zeros(n, T, 3), torch.zeros(n, T, 3), torch.zeros(n, T)
+            kernel_get_contact_forces(torch.from_numpy(f), torch.from_numpy(pos), torch.from_numpy(la), torch.from_numpy(lb), torch.from_numpy(q),
+                                      targets, withs, out_f, out_p, cnt, filt)
+            res[(jobs, filt)] = (out_f.numpy().copy(), out_p.numpy().copy(), cnt.numpy().copy())
+    os.environ.pop("GF_TI_JOBS")
+    for filt in (0, 1):
+        for a, b in zip(res[("1", filt)], res[("8", filt)]):
+            assert np.array_equal(a, b, equal_nan=True), "chunked emulation differs from the serial one"
+        assert np.abs(np.nan_to_num(res[("1", filt)][0])).sum() > 0
+    print("check_ti_parallel: serial == chunked (8 workers) on", n, "envs, with and without the filter")
+
+
 def gen_contact_kernel():
     """ContactManager.step (contact_manager.py:331-336,384-477 + the Taichi kernel contact/kernel.py:5-90, executed from the
     reference's own source under tools/ref_stubs.py's serial ndrange) on ARBITRARY contact arrays: both link_a and link_b range
@@ -973,6 +1003,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "at_size":
         gen_at_size()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "check_ti_parallel":
+        check_ti_parallel()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "check_at_size":
         check_at_size(int(sys.argv[2]), contacts=len(sys.argv) > 3 and sys.argv[3] == "contacts")

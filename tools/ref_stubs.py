@@ -115,7 +115,57 @@ def install():
         return Vec([(v[0] + w * t0) + (b * t2 - c * t1), (v[1] + w * t1) + (c * t0 - a * t2), (v[2] + w * t2) + (a * t1 - b * t0)])
 
     sys.modules["genesis.utils.geom"].ti_inv_transform_by_quat = ti_inv_transform_by_quat
-    mod("gstaichi", kernel=lambda f: f, types=ti_types, i32=int, f32=np.float32, Vector=_VectorNS, static=lambda x: x,
+    def ti_kernel(f):
+        """`@ti.kernel` → the function itself; for large batches the env axis is cut into chunks that run in forked worker processes
+        (GF_TI_JOBS, default: the CPU count).  The kernel's outermost index is the env (kernel.py:35-37) and nothing crosses envs, so
+        every env still sees its contact slots in slot order — the order of the kernel's atomic += — and the result is the serial
+        run's, bit for bit (checked: `tools/gen_golden.py check_ti_parallel`).  ≈ 45 min → ≈ 7 min for the 65 536-env fixture."""
+        import functools
+
+        @functools.wraps(f)
+        def run(*args):
+            import torch
+
+            n = int(args[7].shape[0])   # output_forces: (n_envs, n_target_links, 3)
+            jobs = int(os.environ.get("GF_TI_JOBS", os.cpu_count() or 1))
+            if jobs <= 1 or n < 2048:
+                return f(*args)
+            import multiprocessing as mp
+
+            per_env = [i for i, a in enumerate(args) if hasattr(a, "shape") and len(a.shape) >= 2 and int(a.shape[0]) == n and i not in (5, 6)]
+            outs = (7, 8, 9)
+            bounds = [(n * j // jobs, n * (j + 1) // jobs) for j in range(jobs)]
+            ctx = mp.get_context("fork")
+            pipes, procs = [], []
+            for lo, hi in bounds:
+                rd, wr = ctx.Pipe(duplex=False)
+                pid = os.fork()
+                if pid == 0:
+                    try:
+                        rd.close()
+                        torch.set_num_threads(1)
+                        sub = [a[lo:hi].clone() if i in per_env else a for i, a in enumerate(args)]
+                        f(*sub)
+                        wr.send([sub[i].numpy() if hasattr(sub[i], "numpy") else np.asarray(sub[i]) for i in outs])
+                        wr.close()
+                    finally:
+                        os._exit(0)
+                wr.close()
+                pipes.append(rd); procs.append(pid)
+            for (lo, hi), rd, pid in zip(bounds, pipes, procs):
+                got = rd.recv()
+                os.waitpid(pid, 0)
+                for i, arr in zip(outs, got):
+                    dst = args[i]
+                    if hasattr(dst, "numpy"):
+                        dst[lo:hi] = torch.from_numpy(arr)
+                    else:
+                        dst[lo:hi] = arr
+            return None
+
+        return run
+
+    mod("gstaichi", kernel=ti_kernel, types=ti_types, i32=int, f32=np.float32, Vector=_VectorNS, static=lambda x: x,
         ndrange=lambda *dims: itertools.product(*[range(int(d)) for d in dims]))
 
     class Box:
