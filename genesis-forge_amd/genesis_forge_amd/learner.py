@@ -94,6 +94,8 @@ class RolloutStorage:
 
     def write(self, obs: torch.Tensor, reward: torch.Tensor, terminated: torch.Tensor, truncated: torch.Tensor) -> None:
         """One transition through ``gf_rollout_write`` (the phase-by-phase path; a recorded step fuses it, _trace.py)."""
+        if not obs.is_contiguous():   # (an ObservationManager switched to output="window" after this storage was made)
+            raise ValueError("RolloutStorage copies contiguous observation rows: the observation it follows is a strided view (output='window')")
         a = self._args
         a.obs, a.reward = obs.data_ptr(), reward.data_ptr()
         a.terminated, a.truncated = terminated.data_ptr(), truncated.data_ptr()
@@ -168,6 +170,9 @@ class RolloutStorage:
         """`obs` follows the tensor the observation launch (or the gather of a ring-kept history) writes this step — that
         manager's rotation comes earlier in the table."""
         P = nat.GfReplayPatch
+        if getattr(pol, "_window", False):
+            from ._trace import Untraceable
+            raise Untraceable("the rollout rows of a window-mode observation (a strided view) cannot be copied by the step's launch")
         if getattr(pol, "_unrolled", False):
             return [] if fused else [P(nat.GF_PATCH_COPY, 0, nat.field_addr(args, "obs"), None, nat.field_addr(pol._unroll_args, "out"))]
         return [P(nat.GF_PATCH_COPY, 0, nat.field_addr(args, "obs"), None, nat.field_addr(pol._args, "obs"))]

@@ -127,6 +127,28 @@ def test_rollout_storage_rows_hip(hip_backend, kind, trace, fuse, output):
             assert bool(tr.post_refs.flags & 1) == (kind == "go2_user_reward"), "a Python-level reward term: termination as a launch of its own"
 
 
+def test_rollout_storage_refuses_a_window_mode_observation(oracle_backend):
+    """output="window" hands out a strided view of the history buffer; the storage's rows are copied by the step's launch from contiguous
+    rows — it says so instead of copying the wrong floats, also when the mode is switched on later."""
+    from envs import Go2CommandDirectionEnv
+    from genesis_forge_amd.learner import RolloutStorage
+
+    env = Go2CommandDirectionEnv(num_envs=20, history=3, scene_kwargs=dict(seed=2))
+    env.build()
+    env.observation_manager.output = "window"
+    with pytest.raises(ValueError, match="window"):
+        RolloutStorage(env, 4)
+    env.observation_manager.output = "fresh"
+    st = RolloutStorage(env, 4).attach()
+    st.begin(env.reset()[0])
+    for _ in range(3):
+        env.step(torch.zeros(20, 12))
+    env.observation_manager.output = "window"
+    with pytest.raises(ValueError, match="strided"):
+        for _ in range(3):
+            env.step(torch.zeros(20, 12))
+
+
 def test_rollout_write_abi_validation(oracle_backend):
     import ctypes as C
     from genesis_forge_amd import _native as nat
