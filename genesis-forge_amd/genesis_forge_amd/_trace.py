@@ -817,13 +817,21 @@ def traceable(env, tail_python: bool = False) -> bool:
     # statistics ring), the user's code — `super().step(...)` launch included — follows it as a python phase (on a Genesis-shaped scene
     # in front of StepTrace._scene_pre, which then leaves sending the targets to it).
     phase_act = {id(am)}
+    # On a Genesis-shaped scene a reset(ids) override of a manager that writes SIMULATOR state (action: joint positions, entity: base
+    # pose) goes through the envs_idx setters in the middle of the step; the phases behind it would read this tick's snapshot, which
+    # those setters do not touch: such a step stays ordinary (every getter call fetches again).
+    writes_sim = set(map(id, env.managers["entity"] + [am])) if env._adapter is not None else set()
     for m in env._all_managers() + env.managers["terrain"]:
         for meth in ("step", "reset", "get_observations", "_perform_observation", "handle_actions"):
             if hasattr(m, meth) and not _most_derived_is_ours(m, meth):
+                if meth == "reset" and id(m) in writes_sim:
+                    return False
                 if id(m) in between and meth in ("step", "reset"):
                     continue
                 if id(m) in phase_step and meth == "step":
                     continue
+                if (id(m) in phase_step or id(m) in phase_act) and meth == "reset":
+                    continue   # (a manager with its own reset() is reset by index list behind the masked reset: _reset_partition, _indexed_reset)
                 if id(m) in phase_act and meth in ("step", "handle_actions"):
                     continue
                 if id(m) in phase_obs and meth in ("get_observations", "_perform_observation"):

@@ -314,6 +314,15 @@ class ManagedEnvironment(GenesisEnv):
         if ids.numel() > 0:
             for m in indexed:
                 m.reset(ids)
+            self._after_indexed_reset(indexed)
+
+    def _after_indexed_reset(self, indexed: list) -> None:
+        """Genesis-shaped scene: the reset(ids) of an action / entity manager goes through the simulator's envs_idx setters (joint
+        positions, base pose — also a Python on_reset entry); this tick's snapshot does not know, so what reads state from here on
+        fetches it again, as the reference's getters do.  (Such a step is never a recorded one: _trace.traceable.)"""
+        ad = self._adapter
+        if ad is not None and any(m is self.managers["action"] or m in self.managers["entity"] for m in indexed):
+            ad.invalidate()
 
     def _end_step(self) -> None:
         super()._end_step()
@@ -395,6 +404,7 @@ class ManagedEnvironment(GenesisEnv):
                 if not isinstance(ids, torch.Tensor) or ids.numel() > 0:
                     for m in indexed:
                         m.reset(ids)
+                    self._after_indexed_reset(indexed)
         self.invalidate_views()
 
     def _verify_adapter_setters(self) -> None:

@@ -261,7 +261,9 @@ def test_random_configs_on_genesis_like_scene_cpu(oracle_backend, seed):
 
     want, _ = _fuzz_on(None, seed, "cpu", trace=False)
     got, info = _fuzz_on(GenesisLikeScene, seed, "cpu", trace=True)
-    assert info["recorded"], info["env"]._untraceable
+    # (a reset(ids) override of the action manager writes joint positions through the simulator's setters in the middle of the step: on such
+    #  a scene the step stays ordinary — every getter call fetches again — and must equal the synthetic run all the same)
+    assert info["recorded"] or "action" in info["env"].user_reset_cls, info["env"]._untraceable
     fz._compare(got, want, 0, f"seed {seed} on the Genesis-shaped double")
 
 
@@ -279,7 +281,7 @@ def test_random_configs_on_genesis_like_scene_hip(hip_backend, seed):
 
     want, _ = _fuzz_on(None, seed, "cuda", trace=True)
     got, info = _fuzz_on(GenesisLikeScene, seed, "cuda", trace=True)
-    assert info["recorded"], info["env"]._untraceable
+    assert info["recorded"] or "action" in info["env"].user_reset_cls, info["env"]._untraceable
     fz._compare(got, want, 0, f"seed {seed} on the Genesis-shaped double (HIP)")
 
 

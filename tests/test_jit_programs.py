@@ -63,7 +63,7 @@ def test_every_fuzz_config_gets_a_program_without_a_gpu(signatures):
     """signature → source → hipcc (gfx950) → dlopen → the library's matcher picks the plugin for exactly that descriptor."""
     hip = nat.HipBackend()   # loads the library; nothing is launched
     seeds = [s for s in signatures if isinstance(s, int)]
-    assert len(seeds) >= 15   # (configs with a reset() override or a user manager class have no fused launch)
+    assert len(seeds) >= 10   # (configs with a reset() override, a user manager class or a manager reset(ids) override have no fused launch)
     ids = {}
     for seed in seeds:
         sig = signatures[seed]
@@ -73,7 +73,7 @@ def test_every_fuzz_config_gets_a_program_without_a_gpu(signatures):
         assert os.path.exists(so), f"seed {seed}: plugin was not built"
         ids[seed] = hip.register_program(so)
         assert ids[seed] >= 100
-    assert len(ids) >= 15, "the fuzz configs should not match built-in programs"
+    assert len(ids) >= 10, "the fuzz configs should not match built-in programs"
     # every config now selects ITS program (not the interpreter, not another config's): re-run 4 steps on the oracle for the
     # descriptors and ask the library which kernel it would launch
     from genesis_forge_amd import gs

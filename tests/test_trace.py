@@ -431,6 +431,70 @@ def test_user_observation_code_is_a_python_phase_behind_the_fused_launch(oracle_
     assert (Obs.calls, Env.env_calls) == counts_a and sum(counts_a) >= 50
 
 
+def _user_reset_env(which):
+    """User manager classes that override reset(ids) of the ACTION / REWARD / TERMINATION manager (around the library's): such a manager
+    is reset by index list behind the masked reset, the others stay sections of it."""
+    from genesis_forge_amd.managers import PositionActionManager, RewardManager, TerminationManager
+
+    seen = {"action": 0, "reward": 0, "termination": 0}
+
+    class CountingActions(PositionActionManager):
+        def reset(self, envs_idx=None):
+            seen["action"] += 1 if envs_idx is None else int(len(envs_idx))
+            return super().reset(envs_idx)
+
+    class CountingRewards(RewardManager):
+        def reset(self, envs_idx=None):
+            seen["reward"] += 1 if envs_idx is None else int(len(envs_idx))
+            return super().reset(envs_idx)
+
+    class CountingTerminations(TerminationManager):
+        def reset(self, envs_idx=None):
+            seen["termination"] += 1 if envs_idx is None else int(len(envs_idx))
+            return super().reset(envs_idx)
+
+    class Env(Go2CommandDirectionEnv):
+        if "action" in which:
+            action_cls = CountingActions
+
+        def config(self):
+            super().config()
+            if "reward" in which:
+                rc = {k: {"weight": v.weight, "fn": v.fn, "params": dict(v.params)} for k, v in self.reward_manager.cfg.items()}
+                self.managers["reward"] = None
+                self.reward_manager = CountingRewards(self, logging_enabled=True, cfg=rc)
+            if "termination" in which:
+                tc = {k: {"fn": v.fn, "params": dict(v.params), "time_out": v.time_out} for k, v in self.termination_manager.term_cfg.items()}
+                self.managers["termination"] = None
+                self.termination_manager = CountingTerminations(self, logging_enabled=True, term_cfg=tc)
+
+    return Env, seen
+
+
+@pytest.mark.parametrize("which", ["reward", "action", "termination", "action+reward+termination"])
+def test_manager_reset_overrides_are_reset_by_index_list_in_a_recorded_step(oracle_backend, which):
+    Env, seen = _user_reset_env(which)
+    a, _ = _run("cpu", False, cls=Env)
+    counts_a = dict(seen)
+    for k in seen:
+        seen[k] = 0
+    before = oracle_backend.replays
+    b, env = _run("cpu", True, cls=Env)
+    _same(a, b)
+    assert env._trace is not None, f"not recorded: {env._untraceable}"
+    assert oracle_backend.replays - before >= 40
+    assert dict(seen) == counts_a and all(counts_a[k] > 0 for k in which.split("+")), (seen, counts_a)
+
+
+@pytest.mark.gpu
+def test_manager_reset_overrides_recorded_hip(hip_backend):
+    Env, seen = _user_reset_env("action+reward+termination")
+    a, _ = _run("cuda", False, n=1000, cls=Env)
+    b, env = _run("cuda", True, n=1000, cls=Env)
+    assert env._trace is not None
+    _same(a, b)
+
+
 def _user_action_env(which):
     """A user-defined action manager CLASS: `handle_actions()` overridden (the reference's documented extension point,
     position_action_manager.py:389-392 — here a first-order low-pass on the incoming actions in front of the library's processing) or
