@@ -40,8 +40,9 @@ class BaseManager:
 
     @enabled.setter
     def enabled(self, v: bool):
+        changed = bool(v) != bool(self._enabled)
         self._enabled = v
-        if hasattr(self.env, "invalidate_trace"):
+        if changed and hasattr(self.env, "invalidate_trace"):   # (the same value again — a per-step curriculum hook — changes nothing)
             self.env.invalidate_trace()
 
     def build(self):

@@ -14,6 +14,23 @@ import inspect
 from typing import Callable, Optional
 
 
+def _same_plain(old, new) -> bool:
+    """An assignment that changes nothing: the same immutable scalar again.  The reference's own curriculum recipe assigns its params
+    on EVERY step, mostly with the value they already have (docs/guide/managers/termination.md "Curriculum-Based Termination": step() →
+    update_curriculum() → ``term_cfg[...].params["angle_limit"] = angle_limit``); there that costs nothing, here a change drops the
+    compiled term table and the recorded step.  Only plain immutable values qualify — re-assigning a mutable value (a list, a tensor) is
+    the documented way to announce an in-place edit and must keep marking the table dirty."""
+    if old is None or new is None:
+        return old is new
+    if isinstance(old, bool) or isinstance(new, bool):
+        return isinstance(old, bool) and isinstance(new, bool) and old == new
+    if isinstance(old, (int, float)) and isinstance(new, (int, float)):
+        return old == new   # (10 and 10.0 compile to the same table entry; NaN never equals itself: treated as a change)
+    if isinstance(old, str) and isinstance(new, str):
+        return old == new
+    return False
+
+
 class ParamsDict(dict):
     """dict that reports every mutation to ``on_change``.
 
@@ -28,16 +45,21 @@ class ParamsDict(dict):
         self._on_change = on_change
 
     def __setitem__(self, key, value):
+        same = key in self and _same_plain(self[key], value)
         super().__setitem__(key, value)
-        self._on_change()
+        if not same:
+            self._on_change()
 
     def __delitem__(self, key):
         super().__delitem__(key)
         self._on_change()
 
     def update(self, *args, **kwargs):
-        super().update(*args, **kwargs)
-        self._on_change()
+        new = dict(*args, **kwargs)
+        same = all(k in self and _same_plain(self[k], v) for k, v in new.items())
+        super().update(new)
+        if not same:
+            self._on_change()
 
     def pop(self, *args):
         out = super().pop(*args)
@@ -61,8 +83,7 @@ class ParamsDict(dict):
         self._on_change()
 
     def __ior__(self, other):
-        super().update(other)
-        self._on_change()
+        self.update(other)
         return self
 
 
@@ -156,8 +177,10 @@ class _Field:
         return self if obj is None else getattr(obj, self.name)
 
     def __set__(self, obj, value):
+        same = _same_plain(getattr(obj, self.name, None), value) and hasattr(obj, self.name)
         setattr(obj, self.name, value)
-        obj._dirty()
+        if not same:
+            obj._dirty()
 
 
 class TerminationConfigItem(ConfigItem):

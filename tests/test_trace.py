@@ -194,6 +194,51 @@ def test_params_dict_bulk_mutations_take_effect(oracle_backend, trace):
             assert torch.equal(a, b), f"{how}: reward differs at step {t} — the mutation did not reach the term table"
 
 
+def test_assignments_that_change_nothing_keep_the_recorded_step(oracle_backend):
+    """The reference's documented curriculum recipe assigns its params on EVERY step, mostly with the value they already have
+    (docs/guide/managers/termination.md, "Curriculum-Based Termination": step() → update_curriculum() → params[...] = value).  Such an
+    assignment must not drop the compiled tables / the recorded step; a changed value must; re-assigning a MUTABLE value (the documented
+    way to announce an in-place edit) still must."""
+    env = Go2CommandDirectionEnv(num_envs=33, contacts=True, history=2, scene_kwargs=dict(ang_noise=0.3, seed=3))
+    env.build()
+    env.seed(5)
+    env.reset()
+    for _ in range(4):
+        env.step(torch.zeros(33, 12))
+    tm, rm, om, vc = env.termination_manager, env.reward_manager, env.observation_manager, env.velocity_command
+    item = next(iter(om.cfg))
+
+    def curriculum():
+        tm.term_cfg["fall_over"].params["limit_angle"] = 10.0
+        tm.term_cfg["fall_over"].params.update(limit_angle=10)
+        tm.term_cfg["timeout"].time_out = True
+        rm.cfg["action_rate"].weight = rm.cfg["action_rate"].weight
+        rm.cfg["base_height_target"].params["target_height"] = 0.3
+        om.cfg[item].scale = om.cfg[item].scale
+        om.cfg[item].noise = om.cfg[item].noise
+        om.noise = om.noise
+        rm.logging_enabled = True
+        env.foot_contacts.enabled = True
+        vc.resample_time_sec = vc.resample_time_sec
+
+    before = oracle_backend.replays
+    for _ in range(12):
+        curriculum()
+        env.step(torch.zeros(33, 12))
+    assert env._trace is not None and oracle_backend.replays - before == 12, "an assignment that changes nothing dropped the recorded step"
+    tm.term_cfg["fall_over"].params["limit_angle"] = 12.5      # a real change
+    assert env._trace is None
+    for _ in range(3):
+        env.step(torch.zeros(33, 12))
+    assert env._trace is not None
+    pos = env.robot_manager.on_reset["position"].params
+    vec = pos["position"]
+    assert isinstance(vec, list)
+    vec[2] = 0.45
+    pos["position"] = vec     # the same mutable object again: "I edited it in place"
+    assert env._trace is None
+
+
 def test_parity_draws_disable_trace(oracle_backend):
     env = Go2CommandDirectionEnv(num_envs=8)
     env.build()

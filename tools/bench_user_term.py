@@ -4,7 +4,8 @@
 term and an observation item reading it (the shape of the reference's examples/gait_trainer/gait_command_manager.py) — or (`classes`)
 user-defined RewardManager and TerminationManager CLASSES whose step() wraps the library's (round 4: python phases of a recorded step).
 or (`action`) a user-defined ACTION manager class overriding handle_actions(), the reference's extension point.
-    python tools/bench_user_term.py [num_envs] [reward|obs|manager|classes|obsclass|action]"""
+or (`curriculum`) the reference's documented curriculum recipe: step() assigns termination params on EVERY step, mostly unchanged values.
+    python tools/bench_user_term.py [num_envs] [reward|obs|manager|classes|obsclass|action|curriculum]"""
 import os
 import sys
 import time
@@ -32,6 +33,15 @@ def run(n, trace, steps=400):
             def get_observations(self):
                 o = super().get_observations()
                 return None if o is None else o * 0.5
+    if KIND == "curriculum":   # docs/guide/managers/termination.md "Curriculum-Based Termination", verbatim in shape
+        class env_cls(Go2CommandDirectionEnv):   # noqa: F811
+            def step(self, actions):
+                self.update_curriculum()
+                return super().step(actions)
+
+            def update_curriculum(self):
+                limit = 10.0 if self.step_count > 200 else 12.0
+                self.termination_manager.term_cfg["fall_over"].params["limit_angle"] = limit
     if KIND == "action":   # a low-pass on the incoming actions in front of the library's processing
         from genesis_forge_amd.managers import PositionActionManager
 
