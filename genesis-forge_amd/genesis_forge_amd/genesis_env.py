@@ -221,6 +221,8 @@ class GenesisEnv:
         self._trace = None
         self._trace_epoch += 1
         self._last_signature = None
+        if getattr(self, "_soft_dirty", None):
+            self._soft_dirty.clear()
 
     @property
     def _rng_stream(self) -> int:

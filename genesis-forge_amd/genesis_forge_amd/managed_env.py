@@ -81,6 +81,7 @@ class ManagedEnvironment(GenesisEnv):
         self._no_trace_epoch = -1
         self._partition_cache = None
         self._program_pending = None   # a static program of this config being compiled in a child process (_programs.Pending)
+        self._soft_dirty: set = set()   # managers whose term-table NUMBERS changed since the last step (a recorded step refreshes them in place)
         self._program_info: Optional[dict] = None   # what became of it: signature, plugin path, compile seconds (or the error)
         self._program_info_tail: Optional[dict] = None   # the same for the observation-only launch of a reset()-override tail
         #: "off" / "sync" / "async": compile a static program of the fused post-physics kernel for this config's structure when no
@@ -172,6 +173,8 @@ class ManagedEnvironment(GenesisEnv):
         if actions.dtype != torch.float32 or not actions.is_contiguous():
             actions = actions.to(torch.float32).contiguous()
         tr = self._trace
+        if self._soft_dirty:
+            tr = self._refresh_soft()
         if tr is not None:
             if tr.epoch == self._trace_epoch and not self._draws:
                 if tr.fresh():
@@ -207,6 +210,21 @@ class ManagedEnvironment(GenesisEnv):
             self._last_signature = sig
             self._last_images = rec.images
         return out
+
+    def _refresh_soft(self):
+        """Weights / param values were assigned since the last step (a curriculum).  With a recorded step: every manager concerned
+        compiles its table again and writes the new numbers into the descriptor the recording froze; one whose STRUCTURE changed drops
+        the recording (its _compile does).  Without one: nothing to do here — the managers are dirty and compile at their phase."""
+        todo, self._soft_dirty = list(self._soft_dirty), set()
+        if self._trace is None:
+            return None
+        ok = False
+        try:
+            ok = all([m._refresh_in_place() for m in todo])
+        finally:
+            if not ok and self._trace is not None:   # (also when a compile raised — a bad param value: never go on with the old table)
+                self.invalidate_trace()
+        return self._trace
 
     def _begin_step_light(self) -> None:
         """_begin_step without the statistics clear (a recorded step carries it as its first op)."""

@@ -272,6 +272,46 @@ class RewardProgram:
         self._keep = keep
 
 
+def same_structure(old, new) -> bool:
+    """Two compiled programs (RewardProgram / TerminationProgram) that differ at most in NUMBERS — term weights and params: same terms in
+    the same order with the same opcodes, flags, rows and view slots, the same entity / action manager, the same command / contact /
+    state / terrain sources, as many Python-level terms.  Then ``old``'s descriptor — the one a recorded step froze — can take ``new``'s
+    term table as it is (refresh_terms)."""
+    if old is None or new is None or type(old) is not type(new) or old.n != new.n or old.entity is not new.entity:
+        return False
+    for name in ("action_manager",):
+        if getattr(old, name, None) is not getattr(new, name, None):
+            return False
+    for name in ("needs_actions", "needs_terminated"):
+        if getattr(old, name, False) != getattr(new, name, False):
+            return False
+    if len(getattr(old, "after", ())) != len(getattr(new, "after", ())):
+        return False
+    so, sn = old.slots, new.slots
+    if so.volatile or sn.volatile or so.terrain is not sn.terrain or len(so.exts) != len(sn.exts):
+        return False
+    if len(so.cmds) != len(sn.cmds) or any(a is not b for a, b in zip(so.cmds, sn.cmds)):
+        return False
+    if len(so.contacts) != len(sn.contacts) or any(a[0] is not b[0] or a[1:] != b[1:] for a, b in zip(so.contacts, sn.contacts)):
+        return False
+    if len(so.states) != len(sn.states) or any(a is not b and a.data_ptr() != b.data_ptr() for a, b in zip(so.states, sn.states)):
+        return False
+    for k in range(old.n):
+        a, b = old.args.terms[k], new.args.terms[k]
+        if a.op != b.op or a.flags != b.flags or a.row != b.row or any(a.i[j] != b.i[j] for j in range(4)):
+            return False
+    return True
+
+
+def refresh_terms(old, new) -> None:
+    """``new``'s numbers into ``old``'s descriptor (same_structure holds): the term table, entry by entry."""
+    for k in range(old.n):
+        a, b = old.args.terms[k], new.args.terms[k]
+        a.w = b.w
+        for j in range(4):
+            a.p[j] = b.p[j]
+
+
 def _program_trace_pre(prog, ext_dtype):
     """Recorded step: what must run in Python right before this program's op — its Python-level terms."""
     if not prog.slots.exts:

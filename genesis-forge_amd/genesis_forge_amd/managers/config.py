@@ -117,15 +117,26 @@ class ConfigItem:
         self._env = env
         self._kwargs: dict = {}
         self._on_dirty = on_dirty
+        self._soft_ok = False
+        if on_dirty is not None:
+            try:
+                self._soft_ok = "soft" in inspect.signature(on_dirty).parameters
+            except (TypeError, ValueError):
+                pass
         self._cfg = cfg
         self._fn = cfg["fn"]
         self._params = ParamsDict(cfg.get("params", {}) or {}, self._rebuild)
         self._is_class = inspect.isclass(cfg["fn"])
         self._initialized = not self._is_class
 
-    def _dirty(self):
+    def _dirty(self, soft: bool = False):
+        """``soft``: only NUMBERS of the compiled term table can have changed (a param value, a weight): a manager that knows how may
+        refresh the table a recorded step uses in place instead of dropping the recording (RewardManager / TerminationManager)."""
         if self._on_dirty is not None:
-            self._on_dirty()
+            if soft and self._soft_ok:
+                self._on_dirty(soft=True)
+            else:
+                self._on_dirty()
 
     @property
     def fn(self):
@@ -162,7 +173,7 @@ class ConfigItem:
         self._initialized = True
 
     def _rebuild(self):
-        self._dirty()
+        self._dirty(soft=not self._is_class)   # (a class-style fn is re-built from its params: anything may change)
         if self._is_class and self._initialized and hasattr(self._fn, "build"):
             self._fn.build()
 
@@ -180,7 +191,7 @@ class _Field:
         same = _same_plain(getattr(obj, self.name, None), value) and hasattr(obj, self.name)
         setattr(obj, self.name, value)
         if not same:
-            obj._dirty()
+            obj._dirty(soft=self.name == "_weight")
 
 
 class TerminationConfigItem(ConfigItem):

@@ -16,7 +16,7 @@ import torch
 from .. import _native as nat
 from .. import gs
 from .._stats import GroupRingSnapshot, RingSnapshot
-from ._program import RewardProgram, spec_of
+from ._program import RewardProgram, refresh_terms, same_structure, spec_of
 from .base import BaseManager, LiveAttr
 from .config import RewardConfigItem
 
@@ -59,11 +59,26 @@ class RewardManager(BaseManager):
         self._dirty = True
         self._pending: list = []  # snapshots with unreduced episode means (for last_episode_mean_reward)
 
-    def _mark_dirty(self):
+    def _mark_dirty(self, soft: bool = False):
+        """``soft`` (a weight or a param VALUE was assigned — a curriculum): nothing is dropped; the next step compiles the table again and,
+        when only numbers differ, writes them into the descriptor it already has — the one a recorded step froze
+        (_compile, ManagedEnvironment._refresh_soft).  Anything else drops the recorded step right away."""
         self._dirty = True
         self._log_names = None
-        if hasattr(self.env, "invalidate_trace"):
-            self.env.invalidate_trace()
+        env = self.env
+        if soft and hasattr(env, "_soft_dirty"):
+            env._soft_dirty.add(self)
+        elif hasattr(env, "invalidate_trace"):
+            env.invalidate_trace()
+
+    def _refresh_in_place(self) -> bool:
+        """A weight / param edit while a recorded step exists: True when the compile kept the descriptor (only numbers differed);
+        otherwise the structure changed (a weight to or from zero, a stateful term's buffer …) and the compile dropped the recording."""
+        old = self._program
+        if old is None or not self.enabled:
+            return False
+        self._compile()
+        return self._program is old
 
     @property
     def rewards(self) -> torch.Tensor:
@@ -107,6 +122,7 @@ class RewardManager(BaseManager):
 
     def _compile(self):
         env = self.env
+        old = self._program
         prog = RewardProgram(env)
         dt = env.dt
         for row, (name, cfg) in enumerate(self.cfg.items()):
@@ -124,6 +140,13 @@ class RewardManager(BaseManager):
         a.episode_sums = self._episode_sums.data_ptr()
         a.episode_seconds = self._episode_seconds.data_ptr()
         prog.manager = self
+        if old is not None and same_structure(old, prog) and old.args.logging_enabled == a.logging_enabled:
+            # only numbers differ (a curriculum edit): they go into the descriptor that exists — a recorded step that froze it goes on,
+            # and a recording in progress keeps seeing the same descriptor from step to step
+            refresh_terms(old, prog)
+            prog = old
+        elif old is not None and getattr(env, "_trace", None) is not None:
+            env.invalidate_trace()   # another structure under a recorded step
         self._program = prog
         self._dirty = False
 

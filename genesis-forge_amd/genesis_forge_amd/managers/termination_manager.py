@@ -14,7 +14,7 @@ import torch
 
 from .. import _native as nat
 from .. import gs
-from ._program import TerminationProgram, spec_of
+from ._program import TerminationProgram, spec_of, refresh_terms, same_structure
 from .base import BaseManager, LiveAttr
 from .config import TerminationConfigItem
 
@@ -44,10 +44,22 @@ class TerminationManager(BaseManager):
         self._program: Optional[TerminationProgram] = None
         self._dirty = True
 
-    def _mark_dirty(self):
+    def _mark_dirty(self, soft: bool = False):
+        """``soft``: a param VALUE was assigned — see RewardManager._mark_dirty."""
         self._dirty = True
-        if hasattr(self.env, "invalidate_trace"):
-            self.env.invalidate_trace()
+        env = self.env
+        if soft and hasattr(env, "_soft_dirty"):
+            env._soft_dirty.add(self)
+        elif hasattr(env, "invalidate_trace"):
+            env.invalidate_trace()
+
+    def _refresh_in_place(self) -> bool:
+        """See RewardManager._refresh_in_place."""
+        old = self._program
+        if old is None or not self.enabled:
+            return False
+        self._compile()
+        return self._program is old
 
     @property
     def dones(self) -> torch.Tensor:
@@ -67,6 +79,7 @@ class TerminationManager(BaseManager):
 
     def _compile(self):
         env = self.env
+        old = self._program
         prog = TerminationProgram(env)
         for name, item in self.term_cfg.items():
             fn, params = item.fn, item.params
@@ -81,6 +94,11 @@ class TerminationManager(BaseManager):
             prog.add(spec_of(fn, env, params), fallback, bool(item.time_out))
         prog.args.terminated = self._terminated_buf.data_ptr()
         prog.args.truncated = self._truncated_buf.data_ptr()
+        if old is not None and same_structure(old, prog):
+            refresh_terms(old, prog)   # only numbers differ: the descriptor that exists takes them (RewardManager._compile)
+            prog = old
+        elif old is not None and getattr(env, "_trace", None) is not None:
+            env.invalidate_trace()     # another structure under a recorded step
         self._program = prog
         self._dirty = False
 

@@ -226,8 +226,18 @@ def test_assignments_that_change_nothing_keep_the_recorded_step(oracle_backend):
         curriculum()
         env.step(torch.zeros(33, 12))
     assert env._trace is not None and oracle_backend.replays - before == 12, "an assignment that changes nothing dropped the recorded step"
-    tm.term_cfg["fall_over"].params["limit_angle"] = 12.5      # a real change
-    assert env._trace is None
+    tm.term_cfg["fall_over"].params["limit_angle"] = 12.5      # a real change of a NUMBER: the recorded step's term table is refreshed in place
+    rm.cfg["action_rate"].weight = -0.02
+    before = oracle_backend.replays
+    for _ in range(3):
+        env.step(torch.zeros(33, 12))
+    assert env._trace is not None and oracle_backend.replays - before == 3
+    import math
+    assert any(abs(tm._program.args.terms[k].p[j] - math.sin(math.radians(12.5))) < 1e-6 for k in range(tm._program.n) for j in range(4)), \
+        "the termination table the recorded step uses did not take the new limit"
+    rm.cfg["action_rate"].weight = 0.0                           # … to zero: the term leaves the table — a structural change
+    env.step(torch.zeros(33, 12))
+    assert oracle_backend.replays - before == 3, "a weight set to zero must drop the recorded step"
     for _ in range(3):
         env.step(torch.zeros(33, 12))
     assert env._trace is not None
@@ -237,6 +247,23 @@ def test_assignments_that_change_nothing_keep_the_recorded_step(oracle_backend):
     vec[2] = 0.45
     pos["position"] = vec     # the same mutable object again: "I edited it in place"
     assert env._trace is None
+
+
+def test_weights_and_params_annealed_every_step_stay_on_the_recorded_step(oracle_backend):
+    """A curriculum that changes NUMBERS on every step (a weight annealed, a limit tightened): the term tables are compiled again and
+    their numbers go into the descriptors that exist — the step is recorded after the usual two steps and stays recorded; every step
+    equals the ordinary one, logs included."""
+    class Annealed(Go2CommandDirectionEnv):
+        def step(self, actions):
+            self.reward_manager.cfg["action_rate"].weight = -0.005 * (1.0 + 1e-2 * self.step_count)
+            self.termination_manager.term_cfg["fall_over"].params["limit_angle"] = 10.0 + 0.01 * self.step_count
+            return super().step(actions)
+
+    a, _ = _run("cpu", False, cls=Annealed)
+    before = oracle_backend.replays
+    b, env = _run("cpu", True, cls=Annealed)
+    _same(a, b)
+    assert env._trace is not None and oracle_backend.replays - before >= 47
 
 
 def test_parity_draws_disable_trace(oracle_backend):

@@ -5,7 +5,7 @@ term and an observation item reading it (the shape of the reference's examples/g
 user-defined RewardManager and TerminationManager CLASSES whose step() wraps the library's (round 4: python phases of a recorded step).
 or (`action`) a user-defined ACTION manager class overriding handle_actions(), the reference's extension point.
 or (`curriculum`) the reference's documented curriculum recipe: step() assigns termination params on EVERY step, mostly unchanged values.
-    python tools/bench_user_term.py [num_envs] [reward|obs|manager|classes|obsclass|action|curriculum]"""
+    python tools/bench_user_term.py [num_envs] [reward|obs|manager|classes|obsclass|action|curriculum|anneal]"""
 import os
 import sys
 import time
@@ -42,6 +42,11 @@ def run(n, trace, steps=400):
             def update_curriculum(self):
                 limit = 10.0 if self.step_count > 200 else 12.0
                 self.termination_manager.term_cfg["fall_over"].params["limit_angle"] = limit
+    if KIND == "anneal":   # a reward weight annealed on EVERY step: each step refreshes the recorded step's term table in place
+        class env_cls(Go2CommandDirectionEnv):   # noqa: F811
+            def step(self, actions):
+                self.reward_manager.cfg["action_rate"].weight = -0.005 * (1.0 + 1e-4 * self.step_count)
+                return super().step(actions)
     if KIND == "action":   # a low-pass on the incoming actions in front of the library's processing
         from genesis_forge_amd.managers import PositionActionManager
 
