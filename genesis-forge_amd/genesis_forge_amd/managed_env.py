@@ -224,7 +224,16 @@ class ManagedEnvironment(GenesisEnv):
         finally:
             if not ok and self._trace is not None:   # (also when a compile raised — a bad param value: never go on with the old table)
                 self.invalidate_trace()
-        return self._trace
+        tr = self._trace
+        if tr is not None and any(m in self.managers["observation"] for m in todo):
+            # an item's scale / noise switched on or off is part of a run-time compiled program's signature (not of the table layout):
+            # the launch falls back to the interpreter by itself; give the new structure its own program, as a re-recording would
+            from . import _programs
+            if tr.post_refs is not None:
+                _programs.on_recorded(self)
+            if getattr(tr, "_tail_refs", None) is not None and tr.tail_seg:
+                _programs.on_recorded(self, tr._tail_refs)
+        return tr
 
     def _begin_step_light(self) -> None:
         """_begin_step without the statistics clear (a recorded step carries it as its first op)."""

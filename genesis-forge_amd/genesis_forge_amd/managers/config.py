@@ -191,7 +191,7 @@ class _Field:
         same = _same_plain(getattr(obj, self.name, None), value) and hasattr(obj, self.name)
         setattr(obj, self.name, value)
         if not same:
-            obj._dirty(soft=self.name == "_weight")
+            obj._dirty(soft=self.name in ("_weight", "_scale", "_noise"))   # numbers of a compiled table; `time_out` is structure
 
 
 class TerminationConfigItem(ConfigItem):

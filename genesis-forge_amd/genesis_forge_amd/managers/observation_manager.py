@@ -129,10 +129,25 @@ class ObservationManager(BaseManager):
         self._rotor = nat.GfRotor()           # which output slot is current (shared with a recorded step's native patch table)
         self._ring_clock = nat.GfRingClock()  # observations produced in ring mode (slot = (H - calls % H) % H)
 
-    def _mark_dirty(self):
+    def _mark_dirty(self, soft: bool = False):
+        """``soft`` (an item's scale / noise / a param value was assigned): the item table is compiled again into the SAME descriptor
+        before the next step (``_compile`` writes ``self._args`` in place), a recorded step goes on (RewardManager._mark_dirty)."""
         self._dirty = True
-        if hasattr(self.env, "invalidate_trace"):
-            self.env.invalidate_trace()
+        env = self.env
+        if soft and self._bufs and hasattr(env, "_soft_dirty"):
+            env._soft_dirty.add(self)
+        elif hasattr(env, "invalidate_trace"):
+            env.invalidate_trace()
+
+    def _refresh_in_place(self) -> bool:
+        if not self.enabled or not self._bufs:
+            return False
+        before = [(self._args.items[k].op, self._args.items[k].i0, self._args.items[k].i1, self._args.items[k].width) for k in range(self._args.num_items)]
+        exts = len(self._slots.exts)
+        self._compile()
+        a = self._args
+        now = [(a.items[k].op, a.items[k].i0, a.items[k].i1, a.items[k].width) for k in range(a.num_items)]
+        return now == before and len(self._slots.exts) == exts   # (anything else: the caller drops the recording)
 
     @property
     def name(self) -> str:
