@@ -724,6 +724,10 @@ class StepTrace:
                         pre()
                     finally:
                         env.stats.ptr_override = None
+                    if env._soft_dirty:
+                        # the user code assigned a weight / param value: a phase that runs BEHIND it reads the new number in this very
+                        # step, as it does in the ordinary step (where the manager compiles at its phase)
+                        env._refresh_soft()
                 if count or desc.num_patches:
                     self.backend.replay_step(desc, aptr, pr, self.n_params)
         elif self.graph is not None and self.backend.graph_enabled:

@@ -266,6 +266,31 @@ def test_weights_and_params_annealed_every_step_stay_on_the_recorded_step(oracle
     assert env._trace is not None and oracle_backend.replays - before >= 47
 
 
+def test_a_weight_assigned_by_user_code_in_the_middle_of_a_step_reaches_the_phases_behind_it(oracle_backend):
+    """A Python-level termination term that also anneals a reward weight: the reward phase runs behind it and must use the new weight in
+    the same step — recorded (the term is user code between two native pieces) exactly as phase by phase."""
+    from genesis_forge_amd.managers import TerminationManager
+
+    class Env(Go2CommandDirectionEnv):
+        def config(self):
+            super().config()
+            tc = {k: {"fn": v.fn, "params": dict(v.params), "time_out": v.time_out} for k, v in self.termination_manager.term_cfg.items()}
+
+            def far_and_anneal(env):
+                env.reward_manager.cfg["action_rate"].weight = -0.005 * (1.0 + 0.05 * env.step_count)
+                return env.robot.get_pos()[:, :2].abs().sum(dim=1) > 0.6
+
+            tc["far"] = {"fn": far_and_anneal}
+            self.managers["termination"] = None
+            self.termination_manager = TerminationManager(self, logging_enabled=True, term_cfg=tc)
+
+    a, _ = _run("cpu", False, cls=Env)
+    before = oracle_backend.replays
+    b, env = _run("cpu", True, cls=Env)
+    _same(a, b)
+    assert env._trace is not None and oracle_backend.replays - before >= 40
+
+
 def test_parity_draws_disable_trace(oracle_backend):
     env = Go2CommandDirectionEnv(num_envs=8)
     env.build()
