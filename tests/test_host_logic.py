@@ -1,4 +1,5 @@
 """Host-side logic of the operator interface (no kernels beyond the oracle backend)."""
+import os
 import math
 
 import numpy as np
@@ -285,6 +286,51 @@ def test_rsl_rl_3_wrapper_returns_observation_groups_as_a_tensordict(oracle_back
     monkeypatch.setattr(metadata, "version", lambda name: "2.3.1" if name == "rsl-rl-lib" else real(name))
     w2 = RslRlWrapper(env)
     assert not w2.rsl3 and isinstance(w2.get_observations(), tuple) and isinstance(w2.step(torch.zeros(9, 12))[0], torch.Tensor)
+
+
+def test_video_wrapper_drives_the_camera_and_passes_through_without_one(oracle_backend, tmp_path):
+    """wrappers/video.py:90-260: a triggered recording of video_length_sec saved as <start step>.mp4, frames every steps_per_frame steps,
+    a background recording between triggers, the final one saved on close; an env without a camera is passed through with a warning."""
+    import warnings
+
+    from genesis_forge_amd.wrappers import RslRlWrapper, VideoWrapper, capped_cubic_episode_trigger
+
+    assert [e for e in range(30) if capped_cubic_episode_trigger(e)] == [0, 1, 8, 27] and capped_cubic_episode_trigger(2000) and not capped_cubic_episode_trigger(1001)
+
+    class Cam:
+        def __init__(self):
+            self.calls, self._recorded_imgs = [], []
+
+        def start_recording(self): self.calls.append("start")
+        def pause_recording(self): self.calls.append("pause")
+        def render(self): self.calls.append("render")
+        def stop_recording(self, path, fps=None): self.calls.append(("stop", os.path.basename(path), fps))
+
+    env = Go2CommandDirectionEnv(num_envs=5, max_episode_length_s=0.2, scene_kwargs=dict(seed=4))   # 10-step episodes at dt = 0.02
+    env.camera = Cam()
+    w = VideoWrapper(env, video_length_sec=0.1, out_dir=str(tmp_path / "videos"), step_trigger=lambda step: step % 12 == 0, fps=25)
+    assert w.video_length_steps == 5 and w.num_envs == 5
+    r = RslRlWrapper(w)
+    r.build()
+    r.reset()
+    for _ in range(30):
+        obs, rew, dones, extras = r.step(torch.zeros(5, 12))
+    r.close()
+    calls = env.camera.calls
+    stops = [c for c in calls if isinstance(c, tuple)]
+    assert [c[1] for c in stops[:3]] == ["0.mp4", "12.mp4", "24.mp4"] and all(c[2] == 25 for c in stops)
+    assert calls.count("render") == 15 and calls.count("start") >= 3 and os.path.isdir(tmp_path / "videos")
+
+    plain = Go2CommandDirectionEnv(num_envs=5, scene_kwargs=dict(seed=4))
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        v = VideoWrapper(plain, out_dir=str(tmp_path / "none"))
+        v.build()
+    assert any("not a camera" in str(x.message) for x in caught)
+    v.reset()
+    out = v.step(torch.zeros(5, 12))
+    assert len(out) == 5
+    v.close()
 
 
 def test_external_command_controller(oracle_backend):
