@@ -19,6 +19,23 @@ def install(pkg, with_genesis_shim: bool = True) -> None:
     for alias in ("genesis_forge.managers.command", "genesis_forge.managers.command.command_manager",
                   "genesis_forge.managers.command.velocity_command"):
         sys.modules[alias] = _command
+    # … and every other module path of the reference package (deep imports such as
+    # ``from genesis_forge.managers.contact.contact_manager import ContactManager``): each resolves to the module of this package that
+    # holds the same names (the reference splits managers/action, managers/config, managers/contact and wrappers over several files)
+    deep = {
+        "managers.action": "managers.action", "managers.action.base": "managers.action",
+        "managers.action.position_action_manager": "managers.action", "managers.action.position_within_limits": "managers.action",
+        "managers.base": "managers.base",
+        "managers.config.config_item": "managers.config", "managers.config.mdp_fn_class": "managers.config",
+        "managers.config.params_dict": "managers.config",
+        "managers.contact": "managers.contact", "managers.contact.contact_manager": "managers.contact", "managers.contact.config": "managers.contact",
+        "managers.entity_manager": "managers.entity_manager", "managers.observation_manager": "managers.observation_manager",
+        "managers.reward_manager": "managers.reward_manager", "managers.termination_manager": "managers.termination_manager",
+        "managers.terrain_manager": "managers.terrain_manager",
+        "wrappers.rsl_rl": "wrappers", "wrappers.skrl": "wrappers", "wrappers.video": "wrappers", "wrappers.wrapper": "wrappers",
+    }
+    for ref_path, mine in deep.items():
+        sys.modules.setdefault("genesis_forge." + ref_path, importlib.import_module(pkg.__name__ + "." + mine))
     sys.modules["genesis_forge.gamepads"] = _gamepads_module()
     if with_genesis_shim and "genesis" not in sys.modules:
         try:

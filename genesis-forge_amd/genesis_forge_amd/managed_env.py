@@ -542,3 +542,18 @@ class ManagedEnvironment(GenesisEnv):
     def _user_get_observations(self) -> None:
         """An env whose get_observations() is overridden: the whole call is user code behind the step's native phases."""
         self._step_obs = self.get_observations()
+
+
+# -- annotation type of the reference (managed_env.py:20-28) ---------------------------------------------------------------------------
+from typing import TypedDict  # noqa: E402
+
+
+class ManagersDict(TypedDict):
+    contact: list
+    entity: list
+    command: list
+    terrain: list
+    action: Any
+    observation: list
+    reward: Any
+    termination: Any

@@ -222,3 +222,23 @@ class VelocityCommandManager(CommandManager):
 
     def use_gamepad(self, gamepad, lin_vel_y_axis: int = 0, lin_vel_x_axis: int = 1, ang_vel_z_axis: int = 2):
         super().use_gamepad(gamepad, range_axis={"lin_vel_x": lin_vel_x_axis, "lin_vel_y": lin_vel_y_axis, "ang_vel_z": ang_vel_z_axis})
+
+
+# -- annotation types of the reference (velocity_command.py:17-55), for user code that imports them -------------------------------
+from typing import Tuple, TypedDict  # noqa: E402
+
+
+class VelocityCommandRange(TypedDict):
+    lin_vel_x: Tuple[float, float]
+    lin_vel_y: Tuple[float, float]
+    ang_vel_z: Tuple[float, float]
+
+
+class VelocityDebugVisualizerConfig(TypedDict, total=False):
+    """Options of the debug arrows (drawing is Genesis' viewer: out of scope here; the dict is accepted and kept)."""
+    envs_idx: list
+    arrow_offset: float
+    arrow_radius: float
+    arrow_max_length: float
+    commanded_color: Tuple[float, float, float, float]
+    actual_color: Tuple[float, float, float, float]

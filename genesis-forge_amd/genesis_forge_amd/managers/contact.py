@@ -261,3 +261,18 @@ class ContactManager(BaseManager):
         if self._track_air_time:
             attrs.append(f"track_air_time={self._track_air_time}")
         return f"{self.__class__.__name__}({', '.join(attrs)})"
+
+
+# -- annotation types of the reference (contact/config.py:4-26) ----------------------------------------------------------------------
+from typing import Tuple, TypedDict  # noqa: E402
+
+
+class ContactDebugVisualizerConfig(TypedDict, total=False):
+    """Options of the contact markers (drawing is Genesis' viewer: out of scope here; the dict is accepted and kept)."""
+    envs_idx: list
+    color: Tuple[float, float, float, float]
+    radius: float
+    force_threshold: float
+
+
+DEFAULT_VISUALIZER_CONFIG: ContactDebugVisualizerConfig = {"envs_idx": None, "size": 0.03, "color": (0.5, 0.0, 0.0, 1.0), "force_threshold": 1.0}

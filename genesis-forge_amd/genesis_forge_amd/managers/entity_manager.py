@@ -219,3 +219,13 @@ class EntityManager(BaseManager):
                 for j in range(4):
                     a.reset_quat[j] = host[1][j]
             a.zero_velocity = 1 if fn.zero_velocity else 0
+
+
+# -- annotation type of the reference (entity_manager.py:17-40) -----------------------------------------------------------------------
+from typing import Callable, TypedDict  # noqa: E402
+
+
+class EntityResetConfig(TypedDict, total=False):
+    """One ``on_reset`` entry: ``fn(env, entity, envs_idx, **params)`` — a function or a ResetMdpFnClass — and its ``params``."""
+    fn: Callable
+    params: dict

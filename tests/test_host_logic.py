@@ -470,3 +470,58 @@ def test_history_unroll_equals_history_shift(oracle_backend, trace, output):
     assert ops_unroll == ops_shift + (1 if trace else 0), "a recorded step carries the gather as one more op behind the fused launch"
     for t, (a, b) in enumerate(zip(want, got)):
         assert torch.equal(a, b), f"observation {t} differs"
+
+
+#: every module path of the reference package (gamepads and the Taichi kernel aside) with the public classes / functions it defines
+#: (names only, listed from the reference's source tree): user code imports from these paths, e.g.
+#: ``from genesis_forge.managers.contact.contact_manager import ContactManager``
+REFERENCE_MODULES = {
+    'genesis_forge': [],
+    'genesis_forge.genesis_env': ['GenesisEnv'],
+    'genesis_forge.managed_env': ['ManagedEnvironment', 'ManagersDict'],
+    'genesis_forge.managers': [],
+    'genesis_forge.managers.action': [],
+    'genesis_forge.managers.action.base': ['BaseActionManager'],
+    'genesis_forge.managers.action.position_action_manager': ['PositionActionManager'],
+    'genesis_forge.managers.action.position_within_limits': ['PositionWithinLimitsActionManager'],
+    'genesis_forge.managers.base': ['BaseManager'],
+    'genesis_forge.managers.command': [],
+    'genesis_forge.managers.command.command_manager': ['CommandManager'],
+    'genesis_forge.managers.command.velocity_command': ['VelocityCommandManager', 'VelocityCommandRange', 'VelocityDebugVisualizerConfig'],
+    'genesis_forge.managers.config': [],
+    'genesis_forge.managers.config.config_item': ['ConfigItem', 'ObservationConfigItem', 'RewardConfigItem', 'TerminationConfigItem'],
+    'genesis_forge.managers.config.mdp_fn_class': ['MdpFnClass', 'ResetMdpFnClass'],
+    'genesis_forge.managers.config.params_dict': ['ParamsDict'],
+    'genesis_forge.managers.contact': [],
+    'genesis_forge.managers.contact.config': ['ContactDebugVisualizerConfig'],
+    'genesis_forge.managers.contact.contact_manager': ['ContactManager'],
+    'genesis_forge.managers.entity_manager': ['EntityManager', 'EntityResetConfig'],
+    'genesis_forge.managers.observation_manager': ['ObservationConfig', 'ObservationManager'],
+    'genesis_forge.managers.reward_manager': ['RewardConfig', 'RewardManager'],
+    'genesis_forge.managers.termination_manager': ['TerminationConfig', 'TerminationManager'],
+    'genesis_forge.managers.terrain_manager': ['TerrainManager'],
+    'genesis_forge.mdp': [],
+    'genesis_forge.mdp.observations': ['contact_force', 'current_actions', 'entity_angular_velocity', 'entity_dofs_force', 'entity_dofs_position', 'entity_dofs_velocity', 'entity_linear_velocity', 'entity_projected_gravity'],
+    'genesis_forge.mdp.reset': ['position', 'randomize_link_mass_shift', 'randomize_terrain_position', 'set_rotation', 'zero_all_dofs_velocity'],
+    'genesis_forge.mdp.rewards': ['action_rate_l2', 'ang_vel_xy_l2', 'base_height', 'body_acceleration_exp', 'command_tracking_ang_vel', 'command_tracking_lin_vel', 'contact_force', 'dof_similar_to_default', 'feet_air_time', 'feet_slide', 'flat_orientation_l2', 'has_contact', 'is_alive', 'lin_vel_z_l2', 'stand_still_joint_deviation_l1', 'terminated'],
+    'genesis_forge.mdp.terminations': ['bad_orientation', 'base_height_below_minimum', 'contact_force', 'contact_force_with_grace_period', 'has_contact', 'out_of_bounds', 'timeout'],
+    'genesis_forge.utils': ['entity_ang_vel', 'entity_lin_vel', 'entity_projected_gravity', 'links_by_name_pattern'],
+    'genesis_forge.wrappers': [],
+    'genesis_forge.wrappers.rsl_rl': ['RslRlWrapper'],
+    'genesis_forge.wrappers.skrl': ['SkrlEnvWapper'],
+    'genesis_forge.wrappers.video': ['VideoWrapper', 'capped_cubic_episode_trigger'],
+    'genesis_forge.wrappers.wrapper': ['Wrapper'],
+}
+
+
+def test_every_module_path_of_the_reference_resolves_through_the_alias():
+    import importlib
+
+    import genesis_forge_amd
+    from genesis_forge_amd import compat
+
+    compat.install(genesis_forge_amd)
+    for path, names in REFERENCE_MODULES.items():
+        mod = importlib.import_module(path)
+        missing = [n for n in names if not hasattr(mod, n)]
+        assert not missing, f"{path}: {missing}"
