@@ -117,10 +117,11 @@ class ConfigItem:
         self._env = env
         self._kwargs: dict = {}
         self._on_dirty = on_dirty
-        self._soft_ok = False
+        self._soft_ok = self._what_ok = False
         if on_dirty is not None:
             try:
-                self._soft_ok = "soft" in inspect.signature(on_dirty).parameters
+                pars = inspect.signature(on_dirty).parameters
+                self._soft_ok, self._what_ok = "soft" in pars, "what" in pars
             except (TypeError, ValueError):
                 pass
         self._cfg = cfg
@@ -129,12 +130,16 @@ class ConfigItem:
         self._is_class = inspect.isclass(cfg["fn"])
         self._initialized = not self._is_class
 
-    def _dirty(self, soft: bool = False):
+    def _dirty(self, soft: bool = False, what: Optional[str] = None):
         """``soft``: only NUMBERS of the compiled term table can have changed (a param value, a weight): a manager that knows how may
-        refresh the table a recorded step uses in place instead of dropping the recording (RewardManager / TerminationManager)."""
+        refresh the table a recorded step uses in place instead of dropping the recording (RewardManager / TerminationManager).
+        ``what``: the field that was assigned ("_weight" …), for managers that can refresh less than the whole table."""
         if self._on_dirty is not None:
             if soft and self._soft_ok:
-                self._on_dirty(soft=True)
+                if self._what_ok:
+                    self._on_dirty(soft=True, what=what)
+                else:
+                    self._on_dirty(soft=True)
             else:
                 self._on_dirty()
 
@@ -191,7 +196,7 @@ class _Field:
         same = _same_plain(getattr(obj, self.name, None), value) and hasattr(obj, self.name)
         setattr(obj, self.name, value)
         if not same:
-            obj._dirty(soft=self.name in ("_weight", "_scale", "_noise"))   # numbers of a compiled table; `time_out` is structure
+            obj._dirty(soft=self.name in ("_weight", "_scale", "_noise"), what=self.name)   # numbers of a compiled table; `time_out` is structure
 
 
 class TerminationConfigItem(ConfigItem):

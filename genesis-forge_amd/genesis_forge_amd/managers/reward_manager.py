@@ -58,11 +58,15 @@ class RewardManager(BaseManager):
         self._pending_names = None
         self._dirty = True
         self._pending: list = []  # snapshots with unreduced episode means (for last_episode_mean_reward)
+        self._weights_only = False  # every edit since the last compile was a `.weight` assignment (_refresh_in_place)
 
-    def _mark_dirty(self, soft: bool = False):
+    def _mark_dirty(self, soft: bool = False, what: Optional[str] = None):
         """``soft`` (a weight or a param VALUE was assigned — a curriculum): nothing is dropped; the next step compiles the table again and,
         when only numbers differ, writes them into the descriptor it already has — the one a recorded step froze
         (_compile, ManagedEnvironment._refresh_soft).  Anything else drops the recorded step right away."""
+        if not self._dirty:
+            self._weights_only = True
+        self._weights_only = self._weights_only and soft and what == "_weight"   # (since the table was last compiled)
         self._dirty = True
         self._log_names = None
         env = self.env
@@ -77,6 +81,16 @@ class RewardManager(BaseManager):
         old = self._program
         if old is None or not self.enabled:
             return False
+        if self._weights_only:
+            # only `.weight` assignments since the last compile (a weight annealed every step): the rows' weights are written straight
+            # into the table — unless a weight went to or from zero, which changes the table's rows (reward_manager.py:181-182)
+            a, dt = old.args, self.env.dt
+            live = [(row, cfg.weight) for row, cfg in enumerate(self.cfg.values()) if cfg.weight != 0]
+            if [row for row, _w in live] == [a.terms[k].row for k in range(old.n)]:
+                for k, (_row, w) in enumerate(live):
+                    a.terms[k].w = w * dt
+                self._dirty = False
+                return True
         self._compile()
         return self._program is old
 
