@@ -105,6 +105,8 @@ class ObservationManager(BaseManager):
         self._fresh_ptr = 0
         self._unrolled = False       # history kept as a ring + gather launch (module docstring: ``history=``); set by _refresh_modes()
         self._direct_fresh = False   # output="fresh" without history: the launch writes straight into the caller's new tensor
+        self._frame_only = False     # inside _perform_observation(): the launch writes the frame alone
+        self._history: Optional[list] = None   # the reference's frame list — only for a subclass that overrides _perform_observation()
         self._window = False         # output="window" with a history: the returned tensor is a strided view of _win
         self._win: Optional[torch.Tensor] = None    # [N, (S + H - 1) * O]
         self._win_view: Optional[torch.Tensor] = None
@@ -202,6 +204,7 @@ class ObservationManager(BaseManager):
         self._ring_clock.calls, self._ring_clock.length = 0, self._history_len
         self._ring = None
         self._win = self._win_view = None
+        self._history = None
         self._fresh_pool = []
         self._dirty = True
         self._refresh_modes()
@@ -284,10 +287,33 @@ class ObservationManager(BaseManager):
 
     # -- public ---------------------------------------------------------------------------------------
     def get_observations(self) -> torch.Tensor:
-        """observation_manager.py:218-226 → one launch."""
+        """observation_manager.py:218-226 → one launch.  A subclass that overrides ``_perform_observation()`` (the reference's
+        get_observations() calls it for the new frame) gets the reference's own sequence instead: frame list, ``torch.cat``."""
         env = self.env
         if not self.enabled:
             return torch.zeros((env.num_envs, self._observation_size))
+        if type(self)._perform_observation is not ObservationManager._perform_observation:
+            if self._history is None:
+                shape = (env.num_envs, self._frame)
+                self._history = [torch.zeros(shape, device=gs.device, dtype=gs.tc_float) for _ in range(self._history_len)]
+            self._history.pop()
+            self._history.insert(0, self._perform_observation())
+            return torch.cat(self._history, dim=-1)
+        return self._observe()
+
+    def _perform_observation(self) -> torch.Tensor:
+        """observation_manager.py:232-256: one round of observations — the ``[N, O]`` frame, no history (one launch into a new tensor)."""
+        if self._dirty:
+            self._compile()
+        self._frame_only = True
+        try:
+            return self._observe()
+        finally:
+            self._frame_only = False
+            self._args.history_len = self._history_len
+
+    def _observe(self) -> torch.Tensor:
+        env = self.env
         if self._dirty:
             self._compile()
         a = self._args
@@ -335,6 +361,8 @@ class ObservationManager(BaseManager):
         out = self._rotate_ring(a)
         env.backend.call("observe", a, owner=self)
         self._keep = keep
+        if self._frame_only:
+            return out
         if self._unrolled:   # the launch wrote the new frame into the ring: gather the ring into this call's tensor
             u = self._unroll_args
             u.ring_slot, u.out2 = a.history_ring, None
@@ -432,6 +460,11 @@ class ObservationManager(BaseManager):
         return obs.view(n, H, O)[:, self.history_order(), :].reshape(n, H * O)
 
     def _rotate_ring(self, a) -> torch.Tensor:
+        if self._frame_only:   # _perform_observation(): the frame alone, into a tensor of the caller's
+            a.history_len, a.history_ring, a.ring_slots, a.prev_obs = 1, 0, 0, None
+            out = torch.empty((self.env.num_envs, self._frame), device=gs.device, dtype=gs.tc_float)
+            a.obs = out.data_ptr()
+            return out
         if self._window:
             ck = self._ring_clock
             slot = self._window_slot(ck.calls)

@@ -670,6 +670,33 @@ def test_env_get_observations_override_next_to_a_reset_override(oracle_backend):
     _same(a, b)
 
 
+def test_perform_observation_override_is_honoured(oracle_backend):
+    """The reference's get_observations() takes the new frame from self._perform_observation() (observation_manager.py:218-256): a
+    subclass that overrides it (here: clipping the frame before it enters the history) is honoured — the frame list and the concat are
+    then the reference's — and such a manager is user code behind the fused launch of a recorded step."""
+    from genesis_forge_amd.managers import ObservationManager
+
+    class ClippedFrames(ObservationManager):
+        def _perform_observation(self):
+            return super()._perform_observation().clamp(-0.5, 0.5)
+
+    class Env(Go2CommandDirectionEnv):
+        def config(self):
+            super().config()
+            om = self.observation_manager
+            oc = {k: {"fn": v.fn, "params": dict(v.params), "scale": v.scale, "noise": v.noise} for k, v in om.cfg.items()}
+            self.managers["observation"].remove(om)
+            self.observation_manager = ClippedFrames(self, cfg=oc, history_len=2, noise=om.noise)
+
+    plain, _ = _run("cpu", False)
+    a, _ = _run("cpu", False, cls=Env)
+    b, env = _run("cpu", True, cls=Env)
+    _same(a, b)
+    assert env._trace is not None and env._trace.post_refs is not None and len(env._trace.py_marks) == 1
+    for t, (x, y) in enumerate(zip(a, plain)):
+        assert torch.equal(x[0], y[0].clamp(-0.5, 0.5)), f"step {t}: the frames are not the clipped library frames"
+
+
 @pytest.mark.gpu
 def test_user_observation_code_recorded_hip(hip_backend):
     Env, _Obs = _user_obs_env("manager+env")
