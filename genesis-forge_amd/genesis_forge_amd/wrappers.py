@@ -148,95 +148,99 @@ def capped_cubic_episode_trigger(episode_id: int) -> bool:
 
 class VideoWrapper(Wrapper):
     """Records videos of one env through the Genesis camera at ``env.<camera_attr>`` (ctor and schedule as video.py:90-260): a
-    triggered ("active") recording of ``video_length_sec`` is saved as ``<out_dir>/<start step>.mp4``; between triggers a
-    "background" recording of the running episode is kept so that ``close()`` can save the final one.  The wrapper only makes the
-    camera's own calls (``start_recording`` / ``render`` / ``pause_recording`` / ``stop_recording``); rendering is Genesis'.
-    An env without that camera (the synthetic scene) is passed through, with one warning.  With a camera the episode count reads
-    one env's done flags per step — a host synchronisation per step, as in the reference."""
+    triggered recording of ``video_length_sec`` is saved as ``<out_dir>/<start step>.mp4``; between triggers the running episode is
+    recorded in the background so that ``close()`` can save the final one.  The wrapper only makes the camera's own calls
+    (``start_recording`` / ``render`` / ``pause_recording`` / ``stop_recording``); rendering is Genesis'.  An env without that camera
+    (the synthetic scene) is passed through, with one warning.  With a camera the episode count reads one env's done flags per
+    step — a host synchronisation per step, as in the reference.
+
+    State: ``_mode`` is ``None`` (nothing running), ``"active"`` (a triggered clip, saved when its length is reached), ``"background"``
+    (the running episode, kept in the camera's buffer) or ``"held"`` (a background clip paused in the buffer, saved by ``close()``)."""
 
     def __init__(self, env, camera_attr: str = "camera", video_length_sec: int = 8, episode_trigger: Optional[Callable[[int], bool]] = None,
                  step_trigger: Optional[Callable[[int], bool]] = None, out_dir: str = "./videos", fps: int = 60, env_idx: int = 0,
                  filename: Optional[str] = None, record_final_episode: bool = True, logging: bool = True):
         super().__init__(env)
-        self._is_recording = False
-        self._has_recording_buffer = False
-        self._recording_type: Optional[str] = "background"
-        self._logging = logging
-        self._current_step = self._current_episode = 0
-        self._recording_start_step = self._recording_stop_step = 0
-        self._record_final_episode = record_final_episode
-        self._cam = None
-        self._camera_attr, self._out_dir, self._filename, self._env_idx = camera_attr, out_dir, filename, env_idx
-        self._video_length_steps = math.ceil(video_length_sec / self.dt)
-        self._steps_per_frame = max(1, round(1.0 / fps / self.dt))
-        self._actual_fps = round(1.0 / self.dt / self._steps_per_frame)
         if episode_trigger is None and step_trigger is None:
             episode_trigger = capped_cubic_episode_trigger
-        assert (episode_trigger is None) != (step_trigger is None), "Must specify only one trigger"
+        if (episode_trigger is None) == (step_trigger is None):
+            raise AssertionError("Must specify only one trigger")
         self.episode_trigger, self.step_trigger = episode_trigger, step_trigger
-        os.makedirs(self._out_dir, exist_ok=True)
+        self._where = (camera_attr, out_dir, filename, int(env_idx))
+        self._opts = (bool(record_final_episode), bool(logging))
+        dt = self.dt
+        self._clip_steps = math.ceil(video_length_sec / dt)
+        self._frame_every = max(1, round(1.0 / fps / dt))
+        self._file_fps = round(1.0 / dt / self._frame_every)
+        self._cam = None
+        self._mode: Optional[str] = None
+        self._steps = self._episodes = 0
+        self._clip_from = self._clip_until = 0
+        os.makedirs(out_dir, exist_ok=True)
 
     @property
     def video_length_steps(self) -> int:
-        return self._video_length_steps
+        return self._clip_steps
 
     def build(self) -> None:
         super().build()
-        self._cam = getattr(self.unwrapped, self._camera_attr, None)
+        attr = self._where[0]
+        self._cam = getattr(self.unwrapped, attr, None)
         if self._cam is None:
-            warnings.warn(f"VideoWrapper: {type(self.unwrapped).__name__}.{self._camera_attr} is not a camera - nothing will be recorded", RuntimeWarning)
+            warnings.warn(f"VideoWrapper: {type(self.unwrapped).__name__}.{attr} is not a camera - nothing will be recorded", RuntimeWarning)
 
     def step(self, actions: torch.Tensor):
-        out = self.env.step(actions)
-        if self._cam is None:
-            return out
-        _obs, _rew, terminateds, truncateds, _extras = out
-        self._check_recording_trigger()
-        if self._current_step % self._steps_per_frame == 0:
-            self._cam.render()
-        if self._is_recording and self._recording_stop_step <= self._current_step:
+        result = self.env.step(actions)
+        cam = self._cam
+        if cam is None:
+            return result
+        if self._mode != "active" and self._due():
+            self.start_recording("active")
+        if self._steps % self._frame_every == 0:
+            cam.render()
+        if self._mode in ("active", "background") and self._steps >= self._clip_until:
             self.finish_recording()
-        done = bool(terminateds is not None and terminateds[self._env_idx]) or bool(truncateds is not None and truncateds[self._env_idx])
-        if done:
-            self._current_episode += 1
-            if not self._is_recording and self._record_final_episode:
+        k = self._where[3]
+        flags = [f for f in (result[2], result[3]) if f is not None]
+        if any(bool(f[k]) for f in flags):       # the watched env finished an episode
+            self._episodes += 1
+            if self._mode not in ("active", "background") and self._opts[0]:
                 self.start_recording("background")   # (the last of these is what close() saves as the final episode)
-        self._current_step += 1
-        return out
+        self._steps += 1
+        return result
 
-    def close(self):
-        if self._cam is not None and (self._is_recording or self._has_recording_buffer):
-            self.finish_recording()
-        return self.env.close()
+    def _due(self) -> bool:
+        return bool(self.step_trigger(self._steps) if self.episode_trigger is None else self.episode_trigger(self._episodes))
 
     def start_recording(self, type: str = "active"):
-        if self._cam is None:
+        cam = self._cam
+        if cam is None:
             return
-        if hasattr(self._cam, "_recorded_imgs"):
-            self._cam._recorded_imgs.clear()
-        self._is_recording, self._has_recording_buffer, self._recording_type = True, False, type
-        self._recording_start_step = self._current_step
-        self._recording_stop_step = self._current_step + self._video_length_steps
-        self._cam.start_recording()
+        frames = getattr(cam, "_recorded_imgs", None)
+        if frames is not None:
+            frames.clear()
+        self._mode = type
+        self._clip_from, self._clip_until = self._steps, self._steps + self._clip_steps
+        cam.start_recording()
 
     def finish_recording(self):
-        if self._cam is None or (not self._is_recording and not self._has_recording_buffer):
+        cam, mode = self._cam, self._mode
+        if cam is None or mode is None:
             return
-        if self._recording_type == "active" or (not self._is_recording and self._has_recording_buffer):
-            path = os.path.join(self._out_dir, self._filename or f"{self._recording_start_step}.mp4")
-            if self._logging:
-                print(f"Saving recording to {path}")
-            self._cam.stop_recording(path, fps=self._actual_fps)
-            self._has_recording_buffer = False
-        else:
-            self._cam.pause_recording()
-            self._has_recording_buffer = True
-        self._is_recording, self._recording_type, self._recording_stop_step = False, None, 0
+        if mode == "background":        # keep it in the camera's buffer: only close() turns it into a file
+            cam.pause_recording()
+            self._mode = "held"
+            return
+        _attr, out_dir, filename, _k = self._where
+        target = os.path.join(out_dir, filename or f"{self._clip_from}.mp4")
+        if self._opts[1]:
+            print(f"Saving recording to {target}")
+        cam.stop_recording(target, fps=self._file_fps)
+        self._mode, self._clip_until = None, 0
 
-    def _check_recording_trigger(self) -> bool:
-        if self._is_recording and self._recording_type == "active":
-            return False
-        record = bool(self.episode_trigger(self._current_episode) if self.episode_trigger is not None else self.step_trigger(self._current_step))
-        if record:
-            self.start_recording()
-        return record
+    def close(self):
+        if self._cam is not None and self._mode is not None:
+            if self._mode == "background":
+                self._mode = "held"
+            self.finish_recording()
+        return self.env.close()
