@@ -242,8 +242,11 @@ def test_assignments_that_change_nothing_keep_the_recorded_step(oracle_backend):
         env.step(torch.zeros(33, 12))
     assert env._trace is not None
     pos = env.robot_manager.on_reset["position"].params
-    vec = pos["position"]
-    assert isinstance(vec, list)
+    vec = list(pos["position"])   # (a list of this test's own: the config's is a module constant other envs share)
+    pos["position"] = vec
+    for _ in range(3):
+        env.step(torch.zeros(33, 12))
+    assert env._trace is not None
     vec[2] = 0.45
     pos["position"] = vec     # the same mutable object again: "I edited it in place"
     assert env._trace is None
