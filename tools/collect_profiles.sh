@@ -16,7 +16,7 @@ python3 tools/bench_configs.py --scene genesis_like --no-trace --configs go2_cmd
 tools/microbench 1048576 > gpurun_out/${tag}_microbench_1m.txt 2>&1 || true
 tools/microbench 65536 > gpurun_out/${tag}_microbench_65536.txt 2>&1 || true
 python3 tools/bench_rollout.py 65536 > gpurun_out/${tag}_rollout.jsonl 2>> gpurun_out/${tag}_configs.err
-{ for k in reward obs manager classes obsclass action; do python3 tools/bench_user_term.py 65536 $k; done; python3 tools/bench_user_term.py 4096 manager; } > gpurun_out/${tag}_user_term.txt 2>> gpurun_out/${tag}_configs.err
+{ for k in reward obs manager classes obsclass action curriculum anneal; do python3 tools/bench_user_term.py 65536 $k; done; python3 tools/bench_user_term.py 4096 manager; } > gpurun_out/${tag}_user_term.txt 2>> gpurun_out/${tag}_configs.err
 { python3 tools/bench_window.py 65536; python3 tools/bench_window.py 8192; } > gpurun_out/${tag}_window_output.jsonl 2>> gpurun_out/${tag}_configs.err
 python3 tools/bench_reset_override.py > gpurun_out/${tag}_reset_override.txt 2>> gpurun_out/${tag}_configs.err
 tools/prof_by_grid.sh ${tag}_bench bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-profile --no-sweep --no-hbm-point --no-pmc > /dev/null
