@@ -152,7 +152,10 @@ class StepTrace:
                 assert idx <= first_post or self.post_refs is None
                 self.splits.append((k - 1, marks[mark_i][1]))
                 mark_i += 1
-            if scene_pre_at is not None:   # (behind the step() of a user-defined action manager class, which sends the targets itself)
+                if scene_pre_at is not None:   # right behind the step() of a user-defined action manager class (the FIRST mark: it sends
+                    self.splits.append((scene_pre_at, self._scene_pre))   # the targets itself) and in front of any other user code —
+                    scene_pre_at = None                                    # a user termination manager's step() reads this tick's state
+            if scene_pre_at is not None:
                 self.splits.append((scene_pre_at, self._scene_pre))
                 scene_pre_at = None
             if idx < first_post:
@@ -190,7 +193,11 @@ class StepTrace:
                 self.splits.append((self._cur_op, pre))
         for _at, f in marks[mark_i:]:   # user code behind the last launch
             self.splits.append((k - 1, f))
-        assert scene_pre_at is None
+            if scene_pre_at is not None:
+                self.splits.append((scene_pre_at, self._scene_pre))
+                scene_pre_at = None
+        if scene_pre_at is not None:
+            self.splits.append((scene_pre_at, self._scene_pre))
         self.native.extend(self._gait_swaps)   # after the gait managers' own patches (those refill the descriptors)
         post_at = next((i - 1 for i in range(k) if self.ops[i].phase == nat.GF_OP_POST_PHYSICS), -1)
         self.native_op.extend([post_at] * (len(self.native) - len(self.native_op)))   # (they serve the fused launch)

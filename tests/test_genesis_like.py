@@ -252,7 +252,7 @@ def _gl_seeds(default):
     return list(range(int(a), int(b)))
 
 
-@pytest.mark.parametrize("seed", _gl_seeds(list(range(0, 28, 2)) + [123]))
+@pytest.mark.parametrize("seed", _gl_seeds(list(range(0, 28, 2)) + [123, 466]))
 def test_random_configs_on_genesis_like_scene_cpu(oracle_backend, seed):
     """The randomised task configs (tests/test_fuzz_configs.py: drawn reward / termination / observation tables, Python-level terms,
     a third ObservationManager, reset() overrides, output / history modes) on the double, recorded, against the same config on the
@@ -274,7 +274,7 @@ def test_contact_arrays_that_change_shape_every_tick_hip(hip_backend, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", _gl_seeds(list(range(1, 28, 3)) + [140]))
+@pytest.mark.parametrize("seed", _gl_seeds(list(range(1, 28, 3)) + [140, 466]))
 def test_random_configs_on_genesis_like_scene_hip(hip_backend, seed):
     """-m gpu: the same on the HIP kernels — recorded step on the double == recorded step on the synthetic scene, bit for bit."""
     import test_fuzz_configs as fz
