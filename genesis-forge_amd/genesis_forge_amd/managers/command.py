@@ -191,6 +191,7 @@ class CommandManager(BaseManager):
                 axis_map.append(range_axis[key])
         self._gamepad_cfg = {"gamepad": gamepad, "axis_map": axis_map}
         self._gamepad_axis_command_buffer = torch.zeros_like(self._command, device=gs.device)
+        self.env.invalidate_trace()   # (as use_external_controller: a recorded step holds the internal generator's launch)
 
     def _gamepad_axis_command(self, step_count: int) -> torch.Tensor:
         if self._gamepad_cfg is None:
