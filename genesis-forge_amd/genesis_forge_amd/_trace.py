@@ -495,6 +495,10 @@ class StepTrace:
         seg = self.tail_seg.get(part)
         if seg is None:
             return False
+        if self.env._soft_dirty:
+            # the user's reset() override assigned a weight / param / scale / noise (a curriculum): the part of the tail behind it reads
+            # the new number in this very step, as the ordinary step does — refreshed in place, or the recording goes (then: below)
+            self.env._refresh_soft()
         if self.epoch != self.env._trace_epoch or not self.fresh():
             # something the frozen descriptors depend on was mutated since this step began (the user's reset() override ran a
             # curriculum): the rest of the tail walks the managers, which read the live values like the ordinary step does

@@ -21,7 +21,7 @@ class LiveAttr:
         old = getattr(obj, self.slot, None)
         setattr(obj, self.slot, value)
         if had and old != value:
-            obj._live_attr_changed()
+            obj._live_attr_changed(self.slot[len("_live_"):])
 
 
 class BaseManager:
@@ -59,7 +59,7 @@ class BaseManager:
     #: implement ``_fill_reset``; everything else gets ``reset(envs_idx)`` with a compacted index list.
     _fused_reset = False
 
-    def _live_attr_changed(self) -> None:
+    def _live_attr_changed(self, name: str = "") -> None:
         """A plain attribute the reference re-reads on every call was assigned: whatever was compiled from it is stale."""
         if hasattr(self, "_mark_dirty"):
             self._mark_dirty()

@@ -141,6 +141,12 @@ class ObservationManager(BaseManager):
         elif hasattr(env, "invalidate_trace"):
             env.invalidate_trace()
 
+    def _live_attr_changed(self, name: str = "") -> None:
+        if name == "noise":   # the manager-wide noise level is a number of the item table, like an item's own (a noise curriculum)
+            self._mark_dirty(soft=True)
+        else:
+            super()._live_attr_changed(name)
+
     def _refresh_in_place(self) -> bool:
         if not self.enabled or not self._bufs:
             return False

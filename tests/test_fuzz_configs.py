@@ -285,7 +285,7 @@ def _mutations(env, seed):
     out = []
     for _ in range(r.randint(1, 3)):
         at = r.randint(3, 24)
-        kind = r.choice(["reward_weight", "reward_weight", "reward_param", "term_param", "range", "resample", "obs_scale", "obs_noise", "zero_weight"])
+        kind = r.choice(["reward_weight", "reward_weight", "reward_param", "term_param", "range", "resample", "obs_scale", "obs_noise", "mgr_noise", "zero_weight"])
         rm, tm, vc = env.reward_manager, env.termination_manager, env.velocity_command
         if kind in ("reward_weight", "zero_weight"):
             name = r.choice(sorted(rm.cfg))
@@ -309,6 +309,9 @@ def _mutations(env, seed):
         elif kind == "resample":
             sec = round(r.uniform(0.1, 0.6), 3)
             out.append((at, lambda sec=sec: setattr(vc, "resample_time_sec", sec)))
+        elif kind == "mgr_noise":
+            nz = r.choice([None, 0.02, 0.04])
+            out.append((at, lambda nz=nz: setattr(env.observation_manager, "noise", nz)))
         elif kind == "obs_noise":
             om = env.observation_manager
             name = r.choice(sorted(k for k in om.cfg if k != "user_xy"))
